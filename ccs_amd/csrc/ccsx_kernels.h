@@ -1,0 +1,55 @@
+// ccsx_kernels.h — kernel parameter block shared by ccsx_kernels.hip and ccsx_api.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ccsx.h"
+
+struct KParams {
+    int32_t n_zmw, n_reads;
+    int32_t maxL_max;          // longest subread of the batch
+    int32_t vcap_max;          // POA vertex capacity of the largest ZMW
+    int32_t need_max;          // max window-edge columns per read (2 * window slots)
+    ccsx_opts opts;
+    const ccsx_model *model;   // device copy
+    // ---- inputs (HBM resident after ccsx_upload)
+    const float *snr;
+    const int32_t *read_off;
+    const int64_t *base_off;
+    const uint8_t *bases, *pw, *flags;
+    // ---- host-derived layout
+    const int32_t *read_zmw;   // [R] owning ZMW of each read
+    const int32_t *vcap;       // [n] POA vertex capacity
+    const int32_t *dcap;       // [n] draft / consensus capacity
+    const int64_t *seq_off;    // [n+1] offsets of draft and outputs (capacity layout)
+    const int32_t *wb_off;     // [n+1] offsets into wbounds; window slots of z = wb_off[z+1]-wb_off[z]-1
+    const int64_t *ent_off;    // [R] offsets into ent
+    // ---- per-ZMW state
+    float *tabME, *tabINS, *tabDL;
+    uint8_t *draft;
+    int32_t *draft_len, *nwin, *zstat, *nreads_used, *wbounds, *np;
+    int32_t *ticket_poa, *ticket_align;   // adjacent
+    // ---- POA / alignment scratch (per resident slot)
+    uint8_t *poa_scratch;
+    size_t poa_slot_bytes;
+    int32_t poa_slots;
+    int32_t *align_scratch;
+    size_t align_slot_i32;
+    int32_t align_slots;
+    uint8_t *avalid;
+    int32_t *ascore;
+    int32_t *ent;              // entry rows of every window-edge column, per read
+    // ---- per-window polish outputs
+    long long total_wslots;
+    uint8_t *wseq;             // [wslots][32]
+    float *wqv;                // [wslots][32]
+    float *wsum;               // [wslots] sum of p_err over the core
+    int4 *wmeta;               // [wslots] (core length, usable reads, non-convergent, iterations)
+    // ---- results
+    uint8_t *out_seq, *out_qual;
+    float *out_raw;
+    int32_t *out_status, *out_len, *out_iters, *out_nwin;
+    float *out_rq, *out_ec;
+};
+
+void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev);

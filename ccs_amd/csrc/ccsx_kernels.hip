@@ -1,0 +1,897 @@
+// ccsx_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the CCS per-ZMW consensus hot path.
+//
+//   k_setup   A0    per-ZMW Arrow parameter tables           (docs/how-does-ccs-work.md:90-94)
+//   k_poa     D2/D3 sparse-POA draft: one wave per ZMW       (docs/how-does-ccs-work.md:34-51)
+//   k_align   step3 subread -> draft banded alignment        (docs/how-does-ccs-work.md:53-55)
+//   k_post    A7    per-ZMW usable-read accounting           (docs/faq/accuracy-vs-passes.md:37-39)
+//   k_polish  A1-A6 Arrow alpha/beta fill, mutation scoring, polish loop, QVs; one workgroup per window
+//                                                            (docs/how-does-ccs-work.md:57-61,87-106)
+//   k_stitch  step10 concatenate window cores, rq/np/ec      (docs/how-does-ccs-work.md:108-112)
+//
+// The arithmetic follows DESIGN.md §SPEC operation by operation (compiled with -ffp-contract=off, no
+// fast-math) so that sequences are bit-identical to the CPU restatement.  No MFMA: the recurrences are
+// 3-term stencils with data-dependent coefficients.  DP matrices live in LDS (polish) or registers
+// (alignment); only the POA keeps score columns in HBM scratch because its DAG is irregular.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ccsx.h"
+#include "ccsx_kernels.h"
+
+#define LANES 64
+#define NEGV (-(1 << 28))
+#define SC_MATCH 3
+#define SC_MISMATCH (-5)
+#define SC_INS (-4)
+#define SC_DEL (-4)
+#define MV_DIAG 0
+#define MV_DEL 1
+#define MV_INS 2
+#define MUT_EPS 0.01f
+#define MUT_SEP 5
+#define JMIN_DEL 4
+#define AB_TOL 0.01f
+#define TINY_P 1e-30f
+
+// ------------------------------------------------------------------------------------------------
+// deterministic log2 / exp2 (DESIGN.md §SPEC "det math"): only +, *, / (IEEE, correctly rounded) and bit ops
+__device__ __forceinline__ float det_log2f(float x)
+{
+    uint32_t u = __float_as_uint(x);
+    if ((int32_t)u < 0x00800000) return -127.0f;
+    int e = (int)(u >> 23) - 127;
+    float f = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (f > 1.41421356f) { f = f * 0.5f; e = e + 1; }
+    float t = f - 1.0f;
+    float s = __fdiv_rn(t, 2.0f + t);
+    float z = s * s;
+    float p = z * 0.111111111f;
+    p = p + 0.142857143f;
+    p = p * z;
+    p = p + 0.2f;
+    p = p * z;
+    p = p + 0.333333333f;
+    p = p * z;
+    p = p + 1.0f;
+    float ln = (2.0f * s) * p;
+    return (float)e + ln * 1.44269504f;
+}
+
+__device__ __forceinline__ float det_exp2f(float x)
+{
+    if (x < -125.0f) x = -125.0f;
+    if (x > 60.0f) x = 60.0f;
+    float n = floorf(x + 0.5f);
+    float f = (x - n) * 0.693147181f;
+    float p = f * 1.98412698e-4f;
+    p = p + 1.38888889e-3f;
+    p = p * f;
+    p = p + 8.33333333e-3f;
+    p = p * f;
+    p = p + 4.16666667e-2f;
+    p = p * f;
+    p = p + 0.166666667f;
+    p = p * f;
+    p = p + 0.5f;
+    p = p * f;
+    p = p + 1.0f;
+    p = p * f;
+    p = p + 1.0f;
+    int ni = (int)n;
+    return p * __uint_as_float((uint32_t)(ni + 127) << 23);
+}
+
+__device__ __forceinline__ int ctx_of(int prev, int cur) { if (prev > 3) prev = (cur + 2) & 3; return prev * 4 + cur; }
+__device__ __forceinline__ int obs_of(int base, int pw) { int b = pw < 1 ? 1 : (pw > 3 ? 3 : pw); return base * 3 + (b - 1); }
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { int o = __shfl_xor(v, s); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { int o = __shfl_xor(v, s); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { float o = __shfl_xor(v, s); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int bcast_i32(int v, int lane) { return __shfl(v, lane); }
+
+__device__ __forceinline__ int band_lo(int lo_u, int bestrow_u, int I)
+{
+    int lo = bestrow_u + 1 - CCSX_BAND / 2;
+    if (lo < lo_u) lo = lo_u;
+    if (lo > lo_u + 2) lo = lo_u + 2;
+    int hi = I - (CCSX_BAND - 1); if (hi < 0) hi = 0;
+    if (lo > hi) lo = hi;
+    if (lo < 0) lo = 0;
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A0: per-ZMW parameter tables.  One thread per (zmw, ctx).
+__global__ void k_setup(KParams P)
+{
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= P.n_zmw * CCSX_NCTX) return;
+    int z = gid / CCSX_NCTX, k = gid % CCSX_NCTX;
+    const ccsx_model *m = P.model;
+    int cur = k & 3;
+    float s = P.snr[z * 4 + cur];
+    if (s < m->snr_lo) s = m->snr_lo;
+    if (s > m->snr_hi) s = m->snr_hi;
+    float w[3];
+#pragma unroll
+    for (int mv = 0; mv < 3; ++mv) {
+        const float *c = m->trans_poly[k][mv];
+        float t = c[3] * s;
+        t = t + c[2];
+        t = t * s;
+        t = t + c[1];
+        t = t * s;
+        t = t + c[0];
+        if (t < 1e-6f) t = 1e-6f;
+        w[mv] = t;
+    }
+    float den = 1.0f + w[0];
+    den = den + w[1];
+    den = den + w[2];
+    float pM = __fdiv_rn(1.0f, den), pB = __fdiv_rn(w[0], den), pS = __fdiv_rn(w[1], den), pD = __fdiv_rn(w[2], den);
+    float *ME = P.tabME + (size_t)z * 192, *INS = P.tabINS + (size_t)z * 192;
+    for (int o = 0; o < CCSX_NOBS; ++o) {
+        int b = o / 3, pwb = o % 3;
+        ME[k * CCSX_NOBS + o] = (pM * m->em_match[k][o]) * 4.0f;
+        if (b == cur) INS[k * CCSX_NOBS + o] = (pB * m->em_branch[k][pwb]) * 4.0f;
+        else          INS[k * CCSX_NOBS + o] = ((pS * m->em_stick[k][pwb]) * 0.333333333f) * 4.0f;
+    }
+    P.tabDL[(size_t)z * 16 + k] = pD;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed 2-bit oriented read in LDS (one wave owns it)
+__device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t *bases, int L, int rev, int lane)
+{
+    int nw = (L + 15) >> 4;
+    for (int w = lane; w < nw; w += LANES) {
+        uint32_t v = 0;
+        int i0 = w << 4;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int i = i0 + k;
+            if (i < L) { uint32_t b = rev ? (uint32_t)(3 - bases[L - 1 - i]) : (uint32_t)bases[i]; v |= (b & 3u) << (2 * k); }
+        }
+        sread[w] = v;
+    }
+}
+__device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { return (int)((sread[i >> 4] >> (2 * (i & 15))) & 3u); }
+
+// ------------------------------------------------------------------------------------------------
+// D2/D3: sparse POA.  One wave per resident graph ("slot"); slots pull ZMWs from an atomic ticket.
+struct PoaSlot {
+    uint8_t *base, *npred, *mv;
+    int32_t *nreads, *lo, *colmax, *bestrow, *pred, *next, *prev, *order, *M, *best, *bp, *pathv;
+};
+
+__device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
+{
+    PoaSlot s;
+    size_t vc = (size_t)P.vcap_max;
+    uint8_t *p = P.poa_scratch + (size_t)slot * P.poa_slot_bytes;
+    s.M = (int32_t *)p;            p += vc * 64 * 4;
+    s.pred = (int32_t *)p;         p += vc * CCSX_MAXPRED * 4;
+    s.nreads = (int32_t *)p;       p += vc * 4;
+    s.lo = (int32_t *)p;           p += vc * 4;
+    s.colmax = (int32_t *)p;       p += vc * 4;
+    s.bestrow = (int32_t *)p;      p += vc * 4;
+    s.next = (int32_t *)p;         p += vc * 4;
+    s.prev = (int32_t *)p;         p += vc * 4;
+    s.order = (int32_t *)p;        p += vc * 4;
+    s.best = (int32_t *)p;         p += vc * 4;
+    s.bp = (int32_t *)p;           p += vc * 4;
+    s.pathv = (int32_t *)p;        p += (size_t)P.maxL_max * 4 + 64;
+    s.mv = p;                      p += vc * 64;
+    s.base = p;                    p += vc;
+    s.npred = p;
+    return s;
+}
+
+__device__ __forceinline__ void poa_add_edge(PoaSlot &g, int from, int to)
+{
+    int np = g.npred[to];
+    for (int k = 0; k < np; ++k) if (g.pred[to * CCSX_MAXPRED + k] == from) return;
+    if (np >= CCSX_MAXPRED) return;
+    g.pred[to * CCSX_MAXPRED + np] = from; g.npred[to] = (uint8_t)(np + 1);
+}
+
+extern __shared__ uint32_t dyn_lds[];
+
+__global__ __launch_bounds__(64) void k_poa(KParams P)
+{
+    const int lane = threadIdx.x;
+    uint32_t *sread = dyn_lds;
+    PoaSlot g = poa_slot(P, blockIdx.x);
+    for (;;) {
+        int z = 0;
+        if (lane == 0) z = atomicAdd(P.ticket_poa, 1);
+        z = bcast_i32(z, 0);
+        if (z >= P.n_zmw) break;
+        const int r0 = P.read_off[z];
+        int nreads = P.read_off[z + 1] - r0;
+        if (P.opts.top_passes > 0 && nreads > P.opts.top_passes) nreads = P.opts.top_passes;
+        if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; }
+        if (nreads < P.opts.min_passes || nreads < 1) { if (lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES; continue; }
+        int npoa = nreads < P.opts.max_poa_cov ? nreads : P.opts.max_poa_cov;
+        const int vcap = P.vcap[z];
+        const int rev0 = P.flags[r0] & 1;
+        int n = 0, head = -1, nadded = 0, ok = 1;
+        for (int rr = 0; rr < npoa && ok; ++rr) {
+            const int r = r0 + rr;
+            const uint8_t *rb = P.bases + P.base_off[r];
+            const int I = (int)(P.base_off[r + 1] - P.base_off[r]);
+            const int rev = ((P.flags[r] & 1) != rev0) ? 1 : 0;
+            __syncthreads();
+            load_read_packed(sread, rb, I, rev, lane);
+            __syncthreads();
+            if (n == 0) {                                   // first read: backbone chain
+                if (I > vcap) { ok = 0; break; }
+                for (int i = lane; i < I; i += LANES) {
+                    g.base[i] = (uint8_t)read_base_packed(sread, i); g.nreads[i] = 1;
+                    g.npred[i] = (uint8_t)(i > 0 ? 1 : 0); g.pred[i * CCSX_MAXPRED] = i - 1;
+                    g.next[i] = (i + 1 < I) ? i + 1 : -1; g.prev[i] = i - 1; g.order[i] = i;
+                }
+                n = I; head = (I > 0) ? 0 : -1; nadded = 1;
+                __threadfence_block();
+                continue;
+            }
+            // ---- DP over the graph in topological order
+            const int n0 = n;
+            int Mprev = NEGV, vprev = -2, vend = -1, bs = NEGV;
+            int lo_prev = 0, cm_prev = NEGV, br_prev = 0;   // metadata of the previous column stays in registers
+            __threadfence_block();
+            for (int k = 0; k < n0; ++k) {
+                const int v = g.order[k];
+                int np = g.npred[v];
+                const int vb = g.base[v];
+                int ulo = 0, ubr = 0;
+                int pu[CCSX_MAXPRED], plo[CCSX_MAXPRED];
+                if (np == 0) { pu[0] = -1; plo[0] = 0; }
+                else {
+                    bool far = false;
+                    for (int q = 0; q < np; ++q) { int u = g.pred[v * CCSX_MAXPRED + q]; pu[q] = u; far |= (u != vprev); }
+                    if (far) __threadfence_block();        // columns other than the previous one come back from HBM/L2
+                    int bestcm = NEGV - 1;
+                    for (int q = 0; q < np; ++q) {
+                        const int u = pu[q];
+                        int l, cm, b;
+                        if (u == vprev) { l = lo_prev; cm = cm_prev; b = br_prev; }
+                        else { l = g.lo[u]; cm = g.colmax[u]; b = g.bestrow[u]; }
+                        plo[q] = l;
+                        if (cm > bestcm) { bestcm = cm; ulo = l; ubr = b; }
+                    }
+                }
+                const int npp = np == 0 ? 1 : np;
+                const int lo = band_lo(ulo, ubr, I);
+                const int i = lo + lane;
+                const int rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
+                int best = NEGV, bm = 0;
+                for (int q = 0; q < npp; ++q) {
+                    const int u = pu[q];
+                    const int o1 = i - 1 - plo[q], o0 = i - plo[q];
+                    int x, y;
+                    if (u < 0) {
+                        x = (o1 >= 0 && o1 < LANES && o1 <= I) ? o1 * SC_INS : NEGV;
+                        y = (o0 >= 0 && o0 < LANES && o0 <= I) ? o0 * SC_INS : NEGV;
+                    } else if (u == vprev) {
+                        int xs = __shfl(Mprev, o1 & 63), ys = __shfl(Mprev, o0 & 63);
+                        x = (o1 >= 0 && o1 < LANES) ? xs : NEGV;
+                        y = (o0 >= 0 && o0 < LANES) ? ys : NEGV;
+                    } else {
+                        const int32_t *Mu = g.M + (size_t)u * 64;
+                        x = (o1 >= 0 && o1 < LANES) ? Mu[o1] : NEGV;
+                        y = (o0 >= 0 && o0 < LANES) ? Mu[o0] : NEGV;
+                    }
+                    if (i >= 1 && i <= I && x > NEGV / 2) { int c = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); if (c > best) { best = c; bm = MV_DIAG | (q << 2); } }
+                    if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; bm = MV_DEL | (q << 2); } }
+                }
+                // insertion chain: x_l = max_k<=l (c_k + (l-k)*INS)  (exact integer max-plus prefix scan)
+                int d = best + 4 * lane;
+#pragma unroll
+                for (int s = 1; s < LANES; s <<= 1) { int o = __shfl_up(d, s); if (lane >= s && o > d) d = o; }
+                int xi = d - 4 * lane;
+                if (xi > best) { best = xi; bm = MV_INS; }
+                if (i > I || best < NEGV / 2) best = NEGV;
+                const int cm = wave_max_i32(best);
+                const unsigned long long bal = __ballot(best == cm);
+                const int br = lo + (__ffsll((long long)bal) - 1);
+                g.M[(size_t)v * 64 + lane] = best;
+                g.mv[(size_t)v * 64 + lane] = (uint8_t)bm;
+                if (lane == 0) { g.lo[v] = lo; g.colmax[v] = cm; g.bestrow[v] = br; }
+                const int oe = I - lo;
+                if (oe >= 0 && oe < LANES) { int xe = __shfl(best, oe); if (xe > NEGV / 2 && xe > bs) { bs = xe; vend = v; } }
+                Mprev = best; vprev = v; lo_prev = lo; cm_prev = cm; br_prev = br;
+            }
+            __threadfence_block();
+            if (vend < 0) continue;                        // read not added
+            // ---- traceback + threading (serial, lane 0)
+            int fail = 0;
+            if (lane == 0) {
+                int v = vend, i = I;
+                while (v >= 0) {
+                    int m = g.mv[(size_t)v * 64 + (i - g.lo[v])];
+                    int t = m & 3, slot = m >> 2;
+                    if (t == MV_INS) { g.pathv[i - 1] = -1; --i; continue; }
+                    int u = (g.npred[v] == 0) ? -1 : g.pred[v * CCSX_MAXPRED + slot];
+                    if (t == MV_DIAG) { g.pathv[i - 1] = (g.base[v] == read_base_packed(sread, i - 1)) ? v : -1; --i; }
+                    v = u;
+                }
+                while (i > 0) { g.pathv[i - 1] = -1; --i; }
+                int prevp = -1;
+                for (i = 0; i < I; ++i) {
+                    int w = g.pathv[i];
+                    if (w >= 0) g.nreads[w] += 1;
+                    else {
+                        if (n >= vcap) { fail = 1; break; }
+                        w = n++;
+                        g.base[w] = (uint8_t)read_base_packed(sread, i); g.nreads[w] = 1; g.npred[w] = 0;
+                        if (prevp < 0) { g.next[w] = head; g.prev[w] = -1; if (head >= 0) g.prev[head] = w; head = w; }
+                        else { int nx = g.next[prevp]; g.next[w] = nx; g.prev[w] = prevp; g.next[prevp] = w; if (nx >= 0) g.prev[nx] = w; }
+                    }
+                    if (prevp >= 0) poa_add_edge(g, prevp, w);
+                    prevp = w;
+                }
+                if (!fail) { int k = 0; for (int v2 = head; v2 >= 0; v2 = g.next[v2]) g.order[k++] = v2; }
+            }
+            fail = bcast_i32(fail, 0); n = bcast_i32(n, 0); head = bcast_i32(head, 0);
+            if (fail) { ok = 0; break; }
+            nadded += 1;
+            __threadfence_block();
+        }
+        // ---- consensus path + windows (serial, lane 0)
+        int Ld = 0, nw = 0, stat = -1;
+        if (lane == 0) {
+            if (ok && n > 0) {
+                int vbest = -1, sb = NEGV;
+                for (int k = 0; k < n; ++k) {
+                    int v = g.order[k];
+                    int b = 0, p = -1;
+                    int np = g.npred[v];
+                    for (int q = 0; q < np; ++q) { int u = g.pred[v * CCSX_MAXPRED + q]; int bu = g.best[u]; if (bu > b) { b = bu; p = u; } }
+                    int bv = b + 2 * g.nreads[v] - nadded;
+                    g.best[v] = bv; g.bp[v] = p;
+                    if (bv > sb) { sb = bv; vbest = v; }
+                }
+                int len = 0;
+                for (int v = vbest; v >= 0; v = g.bp[v]) ++len;
+                if (len <= P.dcap[z]) {
+                    uint8_t *draft = P.draft + P.seq_off[z];
+                    int k = len;
+                    for (int v = vbest; v >= 0; v = g.bp[v]) draft[--k] = g.base[v];
+                    Ld = len;
+                }
+            }
+            if (Ld <= 0) stat = CCSX_DRAFT_FAILURE;
+            else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
+            else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
+            else {
+                const uint8_t *d = P.draft + P.seq_off[z];
+                int32_t *b = P.wbounds + P.wb_off[z];
+                int cur = 0; b[0] = 0;
+                while (cur < Ld) {
+                    int nb;
+                    if (Ld - cur <= CCSX_WIN_CORE + 6) nb = Ld;
+                    else { nb = cur + CCSX_WIN_CORE; int sh = 0; while (sh < 3 && d[nb] == d[nb - 1]) { ++nb; ++sh; } }
+                    b[++nw] = nb; cur = nb;
+                }
+            }
+            P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// step 3: subread -> draft, global, adaptive 64-row band, one wave per read; the previous column lives
+// in registers.  Instead of storing moves and tracing back every cell, each cell carries the row at which
+// its best path ENTERED the most recent window-edge column ("origin"); at every window-edge column the
+// propagated origins are saved (64 x int32), and the entry rows are recovered by hopping edge to edge.
+__global__ __launch_bounds__(64) void k_align(KParams P)
+{
+    const int lane = threadIdx.x;
+    uint32_t *sread = dyn_lds;
+    int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] then lo_need[need]
+    for (;;) {
+        int r = 0;
+        if (lane == 0) r = atomicAdd(P.ticket_align, 1);
+        r = bcast_i32(r, 0);
+        if (r >= P.n_reads) break;
+        const int z = P.read_zmw[r];
+        const int r0 = P.read_off[z];
+        if (lane == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
+        if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z]) continue;
+        const int Ld = P.draft_len[z], nw = P.nwin[z];
+        const uint8_t *d = P.draft + P.seq_off[z];
+        const int32_t *wb = P.wbounds + P.wb_off[z];
+        const int I = (int)(P.base_off[r + 1] - P.base_off[r]);
+        const int rev = ((P.flags[r] & 1) != (P.flags[r0] & 1)) ? 1 : 0;
+        __syncthreads();
+        load_read_packed(sread, P.bases + P.base_off[r], I, rev, lane);
+        __syncthreads();
+        const int nneed = 2 * nw;                      // needed columns: 0, b1-2, b1+2, ..., Ld
+        int32_t *lo_need = Osave + (size_t)P.need_max * 64;
+        int kk = 1;                                    // next needed column index
+        int next_need = (nw == 1) ? Ld : wb[1] - CCSX_WIN_OVERHANG;
+        // column 0 = START
+        int Mprev = (lane <= I) ? lane * SC_INS : NEGV;
+        int Oprev = 0;                                 // entry row at column 0 is 0 for every cell
+        int lo = 0, br = 0;
+        for (int j = 1; j <= Ld; ++j) {
+            const int plo = lo;
+            lo = band_lo(plo, br, I);
+            const int sh = lo - plo;                   // 0..2
+            const int i = lo + lane;
+            const int vb = d[j - 1];
+            const int rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
+            const int o1 = lane + sh - 1, o0 = lane + sh;
+            int xs = __shfl(Mprev, o1 & 63), ys = __shfl(Mprev, o0 & 63);
+            int oxs = __shfl(Oprev, o1 & 63), oys = __shfl(Oprev, o0 & 63);
+            int x = (o1 >= 0 && o1 < LANES) ? xs : NEGV;
+            int y = (o0 < LANES) ? ys : NEGV;
+            int best = NEGV, org = 0;
+            if (i >= 1 && i <= I && x > NEGV / 2) { best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); org = oxs; }
+            if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; org = oys; } }
+            const bool need = (j == next_need);
+            if (need) {
+                Osave[(size_t)kk * 64 + lane] = org;   // origin (previous edge) of the cell's entry move
+                if (lane == 0) lo_need[kk] = lo;
+                org = i;                               // reset: this column is the new edge
+            }
+            int dd = best + 4 * lane, od = org;
+#pragma unroll
+            for (int s = 1; s < LANES; s <<= 1) {
+                int o = __shfl_up(dd, s), oo = __shfl_up(od, s);
+                if (lane >= s && o > dd) { dd = o; od = oo; }
+            }
+            int xi = dd - 4 * lane;
+            if (xi > best) { best = xi; org = od; }
+            if (i > I || best < NEGV / 2) best = NEGV;
+            const int cm = wave_max_i32(best);
+            const unsigned long long bal = __ballot(best == cm);
+            br = lo + (__ffsll((long long)bal) - 1);
+            Mprev = best; Oprev = org;
+            if (need) {
+                ++kk;
+                next_need = (kk >= nneed) ? -1 : ((kk == nneed - 1) ? Ld : wb[(kk + 1) >> 1] + ((kk & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
+            }
+        }
+        const int oe = I - lo;
+        int sc = NEGV, eLast = 0;
+        if (oe >= 0 && oe < LANES) { sc = __shfl(Mprev, oe); eLast = __shfl(Oprev, oe); }
+        int valid = (sc > NEGV / 2 && sc >= Ld) ? 1 : 0;
+        __threadfence_block();
+        if (lane == 0) {
+            P.ascore[r] = sc; P.avalid[r] = (uint8_t)valid;
+            if (valid) {
+                int32_t *ent = P.ent + P.ent_off[r];
+                int e = eLast;
+                ent[nneed - 1] = e;
+                for (int k2 = nneed - 1; k2 >= 2; --k2) { e = Osave[(size_t)k2 * 64 + (e - lo_need[k2])]; ent[k2 - 1] = e; }
+                ent[0] = 0;
+            }
+        }
+        __threadfence_block();
+    }
+}
+
+// per-ZMW: count usable reads, raise TOO_MANY_UNUSABLE (docs/faq/accuracy-vs-passes.md:37-39)
+__global__ void k_post(KParams P)
+{
+    int z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= P.n_zmw) return;
+    if (P.zstat[z] != CCSX_SUCCESS) { P.np[z] = 0; return; }
+    int r0 = P.read_off[z], nr = P.nreads_used[z], np = 0;
+    for (int r = 0; r < nr; ++r) np += P.avalid[r0 + r];
+    P.np[z] = np;
+    if (2 * np <= nr) { P.zstat[z] = CCSX_TOO_MANY_UNUSABLE; P.nwin[z] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1-A6: Arrow polish of one window per workgroup (256 threads = 4 waves).
+#define PW_THREADS 256
+#define PW_MAXREADS 64
+#define GB_FLOATS (10240)            // 40 KB of LDS for gamma/beta of one chunk of reads
+
+struct LaneMut {                     // per-lane constants of one mutation on one strand
+    int c, q, tri, isdel, fin;
+    float dlA, dlL, fA, fB;
+};
+
+__device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_t *t, int J, int lf, const float *sDL)
+{
+    LaneMut L;
+    int Pb = (c > 0) ? t[c - 1] : lf;
+    int pA = Pb, xA = x, nB = 0, q, fin;
+    if (type == 0)      { fin = (c + 1 == J); if (!fin) nB = t[c + 1]; q = c + 2; }
+    else if (type == 2) { fin = (c == J);     if (!fin) nB = t[c];     q = c + 1; }
+    else                { fin = (c + 1 == J); xA = fin ? 0 : t[c + 1]; q = c + 2; }
+    if (pA > 3) pA = (xA + 2) & 3;
+    int kA = pA * 4 + xA, kB = xA * 4 + nB;
+    L.c = c; L.q = q > J ? J : q; L.tri = pA * 16 + xA * 4 + nB; L.isdel = (type == 1); L.fin = fin;
+    L.dlA = sDL[kA]; L.dlL = (type == 1) ? sDL[kA] : sDL[kB];
+    L.fA = (type == 1 && fin) ? 0.0f : 1.0f;
+    L.fB = fin ? 0.0f : 1.0f;
+    return L;
+}
+
+__global__ __launch_bounds__(PW_THREADS) void k_polish(KParams P)
+{
+    __shared__ float sME[192], sINS[192], sDL[16];
+    __shared__ float4 sTRI[CCSX_NOBS * 64];                 // [obs][tri] = (INS[kA], ME[kA], INS[kB], ME[kB])
+    __shared__ float sMEJ[2][32 * CCSX_NOBS], sINSJ[2][32 * CCSX_NOBS], sDLJ[2][32];   // per strand, per column
+    __shared__ uint8_t sT[2][32];                           // template: [0] forward, [1] reverse complement
+    __shared__ uint8_t sObs[PW_MAXREADS][64];
+    __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
+    __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
+    __shared__ float sBase[PW_MAXREADS];
+    __shared__ float sGB[GB_FLOATS];
+    __shared__ float sDelta[256];
+    __shared__ uint8_t sMvalid[256];
+    __shared__ int sAcc[32];
+    __shared__ int sCtl[8];                                 // 0:J 1:cs 2:ce 3:nacc 4:nfav 5:chunk_end
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- locate (zmw, window)
+    int lo_ = 0, hi_ = P.n_zmw;                             // largest z with woff[z] <= blockIdx.x
+    const int bid = blockIdx.x;
+    while (hi_ - lo_ > 1) { int mid = (lo_ + hi_) >> 1; if (P.wb_off[mid] - mid <= bid) lo_ = mid; else hi_ = mid; }
+    const int z = lo_;
+    const int w = bid - (P.wb_off[z] - z);                  // window slots of zmw z = wcap[z]-1 = wb_off[z+1]-wb_off[z]-1
+    if (w >= P.nwin[z]) return;
+    const int nw = P.nwin[z], Ld = P.draft_len[z];
+    const int32_t *wb = P.wbounds + P.wb_off[z];
+    const uint8_t *draft = P.draft + P.seq_off[z];
+    int ws = wb[w] - CCSX_WIN_OVERHANG; if (ws < 0) ws = 0;
+    int we = wb[w + 1] + CCSX_WIN_OVERHANG; if (we > Ld) we = Ld;
+    const int lf = ws > 0 ? draft[ws - 1] : 4, rf = we < Ld ? draft[we] : 4;
+    const int r0 = P.read_off[z], nreads = P.nreads_used[z];
+    const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
+
+    for (int k = tid; k < 192; k += PW_THREADS) { sME[k] = P.tabME[(size_t)z * 192 + k]; sINS[k] = P.tabINS[(size_t)z * 192 + k]; }
+    if (tid < 16) sDL[tid] = P.tabDL[(size_t)z * 16 + tid];
+    if (tid < we - ws) sT[0][tid] = draft[ws + tid];
+    if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb[w] - ws; sCtl[2] = wb[w + 1] - ws; }
+    // read segments (native orientation)
+    for (int r = wave; r < nreads; r += 4) {
+        int n = -1, na = 0;
+        const int rr = r0 + r;
+        const int L = (int)(P.base_off[rr + 1] - P.base_off[rr]);
+        const int st = ((P.flags[rr] & 1) != (P.flags[r0] & 1)) ? 1 : 0;
+        if (P.avalid[rr]) {
+            const int32_t *ent = P.ent + P.ent_off[rr];
+            int a = ent[idx_ws], b = ent[idx_we];
+            n = b - a;
+            if (n < 0 || n > CCSX_IMAX) n = -1;
+            na = st ? L - b : a;
+        }
+        if (lane == 0) { sI[r] = n; sStrand[r] = (uint8_t)st; }
+        if (lane < n) {
+            const int64_t p = P.base_off[rr] + na + lane;
+            sObs[r][lane] = (uint8_t)obs_of(P.bases[p], P.pw[p]);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < CCSX_NOBS * 64; e += PW_THREADS) {
+        int o = e >> 6, tri = e & 63;
+        int kA = tri >> 2, kB = (tri & 15);
+        sTRI[e] = make_float4(sINS[kA * CCSX_NOBS + o], sME[kA * CCSX_NOBS + o], sINS[kB * CCSX_NOBS + o], sME[kB * CCSX_NOBS + o]);
+    }
+
+    const int slot = tid >> 5, cpos = tid & 31;            // my mutation lane m = tid
+    int iters = 0, nonconv = 0, nvalid_last = 0;
+    for (int it = 0; it < CCSX_MAX_ITER; ++it) {
+        __syncthreads();
+        const int J = sCtl[0];
+        const int S = (J + 2) & ~1;                          // even row stride >= J+1
+        // reverse-complement template + per-column tables for both strands
+        if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
+        __syncthreads();
+        const int lfr = (rf < 4) ? 3 - rf : 4;
+        for (int e = tid; e < 2 * 32 * CCSX_NOBS; e += PW_THREADS) {
+            int sd = e / (32 * CCSX_NOBS), rem = e % (32 * CCSX_NOBS), j = rem / CCSX_NOBS, o = rem % CCSX_NOBS;
+            if (j < J) {
+                int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
+                int k = ctx_of(prev, sT[sd][j]);
+                sMEJ[sd][j * CCSX_NOBS + o] = sME[k * CCSX_NOBS + o];
+                sINSJ[sd][j * CCSX_NOBS + o] = sINS[k * CCSX_NOBS + o];
+                if (o == 0) sDLJ[sd][j] = sDL[k];
+            }
+        }
+        // my mutation on both strands
+        int type, x = 0, mval;
+        {
+            const uint8_t *t = sT[0];
+            if (slot < 3) { type = 0; mval = cpos < J; if (mval) x = (t[cpos] + 1 + slot) & 3; }
+            else if (slot == 3) { type = 1; mval = cpos < J && !(cpos > 0 && t[cpos - 1] == t[cpos]); }
+            else { type = 2; x = slot - 4; mval = cpos <= J && !(cpos > 0 && t[cpos - 1] == x); }
+        }
+        LaneMut LF, LR;
+        if (mval) {
+            LF = lane_mut(type, cpos, x, sT[0], J, lf, sDL);
+            LR = lane_mut(type, (type == 2) ? J - cpos : J - 1 - cpos, 3 - x, sT[1], J, lfr, sDL);
+        } else { LF = lane_mut(0, 0, 0, sT[0], J, lf, sDL); LR = LF; }
+        float delta = 0.0f;
+        int nvalid = 0;
+        // ---- chunks of reads whose gamma/beta fit the LDS budget
+        int rbeg = 0;
+        while (rbeg < nreads) {
+            __syncthreads();
+            if (tid == 0) {
+                int off = 0, r = rbeg;
+                for (; r < nreads; ++r) {
+                    int n = sI[r];
+                    if (n < 0) { sGoff[r] = -1; continue; }
+                    int need = (2 * n + 3) * S;
+                    if (off + need > GB_FLOATS) break;
+                    sGoff[r] = off; sBoff[r] = off + (n + 1) * S; off += need;
+                }
+                sCtl[5] = r;
+            }
+            __syncthreads();
+            const int rend = sCtl[5];
+            // ---- A1/A2: fill, one wave per read, lane = row, anti-diagonal sweep
+            for (int r = rbeg + wave; r < rend; r += 4) {
+                const int I = sI[r];
+                if (I < 0) { if (lane == 0) sValid[r] = 0; continue; }
+                const int sd = sStrand[r];
+                float *gam = sGB + sGoff[r], *bet = sGB + sBoff[r];
+                const float *MEJ = sMEJ[sd], *INSJ = sINSJ[sd], *DLJ = sDLJ[sd];
+                const int op = (lane >= 1 && lane <= I) ? sObs[r][lane - 1] : 0;     // o_{i-1}
+                const int oc = (lane < I) ? sObs[r][lane] : 0;                        // o_i
+                float acur = 0.0f, updiag = 0.0f;
+                for (int t = 0; t <= I + J; ++t) {
+                    float up = __shfl_up(acur, 1);
+                    if (lane == 0) up = 0.0f;
+                    const int j = t - lane;
+                    if (lane <= I && j >= 0 && j <= J) {
+                        float gmm;
+                        if (j == 0) gmm = (lane == 0) ? 1.0f : 0.0f;
+                        else { float m = updiag * MEJ[(j - 1) * CCSX_NOBS + op]; float dl = acur * DLJ[j - 1]; gmm = m + dl; }
+                        float st = (lane > 0 && j < J) ? up * INSJ[j * CCSX_NOBS + op] : 0.0f;
+                        gam[lane * S + j] = gmm;
+                        acur = gmm + st;
+                    }
+                    updiag = up;
+                }
+                const float aIJ = __shfl(acur, I);
+                // beta: lane = row i, column j = J - (t - (I - i))
+                float bcur = 0.0f, dndiag = 0.0f;
+                for (int t = 0; t <= I + J; ++t) {
+                    float dn = __shfl_down(bcur, 1);
+                    if (lane >= I) dn = 0.0f;
+                    const int j = J - (t - (I - lane));
+                    if (lane <= I && j >= 0 && j <= J) {
+                        float b;
+                        if (j == J) b = (lane == I) ? 1.0f : 0.0f;
+                        else {
+                            float t1 = (lane < I) ? MEJ[j * CCSX_NOBS + oc] * dndiag : 0.0f;
+                            float t2 = (lane < I) ? INSJ[j * CCSX_NOBS + oc] * dn : 0.0f;
+                            float t3 = DLJ[j] * bcur;
+                            b = (t1 + t2) + t3;
+                        }
+                        bet[lane * S + j] = b;
+                        bcur = b;
+                    }
+                    dndiag = dn;
+                }
+                if (lane < S) bet[(I + 1) * S + lane] = 0.0f;
+                const float b00 = __shfl(bcur, 0);
+                if (lane == 0) {
+                    int v = 0; float la = 0.0f;
+                    if (aIJ > TINY_P && b00 > TINY_P) {
+                        la = det_log2f(aIJ); float lb = det_log2f(b00);
+                        float df = la - lb; if (df < 0.0f) df = -df;
+                        v = !(df > AB_TOL);
+                    }
+                    sValid[r] = (uint8_t)v; sBase[r] = la;
+                }
+            }
+            __syncthreads();
+            // ---- A3/A4: every lane scores its mutation against every read of the chunk
+            for (int r = rbeg; r < rend; ++r) {
+                if (!sValid[r]) continue;
+                ++nvalid;
+                const int I = sI[r];
+                const LaneMut &L = sStrand[r] ? LR : LF;
+                const float *gam = sGB + sGoff[r] + L.c, *bet = sGB + sBoff[r] + L.q;
+                const uint8_t *ob = sObs[r];
+                float ap = 0.0f, bp = 0.0f, acc = 0.0f, b = 0.0f;
+                float4 Tp = make_float4(0.f, 0.f, 0.f, 0.f);
+                float bq = bet[0];
+                for (int i = 0; i <= I; ++i) {
+                    const float gmm = gam[i * S];
+                    float4 T = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < I) T = sTRI[ob[i] * 64 + L.tri];
+                    const float bqn = bet[(i + 1) * S];
+                    const float insA = Tp.x * L.fA, meA = Tp.y, insB = Tp.z * L.fB;
+                    const float a = gmm + ap * insA;
+                    if (L.isdel) b = a;
+                    else b = ((ap * meA) + (a * L.dlA)) + bp * insB;
+                    const float meL = L.isdel ? T.y : T.w;
+                    const float term = (meL * bqn) + (L.dlL * bq);
+                    acc = acc + b * term;
+                    ap = a; bp = b; Tp = T; bq = bqn;
+                }
+                const float res = L.fin ? b : acc;
+                const float dd = det_log2f(res) - sBase[r];
+                delta = delta + dd;
+            }
+            rbeg = rend;
+        }
+        ++iters;
+        nvalid_last = nvalid;
+        if (!mval) delta = 0.0f;
+        sDelta[tid] = delta; sMvalid[tid] = (uint8_t)mval;
+        const int fav = (mval && delta > MUT_EPS) ? 1 : 0;
+        const int anyfav = __syncthreads_or(fav);
+        if (!anyfav) break;
+        if (it == CCSX_MAX_ITER - 1) { nonconv = 1; break; }
+        // ---- A5: greedy selection (wave 0; lane l owns m = l, l+64, l+128, l+192 which share position l&31)
+        if (wave == 0) {
+            int candmask = 0;
+            for (int k = 0; k < 4; ++k) { int m = lane + 64 * k; if (sMvalid[m] && sDelta[m] > MUT_EPS) candmask |= 1 << k; }
+            int Jn = J, nacc = 0;
+            for (;;) {
+                float bd = -1.0f; int bm = 1 << 20;
+                for (int k = 0; k < 4; ++k) if (candmask & (1 << k)) { int m = lane + 64 * k; float dv = sDelta[m]; if (dv > bd) { bd = dv; bm = m; } }
+                const float wmax = wave_max_f32(bd);
+                if (!(wmax > 0.0f)) break;
+                const int msel = wave_min_i32((bd == wmax) ? bm : (1 << 20));
+                if (lane == (msel & 63)) candmask &= ~(1 << (msel >> 6));
+                const int sl = msel >> 5, c = msel & 31;
+                if (sl >= 4 && Jn >= CCSX_JMAX) continue;
+                if (sl == 3 && Jn <= JMIN_DEL + 1) continue;
+                if (sl >= 4) ++Jn; else if (sl == 3) --Jn;
+                if (lane == 0) sAcc[nacc] = msel;
+                ++nacc;
+                int dc = (lane & 31) - c; if (dc < 0) dc = -dc;
+                if (dc < MUT_SEP) candmask = 0;
+            }
+            if (lane == 0) {
+                // apply in descending position order
+                for (int a = 0; a < nacc; ++a) for (int b2 = a + 1; b2 < nacc; ++b2)
+                    if ((sAcc[b2] & 31) > (sAcc[a] & 31)) { int tt = sAcc[a]; sAcc[a] = sAcc[b2]; sAcc[b2] = tt; }
+                int Jc = J, cs = sCtl[1], ce = sCtl[2];
+                uint8_t *t = sT[0];
+                for (int a = 0; a < nacc; ++a) {
+                    const int m = sAcc[a], sl = m >> 5, c = m & 31;
+                    if (sl < 3) t[c] = (uint8_t)((t[c] + 1 + sl) & 3);
+                    else if (sl >= 4) {
+                        for (int k = Jc; k > c; --k) t[k] = t[k - 1];
+                        t[c] = (uint8_t)(sl - 4); ++Jc;
+                        if (c < cs) { ++cs; ++ce; } else if (c < ce) ++ce;
+                    } else {
+                        for (int k = c; k + 1 < Jc; ++k) t[k] = t[k + 1];
+                        --Jc;
+                        if (c < cs) { --cs; --ce; } else if (c < ce) --ce;
+                    }
+                }
+                sCtl[0] = Jc; sCtl[1] = cs; sCtl[2] = ce; sCtl[3] = nacc;
+            }
+        }
+        __syncthreads();
+        if (sCtl[3] == 0) break;
+    }
+    __syncthreads();
+    // ---- A6: QVs of the core positions from the last scoring round
+    const int J = sCtl[0], cs = sCtl[1], ce = sCtl[2];
+    const size_t wi = (size_t)(P.wb_off[z] - z) + w;
+    float *sPerr = sGB;                                     // reuse
+    if (tid < ce - cs) {
+        const int c = cs + tid;
+        float s = 0.0f;
+        for (int sl = 0; sl < 8; ++sl) {
+            int m = sl * 32 + c;
+            if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }
+        }
+        if (c == J - 1) for (int sl = 4; sl < 8; ++sl) {
+            int m = sl * 32 + J;
+            if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }
+        }
+        float p = __fdiv_rn(s, 1.0f + s);
+        if (p < 1e-10f) p = 1e-10f;
+        float qv = -3.01029996f * det_log2f(p);
+        if (qv < 0.0f) qv = 0.0f;
+        if (qv > 93.0f) qv = 93.0f;
+        P.wseq[wi * 32 + tid] = sT[0][c];
+        P.wqv[wi * 32 + tid] = qv;
+        sPerr[tid] = p;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float wsum = 0.0f;
+        for (int k = 0; k < ce - cs; ++k) wsum = wsum + sPerr[k];
+        P.wsum[wi] = wsum;
+        P.wmeta[wi] = make_int4(ce - cs, nvalid_last, nonconv, iters);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// step 10: concatenate window cores; rq = 1 - mean(p_err); ec, np, status.  One wave per ZMW.
+__global__ __launch_bounds__(64) void k_stitch(KParams P)
+{
+    __shared__ double sSum;
+    const int z = blockIdx.x, lane = threadIdx.x;
+    int stat = P.zstat[z];
+    const int nw = (stat == CCSX_SUCCESS) ? P.nwin[z] : 0;
+    const size_t w0 = (size_t)(P.wb_off[z] - z);
+    const int64_t so = P.seq_off[z], cap = P.seq_off[z + 1] - so;
+    int run = 0, nvs = 0, its = 0, ncv = 0;
+    if (lane == 0) sSum = 0.0;
+    for (int wbase = 0; wbase < nw; wbase += LANES) {
+        const int w = wbase + lane;
+        int4 mt = make_int4(0, 0, 0, 0);
+        if (w < nw) mt = P.wmeta[w0 + w];
+        int pre = mt.x;                                     // inclusive scan of lengths
+#pragma unroll
+        for (int s = 1; s < LANES; s <<= 1) { int o = __shfl_up(pre, s); if (lane >= s) pre += o; }
+        const int off = run + pre - mt.x;
+        for (int k = 0; k < mt.x; ++k) {
+            if (off + k < cap) {
+                float qv = P.wqv[(w0 + w) * 32 + k];
+                P.out_seq[so + off + k] = P.wseq[(w0 + w) * 32 + k];
+                P.out_raw[so + off + k] = qv;
+                P.out_qual[so + off + k] = (uint8_t)(qv + 0.5f);
+            }
+        }
+        run += __shfl(pre, 63);
+        nvs += mt.y; ncv |= mt.z; its += mt.w;
+        // fixed-order (window order) double sum of per-window float sums
+        for (int k = 0; k < LANES; ++k) {
+            float v = __shfl((w < nw) ? P.wsum[w0 + w] : 0.0f, k);
+            if (lane == 0 && wbase + k < nw) sSum += (double)v;
+        }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { nvs += __shfl_xor(nvs, s); its += __shfl_xor(its, s); ncv |= __shfl_xor(ncv, s); }
+    if (lane == 0) {
+        int64_t len = run; if (len > cap) len = cap;
+        float rq = 0.0f, ec = 0.0f;
+        if (stat == CCSX_SUCCESS) {
+            rq = len > 0 ? (float)(1.0 - sSum / (double)len) : 0.0f;
+            ec = nw > 0 ? (float)((double)nvs / (double)nw) : 0.0f;
+            if (len == 0) stat = CCSX_EMPTY_WINDOW;
+            else if (ncv) stat = CCSX_NON_CONVERGENT;
+            else if (rq < P.opts.min_rq) stat = CCSX_LOW_RQ;
+        } else len = 0;
+        P.out_status[z] = stat; P.out_len[z] = (int32_t)len; P.out_rq[z] = rq; P.out_ec[z] = ec;
+        P.out_iters[z] = its; P.out_nwin[z] = nw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (called from ccsx_api.cpp, which is plain C++)
+void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or NULL */)
+{
+    if (ev) (void)hipEventRecord(ev[0], st);
+    (void)hipMemsetAsync(P.ticket_poa, 0, 8, st);                // ticket_poa and ticket_align are adjacent
+    {
+        int n = P.n_zmw * CCSX_NCTX;
+        hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, P);
+    }
+    if (ev) (void)hipEventRecord(ev[1], st);
+    const size_t lds_read = (((size_t)P.maxL_max + 15) / 16) * 4 + 64;
+    hipLaunchKernelGGL(k_poa, dim3(P.poa_slots), dim3(64), lds_read, st, P);
+    if (ev) (void)hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL(k_align, dim3(P.align_slots), dim3(64), lds_read, st, P);
+    hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P);
+    if (ev) (void)hipEventRecord(ev[3], st);
+    if (P.total_wslots > 0) hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), 0, st, P);
+    if (ev) (void)hipEventRecord(ev[4], st);
+    hipLaunchKernelGGL(k_stitch, dim3(P.n_zmw), dim3(64), 0, st, P);
+    if (ev) (void)hipEventRecord(ev[5], st);
+}

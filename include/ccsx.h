@@ -1,0 +1,170 @@
+/*
+ * ccsx.h — C ABI of the MI355X-native CCS per-ZMW consensus hot path.
+ *
+ * Drop-in boundary.  The reference (PacificBiosciences/ccs, docs-only mount)
+ * publishes no plugin API; the only documented seam is the block diagram docs/img/ccs-impl.png:
+ * "Draft Stage {GPU | CPU pool}" -> queue(ZMWs, Drafts, Windows) -> "Polish Stage {GPU | CPU pool}".
+ * The entry points below are the GPU consumers of those two queues plus the fused path:
+ *
+ *   ccsx_consensus_*  : steps 2,3,4,8,9,10 of docs/how-does-ccs-work.md:34-112 for a batch of ZMWs
+ *   ccsx_stage_*      : per-stage access (draft / align / polish) used by the parity tests
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary.
+ *   - every function returns 0 on success, <0 on a fatal error (HIP error, OOM, bad argument);
+ *     text via ccsx_last_error().  Algorithmic failures are reported PER ZMW in status[]
+ *     (one status per ZMW, the run continues: docs/faq/reports-aux-files.md:10-12,143-159).
+ *   - the caller owns every input and output buffer; the library owns device memory and streams.
+ *   - a handle is bound to one GPU and is not thread-safe: one handle per host worker per GPU
+ *     (mirrors the reference's "-j" worker pool, docs/faq/parallelize.md:17).
+ *   - there is NO CPU fallback: if no gfx950 device is usable, ccsx_create fails loudly.
+ */
+#ifndef CCSX_H
+#define CCSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCSX_ABI_VERSION 1
+
+/* ---- fixed constants of the algorithm specification ---- */
+#define CCSX_BAND          64   /* DP band rows of the POA / alignment kernels (one wave64)      */
+#define CCSX_MAXPRED       8    /* POA in-edge cap per vertex                                    */
+#define CCSX_WIN_CORE      22   /* target window core size, docs/how-does-ccs-work.md:57-59      */
+#define CCSX_WIN_OVERHANG  2    /* +-2 bp overlap, same citation                                 */
+#define CCSX_JMAX          31   /* max template columns in a polish window                       */
+#define CCSX_IMAX          63   /* max read bases of one subread inside a polish window          */
+#define CCSX_MAX_ITER      8    /* polish iterations per window                                  */
+#define CCSX_NCTX          16   /* dinucleotide contexts (prev base, cur base)                   */
+#define CCSX_NOBS          12   /* emission outcomes: base(4) x pulse-width bin(3)               */
+
+/* ---- per-ZMW status, mirrors docs/faq/reports-aux-files.md:143-159 (subset that this path can raise) ---- */
+enum ccsx_status {
+    CCSX_SUCCESS               = 0,
+    CCSX_TOO_FEW_PASSES        = 1,  /* fewer usable subreads than opts.min_passes                    */
+    CCSX_DRAFT_FAILURE         = 2,  /* POA produced no draft / vertex capacity exceeded              */
+    CCSX_TOO_MANY_UNUSABLE     = 3,  /* <= 50 % of subreads map to the draft (accuracy-vs-passes.md:37-39) */
+    CCSX_NON_CONVERGENT        = 4,  /* some window hit CCSX_MAX_ITER with favourable mutations left   */
+    CCSX_TOO_SHORT             = 5,
+    CCSX_TOO_LONG              = 6,
+    CCSX_LOW_RQ                = 7,  /* predicted accuracy below opts.min_rq                          */
+    CCSX_EMPTY_WINDOW          = 8   /* EMPTY_WINDOW_DURING_POLISHING                                 */
+};
+
+/* ---- Arrow model parameter blob (interface of docs/faq/chemistry.md:27-56 the "arrow" json files) ----
+ * ctx = 4*prev_base + cur_base, bases A,C,G,T = 0..3, obs = base*3 + min(pw,3)-1.
+ * transition weights are cubic polynomials in the SNR of the current base's channel:
+ *   w = c0 + c1 s + c2 s^2 + c3 s^3, s = clamp(snr[cur], snr_lo, snr_hi), w = max(w, 1e-6)
+ *   P(move) = w_move / (1 + w_branch + w_stick + w_del), P(match) = 1 / (1 + ...).            */
+typedef struct ccsx_model {
+    char  name[32];
+    float snr_lo, snr_hi;
+    float trans_poly[CCSX_NCTX][3][4];      /* [ctx][branch,stick,deletion][c0..c3]              */
+    float em_match [CCSX_NCTX][CCSX_NOBS];  /* P(obs | match, ctx)  (sums to 1 over obs)         */
+    float em_branch[CCSX_NCTX][3];          /* P(pw bin | branch, ctx) (base is the cognate)     */
+    float em_stick [CCSX_NCTX][3];          /* P(pw bin | stick, ctx)  (base uniform over 3)     */
+} ccsx_model;
+
+/* ---- run options (CLI names from SURVEY.md App. C) ---- */
+typedef struct ccsx_opts {
+    int32_t max_poa_cov;     /* --maxPoaCoverage (docs/changelog.md:114): subreads threaded into the POA */
+    int32_t min_passes;      /* --min-passes                                                    */
+    int32_t top_passes;      /* --top-passes (0 = unlimited)                                    */
+    int32_t min_length;      /* --min-length                                                    */
+    int32_t max_length;      /* --max-length                                                    */
+    float   min_rq;          /* --min-rq                                                        */
+    int32_t poa_slots;       /* concurrent POA graphs resident on the device (0 = auto)          */
+    int32_t reserved[8];
+} ccsx_opts;
+
+/* ---- input batch: SoA + CSR ---- */
+typedef struct ccsx_batch {
+    int32_t        n_zmw;
+    int32_t        n_reads;      /* R = read_off[n_zmw]                                         */
+    int64_t        n_bases;      /* base_off[R]                                                 */
+    const int32_t *zmw_id;       /* [n_zmw]  hole number (zm tag)                               */
+    const float   *snr;          /* [n_zmw][4] A,C,G,T (sn tag)                                 */
+    const int32_t *read_off;     /* [n_zmw+1] first read of each ZMW                            */
+    const int64_t *base_off;     /* [R+1] first base of each read                               */
+    const uint8_t *bases;        /* [n_bases] codes 0..3 = A,C,G,T, native (sequenced) orientation */
+    const uint8_t *pw;           /* [n_bases] pulse width in frames (pw tag, decoded)           */
+    const uint8_t *ipd;          /* [n_bases] inter-pulse duration (ip tag); may be NULL (unused by the HMM) */
+    const uint8_t *flags;        /* [R] bit0: pass is on the reverse strand (cx REVERSE_PASS)   */
+} ccsx_batch;
+
+/* ---- results: caller-allocated; seq/qual/raw_qv are laid out at seq_off[z] (capacity layout
+ *      from ccsx_result_layout), seq_len[z] bases valid ---- */
+typedef struct ccsx_results {
+    int32_t  n_zmw;
+    int64_t  seq_capacity;       /* total elements in seq / qual / raw_qv                       */
+    int64_t *seq_off;            /* [n_zmw+1] (filled by ccsx_result_layout)                    */
+    int32_t *status;             /* [n_zmw] enum ccsx_status                                    */
+    int32_t *seq_len;            /* [n_zmw]                                                     */
+    uint8_t *seq;                /* [seq_capacity] codes 0..3                                   */
+    uint8_t *qual;               /* [seq_capacity] phred 0..93                                  */
+    float   *raw_qv;             /* [seq_capacity] un-rounded QV (may be NULL)                  */
+    float   *rq;                 /* [n_zmw] predicted accuracy (rq tag)                         */
+    int32_t *np;                 /* [n_zmw] passes used (np tag)                                */
+    float   *ec;                 /* [n_zmw] effective coverage (ec tag)                         */
+    int32_t *iters;              /* [n_zmw] total polish iterations over all windows            */
+    int32_t *n_windows;          /* [n_zmw]                                                     */
+} ccsx_results;
+
+/* ---- per-kernel device timings of the last run, HIP events on the handle's stream (ms) ---- */
+typedef struct ccsx_timings {
+    float setup_ms, draft_ms, align_ms, polish_ms, stitch_ms, total_ms;
+    int64_t polish_workgroups;   /* launched polish workgroups that had work                     */
+} ccsx_timings;
+
+typedef struct ccsx_handle_s *ccsx_handle;
+
+/* library / device */
+int         ccsx_abi_version(void);
+const char *ccsx_last_error(void);
+int         ccsx_device_count(void);
+
+/* model + options */
+void        ccsx_model_default(ccsx_model *m);          /* synthetic parameter set "SYN-1"      */
+void        ccsx_opts_default(ccsx_opts *o);
+
+/* lifecycle: binds to GPU `device_ordinal`, creates a stream, copies the model */
+int         ccsx_create(int device_ordinal, const ccsx_model *model, const ccsx_opts *opts, ccsx_handle *out);
+int         ccsx_destroy(ccsx_handle h);
+
+/* result sizing: fills res->seq_off[0..n] and returns the total capacity needed (elements) */
+int64_t     ccsx_result_layout(const ccsx_batch *b, int64_t *seq_off);
+
+/* fused path, host buffers in / host buffers out (one synchronous call = upload + run + download) */
+int         ccsx_consensus_batch(ccsx_handle h, const ccsx_batch *b, ccsx_results *res);
+
+/* split form used by the benchmark (inputs resident in HBM when the timed region starts)        */
+int         ccsx_upload(ccsx_handle h, const ccsx_batch *b);           /* H2D + workspace sizing */
+int         ccsx_run(ccsx_handle h);                                   /* all kernels, async     */
+int         ccsx_sync(ccsx_handle h);                                  /* wait for the stream    */
+int         ccsx_download(ccsx_handle h, ccsx_results *res);           /* D2H                    */
+int         ccsx_get_timings(ccsx_handle h, ccsx_timings *t);
+
+/* stage access for parity tests (valid after ccsx_run + ccsx_sync on the uploaded batch)        */
+int         ccsx_stage_draft(ccsx_handle h, int32_t zmw_index, uint8_t *draft, int32_t cap, int32_t *len);
+int         ccsx_stage_align(ccsx_handle h, int32_t read_index, int32_t *rstart, int32_t cap,
+                             int32_t *valid, int32_t *score);
+int         ccsx_stage_windows(ccsx_handle h, int32_t zmw_index, int32_t *bounds, int32_t cap, int32_t *n_windows);
+
+/* deterministic synthetic subread generator (SURVEY.md §8d / BASELINE.md §3).  Caller frees with ccsx_synth_free */
+typedef struct ccsx_synth {
+    ccsx_batch batch;            /* arrays are owned by this object                             */
+    int64_t   *tpl_off;          /* [n_zmw+1] */
+    uint8_t   *tpl;              /* true templates, codes 0..3, orientation of read 0           */
+} ccsx_synth;
+int         ccsx_synth_generate(int32_t n_zmw, int32_t first_zmw_id, int32_t passes_lo, int32_t passes_hi,
+                                int32_t len_lo, int32_t len_hi, uint64_t seed, ccsx_synth **out);
+void        ccsx_synth_free(ccsx_synth *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCSX_H */

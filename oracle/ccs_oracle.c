@@ -1,0 +1,811 @@
+/*
+ * ccs_oracle.c — CPU restatement of the CCS per-ZMW consensus hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ *   *** PARITY UNPINNED ***
+ *   /root/reference (PacificBiosciences/ccs) is a documentation-only mount: it holds no source, no
+ *   binary, no tests and no golden vectors (docs/faq/source-code.md:11-15).  The
+ *   arithmetic of this path lives in PacBio's closed `unanimity` library (last public snapshot
+ *   PacificBiosciences/unanimity@6f11a13e, un-vendored, unreachable offline).  This file therefore
+ *   restates the algorithm the reference DOCUMENTS (docs/how-does-ccs-work.md:34-112) under the exact
+ *   specification written in DESIGN.md §SPEC, and is validated by first-principles tests
+ *   (tests/test_oracle_*.py: brute-force HMM, alpha/beta agreement, mutation equivalence,
+ *   recover-the-truth), not by reference outputs.
+ *
+ *   Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *   The product (ccs_amd/, include/ccsx.h) never links, imports or calls it.
+ *
+ * Steps restated (docs/how-does-ccs-work.md):
+ *   :34-51  step 2  draft      -> orc_poa_*      sparse partial-order alignment, adaptive 64-row band
+ *   :53-55  step 3  alignment  -> orc_align      subread -> draft banded global alignment, rstart[]
+ *   :57-61  step 4  windowing  -> orc_windows    22 bp cores, +-2 bp overhang, homopolymer-safe breaks
+ *   :87-101 step 8  polishing  -> orc_polish_window   Arrow pair-HMM (match/branch/stick/deletion,
+ *                                 dinucleotide context, PW + SNR dependent), 3 sub + 4 ins + 1 del per position
+ *   :103-106 step 9 QV         -> inside orc_polish_window (LL ratios), rq = 1 - mean(p_err)
+ *   :108-112 step 10 final     -> orc_consensus_zmw  (concatenate cores, trim overhangs)
+ *
+ * Build:  make -C oracle   (gcc -O2 -ffp-contract=off; no fast-math: bit-reproducibility matters)
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------- specification constants (same values as include/ccsx.h) -------------- */
+#define BAND      64
+#define MAXPRED   8
+#define WIN_CORE  22
+#define WIN_OVH   2
+#define JMAX      31
+#define IMAX      63
+#define MAX_ITER  8
+#define NCTX      16
+#define NOBS      12
+#define SC_MATCH    3
+#define SC_MISMATCH (-5)
+#define SC_INS      (-4)
+#define SC_DEL      (-4)
+#define NEG       (-(1 << 28))
+#define MUT_EPS   0.01f     /* favourable iff summed log2-likelihood gain > MUT_EPS                 */
+#define MUT_SEP   5         /* accepted mutations of one round are >= MUT_SEP columns apart          */
+#define JMIN_DEL  4         /* deletions are not applied when the window would shrink to <= JMIN_DEL */
+#define AB_TOL    0.01f     /* |log2 alpha(I,J) - log2 beta(0,0)| tolerance (alpha/beta agreement)   */
+#define TINY_P    1e-30f    /* a read whose scaled likelihood falls below this is unusable in the window */
+
+typedef struct orc_model {
+    char  name[32];
+    float snr_lo, snr_hi;
+    float trans_poly[NCTX][3][4];
+    float em_match[NCTX][NOBS];
+    float em_branch[NCTX][3];
+    float em_stick[NCTX][3];
+} orc_model;
+
+typedef struct orc_opts {
+    int32_t max_poa_cov, min_passes, top_passes, min_length, max_length;
+    float   min_rq;
+    int32_t poa_slots;
+    int32_t reserved[8];
+} orc_opts;
+
+/* ---------------- deterministic log2 / exp2 (DESIGN.md §SPEC "det math") -------------------------------- */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float orc_log2f(float x)
+{
+    uint32_t u = f2u(x);
+    if ((int32_t)u < 0x00800000) return -127.0f;         /* zero, denormal, negative */
+    int e = (int)(u >> 23) - 127;
+    float f = u2f((u & 0x007fffffu) | 0x3f800000u);       /* [1,2) */
+    if (f > 1.41421356f) { f = f * 0.5f; e = e + 1; }
+    float t = f - 1.0f;
+    float s = t / (2.0f + t);
+    float z = s * s;
+    float p = z * 0.111111111f;
+    p = p + 0.142857143f;
+    p = p * z;
+    p = p + 0.2f;
+    p = p * z;
+    p = p + 0.333333333f;
+    p = p * z;
+    p = p + 1.0f;
+    float ln = (2.0f * s) * p;
+    return (float)e + ln * 1.44269504f;
+}
+
+float orc_exp2f(float x)
+{
+    if (x < -125.0f) x = -125.0f;
+    if (x > 60.0f) x = 60.0f;
+    float n = floorf(x + 0.5f);
+    float f = (x - n) * 0.693147181f;                     /* [-0.3466, 0.3466] */
+    float p = f * 1.98412698e-4f;                         /* 1/5040 */
+    p = p + 1.38888889e-3f;                               /* 1/720 */
+    p = p * f;
+    p = p + 8.33333333e-3f;
+    p = p * f;
+    p = p + 4.16666667e-2f;
+    p = p * f;
+    p = p + 0.166666667f;
+    p = p * f;
+    p = p + 0.5f;
+    p = p * f;
+    p = p + 1.0f;
+    p = p * f;
+    p = p + 1.0f;
+    int ni = (int)n;
+    return p * u2f((uint32_t)(ni + 127) << 23);
+}
+
+/* ---------------- A0: per-ZMW parameter tables (docs/how-does-ccs-work.md:90-94) ------------------------ */
+/* ME[k][o] = 4*P(match|k)*P(o|match,k); INS[k][o] = 4*P(branch or stick emitting o | k); DL[k] = P(deletion|k).
+ * The factor 4 per emitted base is an exact power-of-two range shift (DESIGN.md §SPEC "scaling").            */
+void orc_tables(const orc_model *m, const float *snr, float *ME, float *INS, float *DL)
+{
+    for (int k = 0; k < NCTX; ++k) {
+        int cur = k & 3;
+        float s = snr[cur];
+        if (s < m->snr_lo) s = m->snr_lo;
+        if (s > m->snr_hi) s = m->snr_hi;
+        float w[3];
+        for (int mv = 0; mv < 3; ++mv) {
+            const float *c = m->trans_poly[k][mv];
+            float t = c[3] * s;
+            t = t + c[2];
+            t = t * s;
+            t = t + c[1];
+            t = t * s;
+            t = t + c[0];
+            if (t < 1e-6f) t = 1e-6f;
+            w[mv] = t;
+        }
+        float den = 1.0f + w[0];
+        den = den + w[1];
+        den = den + w[2];
+        float pM = 1.0f / den, pB = w[0] / den, pS = w[1] / den, pD = w[2] / den;
+        for (int o = 0; o < NOBS; ++o) {
+            int b = o / 3, pwb = o % 3;
+            ME[k * NOBS + o] = (pM * m->em_match[k][o]) * 4.0f;
+            if (b == cur) INS[k * NOBS + o] = (pB * m->em_branch[k][pwb]) * 4.0f;
+            else          INS[k * NOBS + o] = ((pS * m->em_stick[k][pwb]) * 0.333333333f) * 4.0f;
+        }
+        DL[k] = pD;
+    }
+}
+
+static inline int ctx_of(int prev, int cur) { if (prev > 3) prev = (cur + 2) & 3; return prev * 4 + cur; }
+static inline int obs_of(int base, int pw) { int b = pw; if (b < 1) b = 1; if (b > 3) b = 3; return base * 3 + (b - 1); }
+
+/* ---------------- steps 2+3: banded DP column shared by POA and alignment ------------------------------- */
+typedef struct {
+    int       cap, n;                 /* vertex capacity / count                                   */
+    uint8_t  *base;
+    int32_t  *nreads;
+    uint8_t  *npred;
+    int32_t  *pred;                   /* [cap][MAXPRED]                                            */
+    int32_t  *next, *prev;            /* topological linked list; head = first, -1 terminated      */
+    int32_t   head, tail;
+    int32_t  *order;                  /* [n] topological order                                     */
+    int32_t  *lo, *colmax, *bestrow;  /* per vertex band start, column max, row of max             */
+    int32_t  *M;                      /* [cap][BAND] scores                                        */
+    uint8_t  *mv;                     /* [cap][BAND] move | pred slot << 2                         */
+    int32_t   nadded;
+} poa_t;
+
+enum { MV_DIAG = 0, MV_DEL = 1, MV_INS = 2 };
+
+static poa_t *poa_new(int cap)
+{
+    poa_t *g = (poa_t *)calloc(1, sizeof(poa_t));
+    g->cap = cap;
+    g->base = (uint8_t *)malloc(cap);
+    g->nreads = (int32_t *)malloc(sizeof(int32_t) * cap);
+    g->npred = (uint8_t *)malloc(cap);
+    g->pred = (int32_t *)malloc(sizeof(int32_t) * cap * MAXPRED);
+    g->next = (int32_t *)malloc(sizeof(int32_t) * cap);
+    g->prev = (int32_t *)malloc(sizeof(int32_t) * cap);
+    g->order = (int32_t *)malloc(sizeof(int32_t) * cap);
+    g->lo = (int32_t *)malloc(sizeof(int32_t) * cap);
+    g->colmax = (int32_t *)malloc(sizeof(int32_t) * cap);
+    g->bestrow = (int32_t *)malloc(sizeof(int32_t) * cap);
+    g->M = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap * BAND);
+    g->mv = (uint8_t *)malloc((size_t)cap * BAND);
+    g->head = g->tail = -1;
+    return g;
+}
+static void poa_free(poa_t *g)
+{
+    free(g->base); free(g->nreads); free(g->npred); free(g->pred); free(g->next); free(g->prev);
+    free(g->order); free(g->lo); free(g->colmax); free(g->bestrow); free(g->M); free(g->mv); free(g);
+}
+static int poa_new_vertex(poa_t *g, int base, int after /* -1 = list head */)
+{
+    if (g->n >= g->cap) return -1;
+    int v = g->n++;
+    g->base[v] = (uint8_t)base; g->nreads[v] = 1; g->npred[v] = 0;
+    if (after < 0) { g->next[v] = g->head; g->prev[v] = -1; if (g->head >= 0) g->prev[g->head] = v; g->head = v; if (g->tail < 0) g->tail = v; }
+    else { int nx = g->next[after]; g->next[v] = nx; g->prev[v] = after; g->next[after] = v; if (nx >= 0) g->prev[nx] = v; else g->tail = v; }
+    return v;
+}
+static void poa_add_edge(poa_t *g, int from, int to)
+{
+    int np = g->npred[to];
+    for (int k = 0; k < np; ++k) if (g->pred[to * MAXPRED + k] == from) return;
+    if (np >= MAXPRED) return;                         /* SPEC: in-edge cap, extra edges are dropped */
+    g->pred[to * MAXPRED + np] = from; g->npred[to] = (uint8_t)(np + 1);
+}
+static void poa_renumber(poa_t *g) { int k = 0; for (int v = g->head; v >= 0; v = g->next[v]) g->order[k++] = v; }
+
+/* band start of a column whose best predecessor column has (lo_u, bestrow_u); I = read length */
+static inline int band_lo(int lo_u, int bestrow_u, int I)
+{
+    int lo = bestrow_u + 1 - BAND / 2;
+    if (lo < lo_u) lo = lo_u;
+    if (lo > lo_u + 2) lo = lo_u + 2;
+    int hi = I - (BAND - 1); if (hi < 0) hi = 0;
+    if (lo > hi) lo = hi;
+    if (lo < 0) lo = 0;
+    return lo;
+}
+
+/* One DP column.  preds: npred columns given by (plo[k], pM[k]) ; START column is lo=0, M[l] = l*INS (l<=I).
+ * Writes M[BAND], mv[BAND], returns colmax/bestrow through pointers.                                        */
+static void dp_column(int vbase, const uint8_t *r, int I, int lo, int npred, const int32_t *plo, const int32_t *const *pM,
+                      int32_t *M, uint8_t *mv, int32_t *colmax, int32_t *bestrow)
+{
+    for (int l = 0; l < BAND; ++l) {
+        int i = lo + l;
+        int32_t best = NEG; uint8_t bm = 0;
+        if (i <= I) {
+            for (int k = 0; k < npred; ++k) {
+                int o1 = i - 1 - plo[k], o0 = i - plo[k];
+                if (i >= 1 && o1 >= 0 && o1 < BAND) {
+                    int32_t x = pM[k][o1];
+                    if (x > NEG / 2) { int32_t c = x + (vbase == r[i - 1] ? SC_MATCH : SC_MISMATCH); if (c > best) { best = c; bm = (uint8_t)(MV_DIAG | (k << 2)); } }
+                }
+                if (o0 >= 0 && o0 < BAND) {
+                    int32_t y = pM[k][o0];
+                    if (y > NEG / 2) { int32_t c = y + SC_DEL; if (c > best) { best = c; bm = (uint8_t)(MV_DEL | (k << 2)); } }
+                }
+            }
+        }
+        M[l] = best; mv[l] = bm;
+    }
+    for (int l = 1; l < BAND; ++l) {
+        if (lo + l > I) break;
+        int32_t c = M[l - 1] + SC_INS;
+        if (c > M[l]) { M[l] = c; mv[l] = MV_INS; }
+    }
+    int32_t cm = NEG, br = lo;
+    for (int l = 0; l < BAND; ++l) {
+        if (M[l] < NEG / 2) M[l] = NEG;
+        if (M[l] > cm) { cm = M[l]; br = lo + l; }
+    }
+    *colmax = cm; *bestrow = br;
+}
+
+static void start_column(int I, int32_t *M)
+{
+    for (int l = 0; l < BAND; ++l) M[l] = (l <= I) ? l * SC_INS : NEG;
+}
+
+/* Thread one read (draft orientation) into the graph.  Returns 1 if added, 0 if skipped, -1 on capacity overflow. */
+static int poa_add_read(poa_t *g, const uint8_t *r, int I, int32_t *pathv /* scratch [I] */)
+{
+    if (g->n == 0) {                                     /* SPEC: the first read becomes the backbone chain */
+        int prev = -1;
+        for (int i = 0; i < I; ++i) {
+            int v = poa_new_vertex(g, r[i], prev);
+            if (v < 0) return -1;
+            if (prev >= 0) poa_add_edge(g, prev, v);
+            prev = v;
+        }
+        g->nadded = 1; poa_renumber(g);
+        return 1;
+    }
+    int32_t S[BAND]; start_column(I, S);
+    const int n0 = g->n;
+    for (int k = 0; k < n0; ++k) {
+        int v = g->order[k];
+        int np = g->npred[v];
+        int32_t plo[MAXPRED]; const int32_t *pM[MAXPRED];
+        int ulo, ubr;
+        if (np == 0) { np = 1; plo[0] = 0; pM[0] = S; ulo = 0; ubr = 0; }
+        else {
+            int32_t bestcm = NEG - 1; ulo = 0; ubr = 0;
+            for (int q = 0; q < np; ++q) {
+                int u = g->pred[v * MAXPRED + q];
+                plo[q] = g->lo[u]; pM[q] = g->M + (size_t)u * BAND;
+                if (g->colmax[u] > bestcm) { bestcm = g->colmax[u]; ulo = g->lo[u]; ubr = g->bestrow[u]; }
+            }
+        }
+        int lo = band_lo(ulo, ubr, I);
+        g->lo[v] = lo;
+        dp_column(g->base[v], r, I, lo, np, plo, pM, g->M + (size_t)v * BAND, g->mv + (size_t)v * BAND, &g->colmax[v], &g->bestrow[v]);
+    }
+    /* end vertex: best M[v][I], first in topological order on ties */
+    int vend = -1; int32_t bs = NEG;
+    for (int k = 0; k < n0; ++k) {
+        int v = g->order[k]; int o = I - g->lo[v];
+        if (o >= 0 && o < BAND) { int32_t x = g->M[(size_t)v * BAND + o]; if (x > NEG / 2 && x > bs) { bs = x; vend = v; } }
+    }
+    if (vend < 0) return 0;
+    /* traceback: pathv[i] = matched vertex of read base i, or -1 (new vertex) */
+    int v = vend, i = I;
+    while (v >= 0) {
+        uint8_t m = g->mv[(size_t)v * BAND + (i - g->lo[v])];
+        int t = m & 3, slot = m >> 2;
+        if (t == MV_INS) { pathv[i - 1] = -1; --i; continue; }
+        int u = (g->npred[v] == 0) ? -1 : g->pred[v * MAXPRED + slot];
+        if (t == MV_DIAG) { pathv[i - 1] = (g->base[v] == r[i - 1]) ? v : -1; --i; }
+        v = u;
+    }
+    while (i > 0) { pathv[i - 1] = -1; --i; }               /* leading insertions at START */
+    /* forward replay: thread the read */
+    int prevp = -1;
+    for (i = 0; i < I; ++i) {
+        int w = pathv[i];
+        if (w >= 0) g->nreads[w] += 1;
+        else { w = poa_new_vertex(g, r[i], prevp); if (w < 0) return -1; }
+        if (prevp >= 0) poa_add_edge(g, prevp, w);
+        prevp = w;
+    }
+    g->nadded += 1; poa_renumber(g);
+    return 1;
+}
+
+/* heaviest path: score(v) = 2*nreads(v) - nadded ; best(v) = score(v) + max(0, max_pred best) */
+static int poa_consensus(poa_t *g, uint8_t *draft, int cap)
+{
+    int n = g->n; if (n == 0) return 0;
+    int32_t *best = (int32_t *)malloc(sizeof(int32_t) * n), *bp = (int32_t *)malloc(sizeof(int32_t) * n);
+    int vbest = -1; int32_t sb = NEG;
+    for (int k = 0; k < n; ++k) {
+        int v = g->order[k];
+        int32_t b = 0, p = -1;
+        for (int q = 0; q < g->npred[v]; ++q) { int u = g->pred[v * MAXPRED + q]; if (best[u] > b) { b = best[u]; p = u; } }
+        best[v] = b + 2 * g->nreads[v] - g->nadded; bp[v] = p;
+        if (best[v] > sb) { sb = best[v]; vbest = v; }
+    }
+    int len = 0;
+    for (int v = vbest; v >= 0; v = bp[v]) ++len;
+    if (len > cap) { free(best); free(bp); return -1; }
+    int k = len;
+    for (int v = vbest; v >= 0; v = bp[v]) draft[--k] = g->base[v];
+    free(best); free(bp);
+    return len;
+}
+
+static void orient(const uint8_t *b, const uint8_t *pw, int L, int rev, uint8_t *ob, uint8_t *opw)
+{
+    if (!rev) { memcpy(ob, b, L); if (opw) memcpy(opw, pw, L); }
+    else for (int i = 0; i < L; ++i) { ob[i] = (uint8_t)(3 - b[L - 1 - i]); if (opw) opw[i] = pw[L - 1 - i]; }
+}
+
+/* step 2: draft from the first min(nreads, max_poa_cov) reads.  Orientation = that of read 0.
+ * returns draft length, 0 = failure                                                                          */
+int orc_poa_draft(int nreads, const int64_t *base_off, const uint8_t *bases, const uint8_t *flags, int max_poa_cov,
+                  int vcap, uint8_t *draft, int draft_cap)
+{
+    int npoa = nreads < max_poa_cov ? nreads : max_poa_cov;
+    if (npoa <= 0) return 0;
+    int maxL = 0;
+    for (int r = 0; r < npoa; ++r) { int L = (int)(base_off[r + 1] - base_off[r]); if (L > maxL) maxL = L; }
+    poa_t *g = poa_new(vcap);
+    uint8_t *ob = (uint8_t *)malloc(maxL + 1);
+    int32_t *pathv = (int32_t *)malloc(sizeof(int32_t) * (maxL + 1));
+    int rev0 = flags[0] & 1, ok = 1;
+    for (int r = 0; r < npoa && ok; ++r) {
+        int L = (int)(base_off[r + 1] - base_off[r]);
+        orient(bases + base_off[r], NULL, L, (flags[r] & 1) != rev0, ob, NULL);
+        if (poa_add_read(g, ob, L, pathv) < 0) ok = 0;
+    }
+    int len = ok ? poa_consensus(g, draft, draft_cap) : 0;
+    if (len < 0) len = 0;
+    free(ob); free(pathv); poa_free(g);
+    return len;
+}
+
+/* step 3: read (draft orientation) vs draft, global, adaptive band.  rstart[0..Ld]; returns 1 if valid. */
+int orc_align(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out)
+{
+    int32_t *lo = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
+    uint8_t *mv = (uint8_t *)malloc((size_t)(Ld + 1) * BAND);
+    int32_t A[BAND], B[BAND], *prevM = A, *curM = B;
+    start_column(I, prevM);
+    lo[0] = 0; int32_t cm = 0, br = 0; int plo = 0;
+    for (int j = 1; j <= Ld; ++j) {
+        int l0 = band_lo(plo, br, I);
+        int32_t plos[1] = { plo }; const int32_t *pMs[1] = { prevM };
+        dp_column(d[j - 1], r, I, l0, 1, plos, pMs, curM, mv + (size_t)j * BAND, &cm, &br);
+        lo[j] = l0; plo = l0;
+        int32_t *t = prevM; prevM = curM; curM = t;
+    }
+    int o = I - lo[Ld];
+    int valid = (o >= 0 && o < BAND && prevM[o] > NEG / 2);
+    int32_t sc = valid ? prevM[o] : NEG;
+    if (valid && sc < Ld) valid = 0;                        /* SPEC: alignment score must reach 1.0 per draft base */
+    if (score_out) *score_out = sc;
+    if (valid) {
+        /* rstart[j] = row at which the optimal path ENTERS column j (read bases consumed when draft
+         * position j becomes the next one): insertions emitted while waiting at state j follow it. */
+        int i = I, j = Ld;
+        while (j > 0) {
+            int t = mv[(size_t)j * BAND + (i - lo[j])] & 3;
+            if (t == MV_INS) { --i; continue; }
+            rstart[j] = i;
+            if (t == MV_DIAG) --i;
+            --j;
+        }
+        rstart[0] = 0;
+    }
+    free(lo); free(mv);
+    return valid;
+}
+
+/* step 4: window core boundaries b[0]=0 < ... < b[n]=Ld ; returns n (docs/how-does-ccs-work.md:57-61) */
+int orc_windows(const uint8_t *d, int Ld, int32_t *b, int cap)
+{
+    int n = 0, cur = 0;
+    b[0] = 0;
+    while (cur < Ld) {
+        int nb;
+        if (Ld - cur <= WIN_CORE + 6) nb = Ld;
+        else { nb = cur + WIN_CORE; int sh = 0; while (sh < 3 && d[nb] == d[nb - 1]) { ++nb; ++sh; } }
+        if (n + 1 >= cap) return -1;
+        b[++n] = nb; cur = nb;
+    }
+    return n;
+}
+
+/* ---------------- steps 8+9: Arrow polish of one window -------------------------------------------------- */
+typedef struct { int J, cs, ce, lf, rf; uint8_t t[JMAX + 1]; } wtpl_t;
+
+#define GS (JMAX + 1)                       /* row stride of gamma/beta in the oracle */
+
+static void tpl_ctx(const uint8_t *t, int J, int lf, int *k) { for (int j = 0; j < J; ++j) k[j] = ctx_of(j > 0 ? t[j - 1] : lf, t[j]); }
+
+/* A1/A2: fill gamma (non-stay part of alpha) and beta.  returns alpha(I,J) and beta(0,0) */
+static void fill(const float *ME, const float *INS, const float *DL, const uint8_t *t, int J, int lf,
+                 const uint8_t *o, int I, float *gam, float *bet, float *aIJ, float *b00)
+{
+    int k[JMAX + 1]; tpl_ctx(t, J, lf, k);
+    float acol[IMAX + 2], pcol[IMAX + 2];
+    for (int j = 0; j <= J; ++j) {
+        for (int i = 0; i <= I; ++i) {
+            float g;
+            if (j == 0) g = (i == 0) ? 1.0f : 0.0f;
+            else {
+                float m = (i > 0) ? pcol[i - 1] * ME[k[j - 1] * NOBS + o[i - 1]] : 0.0f;
+                float dl = pcol[i] * DL[k[j - 1]];
+                g = m + dl;
+            }
+            gam[i * GS + j] = g;
+            float st = (i > 0 && j < J) ? acol[i - 1] * INS[k[j] * NOBS + o[i - 1]] : 0.0f;
+            acol[i] = g + st;
+        }
+        memcpy(pcol, acol, sizeof(float) * (I + 1));
+    }
+    *aIJ = pcol[I];
+    for (int i = 0; i <= I + 1; ++i) bet[i * GS + J] = (i == I) ? 1.0f : 0.0f;
+    for (int j = J - 1; j >= 0; --j) {
+        bet[(I + 1) * GS + j] = 0.0f;
+        for (int i = I; i >= 0; --i) {
+            float t1 = (i < I) ? ME[k[j] * NOBS + o[i]] * bet[(i + 1) * GS + j + 1] : 0.0f;
+            float t2 = (i < I) ? INS[k[j] * NOBS + o[i]] * bet[(i + 1) * GS + j] : 0.0f;
+            float t3 = DL[k[j]] * bet[i * GS + j + 1];
+            bet[i * GS + j] = (t1 + t2) + t3;
+        }
+    }
+    *b00 = bet[0];
+}
+
+enum { MT_SUB = 0, MT_DEL = 1, MT_INS = 2 };
+/* lane index m = slot*32 + c ; slots 0..2 = SUB (+1,+2,+3 mod 4), 3 = DEL, 4..7 = INS A,C,G,T */
+static inline int mut_decode(int m, const uint8_t *t, int J, int *type, int *c, int *x)
+{
+    int slot = m >> 5; *c = m & 31;
+    if (slot < 3) { *type = MT_SUB; if (*c >= J) return 0; *x = (t[*c] + 1 + slot) & 3; return 1; }
+    if (slot == 3) { *type = MT_DEL; *x = 0; if (*c >= J) return 0; if (*c > 0 && t[*c - 1] == t[*c]) return 0; return 1; }
+    *type = MT_INS; *x = slot - 4; if (*c > J) return 0; if (*c > 0 && t[*c - 1] == *x) return 0; return 1;
+}
+
+/* A3/A4: likelihood of the read under a virtually mutated template: extend <= 2 alpha columns, link with beta */
+static float score_mut(const float *ME, const float *INS, const float *DL, const uint8_t *t, int J, int lf,
+                       const uint8_t *o, int I, const float *gam, const float *bet, int type, int c, int x)
+{
+    int P = (c > 0) ? t[c - 1] : lf;
+    int kA = 0, kB = 0, q = 0, fin = 0;
+    if (type == MT_SUB)      { kA = ctx_of(P, x); fin = (c + 1 == J); if (!fin) kB = ctx_of(x, t[c + 1]); q = c + 2; }
+    else if (type == MT_INS) { kA = ctx_of(P, x); fin = (c == J);     if (!fin) kB = ctx_of(x, t[c]);     q = c + 1; }
+    else                     { fin = (c + 1 == J); if (!fin) kA = ctx_of(P, t[c + 1]); kB = kA; q = c + 2; }
+    float ap = 0.0f, bp = 0.0f, acc = 0.0f, res = 0.0f;
+    for (int i = 0; i <= I; ++i) {
+        float insA = 0.0f, meA = 0.0f, insB = 0.0f;
+        if (i > 0) {
+            if (!(type == MT_DEL && fin)) insA = INS[kA * NOBS + o[i - 1]];
+            meA = ME[kA * NOBS + o[i - 1]];
+            if (!fin) insB = INS[kB * NOBS + o[i - 1]];
+        }
+        float a = gam[i * GS + c] + ap * insA;
+        float b;
+        if (type == MT_DEL) b = a;
+        else b = ((ap * meA) + (a * DL[kA])) + bp * insB;
+        if (fin) res = b;
+        else {
+            float t1 = (i < I) ? ME[kB * NOBS + o[i]] * bet[(i + 1) * GS + q] : 0.0f;
+            float t3 = DL[kB] * bet[i * GS + q];
+            acc = acc + b * (t1 + t3);
+        }
+        ap = a; bp = b;
+    }
+    return fin ? res : acc;
+}
+
+static void tpl_apply(wtpl_t *w, int type, int c, int x)
+{
+    if (type == MT_SUB) w->t[c] = (uint8_t)x;
+    else if (type == MT_INS) {
+        memmove(w->t + c + 1, w->t + c, w->J - c); w->t[c] = (uint8_t)x; w->J++;
+        if (c < w->cs) { w->cs++; w->ce++; } else if (c < w->ce) w->ce++;
+    } else {
+        memmove(w->t + c, w->t + c + 1, w->J - c - 1); w->J--;
+        if (c < w->cs) { w->cs--; w->ce--; } else if (c < w->ce) w->ce--;
+    }
+}
+
+static void revcomp_tpl(const wtpl_t *w, uint8_t *tr, int *lfr)
+{
+    for (int j = 0; j < w->J; ++j) tr[j] = (uint8_t)(3 - w->t[w->J - 1 - j]);
+    *lfr = (w->rf < 4) ? 3 - w->rf : 4;
+}
+
+/* Polish one window.  obs[r] = native-orientation observation codes of read r's segment, I[r] its length
+ * (I[r] < 0 or > IMAX: read unusable in this window), strand[r] = 1 if the read is reverse to the draft.
+ * Outputs the core sequence, per-base error probability and raw QV.  Returns number of scoring rounds.     */
+int orc_polish_window(const float *ME, const float *INS, const float *DL,
+                      const uint8_t *tpl, int J0, int cs, int ce, int lf, int rf,
+                      int nreads, const uint8_t *const *obs, const int32_t *I, const uint8_t *strand,
+                      uint8_t *out_seq, float *out_perr, float *out_qv, int32_t *out_len,
+                      int32_t *out_nvalid, int32_t *out_nonconv, float *out_delta /* [256] optional */)
+{
+    wtpl_t w; w.J = J0; w.cs = cs; w.ce = ce; w.lf = lf; w.rf = rf; memcpy(w.t, tpl, J0);
+    float *gam = (float *)malloc(sizeof(float) * (size_t)nreads * (IMAX + 2) * GS);
+    float *bet = (float *)malloc(sizeof(float) * (size_t)nreads * (IMAX + 2) * GS);
+    float *base = (float *)malloc(sizeof(float) * nreads);
+    uint8_t *valid = (uint8_t *)malloc(nreads);
+    float delta[256]; uint8_t mvalid[256];
+    int iters = 0, nonconv = 0, nvalid = 0;
+    for (int it = 0; it < MAX_ITER; ++it) {
+        uint8_t tr[JMAX + 1]; int lfr; revcomp_tpl(&w, tr, &lfr);
+        nvalid = 0;
+        for (int r = 0; r < nreads; ++r) {
+            valid[r] = 0;
+            if (I[r] < 0 || I[r] > IMAX) continue;
+            float a, b;
+            float *g = gam + (size_t)r * (IMAX + 2) * GS, *be = bet + (size_t)r * (IMAX + 2) * GS;
+            if (strand[r]) fill(ME, INS, DL, tr, w.J, lfr, obs[r], I[r], g, be, &a, &b);
+            else           fill(ME, INS, DL, w.t, w.J, w.lf, obs[r], I[r], g, be, &a, &b);
+            if (!(a > TINY_P) || !(b > TINY_P)) continue;
+            float la = orc_log2f(a), lb = orc_log2f(b);
+            if (fabsf(la - lb) > AB_TOL) continue;
+            base[r] = la; valid[r] = 1; ++nvalid;
+        }
+        for (int m = 0; m < 256; ++m) {
+            int type, c, x; delta[m] = 0.0f;
+            mvalid[m] = (uint8_t)mut_decode(m, w.t, w.J, &type, &c, &x);
+            if (!mvalid[m]) continue;
+            float dsum = 0.0f;
+            for (int r = 0; r < nreads; ++r) {
+                if (!valid[r]) continue;
+                const float *g = gam + (size_t)r * (IMAX + 2) * GS, *be = bet + (size_t)r * (IMAX + 2) * GS;
+                float res;
+                if (strand[r]) {
+                    int cr = (type == MT_INS) ? w.J - c : w.J - 1 - c;
+                    res = score_mut(ME, INS, DL, tr, w.J, lfr, obs[r], I[r], g, be, type, cr, 3 - x);
+                } else res = score_mut(ME, INS, DL, w.t, w.J, w.lf, obs[r], I[r], g, be, type, c, x);
+                float d = orc_log2f(res) - base[r];
+                dsum = dsum + d;
+            }
+            delta[m] = dsum;
+        }
+        ++iters;
+        /* A5: greedy selection of favourable, well-separated mutations */
+        int acc_m[32], nacc = 0, Jn = w.J, nfav = 0;
+        uint8_t cand[256];
+        for (int m = 0; m < 256; ++m) { cand[m] = (uint8_t)(mvalid[m] && delta[m] > MUT_EPS); nfav += cand[m]; }
+        if (it < MAX_ITER - 1) {
+            for (;;) {
+                int bm = -1; float bd = 0.0f;
+                for (int m = 0; m < 256; ++m) if (cand[m] && (bm < 0 || delta[m] > bd)) { bm = m; bd = delta[m]; }
+                if (bm < 0) break;
+                int slot = bm >> 5, c = bm & 31;
+                cand[bm] = 0;
+                if (slot >= 4 && Jn >= JMAX) continue;
+                if (slot == 3 && Jn <= JMIN_DEL + 1) continue;
+                if (slot >= 4) ++Jn; else if (slot == 3) --Jn;
+                acc_m[nacc++] = bm;
+                for (int m = 0; m < 256; ++m) if (cand[m]) { int d = (m & 31) - c; if (d < 0) d = -d; if (d < MUT_SEP) cand[m] = 0; }
+            }
+        } else nonconv = (nfav > 0);
+        if (nacc == 0) break;
+        /* apply in descending position order */
+        for (int a = 0; a < nacc; ++a) for (int b = a + 1; b < nacc; ++b)
+            if ((acc_m[b] & 31) > (acc_m[a] & 31)) { int t = acc_m[a]; acc_m[a] = acc_m[b]; acc_m[b] = t; }
+        for (int a = 0; a < nacc; ++a) { int type, c, x; mut_decode(acc_m[a], w.t, w.J, &type, &c, &x); tpl_apply(&w, type, c, x); }
+    }
+    /* A6: QVs from the last scoring round */
+    int len = 0;
+    for (int c = w.cs; c < w.ce; ++c) {
+        float s = 0.0f;
+        for (int slot = 0; slot < 8; ++slot) {
+            int m = slot * 32 + c;
+            if (mvalid[m]) { float d = delta[m]; if (d > 20.0f) d = 20.0f; s = s + orc_exp2f(d); }
+        }
+        if (c == w.J - 1) for (int slot = 4; slot < 8; ++slot) {
+            int m = slot * 32 + w.J;
+            if (mvalid[m]) { float d = delta[m]; if (d > 20.0f) d = 20.0f; s = s + orc_exp2f(d); }
+        }
+        float p = s / (1.0f + s);
+        if (p < 1e-10f) p = 1e-10f;
+        float qv = -3.01029996f * orc_log2f(p);
+        if (qv < 0.0f) qv = 0.0f;
+        if (qv > 93.0f) qv = 93.0f;
+        out_seq[len] = w.t[c]; out_perr[len] = p; out_qv[len] = qv; ++len;
+    }
+    *out_len = len; *out_nvalid = nvalid; *out_nonconv = nonconv;
+    if (out_delta) memcpy(out_delta, delta, sizeof(delta));
+    free(gam); free(bet); free(base); free(valid);
+    return iters;
+}
+
+/* ---------------- first-principles helpers for tests/test_oracle_hmm.py ---------------------------------- */
+/* full refill likelihood of an explicit template: returns alpha(I,J) (scaled by 4^I), and beta(0,0) */
+void orc_window_likelihood(const float *ME, const float *INS, const float *DL, const uint8_t *t, int J, int lf,
+                           const uint8_t *o, int I, float *aIJ, float *b00)
+{
+    float *gam = (float *)malloc(sizeof(float) * (IMAX + 2) * GS), *bet = (float *)malloc(sizeof(float) * (IMAX + 2) * GS);
+    fill(ME, INS, DL, t, J, lf, o, I, gam, bet, aIJ, b00);
+    free(gam); free(bet);
+}
+/* extend+link likelihood of lane m on template t (forward strand) */
+float orc_window_mutation_likelihood(const float *ME, const float *INS, const float *DL, const uint8_t *t, int J, int lf,
+                                     const uint8_t *o, int I, int m, int32_t *valid, int32_t *type, int32_t *c, int32_t *x)
+{
+    float *gam = (float *)malloc(sizeof(float) * (IMAX + 2) * GS), *bet = (float *)malloc(sizeof(float) * (IMAX + 2) * GS);
+    float a, b, res = 0.0f; int ty = 0, cc = 0, xx = 0;
+    fill(ME, INS, DL, t, J, lf, o, I, gam, bet, &a, &b);
+    *valid = mut_decode(m, t, J, &ty, &cc, &xx); *type = ty; *c = cc; *x = xx;
+    if (*valid) res = score_mut(ME, INS, DL, t, J, lf, o, I, gam, bet, ty, cc, xx);
+    free(gam); free(bet);
+    return res;
+}
+/* brute force: double-precision sum over ALL alignment paths by plain recursion on probabilities (unscaled model) */
+double orc_bruteforce_likelihood(const float *ME, const float *INS, const float *DL, const uint8_t *t, int J, int lf,
+                                 const uint8_t *o, int I)
+{
+    int k[JMAX + 1]; tpl_ctx(t, J, lf, k);
+    double *A = (double *)calloc((size_t)(I + 1) * (J + 1), sizeof(double));
+    for (int j = 0; j <= J; ++j) for (int i = 0; i <= I; ++i) {
+        double v = (i == 0 && j == 0) ? 1.0 : 0.0;
+        if (j > 0 && i > 0) v += A[(i - 1) * (J + 1) + j - 1] * (double)ME[k[j - 1] * NOBS + o[i - 1]];
+        if (j > 0) v += A[i * (J + 1) + j - 1] * (double)DL[k[j - 1]];
+        if (i > 0 && j < J) v += A[(i - 1) * (J + 1) + j] * (double)INS[k[j] * NOBS + o[i - 1]];
+        A[i * (J + 1) + j] = v;
+    }
+    double r = A[I * (J + 1) + J];
+    free(A);
+    return r;
+}
+
+/* ---------------- whole-ZMW driver (steps 2,3,4,8,9,10) --------------------------------------------------- */
+typedef struct {
+    int32_t status, seq_len, np, iters, n_windows;
+    float rq, ec;
+} orc_zmw_out;
+
+enum { ST_SUCCESS = 0, ST_TOO_FEW = 1, ST_DRAFT_FAIL = 2, ST_UNUSABLE = 3, ST_NONCONV = 4, ST_SHORT = 5, ST_LONG = 6, ST_LOWRQ = 7, ST_EMPTY = 8 };
+
+int orc_consensus_zmw(const orc_model *model, const orc_opts *opts, const float *snr, int nreads_in,
+                      const int64_t *base_off /* [nreads+1], relative to bases */, const uint8_t *bases, const uint8_t *pw,
+                      const uint8_t *flags, uint8_t *seq, uint8_t *qual, float *raw_qv, int64_t cap, orc_zmw_out *out,
+                      uint8_t *draft_out, int32_t *draft_len_out)
+{
+    memset(out, 0, sizeof(*out));
+    int nreads = nreads_in;
+    if (opts->top_passes > 0 && nreads > opts->top_passes) nreads = opts->top_passes;
+    if (nreads < opts->min_passes || nreads < 1) { out->status = ST_TOO_FEW; return 0; }
+    int maxL = 0;
+    for (int r = 0; r < nreads; ++r) { int L = (int)(base_off[r + 1] - base_off[r]); if (L > maxL) maxL = L; }
+    int dcap = maxL + maxL / 4 + 64;
+    uint8_t *draft = (uint8_t *)malloc(dcap);
+    int vcap = (5 * maxL) / 2 + 256;
+    int Ld = orc_poa_draft(nreads, base_off, bases, flags, opts->max_poa_cov, vcap, draft, dcap);
+    if (draft_len_out) *draft_len_out = Ld;
+    if (draft_out && Ld > 0) memcpy(draft_out, draft, Ld);
+    if (Ld <= 0) { out->status = ST_DRAFT_FAIL; free(draft); return 0; }
+    if (Ld < opts->min_length) { out->status = ST_SHORT; free(draft); return 0; }
+    if (Ld > opts->max_length) { out->status = ST_LONG; free(draft); return 0; }
+    /* step 3 */
+    int rev0 = flags[0] & 1;
+    int32_t **rstart = (int32_t **)calloc(nreads, sizeof(int32_t *));
+    uint8_t *strand = (uint8_t *)malloc(nreads), *avalid = (uint8_t *)malloc(nreads);
+    uint8_t *ob = (uint8_t *)malloc(maxL + 1);
+    int np = 0;
+    for (int r = 0; r < nreads; ++r) {
+        int L = (int)(base_off[r + 1] - base_off[r]);
+        strand[r] = (uint8_t)(((flags[r] & 1) != rev0) ? 1 : 0);
+        orient(bases + base_off[r], NULL, L, strand[r], ob, NULL);
+        rstart[r] = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
+        int32_t sc;
+        avalid[r] = (uint8_t)orc_align(ob, L, draft, Ld, rstart[r], &sc);
+        np += avalid[r];
+    }
+    free(ob);
+    out->np = np;
+    int ret = 0;
+    if (2 * np <= nreads) { out->status = ST_UNUSABLE; goto done; }
+    {
+        /* step 4 */
+        int wcap = Ld / WIN_CORE + 4;
+        int32_t *wb = (int32_t *)malloc(sizeof(int32_t) * wcap);
+        int nw = orc_windows(draft, Ld, wb, wcap);
+        out->n_windows = nw;
+        float ME[NCTX * NOBS], INS[NCTX * NOBS], DL[NCTX];
+        orc_tables(model, snr, ME, INS, DL);
+        uint8_t *obuf = (uint8_t *)malloc((size_t)nreads * (IMAX + 1));
+        const uint8_t **obs = (const uint8_t **)malloc(sizeof(uint8_t *) * nreads);
+        int32_t *Iw = (int32_t *)malloc(sizeof(int32_t) * nreads);
+        int64_t len = 0; double perr_sum = 0.0; int64_t nvalid_sum = 0; int nonconv_any = 0, overflow = 0;
+        for (int w = 0; w < nw; ++w) {
+            int ws = wb[w] - WIN_OVH; if (ws < 0) ws = 0;
+            int we = wb[w + 1] + WIN_OVH; if (we > Ld) we = Ld;
+            int J = we - ws, cs = wb[w] - ws, ce = wb[w + 1] - ws;
+            int lf = ws > 0 ? draft[ws - 1] : 4, rf = we < Ld ? draft[we] : 4;
+            for (int r = 0; r < nreads; ++r) {
+                Iw[r] = -1; obs[r] = obuf + (size_t)r * (IMAX + 1);
+                if (!avalid[r]) continue;
+                int a = rstart[r][ws], b = rstart[r][we], L = (int)(base_off[r + 1] - base_off[r]);
+                int n = b - a;
+                if (n < 0 || n > IMAX) continue;
+                Iw[r] = n;
+                int na = strand[r] ? L - b : a;              /* native start of the segment */
+                const uint8_t *bb = bases + base_off[r] + na, *pp = pw + base_off[r] + na;
+                uint8_t *oo = obuf + (size_t)r * (IMAX + 1);
+                for (int i = 0; i < n; ++i) oo[i] = (uint8_t)obs_of(bb[i], pp[i]);
+            }
+            uint8_t wseq[JMAX + 1]; float wperr[JMAX + 1], wqv[JMAX + 1]; int32_t wlen, wnv, wnc;
+            int it = orc_polish_window(ME, INS, DL, draft + ws, J, cs, ce, lf, rf, nreads, obs, Iw, strand,
+                                       wseq, wperr, wqv, &wlen, &wnv, &wnc, NULL);
+            out->iters += it; nvalid_sum += wnv; nonconv_any |= wnc;
+            float wsum = 0.0f;
+            for (int i = 0; i < wlen; ++i) {
+                if (len < cap) { seq[len] = wseq[i]; qual[len] = (uint8_t)(wqv[i] + 0.5f); if (raw_qv) raw_qv[len] = wqv[i]; } else overflow = 1;
+                wsum = wsum + wperr[i]; ++len;
+            }
+            perr_sum += (double)wsum;
+        }
+        if (overflow) len = cap;
+        out->seq_len = (int32_t)len;
+        out->rq = len > 0 ? (float)(1.0 - perr_sum / (double)len) : 0.0f;
+        out->ec = nw > 0 ? (float)((double)nvalid_sum / (double)nw) : 0.0f;
+        if (len == 0) out->status = ST_EMPTY;
+        else if (nonconv_any) out->status = ST_NONCONV;
+        else if (out->rq < opts->min_rq) out->status = ST_LOWRQ;
+        else out->status = ST_SUCCESS;
+        ret = 1;
+        free(wb); free(obuf); free(obs); free(Iw);
+    }
+done:
+    for (int r = 0; r < nreads; ++r) free(rstart[r]);
+    free(rstart); free(strand); free(avalid); free(draft);
+    return ret;
+}
+
+/* batch driver over the ccsx SoA/CSR layout; nthreads > 1 uses OpenMP over ZMWs (cpu_baseline leg of bench.py) */
+int orc_consensus_batch(const orc_model *model, const orc_opts *opts, int n_zmw, const float *snr, const int32_t *read_off,
+                        const int64_t *base_off, const uint8_t *bases, const uint8_t *pw, const uint8_t *flags,
+                        const int64_t *seq_off, int32_t *status, int32_t *seq_len, uint8_t *seq, uint8_t *qual, float *raw_qv,
+                        float *rq, int32_t *np, float *ec, int32_t *iters, int32_t *n_windows, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int z = 0; z < n_zmw; ++z) {
+        int r0 = read_off[z], nr = read_off[z + 1] - r0;
+        int64_t b0 = base_off[r0];
+        int64_t *rel = (int64_t *)malloc(sizeof(int64_t) * (nr + 1));
+        for (int r = 0; r <= nr; ++r) rel[r] = base_off[r0 + r] - b0;
+        orc_zmw_out o;
+        orc_consensus_zmw(model, opts, snr + 4 * z, nr, rel, bases + b0, pw + b0, flags + r0,
+                          seq + seq_off[z], qual + seq_off[z], raw_qv ? raw_qv + seq_off[z] : NULL,
+                          seq_off[z + 1] - seq_off[z], &o, NULL, NULL);
+        status[z] = o.status; seq_len[z] = o.seq_len; rq[z] = o.rq; np[z] = o.np; ec[z] = o.ec; iters[z] = o.iters; n_windows[z] = o.n_windows;
+        free(rel);
+    }
+    return 0;
+}

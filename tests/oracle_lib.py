@@ -1,0 +1,151 @@
+"""ctypes access to oracle/libccs_oracle.so — the CPU restatement (test infrastructure, parity unpinned).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libccs_oracle.so")
+
+NCTX, NOBS, JMAX, IMAX = 16, 12, 31, 63
+
+_lib = None
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "ccs_oracle.c")
+    if (not os.path.exists(ORACLE_SO)) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(ORACLE_SO)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(ORACLE_SO)
+        L.orc_log2f.restype = C.c_float
+        L.orc_log2f.argtypes = [C.c_float]
+        L.orc_exp2f.restype = C.c_float
+        L.orc_exp2f.argtypes = [C.c_float]
+        L.orc_bruteforce_likelihood.restype = C.c_double
+        L.orc_window_mutation_likelihood.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def tables(model, snr):
+    """A0: (ME[16,12], INS[16,12], DL[16]) for one ZMW.  `model` is a ccs_amd.api.Model (same byte layout)."""
+    ME = np.zeros((NCTX, NOBS), np.float32)
+    INS = np.zeros((NCTX, NOBS), np.float32)
+    DL = np.zeros(NCTX, np.float32)
+    snr = np.ascontiguousarray(snr, np.float32)
+    lib().orc_tables(C.byref(model), _p(snr, C.c_float), _p(ME, C.c_float), _p(INS, C.c_float), _p(DL, C.c_float))
+    return ME, INS, DL
+
+
+def poa_draft(batch, z, max_poa_cov=10):
+    r0, r1 = int(batch.read_off[z]), int(batch.read_off[z + 1])
+    b0 = int(batch.base_off[r0])
+    rel = (batch.base_off[r0:r1 + 1] - b0).astype(np.int64)
+    bases = np.ascontiguousarray(batch.bases[b0:int(batch.base_off[r1])])
+    flags = np.ascontiguousarray(batch.flags[r0:r1])
+    maxL = int(np.max(np.diff(rel)))
+    dcap = maxL + maxL // 4 + 64
+    vcap = (5 * maxL) // 2 + 256
+    draft = np.zeros(dcap, np.uint8)
+    n = lib().orc_poa_draft(r1 - r0, _p(rel, C.c_int64), _p(bases, C.c_uint8), _p(flags, C.c_uint8), max_poa_cov,
+                            vcap, _p(draft, C.c_uint8), dcap)
+    return draft[:n].copy()
+
+
+def orient(bases, rev):
+    return (3 - bases[::-1]).astype(np.uint8) if rev else bases.copy()
+
+
+def align(read_oriented, draft):
+    r = np.ascontiguousarray(read_oriented, np.uint8)
+    d = np.ascontiguousarray(draft, np.uint8)
+    rs = np.zeros(len(d) + 1, np.int32)
+    sc = C.c_int32()
+    v = lib().orc_align(_p(r, C.c_uint8), len(r), _p(d, C.c_uint8), len(d), _p(rs, C.c_int32), C.byref(sc))
+    return rs, v, sc.value
+
+
+def windows(draft):
+    d = np.ascontiguousarray(draft, np.uint8)
+    cap = len(d) // 22 + 4
+    b = np.zeros(cap, np.int32)
+    n = lib().orc_windows(_p(d, C.c_uint8), len(d), _p(b, C.c_int32), cap)
+    return b[: n + 1].copy()
+
+
+def polish_window(ME, INS, DL, tpl, cs, ce, lf, rf, obs_list, strand):
+    """obs_list[r]: uint8 array of native-orientation obs codes, or None if the read is unusable here."""
+    n = len(obs_list)
+    tpl = np.ascontiguousarray(tpl, np.uint8)
+    bufs = [np.ascontiguousarray(o if o is not None else np.zeros(1, np.uint8), np.uint8) for o in obs_list]
+    ptrs = (C.POINTER(C.c_uint8) * n)(*[_p(b, C.c_uint8) for b in bufs])
+    I = np.array([len(o) if o is not None else -1 for o in obs_list], np.int32)
+    st = np.ascontiguousarray(strand, np.uint8)
+    seq = np.zeros(JMAX + 1, np.uint8)
+    perr = np.zeros(JMAX + 1, np.float32)
+    qv = np.zeros(JMAX + 1, np.float32)
+    ln, nv, nc = C.c_int32(), C.c_int32(), C.c_int32()
+    delta = np.zeros(256, np.float32)
+    it = lib().orc_polish_window(_p(ME, C.c_float), _p(INS, C.c_float), _p(DL, C.c_float), _p(tpl, C.c_uint8), len(tpl),
+                                 cs, ce, lf, rf, n, ptrs, _p(I, C.c_int32), _p(st, C.c_uint8), _p(seq, C.c_uint8),
+                                 _p(perr, C.c_float), _p(qv, C.c_float), C.byref(ln), C.byref(nv), C.byref(nc),
+                                 _p(delta, C.c_float))
+    k = ln.value
+    return dict(seq=seq[:k].copy(), perr=perr[:k].copy(), qv=qv[:k].copy(), nvalid=nv.value, nonconv=nc.value,
+                iters=it, delta=delta)
+
+
+def window_likelihood(ME, INS, DL, tpl, lf, obs):
+    t = np.ascontiguousarray(tpl, np.uint8)
+    o = np.ascontiguousarray(obs, np.uint8)
+    a, b = C.c_float(), C.c_float()
+    lib().orc_window_likelihood(_p(ME, C.c_float), _p(INS, C.c_float), _p(DL, C.c_float), _p(t, C.c_uint8), len(t), lf,
+                                _p(o, C.c_uint8), len(o), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def mutation_likelihood(ME, INS, DL, tpl, lf, obs, m):
+    t = np.ascontiguousarray(tpl, np.uint8)
+    o = np.ascontiguousarray(obs, np.uint8)
+    v, ty, c, x = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    res = lib().orc_window_mutation_likelihood(_p(ME, C.c_float), _p(INS, C.c_float), _p(DL, C.c_float), _p(t, C.c_uint8),
+                                               len(t), lf, _p(o, C.c_uint8), len(o), m, C.byref(v), C.byref(ty),
+                                               C.byref(c), C.byref(x))
+    return res, v.value, ty.value, c.value, x.value
+
+
+def bruteforce_likelihood(ME, INS, DL, tpl, lf, obs):
+    t = np.ascontiguousarray(tpl, np.uint8)
+    o = np.ascontiguousarray(obs, np.uint8)
+    return lib().orc_bruteforce_likelihood(_p(ME, C.c_float), _p(INS, C.c_float), _p(DL, C.c_float), _p(t, C.c_uint8),
+                                           len(t), lf, _p(o, C.c_uint8), len(o))
+
+
+def consensus_batch(model, opts, batch, results, nthreads=1):
+    """Whole-path oracle over a ccs_amd.api.Batch into a ccs_amd.api.Results (same layout as the product)."""
+    L = lib()
+    L.orc_consensus_batch(C.byref(model), C.byref(opts), batch.n_zmw, _p(batch.snr, C.c_float),
+                          _p(batch.read_off, C.c_int32), _p(batch.base_off, C.c_int64), _p(batch.bases, C.c_uint8),
+                          _p(batch.pw, C.c_uint8), _p(batch.flags, C.c_uint8), _p(results.seq_off, C.c_int64),
+                          _p(results.status, C.c_int32), _p(results.seq_len, C.c_int32), _p(results.seq, C.c_uint8),
+                          _p(results.qual, C.c_uint8), _p(results.raw_qv, C.c_float), _p(results.rq, C.c_float),
+                          _p(results.np_, C.c_int32), _p(results.ec, C.c_float), _p(results.iters, C.c_int32),
+                          _p(results.n_windows, C.c_int32), int(nthreads))
+    return results

@@ -1,0 +1,123 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU restatement on the same seeded inputs.
+
+Bar (BASELINE.json north_star): HiFi sequences bit-identical, per-base QVs within 1e-4.  The oracle is
+"parity unpinned" (docs-only reference) — these tests pin the HIP kernels to the specification.
+"""
+import numpy as np
+import pytest
+
+from ccs_amd import api
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+QV_TOL = 1e-4   # north_star: per-base QVs within 1e-4 of the CPU path
+
+
+@pytest.fixture(scope="module")
+def handle(built):
+    h = api.Handle(0)
+    yield h
+    h.close()
+
+
+def _oracle(h, batch):
+    ref = api.Results.allocate(batch)
+    O.consensus_batch(h.model, h.opts, batch, ref, nthreads=8)
+    return ref
+
+
+def _compare(res, ref, batch):
+    assert np.array_equal(res.status, ref.status)
+    assert np.array_equal(res.seq_len, ref.seq_len)
+    assert np.array_equal(res.np_, ref.np_)
+    assert np.array_equal(res.n_windows, ref.n_windows)
+    assert np.array_equal(res.iters, ref.iters)
+    for z in range(batch.n_zmw):
+        assert np.array_equal(res.sequence(z), ref.sequence(z)), f"zmw {z}: sequence differs"
+        assert np.array_equal(res.quals(z), ref.quals(z)), f"zmw {z}: phred differs"
+        assert np.allclose(res.raw(z), ref.raw(z), atol=QV_TOL, rtol=0), f"zmw {z}: raw QV differs"
+    assert np.allclose(res.rq, ref.rq, atol=1e-6, rtol=0)
+    assert np.allclose(res.ec, ref.ec, atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("n,passes,length,seed", [
+    (8, 3, 1000, 1),          # BASELINE config 1 shape
+    (6, 10, 2000, 2),
+    (4, (3, 12), (300, 1500), 3),   # ragged mix
+    (3, 30, 600, 4),          # deep coverage: several LDS chunks per window
+])
+def test_full_path_bit_exact(handle, n, passes, length, seed):
+    batch = api.synth(n, passes, length, seed=seed)
+    res = handle.consensus(batch)
+    ref = _oracle(handle, batch)
+    _compare(res, ref, batch)
+
+
+def test_stages_match_oracle(handle):
+    batch = api.synth(4, 6, 900, seed=11)
+    handle.upload(batch); handle.run(); handle.sync()
+    for z in range(batch.n_zmw):
+        d_ref = O.poa_draft(batch, z, handle.opts.max_poa_cov)
+        d = handle.stage_draft(z)
+        assert np.array_equal(d, d_ref), f"zmw {z}: draft differs"
+        wb = handle.stage_windows(z)
+        assert np.array_equal(wb, O.windows(d_ref))
+        need = sorted({0, len(d)} | {int(b) - 2 for b in wb[1:-1]} | {int(b) + 2 for b in wb[1:-1]})
+        r0 = int(batch.read_off[z])
+        for r in range(r0, int(batch.read_off[z + 1])):
+            bases, _ = batch.read(r)
+            rev = (batch.flags[r] & 1) != (batch.flags[r0] & 1)
+            rs_ref, v_ref, sc_ref = O.align(O.orient(bases, rev), d_ref)
+            rs, v, sc = handle.stage_align(r, len(d))
+            assert (v, sc) == (v_ref, sc_ref)
+            if v:
+                assert [int(rs[c]) for c in need] == [int(rs_ref[c]) for c in need]
+
+
+def test_degenerate_inputs(handle):
+    """too few passes, a garbage read, single window, empty read."""
+    batch = api.synth(3, 4, 120, seed=5)
+    # zmw 1: replace read 1 with random junk of the same length (must be dropped, not crash)
+    r = int(batch.read_off[1]) + 1
+    a, b = int(batch.base_off[r]), int(batch.base_off[r + 1])
+    rng = np.random.default_rng(0)
+    batch.bases[a:b] = rng.integers(0, 4, b - a, dtype=np.uint8)
+    res = handle.consensus(batch)
+    _compare(res, _oracle(handle, batch), batch)
+    two = api.synth(2, 2, 200, seed=6)     # 2 passes < min_passes 3
+    res2 = handle.consensus(two)
+    assert list(res2.status) == [1, 1]
+    _compare(res2, _oracle(handle, two), two)
+
+
+def test_batch_split_invariance(handle):
+    """results do not depend on how ZMWs are batched (the multi-GPU sharder relies on this)."""
+    batch = api.synth(6, 5, 700, seed=9)
+    whole = handle.consensus(batch)
+    for z0, z1 in [(0, 2), (2, 6)]:
+        part = handle.consensus(batch.slice(z0, z1))
+        for z in range(z0, z1):
+            assert np.array_equal(part.sequence(z - z0), whole.sequence(z))
+            assert np.array_equal(part.raw(z - z0), whole.raw(z))
+            assert part.rq[z - z0] == whole.rq[z]
+
+
+def test_recovers_truth_at_full_size(handle):
+    """size-independent property at the BASELINE config-2 shape (10 passes x 10 kb): consensus ~= template."""
+    batch = api.synth(8, 10, 10000, seed=21)
+    res = handle.consensus(batch)
+    assert (res.status == 0).all()
+    for z in range(batch.n_zmw):
+        tpl = batch.tpl[batch.tpl_off[z]:batch.tpl_off[z + 1]]
+        s = res.sequence(z)
+        assert abs(len(s) - len(tpl)) <= 12
+        # cheap identity proxy: 16-mers of the template present in the consensus
+        def kmers(x):
+            v = np.zeros(len(x) - 15, np.uint64)
+            for k in range(16):
+                v = v * np.uint64(4) + x[k:len(x) - 15 + k].astype(np.uint64)
+            return set(v.tolist())
+        kt, ks = kmers(tpl), kmers(s)
+        assert len(kt & ks) / len(kt) > 0.98
+        assert res.rq[z] > 0.999
