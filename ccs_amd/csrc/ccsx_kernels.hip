@@ -29,6 +29,7 @@
 #define MV_INS 2
 #define MUT_EPS 0.01f
 #define MUT_SEP 5
+#define MULTI_ROUNDS 2
 #define JMIN_DEL 4
 #define AB_TOL 0.01f
 #define TINY_P 1e-30f
@@ -758,6 +759,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_polish(KParams P)
                 if (sl >= 4) ++Jn; else if (sl == 3) --Jn;
                 if (lane == 0) sAcc[nacc] = msel;
                 ++nacc;
+                if (it >= MULTI_ROUNDS) break;
                 int dc = (lane & 31) - c; if (dc < 0) dc = -dc;
                 if (dc < MUT_SEP) candmask = 0;
             }

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -50,6 +51,7 @@
 #define NEG       (-(1 << 28))
 #define MUT_EPS   0.01f     /* favourable iff summed log2-likelihood gain > MUT_EPS                 */
 #define MUT_SEP   5         /* accepted mutations of one round are >= MUT_SEP columns apart          */
+#define MULTI_ROUNDS 2      /* rounds >= MULTI_ROUNDS apply only the single best mutation (cycle guard) */
 #define JMIN_DEL  4         /* deletions are not applied when the window would shrink to <= JMIN_DEL */
 #define AB_TOL    0.01f     /* |log2 alpha(I,J) - log2 beta(0,0)| tolerance (alpha/beta agreement)   */
 #define TINY_P    1e-30f    /* a read whose scaled likelihood falls below this is unusable in the window */
@@ -454,6 +456,7 @@ static void fill(const float *ME, const float *INS, const float *DL, const uint8
 {
     int k[JMAX + 1]; tpl_ctx(t, J, lf, k);
     float acol[IMAX + 2], pcol[IMAX + 2];
+    memset(pcol, 0, sizeof(pcol));
     for (int j = 0; j <= J; ++j) {
         for (int i = 0; i <= I; ++i) {
             float g;
@@ -608,6 +611,7 @@ int orc_polish_window(const float *ME, const float *INS, const float *DL,
                 if (slot == 3 && Jn <= JMIN_DEL + 1) continue;
                 if (slot >= 4) ++Jn; else if (slot == 3) --Jn;
                 acc_m[nacc++] = bm;
+                if (it >= MULTI_ROUNDS) break;
                 for (int m = 0; m < 256; ++m) if (cand[m]) { int d = (m & 31) - c; if (d < 0) d = -d; if (d < MUT_SEP) cand[m] = 0; }
             }
         } else nonconv = (nfav > 0);
@@ -615,7 +619,7 @@ int orc_polish_window(const float *ME, const float *INS, const float *DL,
         /* apply in descending position order */
         for (int a = 0; a < nacc; ++a) for (int b = a + 1; b < nacc; ++b)
             if ((acc_m[b] & 31) > (acc_m[a] & 31)) { int t = acc_m[a]; acc_m[a] = acc_m[b]; acc_m[b] = t; }
-        for (int a = 0; a < nacc; ++a) { int type, c, x; mut_decode(acc_m[a], w.t, w.J, &type, &c, &x); tpl_apply(&w, type, c, x); }
+        for (int a = 0; a < nacc; ++a) { int type = 0, c = 0, x = 0; mut_decode(acc_m[a], w.t, w.J, &type, &c, &x); tpl_apply(&w, type, c, x); }
     }
     /* A6: QVs from the last scoring round */
     int len = 0;
@@ -791,6 +795,9 @@ int orc_consensus_batch(const orc_model *model, const orc_opts *opts, int n_zmw,
                         const int64_t *seq_off, int32_t *status, int32_t *seq_len, uint8_t *seq, uint8_t *qual, float *raw_qv,
                         float *rq, int32_t *np, float *ec, int32_t *iters, int32_t *n_windows, int nthreads)
 {
+    /* keep per-window / per-read scratch on the (per-thread) malloc arenas instead of mmap/munmap per call */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif

@@ -104,7 +104,7 @@ def polish_window(ME, INS, DL, tpl, cs, ce, lf, rf, obs_list, strand):
     ln, nv, nc = C.c_int32(), C.c_int32(), C.c_int32()
     delta = np.zeros(256, np.float32)
     it = lib().orc_polish_window(_p(ME, C.c_float), _p(INS, C.c_float), _p(DL, C.c_float), _p(tpl, C.c_uint8), len(tpl),
-                                 cs, ce, lf, rf, n, ptrs, _p(I, C.c_int32), _p(st, C.c_uint8), _p(seq, C.c_uint8),
+                                 int(cs), int(ce), int(lf), int(rf), n, ptrs, _p(I, C.c_int32), _p(st, C.c_uint8), _p(seq, C.c_uint8),
                                  _p(perr, C.c_float), _p(qv, C.c_float), C.byref(ln), C.byref(nv), C.byref(nc),
                                  _p(delta, C.c_float))
     k = ln.value

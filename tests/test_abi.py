@@ -1,0 +1,86 @@
+"""The C-ABI library loads, exports every symbol include/ccsx.h declares, and fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ccs_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ccsx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ccsx_[a-z_]+)\s*\(", src)))
+
+
+def test_header_and_exports_agree(built):
+    decl = _declared()
+    assert decl == sorted(api.EXPORTS)
+    L = C.CDLL(api.LIB_PATH)
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in include/ccsx.h but not exported by libccsx.so"
+    assert L.ccsx_abi_version() == 1
+
+
+def test_struct_layouts_match_header(built):
+    # sizes implied by include/ccsx.h
+    assert C.sizeof(api.Model) == 32 + 8 + 16 * 3 * 4 * 4 + 16 * 12 * 4 + 16 * 3 * 4 * 2
+    assert C.sizeof(api.Opts) == 4 * 7 + 4 * 8
+    assert C.sizeof(api.CBatch) == 16 + 8 * 8
+    assert C.sizeof(api.CResults) == 16 + 11 * 8
+    m = api.default_model()
+    assert m.name == b"SYN-1" and m.snr_lo == 4.0 and m.snr_hi == 20.0
+    o = api.default_opts()
+    assert (o.max_poa_cov, o.min_passes, o.top_passes, o.min_length, o.max_length) == (10, 3, 60, 10, 50000)
+    assert abs(o.min_rq - 0.99) < 1e-7
+
+
+def test_no_silent_cpu_fallback(built):
+    """Without a usable gfx950 device the product must refuse to run (it never routes through the oracle)."""
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        api.Handle(0)
+    # the product library must not depend on the oracle
+    import subprocess
+    deps = subprocess.run(["ldd", api.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in deps
+    for root, _, files in os.walk(os.path.join(ROOT, "ccs_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle_lib" not in txt and "ccs_oracle" not in txt, f"{f} references the oracle"
+
+
+def test_synth_is_deterministic_and_well_formed(built):
+    a = api.synth(5, (3, 8), (200, 900), seed=42)
+    b = api.synth(5, (3, 8), (200, 900), seed=42)
+    for k in ("snr", "read_off", "base_off", "bases", "pw", "ipd", "flags", "tpl"):
+        assert np.array_equal(getattr(a, k), getattr(b, k))
+    c = api.synth(5, (3, 8), (200, 900), seed=43)
+    assert not np.array_equal(a.bases[:100], c.bases[:100])
+    assert a.bases.max() <= 3 and a.pw.min() >= 1 and a.pw.max() <= 3 and (a.snr >= 4).all()
+    passes = np.diff(a.read_off)
+    assert passes.min() >= 3 and passes.max() <= 8
+    # strands alternate, read lengths are within ~15 % of the template
+    for z in range(5):
+        fl = a.flags[a.read_off[z]:a.read_off[z + 1]]
+        assert list(fl) == [k & 1 for k in range(len(fl))]
+        L = a.tpl_off[z + 1] - a.tpl_off[z]
+        ln = np.diff(a.base_off[a.read_off[z]:a.read_off[z + 1] + 1])
+        assert (np.abs(ln / L - 1.02) < 0.15).all()
+    # ~90 % subread accuracy (docs/how-does-ccs-work.md:46)
+    z0 = a.slice(0, 1)
+    assert z0.n_zmw == 1 and z0.read_off[-1] == passes[0] and z0.base_off[-1] == a.base_off[a.read_off[1]]
+
+
+def test_result_layout_and_algorithmic_bytes(built):
+    a = api.synth(3, 4, 500, seed=1)
+    r = api.Results.allocate(a)
+    maxl = [int(np.diff(a.base_off[a.read_off[z]:a.read_off[z + 1] + 1]).max()) for z in range(3)]
+    assert list(np.diff(r.seq_off)) == [m + m // 4 + 64 for m in maxl]
+    assert a.algorithmic_bytes() == 3 * int(a.base_off[-1]) + 48 * 3 + 2 * 1500

@@ -1,0 +1,117 @@
+"""POA draft / alignment / windowing known answers and recover-the-truth fuzz (item 4)."""
+import numpy as np
+import pytest
+
+from ccs_amd import api
+import oracle_lib as O
+
+
+def _batch_from_reads(reads, flags=None):
+    n = len(reads)
+    flags = np.zeros(n, np.uint8) if flags is None else np.asarray(flags, np.uint8)
+    bo = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    bases = np.concatenate(reads).astype(np.uint8)
+    return api.Batch(np.zeros(1, np.int32), np.array([[9, 16, 8, 13]], np.float32), np.array([0, n], np.int32), bo, bases,
+                     np.full(len(bases), 2, np.uint8), np.ones(len(bases), np.uint8), flags)
+
+
+def test_poa_known_answers(built):
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, 4, 300).astype(np.uint8)
+    # identical reads -> the read
+    assert np.array_equal(O.poa_draft(_batch_from_reads([t, t, t]), 0), t)
+    # majority vote on a SNP
+    s = t.copy(); s[100] = (s[100] + 1) & 3
+    assert np.array_equal(O.poa_draft(_batch_from_reads([s, t, t]), 0), t)
+    assert np.array_equal(O.poa_draft(_batch_from_reads([t, s, s]), 0), s)
+    # one read with an insertion / one with a deletion are out-voted
+    ins = np.insert(t, 150, (t[150] + 2) & 3)
+    dele = np.delete(t, 200)
+    assert np.array_equal(O.poa_draft(_batch_from_reads([ins, t, t]), 0), t)
+    assert np.array_equal(O.poa_draft(_batch_from_reads([t, dele, t, t]), 0), t)
+    # reverse-strand passes are oriented by their flag
+    rc = (3 - t[::-1]).astype(np.uint8)
+    assert np.array_equal(O.poa_draft(_batch_from_reads([t, rc, t], [0, 1, 0]), 0), t)
+    assert np.array_equal(O.poa_draft(_batch_from_reads([rc, t, rc], [1, 0, 1]), 0), rc)
+    # max_poa_cov=1 -> the first read verbatim
+    assert np.array_equal(O.poa_draft(_batch_from_reads([s, t, t]), 0, max_poa_cov=1), s)
+
+
+def test_align_entry_rows(built):
+    rng = np.random.default_rng(1)
+    d = rng.integers(0, 4, 500).astype(np.uint8)
+    rs, v, sc = O.align(d, d)
+    assert v == 1 and sc == 3 * 500 and np.array_equal(rs, np.arange(501))
+    # 3 extra read bases before draft position 250: they are consumed while waiting AT state 250,
+    # so entry rows are unchanged up to 250 and shifted by 3 after it
+    x = (d[250] + 2) & 3
+    r = np.concatenate([d[:250], [x, x, x], d[250:]]).astype(np.uint8)
+    rs, v, _ = O.align(r, d)
+    assert v == 1 and rs[250] == 250 and rs[251] == 254 and rs[500] == 503 and rs[0] == 0
+    # a deleted draft base: entry rows stall
+    r = np.delete(d, 100)
+    rs, v, _ = O.align(r, d)
+    assert v == 1 and rs[500] == 499 and (np.diff(rs) >= 0).all() and (np.diff(rs) <= 1).all()
+    # junk does not align
+    junk = rng.integers(0, 4, 500).astype(np.uint8)
+    assert O.align(junk, d)[1] == 0
+    # a read far longer than the band can absorb fails cleanly
+    assert O.align(np.concatenate([d, d]), d)[1] == 0
+
+
+def test_windows_properties(built):
+    rng = np.random.default_rng(2)
+    for L in [5, 28, 29, 30, 51, 52, 100, 1000, 10007]:
+        d = rng.integers(0, 4, L).astype(np.uint8)
+        d[40:60] = 1 if L > 60 else d[40:60]      # a long homopolymer
+        b = O.windows(d)
+        assert b[0] == 0 and b[-1] == L and (np.diff(b) > 0).all()
+        core = np.diff(b)
+        assert core[:-1].min(initial=22) >= 22 and core[:-1].max(initial=22) <= 25 and core[-1] <= 28
+        assert (core + 4 <= 31).all() or len(core) == 1
+        for x in b[1:-1]:                          # never break a homopolymer unless the 3-base shift is used up
+            if d[x] == d[x - 1]:
+                assert d[x - 1] == d[x - 2] == d[x - 3]
+
+
+@pytest.mark.parametrize("passes,length,max_err", [(8, 600, 2), (12, 1500, 2)])
+def test_recover_the_truth(built, passes, length, max_err):
+    batch = api.synth(6, passes, length, seed=123)
+    m, o = api.default_model(), api.default_opts()
+    res = api.Results.allocate(batch)
+    O.consensus_batch(m, o, batch, res, nthreads=4)
+    import difflib
+    total = 0
+    for z in range(batch.n_zmw):
+        tpl = batch.tpl[batch.tpl_off[z]:batch.tpl_off[z + 1]]
+        s = res.sequence(z)
+        assert res.status[z] in (0, 7)
+        ops = [op for op in difflib.SequenceMatcher(None, bytes(s + 65), bytes(tpl + 65), autojunk=False).get_opcodes() if op[0] != "equal"]
+        assert len(ops) <= max_err
+        total += len(ops)
+        # rq is 1 - mean(p_err) of the emitted bases (docs/how-does-ccs-work.md:104-106)
+        p = 10.0 ** (-res.raw(z).astype(np.float64) / 10.0)
+        assert abs((1 - p.mean()) - res.rq[z]) < 2e-4
+        assert res.np_[z] == passes and abs(res.ec[z] - passes) < 0.5
+    assert total <= 4
+
+
+def test_status_taxonomy(built):
+    m, o = api.default_model(), api.default_opts()
+    two = api.synth(2, 2, 200, seed=1)
+    r = api.Results.allocate(two); O.consensus_batch(m, o, two, r)
+    assert list(r.status) == [1, 1] and list(r.seq_len) == [0, 0]          # TOO_FEW_PASSES
+    b = api.synth(1, 4, 300, seed=2)
+    o2 = api.default_opts(); o2.max_length = 100
+    r = api.Results.allocate(b); O.consensus_batch(m, o2, b, r)
+    assert r.status[0] == 6                                                # TOO_LONG
+    o3 = api.default_opts(); o3.min_length = 1000
+    r = api.Results.allocate(b); O.consensus_batch(m, o3, b, r)
+    assert r.status[0] == 5                                                # TOO_SHORT
+    # 3 of 4 reads replaced by junk -> TOO_MANY_UNUSABLE
+    rng = np.random.default_rng(3)
+    for k in (1, 2, 3):
+        a, e = int(b.base_off[k]), int(b.base_off[k + 1])
+        b.bases[a:e] = rng.integers(0, 4, e - a, dtype=np.uint8)
+    r = api.Results.allocate(b); O.consensus_batch(m, o, b, r)
+    assert r.status[0] == 3 and r.np_[0] <= 2
