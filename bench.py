@@ -24,6 +24,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def effective_cores() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(p)))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,13 +129,14 @@ def main():
         }
         if not args.no_cpu_baseline:
             import oracle_lib
-            cores = len(os.sched_getaffinity(0))
+            cores = effective_cores()
             probe = batch.slice(0, 1)
             pr = api.Results.allocate(probe)
             t1 = time.perf_counter()
             oracle_lib.consensus_batch(h.model, h.opts, probe, pr, nthreads=1)
             t1 = time.perf_counter() - t1
             n_s = int(min(args.zmws, max(cores, round(args.cpu_seconds * cores / max(t1, 1e-3)))))
+            n_s = max(cores, (n_s // cores) * cores)    # whole rounds of one ZMW per thread
             sample = batch.slice(0, n_s)
             sr = api.Results.allocate(sample)
             t2 = time.perf_counter()
