@@ -16,7 +16,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccsx.so")
+LIB_PATH = os.environ.get("CCSX_LIB", os.path.join(_HERE, "libccsx.so"))
 
 BAND, MAXPRED, WIN_CORE, WIN_OVERHANG, JMAX, IMAX, MAX_ITER, NCTX, NOBS = 64, 8, 22, 2, 31, 63, 8, 16, 12
 

@@ -206,7 +206,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     RES(h->d_out_i32, (size_t)n * 4 * 4); RES(h->d_out_f32, (size_t)n * 4 * 2);
 
     // ---- resident POA graphs / alignment slots: as many as fit a memory budget, never more than the work
-    const size_t poa_slot_bytes = ((size_t)vcap_max * 390 + (size_t)maxL_max * 4 + 64 + 255) & ~(size_t)255;
+    const size_t poa_slot_bytes = (((size_t)vcap_max + 64) * 400 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
     const size_t align_slot_i32 = (size_t)need_max * 64 + need_max + 64;
     size_t freeb = 0, totalb = 0;
     HIPTRY(hipMemGetInfo(&freeb, &totalb));
@@ -235,7 +235,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     int32_t *zi = (int32_t *)h->d_zmw_i32.p;
     P.draft_len = zi; P.nwin = zi + n; P.zstat = zi + 2 * (size_t)n; P.nreads_used = zi + 3 * (size_t)n; P.np = zi + 4 * (size_t)n;
     P.wbounds = (int32_t *)h->d_wbounds.p;
-    P.ticket_poa = (int32_t *)h->d_ticket.p; P.ticket_align = P.ticket_poa + 1;
+    P.ticket_poa = (int32_t *)h->d_ticket.p; P.ticket_align = P.ticket_poa + 1; P.debug = P.ticket_poa + 4;
     P.poa_scratch = (uint8_t *)h->d_poa.p; P.poa_slot_bytes = poa_slot_bytes; P.poa_slots = poa_slots;
     P.align_scratch = (int32_t *)h->d_align.p; P.align_slot_i32 = align_slot_i32; P.align_slots = align_slots;
     P.avalid = (uint8_t *)h->d_avalid.p; P.ascore = (int32_t *)h->d_ascore.p; P.ent = (int32_t *)h->d_ent.p;
@@ -265,6 +265,13 @@ int ccsx_sync(ccsx_handle h)
     if (!h) return -1;
     HIPTRY(hipSetDevice(h->device));
     HIPTRY(hipStreamSynchronize(h->stream));
+#ifdef CCSX_DEBUG_CHECKS
+    if (h->uploaded) {
+        int32_t dbg[2] = {0, 0};
+        HIPTRY(hipMemcpy(dbg, h->P.debug, 8, hipMemcpyDeviceToHost));
+        if (dbg[0]) { ccsx_set_error("device bounds check failed: code " + std::to_string(dbg[0]) + " at kernel line " + std::to_string(dbg[1])); return -3; }
+    }
+#endif
     return 0;
 }
 

@@ -29,6 +29,7 @@ struct KParams {
     uint8_t *draft;
     int32_t *draft_len, *nwin, *zstat, *nreads_used, *wbounds, *np;
     int32_t *ticket_poa, *ticket_align;   // adjacent
+    int32_t *debug;            // [4] first failed bounds check (CCSX_DEBUG_CHECKS builds)
     // ---- POA / alignment scratch (per resident slot)
     uint8_t *poa_scratch;
     size_t poa_slot_bytes;

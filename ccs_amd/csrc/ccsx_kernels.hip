@@ -14,11 +14,22 @@
 // (alignment); only the POA keeps score columns in HBM scratch because its DAG is irregular.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include "ccsx.h"
 #include "ccsx_kernels.h"
+#include "wave_ops.h"
 
 #define LANES 64
+#ifdef CCSX_DEBUG_CHECKS
+#ifndef CCSX_CHK_MASK
+#define CCSX_CHK_MASK 0xff
+#endif
+#define CHK(cond, code) do { if (((CCSX_CHK_MASK >> ((code) - 101)) & 1) && !(cond)) { if (atomicCAS(P.debug, 0, (code)) == 0) { P.debug[1] = __LINE__; } return; } } while (0)
+#else
+#define CHK(cond, code) do { } while (0)
+#endif
 #define NEGV (-(1 << 28))
 #define SC_MATCH 3
 #define SC_MISMATCH (-5)
@@ -175,208 +186,381 @@ __device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { 
 
 // ------------------------------------------------------------------------------------------------
 // D2/D3: sparse POA.  One wave per resident graph ("slot"); slots pull ZMWs from an atomic ticket.
+//
+// v2 layout.  By vertex id: vrec {base | npred<<8 | reads<<16, pred0, pred1, pred2}, predx (in-edges 3..7),
+// vdp {lo, colmax, bestrow} and the score column M[64] of the current DP pass, rank (topological position).
+// By topological position: order (ping-pong), move rows mvK[64], loK, ppK (position of in-edge 0).
+// The DP walks positions in blocks of 64: the block's vertex records are fetched with one coalesced load and
+// handed out with v_readlane, the previous column stays in registers (DPP wave shifts), so the common chain
+// step touches no memory on its critical path.  Score/move columns are streamed to HBM fire-and-forget.
 struct PoaSlot {
-    uint8_t *base, *npred, *mv;
-    int32_t *nreads, *lo, *colmax, *bestrow, *pred, *next, *prev, *order, *M, *best, *bp, *pathv;
+    int4 *vrec, *vdp;
+    int32_t *predx, *M, *rank, *order0, *order1, *loK, *ppK, *bestK, *bpK, *pathv;
+    uint8_t *mvK;
 };
 
 __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
 {
     PoaSlot s;
-    size_t vc = (size_t)P.vcap_max;
+    const size_t vc = (size_t)P.vcap_max + 64;
     uint8_t *p = P.poa_scratch + (size_t)slot * P.poa_slot_bytes;
-    s.M = (int32_t *)p;            p += vc * 64 * 4;
-    s.pred = (int32_t *)p;         p += vc * CCSX_MAXPRED * 4;
-    s.nreads = (int32_t *)p;       p += vc * 4;
-    s.lo = (int32_t *)p;           p += vc * 4;
-    s.colmax = (int32_t *)p;       p += vc * 4;
-    s.bestrow = (int32_t *)p;      p += vc * 4;
-    s.next = (int32_t *)p;         p += vc * 4;
-    s.prev = (int32_t *)p;         p += vc * 4;
-    s.order = (int32_t *)p;        p += vc * 4;
-    s.best = (int32_t *)p;         p += vc * 4;
-    s.bp = (int32_t *)p;           p += vc * 4;
-    s.pathv = (int32_t *)p;        p += (size_t)P.maxL_max * 4 + 64;
-    s.mv = p;                      p += vc * 64;
-    s.base = p;                    p += vc;
-    s.npred = p;
+    s.M = (int32_t *)p;       p += vc * 64 * 4;
+    s.vrec = (int4 *)p;       p += vc * 16;
+    s.vdp = (int4 *)p;        p += vc * 16;
+    s.mvK = p;                p += vc * 64;
+    s.predx = (int32_t *)p;   p += vc * 5 * 4;
+    s.rank = (int32_t *)p;    p += vc * 4;
+    s.order0 = (int32_t *)p;  p += vc * 4;
+    s.order1 = (int32_t *)p;  p += vc * 4;
+    s.loK = (int32_t *)p;     p += vc * 4;
+    s.ppK = (int32_t *)p;     p += vc * 4;
+    s.bestK = (int32_t *)p;   p += vc * 4;      // also the run-count / shift array while threading a read
+    s.bpK = (int32_t *)p;     p += vc * 4;
+    s.pathv = (int32_t *)p;
     return s;
 }
 
-__device__ __forceinline__ void poa_add_edge(PoaSlot &g, int from, int to)
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int poa_pred(const PoaSlot &g, const int4 &rec, int v, int q)
 {
-    int np = g.npred[to];
-    for (int k = 0; k < np; ++k) if (g.pred[to * CCSX_MAXPRED + k] == from) return;
-    if (np >= CCSX_MAXPRED) return;
-    g.pred[to * CCSX_MAXPRED + np] = from; g.npred[to] = (uint8_t)(np + 1);
+    return q == 0 ? rec.y : (q == 1 ? rec.z : (q == 2 ? rec.w : g.predx[v * 5 + (q - 3)]));
+}
+
+// append edge from -> to (to's record in registers); SPEC: duplicates ignored, in-edge cap 8
+__device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to, int from)
+{
+    const int np = (rec.x >> 8) & 255;
+    bool found = false;
+    for (int q = 0; q < np; ++q) found |= (poa_pred(g, rec, to, q) == from);
+    if (found || np >= CCSX_MAXPRED) return;
+    if (np == 0) rec.y = from; else if (np == 1) rec.z = from; else if (np == 2) rec.w = from; else g.predx[to * 5 + (np - 3)] = from;
+    rec.x += 1 << 8;
 }
 
 extern __shared__ uint32_t dyn_lds[];
 
-__global__ __launch_bounds__(64) void k_poa(KParams P)
+__global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t sMv[64 * 64];
+    __shared__ int sLo[64], sPp[64], sV[64], sMeta[64];
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
-    PoaSlot g = poa_slot(P, blockIdx.x);
-    for (;;) {
-        int z = 0;
-        if (lane == 0) z = atomicAdd(P.ticket_poa, 1);
-        z = bcast_i32(z, 0);
-        if (z >= P.n_zmw) break;
-        const int r0 = P.read_off[z];
-        int nreads = P.read_off[z + 1] - r0;
+    PoaSlot g = poa_slot(P, blockIdx.x);                   // launched in chunks of poa_slots ZMWs: slot = block
+    const int z = z0 + blockIdx.x;
+    if (z >= P.n_zmw) return;
+    {
+        const int r0 = rfl(P.read_off[z]);
+        int nreads = rfl(P.read_off[z + 1]) - r0;
         if (P.opts.top_passes > 0 && nreads > P.opts.top_passes) nreads = P.opts.top_passes;
         if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; }
-        if (nreads < P.opts.min_passes || nreads < 1) { if (lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES; continue; }
-        int npoa = nreads < P.opts.max_poa_cov ? nreads : P.opts.max_poa_cov;
-        const int vcap = P.vcap[z];
-        const int rev0 = P.flags[r0] & 1;
-        int n = 0, head = -1, nadded = 0, ok = 1;
+        const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
+        if (!enough && lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES;
+        if (enough) {
+        const int npoa = nreads < P.opts.max_poa_cov ? nreads : P.opts.max_poa_cov;
+        const int vcap = rfl(P.vcap[z]);
+        const int rev0 = rfl(P.flags[r0] & 1);
+        int n = 0, nadded = 0, ok = 1;
+        int32_t *order = g.order0, *order_nx = g.order1;
         for (int rr = 0; rr < npoa && ok; ++rr) {
             const int r = r0 + rr;
             const uint8_t *rb = P.bases + P.base_off[r];
-            const int I = (int)(P.base_off[r + 1] - P.base_off[r]);
-            const int rev = ((P.flags[r] & 1) != rev0) ? 1 : 0;
+            const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
+            const int rev = rfl(((P.flags[r] & 1) != rev0) ? 1 : 0);
             __syncthreads();
             load_read_packed(sread, rb, I, rev, lane);
             __syncthreads();
             if (n == 0) {                                   // first read: backbone chain
-                if (I > vcap) { ok = 0; break; }
+                if (I > vcap) ok = 0;
+                else {
                 for (int i = lane; i < I; i += LANES) {
-                    g.base[i] = (uint8_t)read_base_packed(sread, i); g.nreads[i] = 1;
-                    g.npred[i] = (uint8_t)(i > 0 ? 1 : 0); g.pred[i * CCSX_MAXPRED] = i - 1;
-                    g.next[i] = (i + 1 < I) ? i + 1 : -1; g.prev[i] = i - 1; g.order[i] = i;
+                    g.vrec[i] = make_int4(read_base_packed(sread, i) | ((i > 0 ? 1 : 0) << 8) | (1 << 16), i - 1, -1, -1);
+                    g.rank[i] = i; order[i] = i;
                 }
-                n = I; head = (I > 0) ? 0 : -1; nadded = 1;
+                n = I; nadded = 1;
                 __threadfence_block();
-                continue;
-            }
+                }
+            } else {
             // ---- DP over the graph in topological order
             const int n0 = n;
-            int Mprev = NEGV, vprev = -2, vend = -1, bs = NEGV;
-            int lo_prev = 0, cm_prev = NEGV, br_prev = 0;   // metadata of the previous column stays in registers
+            int Mprev = NEGV, vprev = -2, lo_prev = 0, cm_prev = NEGV, br_prev = 0;
+            int kend = -1, bs = NEGV;
             __threadfence_block();
-            for (int k = 0; k < n0; ++k) {
-                const int v = g.order[k];
-                int np = g.npred[v];
-                const int vb = g.base[v];
-                int ulo = 0, ubr = 0;
-                int pu[CCSX_MAXPRED], plo[CCSX_MAXPRED];
-                if (np == 0) { pu[0] = -1; plo[0] = 0; }
-                else {
-                    bool far = false;
-                    for (int q = 0; q < np; ++q) { int u = g.pred[v * CCSX_MAXPRED + q]; pu[q] = u; far |= (u != vprev); }
-                    if (far) __threadfence_block();        // columns other than the previous one come back from HBM/L2
-                    int bestcm = NEGV - 1;
-                    for (int q = 0; q < np; ++q) {
-                        const int u = pu[q];
-                        int l, cm, b;
-                        if (u == vprev) { l = lo_prev; cm = cm_prev; b = br_prev; }
-                        else { l = g.lo[u]; cm = g.colmax[u]; b = g.bestrow[u]; }
-                        plo[q] = l;
-                        if (cm > bestcm) { bestcm = cm; ulo = l; ubr = b; }
+            for (int kb = 0; kb < n0; kb += LANES) {
+                const int kkL = kb + lane;
+                const int vL = kkL < n0 ? order[kkL] : 0;
+                int4 rL = make_int4(0, 0, 0, 0);
+                if (kkL < n0) rL = g.vrec[vL];
+                const int nblk = (n0 - kb) < LANES ? (n0 - kb) : LANES;
+                for (int j = 0; j < nblk; ++j) {
+                    const int k = kb + j;
+                    const int v = rl(vL, j);
+                    const int4 rec = make_int4(rl(rL.x, j), rl(rL.y, j), rl(rL.z, j), rl(rL.w, j));
+                    const int vb = rec.x & 255, np = (rec.x >> 8) & 255;
+                    int lo, best = NEGV, bm = 0, pp, i, rbv;
+                    if (np == 1 && rec.y == vprev) {                       // chain step: everything in registers
+                        lo = rfl(band_lo(lo_prev, br_prev, I));
+                        const int sh = lo - lo_prev;
+                        int x, y;
+                        if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; }
+                        else if (sh == 1) { x = Mprev; y = wave_shl1_i32(Mprev, NEGV); }
+                        else { x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); }
+                        i = lo + lane;
+                        rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
+                        if (i >= 1 && i <= I && x > NEGV / 2) { best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); bm = MV_DIAG; }
+                        if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; bm = MV_DEL; } }
+                        pp = k - 1;
+                    } else {                                               // source vertex or several / far in-edges
+                        int ulo = 0, ubr = 0;
+                        if (np > 0) {
+                            bool far = false;
+                            for (int q = 0; q < np; ++q) far |= (rfl(poa_pred(g, rec, v, q)) != vprev);
+                            if (far) __threadfence_block();                // far columns come back from HBM/L2
+                            int bestcm = NEGV - 1;
+                            for (int q = 0; q < np; ++q) {
+                                const int u = rfl(poa_pred(g, rec, v, q));
+                                int l, cm, b;
+                                if (u == vprev) { l = lo_prev; cm = cm_prev; b = br_prev; }
+                                else { const int4 dpu = g.vdp[u]; l = rfl(dpu.x); cm = rfl(dpu.y); b = rfl(dpu.z); }
+                                if (cm > bestcm) { bestcm = cm; ulo = l; ubr = b; }
+                            }
+                        }
+                        lo = rfl(band_lo(ulo, ubr, I));
+                        i = lo + lane;
+                        rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
+                        const int npp = np == 0 ? 1 : np;
+                        for (int q = 0; q < npp; ++q) {
+                            int x, y;
+                            if (np == 0) {
+                                const int o1 = i - 1, o0 = i;
+                                x = (o1 >= 0 && o1 < LANES && o1 <= I) ? o1 * SC_INS : NEGV;
+                                y = (o0 >= 0 && o0 < LANES && o0 <= I) ? o0 * SC_INS : NEGV;
+                            } else {
+                                const int u = rfl(poa_pred(g, rec, v, q));
+                                if (u == vprev) {
+                                    const int o1 = i - 1 - lo_prev, o0 = i - lo_prev;
+                                    const int xs = __shfl(Mprev, o1 & 63), ys = __shfl(Mprev, o0 & 63);
+                                    x = (o1 >= 0 && o1 < LANES) ? xs : NEGV;
+                                    y = (o0 >= 0 && o0 < LANES) ? ys : NEGV;
+                                } else {
+                                    const int plo = rfl(g.vdp[u].x);
+                                    const int o1 = i - 1 - plo, o0 = i - plo;
+                                    const int32_t *Mu = g.M + (size_t)u * 64;
+                                    x = (o1 >= 0 && o1 < LANES) ? Mu[o1] : NEGV;
+                                    y = (o0 >= 0 && o0 < LANES) ? Mu[o0] : NEGV;
+                                }
+                            }
+                            if (i >= 1 && i <= I && x > NEGV / 2) { int c = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); if (c > best) { best = c; bm = MV_DIAG | (q << 2); } }
+                            if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; bm = MV_DEL | (q << 2); } }
+                        }
+                        pp = (np == 0) ? -1 : ((rec.y == vprev) ? k - 1 : rfl(g.rank[rec.y]));
                     }
+                    // insertion chain: x_l = max_k<=l (c_k + (l-k)*INS): exact integer max-plus prefix scan (7 DPP ops)
+                    const int d = wave_scan_max_i32(best + 4 * lane);
+                    const int xi = d - 4 * lane;
+                    if (xi > best) { best = xi; bm = MV_INS; }
+                    if (i > I || best < NEGV / 2) best = NEGV;
+                    const int cm = wave_reduce_max_i32(best);
+                    const unsigned long long bal = __ballot(best == cm);
+                    const int br = lo + (__ffsll((long long)bal) - 1);
+                    g.M[(size_t)v * 64 + lane] = best;
+                    g.mvK[(size_t)k * 64 + lane] = (uint8_t)bm;
+                    if (lane == 0) { g.vdp[v] = make_int4(lo, cm, br, 0); g.loK[k] = lo; g.ppK[k] = pp; }
+                    const int oe = I - lo;
+                    if (oe >= 0 && oe < LANES) { const int xe = rl(best, oe); if (xe > NEGV / 2 && xe > bs) { bs = xe; kend = k; } }
+                    Mprev = best; vprev = v; lo_prev = lo; cm_prev = cm; br_prev = br;
                 }
-                const int npp = np == 0 ? 1 : np;
-                const int lo = band_lo(ulo, ubr, I);
-                const int i = lo + lane;
-                const int rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
-                int best = NEGV, bm = 0;
-                for (int q = 0; q < npp; ++q) {
-                    const int u = pu[q];
-                    const int o1 = i - 1 - plo[q], o0 = i - plo[q];
-                    int x, y;
-                    if (u < 0) {
-                        x = (o1 >= 0 && o1 < LANES && o1 <= I) ? o1 * SC_INS : NEGV;
-                        y = (o0 >= 0 && o0 < LANES && o0 <= I) ? o0 * SC_INS : NEGV;
-                    } else if (u == vprev) {
-                        int xs = __shfl(Mprev, o1 & 63), ys = __shfl(Mprev, o0 & 63);
-                        x = (o1 >= 0 && o1 < LANES) ? xs : NEGV;
-                        y = (o0 >= 0 && o0 < LANES) ? ys : NEGV;
-                    } else {
-                        const int32_t *Mu = g.M + (size_t)u * 64;
-                        x = (o1 >= 0 && o1 < LANES) ? Mu[o1] : NEGV;
-                        y = (o0 >= 0 && o0 < LANES) ? Mu[o0] : NEGV;
-                    }
-                    if (i >= 1 && i <= I && x > NEGV / 2) { int c = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); if (c > best) { best = c; bm = MV_DIAG | (q << 2); } }
-                    if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; bm = MV_DEL | (q << 2); } }
-                }
-                // insertion chain: x_l = max_k<=l (c_k + (l-k)*INS)  (exact integer max-plus prefix scan)
-                int d = best + 4 * lane;
+            }
+            __threadfence_block();
+            if (kend >= 0) {                                // else: read not added
+            // ---- traceback: lane 0 walks, the block of 64 positions it is in is cached in LDS
+            {
+                int k = kend, i = I;
+                while (k >= 0) {
+                    const int kb = (k >> 6) << 6;
+                    __syncthreads();
+                    {
+                        const int kk = kb + lane;
+                        const bool in = kk < n0;
+                        const int v = in ? order[kk] : 0;
+                        sV[lane] = v; sLo[lane] = in ? g.loK[kk] : 0; sPp[lane] = in ? g.ppK[kk] : -1; sMeta[lane] = in ? g.vrec[v].x : 0;
+                        const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb * 64);
+                        uint4 *dst = (uint4 *)sMv;
 #pragma unroll
-                for (int s = 1; s < LANES; s <<= 1) { int o = __shfl_up(d, s); if (lane >= s && o > d) d = o; }
-                int xi = d - 4 * lane;
-                if (xi > best) { best = xi; bm = MV_INS; }
-                if (i > I || best < NEGV / 2) best = NEGV;
-                const int cm = wave_max_i32(best);
-                const unsigned long long bal = __ballot(best == cm);
-                const int br = lo + (__ffsll((long long)bal) - 1);
-                g.M[(size_t)v * 64 + lane] = best;
-                g.mv[(size_t)v * 64 + lane] = (uint8_t)bm;
-                if (lane == 0) { g.lo[v] = lo; g.colmax[v] = cm; g.bestrow[v] = br; }
-                const int oe = I - lo;
-                if (oe >= 0 && oe < LANES) { int xe = __shfl(best, oe); if (xe > NEGV / 2 && xe > bs) { bs = xe; vend = v; } }
-                Mprev = best; vprev = v; lo_prev = lo; cm_prev = cm; br_prev = br;
+                        for (int q = 0; q < 4; ++q) dst[q * 64 + lane] = src[q * 64 + lane];
+                    }
+                    __syncthreads();
+                    while (k >= kb) {                                  // uniform walk: every lane follows the same (k, i)
+                        const int kl = k - kb;
+                        CHK(i - sLo[kl] >= 0 && i - sLo[kl] < 64 && i >= 0, 101);
+                        const int m = rfl(sMv[kl * 64 + (i - sLo[kl])]);
+                        const int t = m & 3, slot = m >> 2;
+                        CHK(i >= 1 || t == MV_DEL, 102);
+                        if (t == MV_INS) { if (lane == 0) g.pathv[i - 1] = -1; --i; continue; }
+                        const int meta = rfl(sMeta[kl]);
+                        const int np = (meta >> 8) & 255;
+                        int up;
+                        if (np == 0) up = -1;
+                        else if (slot == 0) up = rfl(sPp[kl]);
+                        else { const int v = rfl(sV[kl]); const int4 rec = g.vrec[v]; up = rfl(g.rank[poa_pred(g, rec, v, slot)]); }
+                        if (t == MV_DIAG) {
+                            if (lane == 0) g.pathv[i - 1] = ((meta & 255) == read_base_packed(sread, i - 1)) ? sV[kl] : -1;
+                            --i;
+                        }
+                        CHK(up < k && up >= -1, 103);
+                        k = up;
+                    }
+                    k = rfl(k); i = rfl(i);
+                }
+                for (int q = lane; q < i; q += LANES) g.pathv[q] = -1;     // leading insertions at START
             }
             __threadfence_block();
-            if (vend < 0) continue;                        // read not added
-            // ---- traceback + threading (serial, lane 0)
-            int fail = 0;
-            if (lane == 0) {
-                int v = vend, i = I;
-                while (v >= 0) {
-                    int m = g.mv[(size_t)v * 64 + (i - g.lo[v])];
-                    int t = m & 3, slot = m >> 2;
-                    if (t == MV_INS) { g.pathv[i - 1] = -1; --i; continue; }
-                    int u = (g.npred[v] == 0) ? -1 : g.pred[v * CCSX_MAXPRED + slot];
-                    if (t == MV_DIAG) { g.pathv[i - 1] = (g.base[v] == read_base_packed(sread, i - 1)) ? v : -1; --i; }
-                    v = u;
-                }
-                while (i > 0) { g.pathv[i - 1] = -1; --i; }
-                int prevp = -1;
-                for (i = 0; i < I; ++i) {
-                    int w = g.pathv[i];
-                    if (w >= 0) g.nreads[w] += 1;
-                    else {
-                        if (n >= vcap) { fail = 1; break; }
-                        w = n++;
-                        g.base[w] = (uint8_t)read_base_packed(sread, i); g.nreads[w] = 1; g.npred[w] = 0;
-                        if (prevp < 0) { g.next[w] = head; g.prev[w] = -1; if (head >= 0) g.prev[head] = w; head = w; }
-                        else { int nx = g.next[prevp]; g.next[w] = nx; g.prev[w] = prevp; g.next[prevp] = w; if (nx >= 0) g.prev[nx] = w; }
-                    }
-                    if (prevp >= 0) poa_add_edge(g, prevp, w);
-                    prevp = w;
-                }
-                if (!fail) { int k = 0; for (int v2 = head; v2 >= 0; v2 = g.next[v2]) g.order[k++] = v2; }
+            // ---- thread the read into the graph (wave-parallel; identical result to the serial list insertion)
+            int32_t *cnt = g.bestK;
+            int carry = 0;
+            for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 1: vertex ids of the path
+                const int i = c0 + lane;
+                const int pv = i < I ? g.pathv[i] : 0;
+                const int isnew = (i < I && pv < 0) ? 1 : 0;
+                const int incl = wave_scan_add_i32(isnew);
+                if (i < I) g.pathv[i] = isnew ? n0 + carry + incl - 1 : pv;
+                carry += rl(incl, 63);
             }
-            fail = bcast_i32(fail, 0); n = bcast_i32(n, 0); head = bcast_i32(head, 0);
-            if (fail) { ok = 0; break; }
+            const int nnew = carry;
+            if (n0 + nnew > vcap) ok = 0;
+            else {
+            for (int q = lane; q <= n0; q += LANES) cnt[q] = 0;
+            __threadfence_block();
+            int lastEx = -1;
+            for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 2: records, edges, run counts
+                const int i = c0 + lane;
+                const bool valid = i < I;
+                const int w = valid ? g.pathv[i] : 0;
+                const int pw = (valid && i > 0) ? g.pathv[i - 1] : -1;
+                const bool isnew = valid && w >= n0;
+                const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
+                int ex = wave_shr1_i32(incl, -1);
+                ex = ex > lastEx ? ex : lastEx;                            // last existing path element before i
+                if (valid) {
+                    int4 rec;
+                    if (!isnew) { rec = g.vrec[w]; rec.x += 1 << 16; }
+                    else {
+                        rec = make_int4(read_base_packed(sread, i) | (1 << 16), -1, -1, -1);
+                        // the last vertex of a run of new vertices records the run length at its anchor (plain store, one writer)
+                        const bool lastOfRun = (i + 1 >= I) || (g.pathv[i + 1] < n0);
+                        if (lastOfRun) {
+                            const int apos = ex >= 0 ? g.rank[g.pathv[ex]] : -1;
+                            CHK(apos >= -1 && apos < n0, 106);
+                            cnt[apos + 1] = i - ex;
+                        }
+                    }
+                    if (pw >= 0) poa_add_edge(g, rec, w, pw);
+                    g.vrec[w] = rec;
+                }
+                const int li = rl(incl, 63);
+                lastEx = li > lastEx ? li : lastEx;
+            }
+            __threadfence_block();
+            carry = 0;
+            for (int c0 = 0; c0 <= n0; c0 += LANES) {                      // inclusive prefix sum of run counts
+                const int q = c0 + lane;
+                const int incl = wave_scan_add_i32(q <= n0 ? cnt[q] : 0);
+                if (q <= n0) cnt[q] = carry + incl;
+                carry += rl(incl, 63);
+            }
+            __threadfence_block();
+            lastEx = -1;
+            for (int c0 = 0; c0 < I; c0 += LANES) {                        // new vertices: position right after their anchor
+                const int i = c0 + lane;
+                const bool valid = i < I;
+                const int w = valid ? g.pathv[i] : 0;
+                const bool isnew = valid && w >= n0;
+                const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
+                int ex = wave_shr1_i32(incl, -1);
+                ex = ex > lastEx ? ex : lastEx;
+                if (isnew) {
+                    int pos = i - ex - 1;
+                    if (ex >= 0) { const int apos = g.rank[g.pathv[ex]]; pos += apos + cnt[apos] + 1; }
+                    CHK(pos >= 0 && pos < n0 + nnew && w < vcap, 104);
+                    order_nx[pos] = w; g.rank[w] = pos;
+                }
+                const int li = rl(incl, 63);
+                lastEx = li > lastEx ? li : lastEx;
+            }
+            __threadfence_block();
+            for (int q = lane; q < n0; q += LANES) {                       // existing vertices shift right
+                const int v = order[q];
+                const int np2 = q + cnt[q];
+                CHK(np2 >= 0 && np2 < n0 + nnew && v >= 0 && v < n0, 105);
+                order_nx[np2] = v; g.rank[v] = np2;
+            }
+            { int32_t *t = order; order = order_nx; order_nx = t; }
+            n = n0 + nnew;
             nadded += 1;
             __threadfence_block();
+            }   // capacity ok
+            }   // kend >= 0
+            }   // not the first read
         }
-        // ---- consensus path + windows (serial, lane 0)
+        // ---- consensus: heaviest path (uniform walk, block records via readlane)
         int Ld = 0, nw = 0, stat = -1;
-        if (lane == 0) {
-            if (ok && n > 0) {
-                int vbest = -1, sb = NEGV;
-                for (int k = 0; k < n; ++k) {
-                    int v = g.order[k];
+        if (ok && n > 0) {
+            int kbest = -1, sb = NEGV, best_prev = 0, vprev = -2;
+            for (int kb = 0; kb < n; kb += LANES) {
+                const int kkL = kb + lane;
+                const int vL = kkL < n ? order[kkL] : 0;
+                int4 rL = make_int4(0, 0, 0, 0);
+                if (kkL < n) rL = g.vrec[vL];
+                const int nblk = (n - kb) < LANES ? (n - kb) : LANES;
+                int myBest = 0, myBp = -1;
+                for (int j = 0; j < nblk; ++j) {
+                    const int k = kb + j;
+                    const int v = rl(vL, j);
+                    const int4 rec = make_int4(rl(rL.x, j), rl(rL.y, j), rl(rL.z, j), rl(rL.w, j));
+                    const int np = (rec.x >> 8) & 255, nr = rec.x >> 16;
                     int b = 0, p = -1;
-                    int np = g.npred[v];
-                    for (int q = 0; q < np; ++q) { int u = g.pred[v * CCSX_MAXPRED + q]; int bu = g.best[u]; if (bu > b) { b = bu; p = u; } }
-                    int bv = b + 2 * g.nreads[v] - nadded;
-                    g.best[v] = bv; g.bp[v] = p;
-                    if (bv > sb) { sb = bv; vbest = v; }
+                    for (int q = 0; q < np; ++q) {
+                        const int u = rfl(poa_pred(g, rec, v, q));
+                        int bu, pu;
+                        CHK(u >= 0 && u < n, 108);
+                        if (u == vprev) { bu = best_prev; pu = k - 1; }
+                        else { pu = rfl(g.rank[u]); bu = (pu >= kb) ? rl(myBest, pu - kb) : rfl(g.bestK[pu]); }
+                        if (bu > b) { b = bu; p = pu; }
+                    }
+                    const int bv = b + 2 * nr - nadded;
+                    if (lane == j) { myBest = bv; myBp = p; }
+                    if (bv > sb) { sb = bv; kbest = k; }
+                    best_prev = bv; vprev = v;
                 }
-                int len = 0;
-                for (int v = vbest; v >= 0; v = g.bp[v]) ++len;
-                if (len <= P.dcap[z]) {
-                    uint8_t *draft = P.draft + P.seq_off[z];
-                    int k = len;
-                    for (int v = vbest; v >= 0; v = g.bp[v]) draft[--k] = g.base[v];
-                    Ld = len;
+                if (kkL < n) { g.bestK[kkL] = myBest; g.bpK[kkL] = myBp; }
+                __threadfence_block();
+            }
+            // backtrack (uniform), bases collected in reverse into scratch
+            uint8_t *tmp = (uint8_t *)g.pathv;
+            int len = 0, k = kbest;
+            while (k >= 0) {
+                const int kb = (k >> 6) << 6;
+                const int kk = kb + lane;
+                const int bpL = kk < n ? g.bpK[kk] : -1;
+                const int bL = kk < n ? (g.vrec[order[kk]].x & 255) : 0;
+                while (k >= kb) {
+                    const int kl = k - kb;
+                    CHK(len < n, 107);
+                    if (lane == 0) tmp[len] = (uint8_t)rl(bL, kl);
+                    ++len;
+                    k = rl(bpL, kl);
                 }
             }
+            __threadfence_block();
+            if (len <= P.dcap[z]) {
+                uint8_t *draft = P.draft + P.seq_off[z];
+                for (int q = lane; q < len; q += LANES) draft[q] = tmp[len - 1 - q];
+                Ld = len;
+            }
+            __threadfence_block();
+        }
+        if (lane == 0) {
             if (Ld <= 0) stat = CCSX_DRAFT_FAILURE;
             else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
             else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
@@ -393,6 +577,7 @@ __global__ __launch_bounds__(64) void k_poa(KParams P)
             }
             P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat;
         }
+        }   // enough
     }
 }
 
@@ -877,22 +1062,37 @@ __global__ __launch_bounds__(64) void k_stitch(KParams P)
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from ccsx_api.cpp, which is plain C++)
+static void trace_sync(hipStream_t st, const char *what)
+{
+    static const bool on = getenv("CCSX_TRACE") != nullptr;     // debugging aid: serialise and name every launch
+    if (!on) return;
+    hipError_t e = hipStreamSynchronize(st);
+    fprintf(stderr, "[ccsx] %s done: %s\n", what, hipGetErrorString(e));
+}
+
 void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or NULL */)
 {
     if (ev) (void)hipEventRecord(ev[0], st);
-    (void)hipMemsetAsync(P.ticket_poa, 0, 8, st);                // ticket_poa and ticket_align are adjacent
+    (void)hipMemsetAsync(P.ticket_poa, 0, 32, st);                // ticket_poa and ticket_align are adjacent
     {
         int n = P.n_zmw * CCSX_NCTX;
         hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, P);
     }
+    trace_sync(st, "k_setup");
     if (ev) (void)hipEventRecord(ev[1], st);
     const size_t lds_read = (((size_t)P.maxL_max + 15) / 16) * 4 + 64;
-    hipLaunchKernelGGL(k_poa, dim3(P.poa_slots), dim3(64), lds_read, st, P);
+    for (int z0 = 0; z0 < P.n_zmw; z0 += P.poa_slots) {
+        const int nb = (P.n_zmw - z0) < P.poa_slots ? (P.n_zmw - z0) : P.poa_slots;
+        hipLaunchKernelGGL(k_poa, dim3(nb), dim3(64), lds_read, st, P, z0);
+    }
+    trace_sync(st, "k_poa");
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_align, dim3(P.align_slots), dim3(64), lds_read, st, P);
+    trace_sync(st, "k_align");
     hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P);
     if (ev) (void)hipEventRecord(ev[3], st);
     if (P.total_wslots > 0) hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), 0, st, P);
+    trace_sync(st, "k_polish");
     if (ev) (void)hipEventRecord(ev[4], st);
     hipLaunchKernelGGL(k_stitch, dim3(P.n_zmw), dim3(64), 0, st, P);
     if (ev) (void)hipEventRecord(ev[5], st);

@@ -1,0 +1,48 @@
+// wave_ops.h — wave64 cross-lane primitives for gfx950 built on DPP (no LDS traffic, 1 VALU op each).
+// DPP control codes (GFX9): row_shr:n = 0x110+n, wave_shl:1 = 0x130, wave_shr:1 = 0x138,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+// lane l <- x[l-1]; lane 0 <- fill
+__device__ __forceinline__ int wave_shr1_i32(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, DPP_WAVE_SHR1, 0xf, 0xf, false); }
+// lane l <- x[l+1]; lane 63 <- fill
+__device__ __forceinline__ int wave_shl1_i32(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, DPP_WAVE_SHL1, 0xf, 0xf, false); }
+__device__ __forceinline__ float wave_shr1_f32(float x, float fill) { return __int_as_float(wave_shr1_i32(__float_as_int(x), __float_as_int(fill))); }
+__device__ __forceinline__ float wave_shl1_f32(float x, float fill) { return __int_as_float(wave_shl1_i32(__float_as_int(x), __float_as_int(fill))); }
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// inclusive prefix maximum over the 64 lanes (7 DPP ops)
+__device__ __forceinline__ int wave_scan_max_i32(int v)
+{
+    int s = imax(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_SHR(2), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_SHR(3), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(s, s, DPP_ROW_SHR(4), 0xf, 0xe, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(s, s, DPP_ROW_SHR(8), 0xf, 0xc, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(s, s, DPP_ROW_BCAST15, 0xa, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(s, s, DPP_ROW_BCAST31, 0xc, 0xf, false));
+    return s;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_scan_add_i32(int v)
+{
+    int s = v + __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, false);
+    s = s + __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, false);
+    s = s + __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(3), 0xf, 0xf, false);
+    s = s + __builtin_amdgcn_update_dpp(0, s, DPP_ROW_SHR(4), 0xf, 0xe, false);
+    s = s + __builtin_amdgcn_update_dpp(0, s, DPP_ROW_SHR(8), 0xf, 0xc, false);
+    s = s + __builtin_amdgcn_update_dpp(0, s, DPP_ROW_BCAST15, 0xa, 0xf, false);
+    s = s + __builtin_amdgcn_update_dpp(0, s, DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return s;
+}
+// wave-wide maximum, returned uniformly (scan + readlane 63)
+__device__ __forceinline__ int wave_reduce_max_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_max_i32(v), 63); }
+__device__ __forceinline__ int wave_reduce_add_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_add_i32(v), 63); }
