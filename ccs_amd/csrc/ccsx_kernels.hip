@@ -688,12 +688,20 @@ __global__ void k_post(KParams P)
 
 // ------------------------------------------------------------------------------------------------
 // A1-A6: Arrow polish of one window per workgroup (256 threads = 4 waves).
+//
+// v2.  LDS holds: sCTX[obs][ctx] = (ME, INS) as float2 — 16 contexts = 16 distinct 8-byte slots, so a wave's
+// ds_read_b64 with a uniform obs row is bank-conflict free by construction; per-column copies sMI[strand][j][obs]
+// (row stride 13) for the fill; gamma/beta of one chunk of reads (sGB).  Fill: two reads per wave (lanes 0-31 /
+// 32-63, lane = read row) when both have <= 31 bases, alpha and beta swept in the same anti-diagonal loop
+// (two independent dependency chains), neighbours via DPP wave shifts.  Scoring: one lane per mutation, two
+// reads per loop (two chains), serial over read rows exactly as the SPEC orders the operations.
 #define PW_THREADS 256
 #define PW_MAXREADS 64
-#define GB_FLOATS (10240)            // 40 KB of LDS for gamma/beta of one chunk of reads
+#define GB_FLOATS 14336              // 56 KB of LDS for gamma/beta of one chunk of reads
+#define MI_STRIDE 13
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
-    int c, q, tri, isdel, fin;
+    int c, q, kA, kB, isdel, fin;
     float dlA, dlL, fA, fB;
 };
 
@@ -706,37 +714,61 @@ __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_
     else if (type == 2) { fin = (c == J);     if (!fin) nB = t[c];     q = c + 1; }
     else                { fin = (c + 1 == J); xA = fin ? 0 : t[c + 1]; q = c + 2; }
     if (pA > 3) pA = (xA + 2) & 3;
-    int kA = pA * 4 + xA, kB = xA * 4 + nB;
-    L.c = c; L.q = q > J ? J : q; L.tri = pA * 16 + xA * 4 + nB; L.isdel = (type == 1); L.fin = fin;
-    L.dlA = sDL[kA]; L.dlL = (type == 1) ? sDL[kA] : sDL[kB];
+    const int kA = pA * 4 + xA, kB = (type == 1) ? kA : xA * 4 + nB;
+    L.c = c; L.q = q > J ? J : q; L.kA = kA; L.kB = kB; L.isdel = (type == 1); L.fin = fin;
+    L.dlA = sDL[kA]; L.dlL = sDL[kB];
     L.fA = (type == 1 && fin) ? 0.0f : 1.0f;
     L.fB = fin ? 0.0f : 1.0f;
     return L;
 }
 
-__global__ __launch_bounds__(PW_THREADS) void k_polish(KParams P)
+struct ScoreChain {                  // running state of one (lane, read) mutation evaluation
+    float ap, bp, acc, b, bq;
+    float2 pA, pB;
+};
+
+__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, const float2 *sCTX, const float *gam, const float *bet,
+                                           int S, int i, int o, bool last)
 {
-    __shared__ float sME[192], sINS[192], sDL[16];
-    __shared__ float4 sTRI[CCSX_NOBS * 64];                 // [obs][tri] = (INS[kA], ME[kA], INS[kB], ME[kB])
-    __shared__ float sMEJ[2][32 * CCSX_NOBS], sINSJ[2][32 * CCSX_NOBS], sDLJ[2][32];   // per strand, per column
-    __shared__ uint8_t sT[2][32];                           // template: [0] forward, [1] reverse complement
+    const float gmm = gam[i * S];
+    float2 nA = make_float2(0.f, 0.f), nB = make_float2(0.f, 0.f);
+    if (!last) { nA = sCTX[o * 16 + L.kA]; nB = sCTX[o * 16 + L.kB]; }
+    const float bqn = bet[(i + 1) * S];
+    const float insA = s.pA.y * L.fA, meA = s.pA.x, insB = s.pB.y * L.fB;
+    const float a = gmm + s.ap * insA;
+    float b;
+    if (L.isdel) b = a;
+    else b = ((s.ap * meA) + (a * L.dlA)) + s.bp * insB;
+    const float term = (nB.x * bqn) + (L.dlL * s.bq);
+    s.acc = s.acc + b * term;
+    s.ap = a; s.bp = b; s.b = b; s.pA = nA; s.pB = nB; s.bq = bqn;
+}
+
+__global__ __launch_bounds__(PW_THREADS, 2) void k_polish(KParams P)
+{
+    __shared__ float2 sCTX[CCSX_NOBS * 16];                  // [obs][ctx] = (ME, INS)
+    __shared__ float sDL[16];
+    __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
+    __shared__ float sDLJ[2][32];
+    __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
     __shared__ uint8_t sObs[PW_MAXREADS][64];
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
     __shared__ float sBase[PW_MAXREADS];
+    __shared__ short2 sTask[PW_MAXREADS];                    // fill tasks: (read A, read B or -1)
     __shared__ float sGB[GB_FLOATS];
     __shared__ float sDelta[256];
     __shared__ uint8_t sMvalid[256];
     __shared__ int sAcc[32];
-    __shared__ int sCtl[8];                                 // 0:J 1:cs 2:ce 3:nacc 4:nfav 5:chunk_end
+    __shared__ int sCtl[8];                                  // 0:J 1:cs 2:ce 3:nacc 5:chunk_end 6:ntasks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- locate (zmw, window)
-    int lo_ = 0, hi_ = P.n_zmw;                             // largest z with woff[z] <= blockIdx.x
+    int lo_ = 0, hi_ = P.n_zmw;
     const int bid = blockIdx.x;
     while (hi_ - lo_ > 1) { int mid = (lo_ + hi_) >> 1; if (P.wb_off[mid] - mid <= bid) lo_ = mid; else hi_ = mid; }
     const int z = lo_;
-    const int w = bid - (P.wb_off[z] - z);                  // window slots of zmw z = wcap[z]-1 = wb_off[z+1]-wb_off[z]-1
+    const int w = bid - (P.wb_off[z] - z);
     if (w >= P.nwin[z]) return;
     const int nw = P.nwin[z], Ld = P.draft_len[z];
     const int32_t *wb = P.wbounds + P.wb_off[z];
@@ -747,7 +779,10 @@ __global__ __launch_bounds__(PW_THREADS) void k_polish(KParams P)
     const int r0 = P.read_off[z], nreads = P.nreads_used[z];
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
 
-    for (int k = tid; k < 192; k += PW_THREADS) { sME[k] = P.tabME[(size_t)z * 192 + k]; sINS[k] = P.tabINS[(size_t)z * 192 + k]; }
+    for (int e = tid; e < CCSX_NOBS * 16; e += PW_THREADS) {
+        const int o = e >> 4, k = e & 15;
+        sCTX[e] = make_float2(P.tabME[(size_t)z * 192 + k * CCSX_NOBS + o], P.tabINS[(size_t)z * 192 + k * CCSX_NOBS + o]);
+    }
     if (tid < 16) sDL[tid] = P.tabDL[(size_t)z * 16 + tid];
     if (tid < we - ws) sT[0][tid] = draft[ws + tid];
     if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb[w] - ws; sCtl[2] = wb[w + 1] - ws; }
@@ -770,30 +805,23 @@ __global__ __launch_bounds__(PW_THREADS) void k_polish(KParams P)
             sObs[r][lane] = (uint8_t)obs_of(P.bases[p], P.pw[p]);
         }
     }
-    __syncthreads();
-    for (int e = tid; e < CCSX_NOBS * 64; e += PW_THREADS) {
-        int o = e >> 6, tri = e & 63;
-        int kA = tri >> 2, kB = (tri & 15);
-        sTRI[e] = make_float4(sINS[kA * CCSX_NOBS + o], sME[kA * CCSX_NOBS + o], sINS[kB * CCSX_NOBS + o], sME[kB * CCSX_NOBS + o]);
-    }
 
     const int slot = tid >> 5, cpos = tid & 31;            // my mutation lane m = tid
+    const int half = lane >> 5, hrow = lane & 31;          // fill: which read of the pair, row within it
     int iters = 0, nonconv = 0, nvalid_last = 0;
     for (int it = 0; it < CCSX_MAX_ITER; ++it) {
         __syncthreads();
         const int J = sCtl[0];
         const int S = (J + 2) & ~1;                          // even row stride >= J+1
-        // reverse-complement template + per-column tables for both strands
         if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
         __syncthreads();
         const int lfr = (rf < 4) ? 3 - rf : 4;
         for (int e = tid; e < 2 * 32 * CCSX_NOBS; e += PW_THREADS) {
-            int sd = e / (32 * CCSX_NOBS), rem = e % (32 * CCSX_NOBS), j = rem / CCSX_NOBS, o = rem % CCSX_NOBS;
+            const int sd = e / (32 * CCSX_NOBS), rem = e - sd * (32 * CCSX_NOBS), j = rem / CCSX_NOBS, o = rem - j * CCSX_NOBS;
             if (j < J) {
-                int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
-                int k = ctx_of(prev, sT[sd][j]);
-                sMEJ[sd][j * CCSX_NOBS + o] = sME[k * CCSX_NOBS + o];
-                sINSJ[sd][j * CCSX_NOBS + o] = sINS[k * CCSX_NOBS + o];
+                const int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
+                const int k = ctx_of(prev, sT[sd][j]);
+                sMI[sd][j * MI_STRIDE + o] = sCTX[o * 16 + k];
                 if (o == 0) sDLJ[sd][j] = sDL[k];
             }
         }
@@ -817,104 +845,130 @@ __global__ __launch_bounds__(PW_THREADS) void k_polish(KParams P)
         while (rbeg < nreads) {
             __syncthreads();
             if (tid == 0) {
-                int off = 0, r = rbeg;
+                int off = 0, r = rbeg, nt = 0, pend = -1;
                 for (; r < nreads; ++r) {
-                    int n = sI[r];
-                    if (n < 0) { sGoff[r] = -1; continue; }
-                    int need = (2 * n + 3) * S;
+                    const int n = sI[r];
+                    if (n < 0) { sGoff[r] = -1; sValid[r] = 0; continue; }
+                    const int need = (2 * n + 3) * S;
                     if (off + need > GB_FLOATS) break;
                     sGoff[r] = off; sBoff[r] = off + (n + 1) * S; off += need;
+                    if (n > 31) sTask[nt++] = make_short2((short)r, (short)-1);           // long segment: a wave of its own
+                    else if (pend < 0) pend = r;
+                    else { sTask[nt++] = make_short2((short)pend, (short)r); pend = -1; }
                 }
-                sCtl[5] = r;
+                if (pend >= 0) sTask[nt++] = make_short2((short)pend, (short)-1);
+                sCtl[5] = r; sCtl[6] = nt;
             }
             __syncthreads();
-            const int rend = sCtl[5];
-            // ---- A1/A2: fill, one wave per read, lane = row, anti-diagonal sweep
-            for (int r = rbeg + wave; r < rend; r += 4) {
-                const int I = sI[r];
-                if (I < 0) { if (lane == 0) sValid[r] = 0; continue; }
-                const int sd = sStrand[r];
-                float *gam = sGB + sGoff[r], *bet = sGB + sBoff[r];
-                const float *MEJ = sMEJ[sd], *INSJ = sINSJ[sd], *DLJ = sDLJ[sd];
-                const int op = (lane >= 1 && lane <= I) ? sObs[r][lane - 1] : 0;     // o_{i-1}
-                const int oc = (lane < I) ? sObs[r][lane] : 0;                        // o_i
-                float acur = 0.0f, updiag = 0.0f;
-                for (int t = 0; t <= I + J; ++t) {
-                    float up = __shfl_up(acur, 1);
-                    if (lane == 0) up = 0.0f;
-                    const int j = t - lane;
-                    if (lane <= I && j >= 0 && j <= J) {
+            const int rend = sCtl[5], ntask = sCtl[6];
+            // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals
+            for (int tk = wave; tk < ntask; tk += 4) {
+                const short2 task = sTask[tk];
+                const bool paired = task.y >= 0;
+                const int myr = paired ? (half ? task.y : task.x) : task.x;
+                const int row = paired ? hrow : lane;
+                const int I = sI[myr];
+                const int Ia = sI[task.x], Ib = paired ? sI[task.y] : -1;
+                const int Tmax = (Ia > Ib ? Ia : Ib) + J;
+                const int sd = sStrand[myr];
+                float *gam = sGB + sGoff[myr] + row * S, *bet = sGB + sBoff[myr] + row * S;
+                const float2 *MI = sMI[sd];
+                const float *DLJ = sDLJ[sd];
+                const bool rowok = row <= I;
+                const int op = (row >= 1 && rowok) ? sObs[myr][row - 1] : 0;            // o_{i-1}
+                const int oc = (row < I) ? sObs[myr][row] : 0;                           // o_i
+                float acur = 0.0f, updiag = 0.0f, mePrev = 0.0f, dlPrev = 0.0f;
+                float bcur = 0.0f, dndiag = 0.0f;
+                for (int t = 0; t <= Tmax; ++t) {
+                    float up = wave_shr1_f32(acur, 0.0f);
+                    if (row == 0) up = 0.0f;
+                    float dn = wave_shl1_f32(bcur, 0.0f);
+                    if (row >= I) dn = 0.0f;
+                    const int j = t - row;
+                    if (rowok && j >= 0 && j <= J) {
                         float gmm;
-                        if (j == 0) gmm = (lane == 0) ? 1.0f : 0.0f;
-                        else { float m = updiag * MEJ[(j - 1) * CCSX_NOBS + op]; float dl = acur * DLJ[j - 1]; gmm = m + dl; }
-                        float st = (lane > 0 && j < J) ? up * INSJ[j * CCSX_NOBS + op] : 0.0f;
-                        gam[lane * S + j] = gmm;
+                        if (j == 0) gmm = (row == 0) ? 1.0f : 0.0f;
+                        else { const float m = updiag * mePrev; const float dl = acur * dlPrev; gmm = m + dl; }
+                        float st = 0.0f;
+                        if (j < J) {
+                            const float2 pr = MI[j * MI_STRIDE + op];
+                            if (row > 0) st = up * pr.y;
+                            mePrev = pr.x; dlPrev = DLJ[j];
+                        }
+                        gam[j] = gmm;
                         acur = gmm + st;
                     }
                     updiag = up;
-                }
-                const float aIJ = __shfl(acur, I);
-                // beta: lane = row i, column j = J - (t - (I - i))
-                float bcur = 0.0f, dndiag = 0.0f;
-                for (int t = 0; t <= I + J; ++t) {
-                    float dn = __shfl_down(bcur, 1);
-                    if (lane >= I) dn = 0.0f;
-                    const int j = J - (t - (I - lane));
-                    if (lane <= I && j >= 0 && j <= J) {
+                    const int jb = J - (t - (I - row));
+                    if (rowok && jb >= 0 && jb <= J) {
                         float b;
-                        if (j == J) b = (lane == I) ? 1.0f : 0.0f;
+                        if (jb == J) b = (row == I) ? 1.0f : 0.0f;
                         else {
-                            float t1 = (lane < I) ? MEJ[j * CCSX_NOBS + oc] * dndiag : 0.0f;
-                            float t2 = (lane < I) ? INSJ[j * CCSX_NOBS + oc] * dn : 0.0f;
-                            float t3 = DLJ[j] * bcur;
+                            const float2 pr = MI[jb * MI_STRIDE + oc];
+                            const float t1 = (row < I) ? pr.x * dndiag : 0.0f;
+                            const float t2 = (row < I) ? pr.y * dn : 0.0f;
+                            const float t3 = DLJ[jb] * bcur;
                             b = (t1 + t2) + t3;
                         }
-                        bet[lane * S + j] = b;
+                        bet[jb] = b;
                         bcur = b;
                     }
                     dndiag = dn;
                 }
-                if (lane < S) bet[(I + 1) * S + lane] = 0.0f;
-                const float b00 = __shfl(bcur, 0);
-                if (lane == 0) {
+                // zero row I+1 of beta, validity
+                if (row < S && (paired || lane < 32) ) sGB[sBoff[myr] + (I + 1) * S + row] = 0.0f;
+                const int basel = paired ? (half << 5) : 0;
+                const float aIJ = __shfl(acur, basel + I);
+                const float b00 = __shfl(bcur, basel);
+                if (row == 0 && (paired || lane == 0)) {
                     int v = 0; float la = 0.0f;
                     if (aIJ > TINY_P && b00 > TINY_P) {
-                        la = det_log2f(aIJ); float lb = det_log2f(b00);
+                        la = det_log2f(aIJ); const float lb = det_log2f(b00);
                         float df = la - lb; if (df < 0.0f) df = -df;
                         v = !(df > AB_TOL);
                     }
-                    sValid[r] = (uint8_t)v; sBase[r] = la;
+                    sValid[myr] = (uint8_t)v; sBase[myr] = la;
                 }
             }
             __syncthreads();
-            // ---- A3/A4: every lane scores its mutation against every read of the chunk
-            for (int r = rbeg; r < rend; ++r) {
-                if (!sValid[r]) continue;
-                ++nvalid;
-                const int I = sI[r];
-                const LaneMut &L = sStrand[r] ? LR : LF;
-                const float *gam = sGB + sGoff[r] + L.c, *bet = sGB + sBoff[r] + L.q;
-                const uint8_t *ob = sObs[r];
-                float ap = 0.0f, bp = 0.0f, acc = 0.0f, b = 0.0f;
-                float4 Tp = make_float4(0.f, 0.f, 0.f, 0.f);
-                float bq = bet[0];
-                for (int i = 0; i <= I; ++i) {
-                    const float gmm = gam[i * S];
-                    float4 T = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (i < I) T = sTRI[ob[i] * 64 + L.tri];
-                    const float bqn = bet[(i + 1) * S];
-                    const float insA = Tp.x * L.fA, meA = Tp.y, insB = Tp.z * L.fB;
-                    const float a = gmm + ap * insA;
-                    if (L.isdel) b = a;
-                    else b = ((ap * meA) + (a * L.dlA)) + bp * insB;
-                    const float meL = L.isdel ? T.y : T.w;
-                    const float term = (meL * bqn) + (L.dlL * bq);
-                    acc = acc + b * term;
-                    ap = a; bp = b; Tp = T; bq = bqn;
+            // ---- A3/A4: every lane scores its mutation against the reads of the chunk, two reads per loop
+            int ra = rbeg;
+            while (ra < rend) {
+                while (ra < rend && !sValid[ra]) ++ra;
+                if (ra >= rend) break;
+                int rb = ra + 1;
+                while (rb < rend && !sValid[rb]) ++rb;
+                const bool two = rb < rend;
+                const int Ia = sI[ra], Ib = two ? sI[rb] : -1;
+                const LaneMut La = sStrand[ra] ? LR : LF;
+                const LaneMut Lb = (two && sStrand[rb]) ? LR : LF;
+                const float *gamA = sGB + sGoff[ra] + La.c, *betA = sGB + sBoff[ra] + La.q;
+                const float *gamB = sGB + sGoff[two ? rb : ra] + Lb.c, *betB = sGB + sBoff[two ? rb : ra] + Lb.q;
+                const uint8_t *obA = sObs[ra], *obB = sObs[two ? rb : ra];
+                ScoreChain ca, cb;
+                ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f); ca.bq = betA[0];
+                cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f); cb.bq = betB[0];
+                const int Imin = two ? (Ia < Ib ? Ia : Ib) : -1;
+                int i = 0;
+                for (; i < Imin; ++i) {                                    // both chains, neither at its last row
+                    score_step(ca, La, sCTX, gamA, betA, S, i, obA[i], false);
+                    score_step(cb, Lb, sCTX, gamB, betB, S, i, obB[i], false);
                 }
-                const float res = L.fin ? b : acc;
-                const float dd = det_log2f(res) - sBase[r];
-                delta = delta + dd;
+                for (int ia = i; ia <= Ia; ++ia) score_step(ca, La, sCTX, gamA, betA, S, ia, ia < Ia ? obA[ia] : 0, ia == Ia);
+                if (two) for (int ib = i; ib <= Ib; ++ib) score_step(cb, Lb, sCTX, gamB, betB, S, ib, ib < Ib ? obB[ib] : 0, ib == Ib);
+                {
+                    const float res = La.fin ? ca.b : ca.acc;
+                    const float dd = det_log2f(res) - sBase[ra];
+                    delta = delta + dd;
+                }
+                ++nvalid;
+                if (two) {
+                    const float res = Lb.fin ? cb.b : cb.acc;
+                    const float dd = det_log2f(res) - sBase[rb];
+                    delta = delta + dd;
+                    ++nvalid;
+                }
+                ra = two ? rb + 1 : rend;
             }
             rbeg = rend;
         }
