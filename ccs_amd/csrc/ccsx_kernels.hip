@@ -697,7 +697,7 @@ __global__ void k_post(KParams P)
 // reads per loop (two chains), serial over read rows exactly as the SPEC orders the operations.
 #define PW_THREADS 256
 #define PW_MAXREADS 64
-#define GB_FLOATS 14336              // 56 KB of LDS for gamma/beta of one chunk of reads
+#define GB_FLOATS 9216               // 36 KB of LDS for gamma/beta of one chunk of reads (3 workgroups per CU)
 #define MI_STRIDE 13
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
@@ -744,7 +744,7 @@ __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, cons
     s.ap = a; s.bp = b; s.b = b; s.pA = nA; s.pB = nB; s.bq = bqn;
 }
 
-__global__ __launch_bounds__(PW_THREADS, 2) void k_polish(KParams P)
+__global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
 {
     __shared__ float2 sCTX[CCSX_NOBS * 16];                  // [obs][ctx] = (ME, INS)
     __shared__ float sDL[16];
