@@ -586,91 +586,85 @@ __global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
 // in registers.  Instead of storing moves and tracing back every cell, each cell carries the row at which
 // its best path ENTERED the most recent window-edge column ("origin"); at every window-edge column the
 // propagated origins are saved (64 x int32), and the entry rows are recovered by hopping edge to edge.
-__global__ __launch_bounds__(64) void k_align(KParams P)
+__global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
 {
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
     int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] then lo_need[need]
-    for (;;) {
-        int r = 0;
-        if (lane == 0) r = atomicAdd(P.ticket_align, 1);
-        r = bcast_i32(r, 0);
-        if (r >= P.n_reads) break;
-        const int z = P.read_zmw[r];
-        const int r0 = P.read_off[z];
-        if (lane == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
-        if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z]) continue;
-        const int Ld = P.draft_len[z], nw = P.nwin[z];
-        const uint8_t *d = P.draft + P.seq_off[z];
-        const int32_t *wb = P.wbounds + P.wb_off[z];
-        const int I = (int)(P.base_off[r + 1] - P.base_off[r]);
-        const int rev = ((P.flags[r] & 1) != (P.flags[r0] & 1)) ? 1 : 0;
-        __syncthreads();
-        load_read_packed(sread, P.bases + P.base_off[r], I, rev, lane);
-        __syncthreads();
-        const int nneed = 2 * nw;                      // needed columns: 0, b1-2, b1+2, ..., Ld
-        int32_t *lo_need = Osave + (size_t)P.need_max * 64;
-        int kk = 1;                                    // next needed column index
-        int next_need = (nw == 1) ? Ld : wb[1] - CCSX_WIN_OVERHANG;
-        // column 0 = START
-        int Mprev = (lane <= I) ? lane * SC_INS : NEGV;
-        int Oprev = 0;                                 // entry row at column 0 is 0 for every cell
-        int lo = 0, br = 0;
-        for (int j = 1; j <= Ld; ++j) {
+    const int r = rbase + blockIdx.x;                   // launched in chunks of align_slots reads: slot = block
+    if (r >= P.n_reads) return;
+    const int z = rfl(P.read_zmw[r]);
+    const int r0 = rfl(P.read_off[z]);
+    if (lane == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
+    if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z]) return;
+    const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
+    const uint8_t *d = P.draft + P.seq_off[z];
+    const int32_t *wb = P.wbounds + P.wb_off[z];
+    const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
+    const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0] & 1)) ? 1 : 0);
+    load_read_packed(sread, P.bases + P.base_off[r], I, rev, lane);
+    __syncthreads();
+    const int nneed = 2 * nw;                           // needed columns: 0, b1-2, b1+2, ..., Ld
+    int32_t *lo_need = Osave + (size_t)P.need_max * 64;
+    int kk = 1;                                         // next needed column index
+    int next_need = (nw == 1) ? Ld : rfl(wb[1]) - CCSX_WIN_OVERHANG;
+    // column 0 = START
+    int Mprev = (lane <= I) ? lane * SC_INS : NEGV;
+    int Oprev = 0;                                      // entry row at column 0 is 0 for every cell
+    int lo = 0, br = 0;
+    for (int jb = 0; jb < Ld; jb += LANES) {            // draft bases: one coalesced load per 64 columns
+        const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
+        const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
+        for (int jj = 0; jj < nblk; ++jj) {
+            const int j = jb + jj + 1;
             const int plo = lo;
-            lo = band_lo(plo, br, I);
-            const int sh = lo - plo;                   // 0..2
+            lo = rfl(band_lo(plo, br, I));
+            const int sh = lo - plo;                    // 0..2
             const int i = lo + lane;
-            const int vb = d[j - 1];
+            const int vb = rl(dL, jj);
             const int rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
-            const int o1 = lane + sh - 1, o0 = lane + sh;
-            int xs = __shfl(Mprev, o1 & 63), ys = __shfl(Mprev, o0 & 63);
-            int oxs = __shfl(Oprev, o1 & 63), oys = __shfl(Oprev, o0 & 63);
-            int x = (o1 >= 0 && o1 < LANES) ? xs : NEGV;
-            int y = (o0 < LANES) ? ys : NEGV;
+            int x, y, ox, oy;
+            if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; ox = wave_shr1_i32(Oprev, 0); oy = Oprev; }
+            else if (sh == 1) { x = Mprev; y = wave_shl1_i32(Mprev, NEGV); ox = Oprev; oy = wave_shl1_i32(Oprev, 0); }
+            else { x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); ox = wave_shl1_i32(Oprev, 0); oy = wave_shl1_i32(ox, 0); }
             int best = NEGV, org = 0;
-            if (i >= 1 && i <= I && x > NEGV / 2) { best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); org = oxs; }
-            if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; org = oys; } }
+            if (i >= 1 && i <= I && x > NEGV / 2) { best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); org = ox; }
+            if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; org = oy; } }
             const bool need = (j == next_need);
             if (need) {
-                Osave[(size_t)kk * 64 + lane] = org;   // origin (previous edge) of the cell's entry move
+                Osave[(size_t)kk * 64 + lane] = org;    // origin (previous edge) of the cell's entry move
                 if (lane == 0) lo_need[kk] = lo;
-                org = i;                               // reset: this column is the new edge
+                org = i;                                // reset: this column is the new edge
             }
             int dd = best + 4 * lane, od = org;
-#pragma unroll
-            for (int s = 1; s < LANES; s <<= 1) {
-                int o = __shfl_up(dd, s), oo = __shfl_up(od, s);
-                if (lane >= s && o > dd) { dd = o; od = oo; }
-            }
-            int xi = dd - 4 * lane;
+            wave_scan_max_pair(dd, od);
+            const int xi = dd - 4 * lane;
             if (xi > best) { best = xi; org = od; }
             if (i > I || best < NEGV / 2) best = NEGV;
-            const int cm = wave_max_i32(best);
+            const int cm = wave_reduce_max_i32(best);
             const unsigned long long bal = __ballot(best == cm);
             br = lo + (__ffsll((long long)bal) - 1);
             Mprev = best; Oprev = org;
             if (need) {
                 ++kk;
-                next_need = (kk >= nneed) ? -1 : ((kk == nneed - 1) ? Ld : wb[(kk + 1) >> 1] + ((kk & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
+                next_need = (kk >= nneed) ? -1 : ((kk == nneed - 1) ? Ld : rfl(wb[(kk + 1) >> 1]) + ((kk & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
             }
         }
-        const int oe = I - lo;
-        int sc = NEGV, eLast = 0;
-        if (oe >= 0 && oe < LANES) { sc = __shfl(Mprev, oe); eLast = __shfl(Oprev, oe); }
-        int valid = (sc > NEGV / 2 && sc >= Ld) ? 1 : 0;
-        __threadfence_block();
-        if (lane == 0) {
-            P.ascore[r] = sc; P.avalid[r] = (uint8_t)valid;
-            if (valid) {
-                int32_t *ent = P.ent + P.ent_off[r];
-                int e = eLast;
-                ent[nneed - 1] = e;
-                for (int k2 = nneed - 1; k2 >= 2; --k2) { e = Osave[(size_t)k2 * 64 + (e - lo_need[k2])]; ent[k2 - 1] = e; }
-                ent[0] = 0;
-            }
+    }
+    const int oe = I - lo;
+    int sc = NEGV, eLast = 0;
+    if (oe >= 0 && oe < LANES) { sc = rl(Mprev, oe); eLast = rl(Oprev, oe); }
+    const int valid = (sc > NEGV / 2 && sc >= Ld) ? 1 : 0;
+    __threadfence_block();
+    if (lane == 0) {
+        P.ascore[r] = sc; P.avalid[r] = (uint8_t)valid;
+        if (valid) {
+            int32_t *ent = P.ent + P.ent_off[r];
+            int e = eLast;
+            ent[nneed - 1] = e;
+            for (int k2 = nneed - 1; k2 >= 2; --k2) { e = Osave[(size_t)k2 * 64 + (e - lo_need[k2])]; ent[k2 - 1] = e; }
+            ent[0] = 0;
         }
-        __threadfence_block();
     }
 }
 
@@ -1141,7 +1135,10 @@ void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or 
     }
     trace_sync(st, "k_poa");
     if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_align, dim3(P.align_slots), dim3(64), lds_read, st, P);
+    for (int rb = 0; rb < P.n_reads; rb += P.align_slots) {
+        const int nb = (P.n_reads - rb) < P.align_slots ? (P.n_reads - rb) : P.align_slots;
+        hipLaunchKernelGGL(k_align, dim3(nb), dim3(64), lds_read, st, P, rb);
+    }
     trace_sync(st, "k_align");
     hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P);
     if (ev) (void)hipEventRecord(ev[3], st);

@@ -46,3 +46,24 @@ __device__ __forceinline__ int wave_scan_add_i32(int v)
 // wave-wide maximum, returned uniformly (scan + readlane 63)
 __device__ __forceinline__ int wave_reduce_max_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_max_i32(v), 63); }
 __device__ __forceinline__ int wave_reduce_add_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_add_i32(v), 63); }
+
+// inclusive prefix "arg-max" over the 64 lanes for pairs (d, o): the pair of a lower lane replaces the running
+// pair only if its d is strictly greater (ties keep the higher lane), o rides along.  7 steps, DPP only.
+#define WAVE_PAIR_STEP(SRC_D, SRC_O, CTRL, RM, BM)                                                    \
+    {                                                                                                 \
+        const int td = __builtin_amdgcn_update_dpp(d, SRC_D, CTRL, RM, BM, false);                    \
+        const int to = __builtin_amdgcn_update_dpp(o, SRC_O, CTRL, RM, BM, false);                    \
+        const bool take = td > d;                                                                     \
+        d = take ? td : d; o = take ? to : o;                                                         \
+    }
+__device__ __forceinline__ void wave_scan_max_pair(int &d, int &o)
+{
+    const int d0 = d, o0 = o;
+    WAVE_PAIR_STEP(d0, o0, DPP_ROW_SHR(1), 0xf, 0xf)
+    WAVE_PAIR_STEP(d0, o0, DPP_ROW_SHR(2), 0xf, 0xf)
+    WAVE_PAIR_STEP(d0, o0, DPP_ROW_SHR(3), 0xf, 0xf)
+    WAVE_PAIR_STEP(d, o, DPP_ROW_SHR(4), 0xf, 0xe)
+    WAVE_PAIR_STEP(d, o, DPP_ROW_SHR(8), 0xf, 0xc)
+    WAVE_PAIR_STEP(d, o, DPP_ROW_BCAST15, 0xa, 0xf)
+    WAVE_PAIR_STEP(d, o, DPP_ROW_BCAST31, 0xc, 0xf)
+}

@@ -28,3 +28,4 @@ int main()
     }
     printf("wave_ops mismatches: %d\n", bad); return bad != 0;
 }
+// (pair scan is validated end-to-end by the alignment parity tests)
