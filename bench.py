@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--zmws", type=int, default=2048, help="ZMWs per GPU per step")
+    ap.add_argument("--zmws", type=int, default=4096, help="ZMWs per GPU per step")
     ap.add_argument("--passes", type=int, default=10)
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")

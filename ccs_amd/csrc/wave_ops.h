@@ -19,16 +19,18 @@ __device__ __forceinline__ float wave_shl1_f32(float x, float fill) { return __i
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// inclusive prefix maximum over the 64 lanes (7 DPP ops)
+// inclusive prefix maximum over the 64 lanes.  `old` = INT_MIN (the identity of max) lets the DPP combiner
+// fold every move into its v_max_i32_dpp: 7 VALU ops in total.
+#define WAVE_IMIN ((int)0x80000000)
 __device__ __forceinline__ int wave_scan_max_i32(int v)
 {
-    int s = imax(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_SHR(2), 0xf, 0xf, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_SHR(3), 0xf, 0xf, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(s, s, DPP_ROW_SHR(4), 0xf, 0xe, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(s, s, DPP_ROW_SHR(8), 0xf, 0xc, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(s, s, DPP_ROW_BCAST15, 0xa, 0xf, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(s, s, DPP_ROW_BCAST31, 0xc, 0xf, false));
+    int s = imax(v, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_SHR(2), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_SHR(3), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(4), 0xf, 0xe, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(8), 0xf, 0xc, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_BCAST15, 0xa, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_BCAST31, 0xc, 0xf, false));
     return s;
 }
 // inclusive prefix sum over the 64 lanes
