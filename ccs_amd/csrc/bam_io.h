@@ -1,0 +1,394 @@
+// bam_io.h — minimal PacBio-BAM reader / writer for the `ccs` driver (App. B).
+//
+// BGZF = concatenated gzip members (<= 64 KiB each, BC extra field carries the block size): blocks are
+// independent, so inflate / deflate run on a thread pool and are re-ordered (the reference's "-j" threads,
+// docs/faq/parallelize.md:17).  Records are unaligned (FLAG 4) PacBio subreads with the tags this path needs:
+// zm:i hole number, sn:B,f SNR (A,C,G,T), pw:B,C|S pulse widths, ip:B,C|S, cx:i local context
+// (docs/faq/bam-output.md:9-30, docs/faq/missing-adapters.md:11-12).  htslib/pbbam are not in the image;
+// zlib is.
+#pragma once
+#include <zlib.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <future>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace bamio {
+
+// ---------------------------------------------------------------------------------------------- thread pool
+class ThreadPool {
+public:
+    explicit ThreadPool(int n)
+    {
+        if (n < 1) n = 1;
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { run(); });
+    }
+    ~ThreadPool()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    template <class F> auto submit(F f) -> std::future<decltype(f())>
+    {
+        auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::move(f));
+        auto fut = task->get_future();
+        { std::lock_guard<std::mutex> l(m_); q_.emplace_back([task] { (*task)(); }); }
+        cv_.notify_one();
+        return fut;
+    }
+    int size() const { return (int)workers_.size(); }
+
+private:
+    void run()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return stop_ || !q_.empty(); });
+                if (stop_ && q_.empty()) return;
+                f = std::move(q_.front()); q_.pop_front();
+            }
+            f();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::deque<std::function<void()>> q_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+// ---------------------------------------------------------------------------------------------- BGZF
+inline std::vector<uint8_t> inflate_block(const std::vector<uint8_t> &blk)
+{
+    // blk = one whole gzip member; payload starts after the 12-byte header + XLEN extra, ends 8 bytes before the end
+    const size_t xlen = blk[10] | (blk[11] << 8);
+    const size_t off = 12 + xlen;
+    const uint32_t isize = blk[blk.size() - 4] | (blk[blk.size() - 3] << 8) | (blk[blk.size() - 2] << 16) | ((uint32_t)blk[blk.size() - 1] << 24);
+    std::vector<uint8_t> out(isize);
+    if (isize == 0) return out;
+    z_stream zs; std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+    zs.next_in = const_cast<Bytef *>(blk.data() + off); zs.avail_in = (uInt)(blk.size() - off - 8);
+    zs.next_out = out.data(); zs.avail_out = isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) throw std::runtime_error("BGZF block does not inflate");
+    return out;
+}
+
+inline std::vector<uint8_t> deflate_block(const uint8_t *data, size_t n, int level)
+{
+    std::vector<uint8_t> out(18 + compressBound((uLong)n) + 8);
+    static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    std::memcpy(out.data(), hdr, 16);
+    z_stream zs; std::memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    zs.next_in = const_cast<Bytef *>(data); zs.avail_in = (uInt)n;
+    zs.next_out = out.data() + 18; zs.avail_out = (uInt)(out.size() - 18 - 8);
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) throw std::runtime_error("deflate failed");
+    const size_t total = 18 + clen + 8;
+    if (total > 65536) throw std::runtime_error("BGZF block too large");
+    out[16] = (uint8_t)((total - 1) & 0xff); out[17] = (uint8_t)((total - 1) >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n);
+    uint8_t *t = out.data() + 18 + clen;
+    for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i));
+    for (int i = 0; i < 4; ++i) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+    out.resize(total);
+    return out;
+}
+
+class BgzfReader {   // sequential compressed read, pooled inflate, in-order byte stream
+public:
+    BgzfReader(const std::string &path, ThreadPool &pool, int lookahead = 64) : pool_(pool), lookahead_(lookahead)
+    {
+        f_ = std::fopen(path.c_str(), "rb");
+        if (!f_) throw std::runtime_error("cannot open " + path);
+    }
+    ~BgzfReader() { if (f_) std::fclose(f_); }
+    // read exactly n bytes; returns false on clean EOF at a record boundary (n bytes not available)
+    bool read(void *dst, size_t n)
+    {
+        uint8_t *d = (uint8_t *)dst;
+        while (n > 0) {
+            if (pos_ == cur_.size()) { if (!next_block()) return false; continue; }
+            const size_t k = std::min(n, cur_.size() - pos_);
+            std::memcpy(d, cur_.data() + pos_, k);
+            d += k; pos_ += k; n -= k;
+        }
+        return true;
+    }
+
+private:
+    bool next_block()
+    {
+        while (!eof_ && (int)pending_.size() < lookahead_) {
+            uint8_t h[18];
+            const size_t got = std::fread(h, 1, 18, f_);
+            if (got == 0) { eof_ = true; break; }
+            if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) throw std::runtime_error("not a BGZF file");
+            // find the BC subfield
+            const size_t xlen = h[10] | (h[11] << 8);
+            std::vector<uint8_t> blk(18);
+            std::memcpy(blk.data(), h, 18);
+            size_t bsize = 0;
+            if (h[12] == 'B' && h[13] == 'C') bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
+            else {   // BC is not the first extra subfield: read the whole extra area
+                blk.resize(12 + xlen);
+                if (std::fread(blk.data() + 18, 1, 12 + xlen - 18, f_) != 12 + xlen - 18) throw std::runtime_error("truncated BGZF header");
+                for (size_t p = 12; p + 4 <= 12 + xlen;) {
+                    const size_t sl = blk[p + 2] | (blk[p + 3] << 8);
+                    if (blk[p] == 'B' && blk[p + 1] == 'C') bsize = (size_t)(blk[p + 4] | (blk[p + 5] << 8)) + 1;
+                    p += 4 + sl;
+                }
+                if (!bsize) throw std::runtime_error("BGZF block without BC field");
+            }
+            const size_t have = blk.size();
+            blk.resize(bsize);
+            if (std::fread(blk.data() + have, 1, bsize - have, f_) != bsize - have) throw std::runtime_error("truncated BGZF block");
+            auto sp = std::make_shared<std::vector<uint8_t>>(std::move(blk));
+            pending_.push_back(pool_.submit([sp] { return inflate_block(*sp); }));
+        }
+        if (pending_.empty()) return false;
+        cur_ = pending_.front().get(); pending_.pop_front(); pos_ = 0;
+        return true;
+    }
+    ThreadPool &pool_;
+    int lookahead_;
+    FILE *f_ = nullptr;
+    bool eof_ = false;
+    std::deque<std::future<std::vector<uint8_t>>> pending_;
+    std::vector<uint8_t> cur_;
+    size_t pos_ = 0;
+};
+
+class BgzfWriter {   // pooled deflate, in-order write
+public:
+    BgzfWriter(const std::string &path, ThreadPool &pool, int level = 4) : pool_(pool), level_(level)
+    {
+        f_ = std::fopen(path.c_str(), "wb");
+        if (!f_) throw std::runtime_error("cannot create " + path);
+    }
+    ~BgzfWriter() { try { close(); } catch (...) {} }
+    void write(const void *src, size_t n)
+    {
+        const uint8_t *s = (const uint8_t *)src;
+        while (n > 0) {
+            const size_t k = std::min(n, kBlock - buf_.size());
+            buf_.insert(buf_.end(), s, s + k);
+            s += k; n -= k;
+            if (buf_.size() == kBlock) flush_block();
+        }
+    }
+    void close()
+    {
+        if (!f_) return;
+        if (!buf_.empty()) flush_block();
+        drain(0);
+        static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        std::fwrite(eof, 1, 28, f_);
+        std::fclose(f_); f_ = nullptr;
+    }
+
+private:
+    static constexpr size_t kBlock = 0xff00;
+    void flush_block()
+    {
+        auto sp = std::make_shared<std::vector<uint8_t>>(std::move(buf_));
+        buf_.clear(); buf_.reserve(kBlock);
+        const int lvl = level_;
+        pending_.push_back(pool_.submit([sp, lvl] { return deflate_block(sp->data(), sp->size(), lvl); }));
+        drain(128);
+    }
+    void drain(size_t keep)
+    {
+        while (pending_.size() > keep) {
+            const std::vector<uint8_t> c = pending_.front().get(); pending_.pop_front();
+            if (std::fwrite(c.data(), 1, c.size(), f_) != c.size()) throw std::runtime_error("short write");
+        }
+    }
+    ThreadPool &pool_;
+    int level_;
+    FILE *f_ = nullptr;
+    std::vector<uint8_t> buf_;
+    std::deque<std::future<std::vector<uint8_t>>> pending_;
+};
+
+// ---------------------------------------------------------------------------------------------- BAM records
+struct Subread {
+    std::string name;
+    int32_t zm = -1;
+    int32_t cx = -1;            // -1: tag absent
+    float snr[4] = {0, 0, 0, 0};
+    bool has_snr = false, has_n = false;
+    std::vector<uint8_t> bases;  // 0..3
+    std::vector<uint8_t> pw, ipd;
+};
+
+struct BamHeader {
+    std::string text;
+    std::vector<std::pair<std::string, uint32_t>> refs;
+};
+
+inline uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+inline bool read_header(BgzfReader &in, BamHeader &h)
+{
+    uint8_t magic[4];
+    if (!in.read(magic, 4) || std::memcmp(magic, "BAM\1", 4)) throw std::runtime_error("not a BAM file");
+    uint8_t b4[4];
+    in.read(b4, 4);
+    h.text.resize(rd32(b4));
+    if (!h.text.empty()) in.read(&h.text[0], h.text.size());
+    in.read(b4, 4);
+    const uint32_t nref = rd32(b4);
+    for (uint32_t i = 0; i < nref; ++i) {
+        in.read(b4, 4);
+        std::string nm(rd32(b4), '\0');
+        in.read(&nm[0], nm.size());
+        in.read(b4, 4);
+        h.refs.emplace_back(nm.c_str(), rd32(b4));
+    }
+    return true;
+}
+
+// CodecV1 frames -> pulse-width / IPD value (only min(pw,3) matters to the HMM; clamp to 255)
+inline uint8_t codec_v1(uint8_t c)
+{
+    unsigned v = c < 64 ? c : (c < 128 ? 64 + (c - 64) * 2 : (c < 192 ? 192 + (c - 128) * 4 : 448 + (c - 192) * 8));
+    return (uint8_t)(v > 255 ? 255 : v);
+}
+
+inline size_t tag_value_size(char t)
+{
+    switch (t) { case 'c': case 'C': case 'A': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; }
+}
+
+inline bool read_subread(BgzfReader &in, std::vector<uint8_t> &buf, Subread &r)
+{
+    uint8_t b4[4];
+    if (!in.read(b4, 4)) return false;
+    const uint32_t bs = rd32(b4);
+    buf.resize(bs);
+    if (!in.read(buf.data(), bs)) throw std::runtime_error("truncated BAM record");
+    const uint8_t *p = buf.data();
+    const uint32_t l_name = p[8], n_cig = p[12] | (p[13] << 8), l_seq = rd32(p + 16);
+    r = Subread();
+    r.name.assign((const char *)p + 32, l_name ? l_name - 1 : 0);
+    const uint8_t *seq = p + 32 + l_name + 4 * n_cig;
+    r.bases.resize(l_seq);
+    static const int8_t nib2code[16] = {-1, 0, 1, -1, 2, -1, -1, -1, 3, -1, -1, -1, -1, -1, -1, -1};
+    for (uint32_t i = 0; i < l_seq; ++i) {
+        const int nib = (seq[i >> 1] >> ((i & 1) ? 0 : 4)) & 15;
+        const int c = nib2code[nib];
+        if (c < 0) { r.has_n = true; r.bases[i] = 0; } else r.bases[i] = (uint8_t)c;
+    }
+    const uint8_t *t = seq + (l_seq + 1) / 2 + l_seq, *end = buf.data() + bs;
+    while (t + 3 <= end) {
+        const char t0 = (char)t[0], t1 = (char)t[1], ty = (char)t[2];
+        t += 3;
+        auto rdint = [&](char tt, const uint8_t *q) -> int64_t {
+            switch (tt) {
+                case 'c': return (int8_t)q[0]; case 'C': return q[0];
+                case 's': return (int16_t)(q[0] | (q[1] << 8)); case 'S': return (uint16_t)(q[0] | (q[1] << 8));
+                case 'i': return (int32_t)rd32(q); case 'I': return rd32(q);
+                default: return 0;
+            }
+        };
+        if (ty == 'Z' || ty == 'H') { while (t < end && *t) ++t; ++t; continue; }
+        if (ty == 'B') {
+            const char st = (char)t[0];
+            const uint32_t n = rd32(t + 1);
+            const uint8_t *q = t + 5;
+            const size_t es = tag_value_size(st);
+            if (t0 == 's' && t1 == 'n' && st == 'f' && n == 4) { std::memcpy(r.snr, q, 16); r.has_snr = true; }
+            else if ((t0 == 'p' && t1 == 'w') || (t0 == 'i' && t1 == 'p')) {
+                std::vector<uint8_t> &dst = (t0 == 'p') ? r.pw : r.ipd;
+                dst.resize(n);
+                for (uint32_t i = 0; i < n; ++i) {
+                    if (es == 1) dst[i] = codec_v1(q[i]);
+                    else { const int64_t v = rdint(st, q + i * es); dst[i] = (uint8_t)(v > 255 ? 255 : (v < 0 ? 0 : v)); }
+                }
+            }
+            t = q + (size_t)n * es;
+            continue;
+        }
+        const size_t vs = tag_value_size(ty);
+        if (!vs) throw std::runtime_error("unknown BAM tag type");
+        if (t0 == 'z' && t1 == 'm') r.zm = (int32_t)rdint(ty, t);
+        else if (t0 == 'c' && t1 == 'x') r.cx = (int32_t)rdint(ty, t);
+        t += vs;
+    }
+    return true;
+}
+
+// ---- record builders -------------------------------------------------------------------------------
+struct RecordBuilder {
+    std::vector<uint8_t> b;
+    void u32(uint32_t v) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+    void begin(const std::string &name, const uint8_t *bases, const uint8_t *qual, uint32_t n)
+    {
+        b.clear();
+        u32(0);                               // block size, patched in finish()
+        u32((uint32_t)-1); u32((uint32_t)-1); // refID, pos
+        b.push_back((uint8_t)(name.size() + 1)); b.push_back(255);   // l_read_name, mapq
+        b.push_back(4680 & 0xff); b.push_back(4680 >> 8);            // bin
+        b.push_back(0); b.push_back(0);                              // n_cigar
+        b.push_back(4); b.push_back(0);                              // flag = unmapped
+        u32(n); u32((uint32_t)-1); u32((uint32_t)-1); u32(0);
+        b.insert(b.end(), name.begin(), name.end()); b.push_back(0);
+        static const uint8_t code2nib[4] = {1, 2, 4, 8};
+        for (uint32_t i = 0; i < n; i += 2) {
+            const uint8_t hi = code2nib[bases[i] & 3], lo = (i + 1 < n) ? code2nib[bases[i + 1] & 3] : 0;
+            b.push_back((uint8_t)((hi << 4) | lo));
+        }
+        if (qual) b.insert(b.end(), qual, qual + n); else b.insert(b.end(), n, 0xff);
+    }
+    void tagZ(const char *t, const std::string &v) { b.push_back(t[0]); b.push_back(t[1]); b.push_back('Z'); b.insert(b.end(), v.begin(), v.end()); b.push_back(0); }
+    void tagi(const char *t, int32_t v) { b.push_back(t[0]); b.push_back(t[1]); b.push_back('i'); u32((uint32_t)v); }
+    void tagC(const char *t, uint8_t v) { b.push_back(t[0]); b.push_back(t[1]); b.push_back('C'); b.push_back(v); }
+    void tagf(const char *t, float v) { uint32_t u; std::memcpy(&u, &v, 4); b.push_back(t[0]); b.push_back(t[1]); b.push_back('f'); u32(u); }
+    void tagBf(const char *t, const float *v, uint32_t n)
+    {
+        b.push_back(t[0]); b.push_back(t[1]); b.push_back('B'); b.push_back('f'); u32(n);
+        for (uint32_t i = 0; i < n; ++i) { uint32_t u; std::memcpy(&u, v + i, 4); u32(u); }
+    }
+    void tagBC(const char *t, const uint8_t *v, uint32_t n)
+    {
+        b.push_back(t[0]); b.push_back(t[1]); b.push_back('B'); b.push_back('C'); u32(n);
+        b.insert(b.end(), v, v + n);
+    }
+    void finish(BgzfWriter &out)
+    {
+        const uint32_t bs = (uint32_t)b.size() - 4;
+        for (int i = 0; i < 4; ++i) b[i] = (uint8_t)(bs >> (8 * i));
+        out.write(b.data(), b.size());
+    }
+};
+
+inline void write_header(BgzfWriter &out, const std::string &text)
+{
+    out.write("BAM\1", 4);
+    uint8_t b4[4];
+    const uint32_t n = (uint32_t)text.size();
+    for (int i = 0; i < 4; ++i) b4[i] = (uint8_t)(n >> (8 * i));
+    out.write(b4, 4); out.write(text.data(), n);
+    std::memset(b4, 0, 4); out.write(b4, 4);   // n_ref = 0
+}
+
+}  // namespace bamio

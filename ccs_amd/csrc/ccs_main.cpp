@@ -1,0 +1,464 @@
+// ccs — `ccs [options] IN.subreads.bam OUT.bam` on MI355X (reference CLI: docs/index.md:52-64,
+// docs/faq/parallelize.md:8-20; flag spellings from SURVEY.md App. C).
+//
+// Pipeline (the reference's docs/img/ccs-impl.png with the GPU consumers only):
+//   reader thread   BGZF inflate on the -j pool -> subread records -> ZMW grouping -> step-1 filters
+//                   (docs/how-does-ccs-work.md:19-32) -> SoA batches of --batch-size ZMWs
+//   GPU workers     one per device, each owns a ccsx_handle: ccsx_consensus_batch (draft + polish on the GPU)
+//   writer          restores input order, writes hifi BAM records with tags rq np ec sn zm RG
+//                   (docs/faq/bam-output.md:9-30), BGZF deflate on the pool, ccs_report.txt
+//                   (docs/faq/reports-aux-files.md:16-72)
+// There is no CPU consensus fallback: without a gfx950 device the program exits with an error.
+#include <algorithm>
+#include <chrono>
+#include <cinttypes>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bam_io.h"
+#include "ccsx.h"
+
+using namespace bamio;
+
+namespace {
+
+struct Options {
+    std::string in, out, report;
+    int threads = 0;
+    double min_snr = 2.5;
+    int batch = 2048;
+    int chunk_i = 1, chunk_n = 1;
+    std::vector<int> gpus;
+    ccsx_opts o;
+    bool all_gpus = false;
+    std::string write_synth;      // "N,P,L[,seed]" -> write a synthetic subreads.bam to `out`
+    bool dump = false;            // print one line per ZMW after the step-1 filters, no GPU
+    int log_level = 1;
+};
+
+enum HostStatus { HS_OK = 0, HS_POOR_SNR = 100, HS_NO_SUBREADS = 101, HS_TOO_FEW = 102 };
+
+struct ZmwIn {
+    int32_t zm = 0;
+    float snr[4] = {0, 0, 0, 0};
+    std::vector<Subread> reads;   // after filters: full-length passes only
+    int host_status = HS_OK;
+    int64_t order = 0;
+};
+
+struct Batch {
+    int64_t index = 0;
+    std::vector<ZmwIn> zmws;      // including host-failed ones (they are only counted)
+    // SoA of the ZMWs with host_status == OK
+    std::vector<int32_t> zmw_id, read_off;
+    std::vector<float> snr;
+    std::vector<int64_t> base_off;
+    std::vector<uint8_t> bases, pw, ipd, flags;
+    std::vector<int> slot;        // per zmws[]: index into the SoA or -1
+    // results
+    std::vector<int64_t> seq_off;
+    std::vector<int32_t> status, seq_len, np, iters, n_windows;
+    std::vector<uint8_t> seq, qual;
+    std::vector<float> rq, ec;
+};
+
+template <class T> class Channel {
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    void push(T v)
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_full_.wait(l, [this] { return q_.size() < cap_; });
+        q_.push(std::move(v));
+        cv_empty_.notify_one();
+    }
+    bool pop(T &v)
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_empty_.wait(l, [this] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front()); q_.pop();
+        cv_full_.notify_one();
+        return true;
+    }
+    void close() { std::lock_guard<std::mutex> l(m_); closed_ = true; cv_empty_.notify_all(); }
+
+private:
+    std::queue<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+    std::mutex m_;
+    std::condition_variable cv_full_, cv_empty_;
+};
+
+void usage()
+{
+    std::fprintf(stderr,
+                 "ccs (MI355X) - generate HiFi reads from PacBio subreads\n"
+                 "usage: ccs [options] IN.subreads.bam OUT.bam\n"
+                 "  -j, --num-threads N       host threads for BAM (de)compression [all]\n"
+                 "      --min-passes N        minimum full-length passes [3]\n"
+                 "      --top-passes N        use at most N passes, 0 = all [60]\n"
+                 "      --min-snr F           minimum SNR of a ZMW [2.5]\n"
+                 "      --min-length N        minimum draft length [10]\n"
+                 "      --max-length N        maximum draft length [50000]\n"
+                 "      --min-rq F            minimum predicted accuracy [0.99]\n"
+                 "      --maxPoaCoverage N    subreads used for the draft [10]\n"
+                 "      --chunk i/N           process only the i-th of N ZMW chunks\n"
+                 "      --batch-size N        ZMWs per GPU batch [2048]\n"
+                 "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"
+                 "      --report-file F       ccs_report.txt path [<OUT prefix>.ccs_report.txt]\n"
+                 "      --log-level L         ERROR|WARN|INFO [WARN]\n"
+                 "  test helpers (not in the reference):\n"
+                 "      --write-synthetic N,P,L[,seed]  write a synthetic subreads.bam to OUT (no IN)\n"
+                 "      --dump-zmws                     list ZMWs after the step-1 filters (no GPU, no OUT)\n");
+}
+
+bool parse(int argc, char **argv, Options &o)
+{
+    ccsx_opts_default(&o.o);
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&](const char *n) -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", n); std::exit(2); } return argv[++i]; };
+        if (a == "-h" || a == "--help") { usage(); std::exit(0); }
+        else if (a == "-j" || a == "--num-threads") o.threads = std::atoi(need("-j").c_str());
+        else if (a == "--min-passes") o.o.min_passes = std::atoi(need(a.c_str()).c_str());
+        else if (a == "--top-passes") o.o.top_passes = std::atoi(need(a.c_str()).c_str());
+        else if (a == "--min-snr") o.min_snr = std::atof(need(a.c_str()).c_str());
+        else if (a == "--min-length") o.o.min_length = std::atoi(need(a.c_str()).c_str());
+        else if (a == "--max-length") o.o.max_length = std::atoi(need(a.c_str()).c_str());
+        else if (a == "--min-rq") o.o.min_rq = (float)std::atof(need(a.c_str()).c_str());
+        else if (a == "--maxPoaCoverage") o.o.max_poa_cov = std::atoi(need(a.c_str()).c_str());
+        else if (a == "--batch-size") o.batch = std::atoi(need(a.c_str()).c_str());
+        else if (a == "--report-file") o.report = need(a.c_str());
+        else if (a == "--chunk") { if (std::sscanf(need(a.c_str()).c_str(), "%d/%d", &o.chunk_i, &o.chunk_n) != 2 || o.chunk_i < 1 || o.chunk_i > o.chunk_n) { std::fprintf(stderr, "bad --chunk\n"); return false; } }
+        else if (a == "--gpus") { std::string v = need(a.c_str()); if (v == "all") o.all_gpus = true; else { size_t p = 0; while (p < v.size()) { o.gpus.push_back(std::atoi(v.c_str() + p)); p = v.find(',', p); if (p == std::string::npos) break; ++p; } } }
+        else if (a == "--log-level") { std::string v = need(a.c_str()); o.log_level = v == "INFO" ? 2 : (v == "ERROR" ? 0 : 1); }
+        else if (a == "--write-synthetic") o.write_synth = need(a.c_str());
+        else if (a == "--dump-zmws") o.dump = true;
+        else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
+        else pos.push_back(a);
+    }
+    if (!o.write_synth.empty()) { if (pos.size() != 1) return false; o.out = pos[0]; return true; }
+    if (o.dump) { if (pos.size() != 1) return false; o.in = pos[0]; return true; }
+    if (pos.size() != 2) return false;
+    o.in = pos[0]; o.out = pos[1];
+    if (o.report.empty()) { std::string p = o.out; const size_t d = p.rfind(".bam"); if (d != std::string::npos) p = p.substr(0, d); o.report = p + ".ccs_report.txt"; }
+    if (o.batch < 1) o.batch = 1;
+    return true;
+}
+
+std::string movie_of(const std::string &qname) { const size_t p = qname.find('/'); return p == std::string::npos ? qname : qname.substr(0, p); }
+
+// ---- synthetic subreads.bam (test helper) ----------------------------------------------------------
+int write_synthetic(const Options &o, ThreadPool &pool)
+{
+    int n = 0, P = 0, L = 0; unsigned long long seed = 1;
+    if (std::sscanf(o.write_synth.c_str(), "%d,%d,%d,%llu", &n, &P, &L, &seed) < 3) { std::fprintf(stderr, "bad --write-synthetic\n"); return 2; }
+    ccsx_synth *s = nullptr;
+    if (ccsx_synth_generate(n, 1000, P, P, L, L, seed, &s)) { std::fprintf(stderr, "%s\n", ccsx_last_error()); return 1; }
+    BgzfWriter out(o.out, pool);
+    const std::string movie = "m64000_synth";
+    write_header(out, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:synth001\tPL:PACBIO\tDS:READTYPE=SUBREAD;Ipd:CodecV1=ip;PulseWidth:CodecV1=pw;"
+                      "BINDINGKIT=101-789-500;SEQUENCINGKIT=101-826-100;BASECALLERVERSION=5.0.0;FRAMERATEHZ=100.000000\tPU:" + movie + "\tPM:SEQUELII\n");
+    const ccsx_batch &b = s->batch;
+    RecordBuilder rb;
+    for (int z = 0; z < b.n_zmw; ++z) {
+        int64_t q = 0;
+        for (int r = b.read_off[z]; r < b.read_off[z + 1]; ++r) {
+            const int64_t a = b.base_off[r], len = b.base_off[r + 1] - a;
+            const std::string name = movie + "/" + std::to_string(b.zmw_id[z]) + "/" + std::to_string(q) + "_" + std::to_string(q + len);
+            rb.begin(name, b.bases + a, nullptr, (uint32_t)len);
+            rb.tagZ("RG", "synth001");
+            rb.tagi("zm", b.zmw_id[z]);
+            rb.tagi("qs", (int32_t)q); rb.tagi("qe", (int32_t)(q + len));
+            rb.tagf("rq", 0.8f);
+            rb.tagBf("sn", b.snr + 4 * z, 4);
+            rb.tagBC("ip", b.ipd + a, (uint32_t)len);
+            rb.tagBC("pw", b.pw + a, (uint32_t)len);
+            rb.tagC("cx", (uint8_t)(3 | ((b.flags[r] & 1) ? 32 : 16)));      // ADAPTER_BEFORE|AFTER + FORWARD/REVERSE_PASS
+            rb.finish(out);
+            q += len + 45;
+        }
+    }
+    out.close();
+    ccsx_synth_free(s);
+    return 0;
+}
+
+// ---- step-1 filters (docs/how-does-ccs-work.md:19-32) ----------------------------------------------
+void finish_zmw(ZmwIn &z, const Options &o)
+{
+    if (z.reads.empty()) { z.host_status = HS_NO_SUBREADS; return; }
+    float mn = z.snr[0];
+    for (int c = 1; c < 4; ++c) mn = std::min(mn, z.snr[c]);
+    if (mn < (float)o.min_snr) { z.host_status = HS_POOR_SNR; z.reads.clear(); return; }
+    std::vector<size_t> lens;
+    for (auto &r : z.reads) lens.push_back(r.bases.size());
+    std::vector<size_t> s = lens;
+    std::nth_element(s.begin(), s.begin() + s.size() / 2, s.end());
+    const double med = (double)s[s.size() / 2];
+    std::vector<Subread> keep;
+    bool any_len_ok = false;
+    for (auto &r : z.reads) {
+        const double l = (double)r.bases.size();
+        if (l < 0.5 * med || l > 2.0 * med) continue;            // length filter
+        any_len_ok = true;
+        const bool full = (r.cx < 0) || ((r.cx & 3) == 3);       // flanked by adapters (docs/faq/accuracy-vs-passes.md:17-18)
+        if (!full || r.has_n || r.bases.empty()) continue;
+        if (r.pw.size() != r.bases.size()) r.pw.assign(r.bases.size(), 2);
+        if (r.ipd.size() != r.bases.size()) r.ipd.assign(r.bases.size(), 1);
+        keep.push_back(std::move(r));
+    }
+    z.reads.swap(keep);
+    if (!any_len_ok) { z.host_status = HS_NO_SUBREADS; z.reads.clear(); return; }
+    if ((int)z.reads.size() < o.o.min_passes) { z.host_status = HS_TOO_FEW; z.reads.clear(); return; }
+}
+
+void pack(Batch &b)
+{
+    b.read_off.assign(1, 0); b.base_off.assign(1, 0);
+    b.slot.assign(b.zmws.size(), -1);
+    for (size_t i = 0; i < b.zmws.size(); ++i) {
+        ZmwIn &z = b.zmws[i];
+        if (z.host_status != HS_OK) continue;
+        b.slot[i] = (int)b.zmw_id.size();
+        b.zmw_id.push_back(z.zm);
+        b.snr.insert(b.snr.end(), z.snr, z.snr + 4);
+        bool alt = false;
+        for (size_t k = 0; k < z.reads.size(); ++k) {
+            Subread &r = z.reads[k];
+            b.bases.insert(b.bases.end(), r.bases.begin(), r.bases.end());
+            b.pw.insert(b.pw.end(), r.pw.begin(), r.pw.end());
+            b.ipd.insert(b.ipd.end(), r.ipd.begin(), r.ipd.end());
+            // strand: cx REVERSE_PASS (32) / FORWARD_PASS (16) when present, else consecutive passes alternate
+            uint8_t f = (r.cx >= 0 && (r.cx & 48)) ? (uint8_t)((r.cx & 32) ? 1 : 0) : (uint8_t)(alt ? 1 : 0);
+            alt = !alt;
+            b.flags.push_back(f);
+            b.base_off.push_back((int64_t)b.bases.size());
+            std::vector<uint8_t>().swap(r.bases); std::vector<uint8_t>().swap(r.pw); std::vector<uint8_t>().swap(r.ipd);
+        }
+        b.read_off.push_back((int32_t)b.flags.size());
+    }
+}
+
+struct Report {
+    int64_t input = 0, pass = 0;
+    std::map<std::string, int64_t> fail;
+    std::vector<int32_t> lens; std::vector<float> rqs; int64_t np_sum = 0;
+};
+
+const char *fail_label(int st)
+{
+    switch (st) {
+        case HS_POOR_SNR: return "Below SNR threshold";
+        case HS_NO_SUBREADS: return "Median length filter";
+        case HS_TOO_FEW: case CCSX_TOO_FEW_PASSES: return "Lacking full passes";
+        case CCSX_DRAFT_FAILURE: return "Draft generation error";
+        case CCSX_TOO_MANY_UNUSABLE: return "Reads failed polishing";
+        case CCSX_NON_CONVERGENT: return "CCS did not converge";
+        case CCSX_TOO_SHORT: return "Draft below --min-length";
+        case CCSX_TOO_LONG: return "Draft above --max-length";
+        case CCSX_LOW_RQ: return "CCS below minimum RQ";
+        case CCSX_EMPTY_WINDOW: return "Empty coverage windows";
+        default: return "Unknown error";
+    }
+}
+
+void write_report(const Options &o, const Report &r)
+{
+    FILE *f = std::fopen(o.report.c_str(), "w");
+    if (!f) return;
+    const int64_t failed = r.input - r.pass;
+    auto pct = [](int64_t a, int64_t b) { return b ? 100.0 * (double)a / (double)b : 0.0; };
+    std::fprintf(f, "ZMWs input                    : %" PRId64 "\n\n", r.input);
+    std::fprintf(f, "ZMWs pass filters             : %" PRId64 " (%.2f%%)\n", r.pass, pct(r.pass, r.input));
+    std::fprintf(f, "ZMWs fail filters             : %" PRId64 " (%.2f%%)\n", failed, pct(failed, r.input));
+    std::fprintf(f, "ZMWs shortcut filters         : 0 (0.00%%)\n\n");
+    std::fprintf(f, "Exclusive failed counts\n");
+    static const char *order[] = {"Below SNR threshold", "Median length filter", "Lacking full passes", "Draft generation error",
+                                  "Draft above --max-length", "Draft below --min-length", "Reads failed polishing", "Empty coverage windows",
+                                  "CCS did not converge", "CCS below minimum RQ", "Unknown error"};
+    for (const char *k : order) {
+        auto it = r.fail.find(k);
+        const int64_t c = it == r.fail.end() ? 0 : it->second;
+        std::fprintf(f, "%-30s: %" PRId64 " (%.2f%%)\n", k, c, pct(c, failed));
+    }
+    std::fprintf(f, "\n- - - - - - - - - - - - - - - : - - - - -\n\n");
+    int64_t yield = 0;
+    for (int32_t l : r.lens) yield += l;
+    std::vector<int32_t> s = r.lens; std::sort(s.begin(), s.end());
+    std::vector<float> q = r.rqs; std::sort(q.begin(), q.end());
+    auto qv = [](float rq) { return rq >= 1.0f ? 60 : (int)std::floor(-10.0 * std::log10(1.0 - (double)rq)); };
+    std::fprintf(f, "HiFi Reads                    : %zu\n", r.lens.size());
+    std::fprintf(f, "HiFi Yield (bp)               : %" PRId64 "\n", yield);
+    std::fprintf(f, "HiFi Read Length (mean, bp)   : %" PRId64 "\n", r.lens.empty() ? 0 : yield / (int64_t)r.lens.size());
+    std::fprintf(f, "HiFi Read Length (median, bp) : %d\n", s.empty() ? 0 : s[s.size() / 2]);
+    std::fprintf(f, "HiFi Read Quality (median)    : %d\n", q.empty() ? 0 : qv(q[q.size() / 2]));
+    std::fprintf(f, "HiFi Number of Passes (mean)  : %" PRId64 "\n", r.lens.empty() ? 0 : r.np_sum / (int64_t)r.lens.size());
+    std::fclose(f);
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Options opt;
+    if (!parse(argc, argv, opt)) { usage(); return 2; }
+    int nthreads = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    try {
+        ThreadPool pool(nthreads);
+        if (!opt.write_synth.empty()) return write_synthetic(opt, pool);
+
+        // ---- devices (not needed for --dump-zmws)
+        std::vector<ccsx_handle> handles;
+        ccsx_model model; ccsx_model_default(&model);
+        if (!opt.dump) {
+            const int ndev = ccsx_device_count();
+            if (ndev <= 0) { std::fprintf(stderr, "ccs: no gfx950 GPU available (this build has no CPU consensus path)\n"); return 1; }
+            if (opt.all_gpus) for (int d = 0; d < ndev; ++d) opt.gpus.push_back(d);
+            if (opt.gpus.empty()) opt.gpus.push_back(0);
+            for (int d : opt.gpus) {
+                ccsx_handle h = nullptr;
+                if (ccsx_create(d, &model, &opt.o, &h)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); return 1; }
+                handles.push_back(h);
+            }
+        }
+
+        BgzfReader in(opt.in, pool);
+        BamHeader hdr; read_header(in, hdr);
+        Channel<std::shared_ptr<Batch>> to_gpu(2 * std::max<size_t>(1, handles.size())), to_writer(4 * std::max<size_t>(1, handles.size()));
+        std::string movie;
+        const auto t_start = std::chrono::steady_clock::now();
+
+        // ---- reader
+        std::thread reader([&] {
+            std::vector<uint8_t> buf;
+            Subread rec;
+            ZmwIn cur; bool have = false;
+            int64_t nz = 0, nb = 0;
+            auto batch = std::make_shared<Batch>();
+            auto flush_zmw = [&] {
+                if (!have) return;
+                const bool mine = ((nz % opt.chunk_n) == (opt.chunk_i - 1));     // --chunk i/N (round-robin over ZMWs; needs no .pbi)
+                cur.order = nz++;
+                if (mine) {
+                    finish_zmw(cur, opt);
+                    if (opt.dump) std::printf("%d\t%d\t%zu\t%.2f,%.2f,%.2f,%.2f\n", cur.zm, cur.host_status, cur.reads.size(), cur.snr[0], cur.snr[1], cur.snr[2], cur.snr[3]);
+                    else {
+                        batch->zmws.push_back(std::move(cur));
+                        if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; pack(*batch); to_gpu.push(batch); batch = std::make_shared<Batch>(); }
+                    }
+                }
+                cur = ZmwIn(); have = false;
+            };
+            while (read_subread(in, buf, rec)) {
+                if (movie.empty()) movie = movie_of(rec.name);
+                if (!have || rec.zm != cur.zm) { flush_zmw(); cur.zm = rec.zm; have = true; }
+                if (rec.has_snr) std::memcpy(cur.snr, rec.snr, 16);
+                cur.reads.push_back(std::move(rec));
+            }
+            flush_zmw();
+            if (!opt.dump && !batch->zmws.empty()) { batch->index = nb++; pack(*batch); to_gpu.push(batch); }
+            to_gpu.close();
+        });
+        if (opt.dump) { reader.join(); return 0; }
+
+        // ---- GPU workers
+        std::vector<std::thread> workers;
+        std::atomic<int> failed{0};
+        for (ccsx_handle h : handles) workers.emplace_back([&, h] {
+            std::shared_ptr<Batch> b;
+            while (to_gpu.pop(b)) {
+                const int n = (int)b->zmw_id.size();
+                if (n > 0) {
+                    ccsx_batch cb{n, (int32_t)b->flags.size(), (int64_t)b->bases.size(), b->zmw_id.data(), b->snr.data(), b->read_off.data(),
+                                  b->base_off.data(), b->bases.data(), b->pw.data(), b->ipd.data(), b->flags.data()};
+                    b->seq_off.resize(n + 1);
+                    const int64_t cap = ccsx_result_layout(&cb, b->seq_off.data());
+                    b->status.resize(n); b->seq_len.resize(n); b->np.resize(n); b->iters.resize(n); b->n_windows.resize(n);
+                    b->rq.resize(n); b->ec.resize(n); b->seq.resize(cap); b->qual.resize(cap);
+                    ccsx_results r{n, cap, b->seq_off.data(), b->status.data(), b->seq_len.data(), b->seq.data(), b->qual.data(), nullptr,
+                                   b->rq.data(), b->np.data(), b->ec.data(), b->iters.data(), b->n_windows.data()};
+                    if (ccsx_consensus_batch(h, &cb, &r)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); failed = 1; }
+                    std::vector<uint8_t>().swap(b->bases); std::vector<uint8_t>().swap(b->pw); std::vector<uint8_t>().swap(b->ipd);
+                }
+                to_writer.push(b);
+            }
+        });
+
+        // ---- writer (restores batch order)
+        Report rep;
+        std::thread writer([&] {
+            BgzfWriter out(opt.out, pool);
+            bool header_done = false;
+            std::map<int64_t, std::shared_ptr<Batch>> hold;
+            int64_t next = 0;
+            RecordBuilder rb;
+            std::shared_ptr<Batch> b;
+            auto emit = [&](Batch &bt) {
+                if (!header_done) {
+                    write_header(out, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:" + movie +
+                                          "\tPM:SEQUELII\n@PG\tID:ccs\tPN:ccs\tVN:amd-mi355x-r1\tDS:Generate circular consensus sequences (ccs) from subreads.\n");
+                    header_done = true;
+                }
+                for (size_t i = 0; i < bt.zmws.size(); ++i) {
+                    ++rep.input;
+                    const ZmwIn &z = bt.zmws[i];
+                    int st = z.host_status;
+                    const int s = bt.slot[i];
+                    if (st == HS_OK) st = bt.status.empty() ? CCSX_DRAFT_FAILURE : bt.status[s];
+                    if (st != CCSX_SUCCESS) { rep.fail[fail_label(st)]++; continue; }
+                    ++rep.pass;
+                    const int64_t o = bt.seq_off[s]; const int32_t len = bt.seq_len[s];
+                    rb.begin(movie + "/" + std::to_string(z.zm) + "/ccs", bt.seq.data() + o, bt.qual.data() + o, (uint32_t)len);
+                    rb.tagZ("RG", "ccsamd01");
+                    rb.tagf("ec", bt.ec[s]);
+                    rb.tagi("np", bt.np[s]);
+                    rb.tagf("rq", bt.rq[s]);
+                    rb.tagBf("sn", z.snr, 4);
+                    rb.tagi("zm", z.zm);
+                    rb.finish(out);
+                    rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.np_sum += bt.np[s];
+                }
+            };
+            while (to_writer.pop(b)) {
+                hold[b->index] = b;
+                while (!hold.empty() && hold.begin()->first == next) { emit(*hold.begin()->second); hold.erase(hold.begin()); ++next; }
+                if (opt.log_level >= 2) {
+                    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                    std::fprintf(stderr, "%" PRId64 "/%.1f %" PRId64 "/%.1f\n", rep.input, rep.input / el * 60, rep.pass, rep.pass / el * 60);
+                }
+            }
+            for (auto &kv : hold) emit(*kv.second);
+            if (!header_done) write_header(out, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:unknown\n");
+            out.close();
+        });
+
+        reader.join();
+        for (auto &w : workers) w.join();
+        to_writer.close();
+        writer.join();
+        for (ccsx_handle h : handles) ccsx_destroy(h);
+        write_report(opt, rep);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        if (opt.log_level >= 1)
+            std::fprintf(stderr, "ccs: %" PRId64 " ZMWs in, %" PRId64 " HiFi reads out, %.2f s (%.1f ZMWs/s, %d host threads, %zu GPU%s)\n", rep.input, rep.pass, el,
+                         rep.input / el, nthreads, handles.size(), handles.size() == 1 ? "" : "s");
+        return failed ? 1 : 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "ccs: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,84 @@
+"""`ccs` command-line driver (C++ host over the C ABI): BAM I/O, step-1 filters and, on the GPU box, the whole
+`subreads.bam -> hifi.bam` path against the library API (docs/index.md:52-64, docs/faq/bam-output.md:9-30)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ccs_amd import api
+import bam_util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CCS = os.path.join(ROOT, "ccs_amd", "bin", "ccs")
+
+
+def _run(*args, check=True):
+    return subprocess.run([CCS, *map(str, args)], capture_output=True, text=True, check=check, timeout=600)
+
+
+def test_synthetic_subreads_bam_roundtrip(built, tmp_path):
+    bam = tmp_path / "s.subreads.bam"
+    _run("--write-synthetic", "5,4,300,9", bam)
+    text, recs = bam_util.read_bam(bam)
+    assert "READTYPE=SUBREAD" in text and "PL:PACBIO" in text
+    b = api.synth(5, 4, 300, seed=9, first_zmw_id=1000)
+    assert len(recs) == int(b.read_off[-1])
+    r = 0
+    for z in range(5):
+        for k in range(4):
+            rec = recs[r]
+            bases, pw = b.read(r)
+            assert rec["flag"] == 4 and rec["name"].startswith(f"m64000_synth/{1000 + z}/")
+            assert np.array_equal(rec["seq"], bases) and np.array_equal(rec["tags"]["pw"], pw)
+            assert rec["tags"]["zm"] == 1000 + z and np.allclose(rec["tags"]["sn"], b.snr[z])
+            assert rec["tags"]["cx"] == (3 | (32 if b.flags[r] else 16))
+            r += 1
+
+
+def test_step1_filters_without_gpu(built, tmp_path):
+    bam = tmp_path / "s.subreads.bam"
+    _run("--write-synthetic", "4,4,200,3", bam)
+    lines = _run("--dump-zmws", bam).stdout.strip().split("\n")
+    assert [l.split("\t")[:3] for l in lines] == [[str(1000 + z), "0", "4"] for z in range(4)]
+    # --min-passes above the pass count -> "Lacking full passes" (TOO_FEW_PASSES); --min-snr above the SNR -> POOR_SNR
+    assert all(l.split("\t")[1] == "102" for l in _run("--dump-zmws", "--min-passes", 5, bam).stdout.strip().split("\n"))
+    assert all(l.split("\t")[1] == "100" for l in _run("--dump-zmws", "--min-snr", 30, bam).stdout.strip().split("\n"))
+    # --chunk i/N partitions the ZMWs
+    a = _run("--dump-zmws", "--chunk", "1/2", bam).stdout.strip().split("\n")
+    c = _run("--dump-zmws", "--chunk", "2/2", bam).stdout.strip().split("\n")
+    assert sorted(a + c) == sorted(lines) and len(a) == 2 and len(c) == 2
+
+
+def test_cli_refuses_without_gpu(built, tmp_path):
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    bam = tmp_path / "s.subreads.bam"
+    _run("--write-synthetic", "2,3,150,1", bam)
+    p = _run(bam, tmp_path / "o.bam", check=False)
+    assert p.returncode == 1 and "no gfx950 GPU" in p.stderr
+    assert _run("--help").returncode == 0 and _run("--bogus", check=False).returncode == 2
+
+
+@pytest.mark.gpu
+def test_cli_matches_library(built, tmp_path):
+    bam, out = tmp_path / "s.subreads.bam", tmp_path / "o.hifi.bam"
+    _run("--write-synthetic", "7,6,800,21", bam)
+    p = _run(bam, out, "--batch-size", 3, "-j", 4, "--log-level", "INFO")
+    text, recs = bam_util.read_bam(out)
+    assert "READTYPE=CCS" in text and "@PG\tID:ccs" in text
+    batch = api.synth(7, 6, 800, seed=21, first_zmw_id=1000)
+    h = api.Handle(0)
+    res = h.consensus(batch)
+    h.close()
+    ok = [z for z in range(7) if res.status[z] == 0]
+    assert len(recs) == len(ok) > 0
+    for rec, z in zip(recs, ok):
+        assert rec["name"] == f"m64000_synth/{1000 + z}/ccs" and rec["flag"] == 4
+        assert np.array_equal(rec["seq"], res.sequence(z)) and np.array_equal(rec["qual"], res.quals(z))
+        t = rec["tags"]
+        assert t["zm"] == 1000 + z and t["np"] == res.np_[z] and t["RG"] == "ccsamd01"
+        assert t["rq"] == pytest.approx(float(res.rq[z]), abs=0) and t["ec"] == pytest.approx(float(res.ec[z]), abs=0)
+        assert np.allclose(t["sn"], batch.snr[z])
+    rep = open(tmp_path / "o.hifi.ccs_report.txt").read()
+    assert f"ZMWs input                    : 7" in rep and f"ZMWs pass filters             : {len(ok)}" in rep
