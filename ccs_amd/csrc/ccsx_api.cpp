@@ -206,7 +206,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     RES(h->d_out_i32, (size_t)n * 4 * 4); RES(h->d_out_f32, (size_t)n * 4 * 2);
 
     // ---- resident POA graphs / alignment slots: as many as fit a memory budget, never more than the work
-    const size_t poa_slot_bytes = (((size_t)vcap_max + 64) * 400 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
+    const size_t poa_slot_bytes = (((size_t)vcap_max + 64) * 392 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
     const size_t align_slot_i32 = (size_t)need_max * 64 + need_max + 64;
     size_t freeb = 0, totalb = 0;
     HIPTRY(hipMemGetInfo(&freeb, &totalb));

@@ -188,14 +188,15 @@ __device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { 
 // D2/D3: sparse POA.  One wave per resident graph ("slot"); slots pull ZMWs from an atomic ticket.
 //
 // v2 layout.  By vertex id: vrec {base | npred<<8 | reads<<16, pred0, pred1, pred2}, predx (in-edges 3..7),
-// vdp {lo, colmax, bestrow} and the score column M[64] of the current DP pass, rank (topological position).
-// By topological position: order (ping-pong), move rows mvK[64], loK, ppK (position of in-edge 0).
+// rank (topological position).  By topological position: order (ping-pong), the score column Mk[64] and move
+// row mvK[64] of the current DP pass, kinfo {lo, colmax, bestrow, position of in-edge 0}.
 // The DP walks positions in blocks of 64: the block's vertex records are fetched with one coalesced load and
-// handed out with v_readlane, the previous column stays in registers (DPP wave shifts), so the common chain
-// step touches no memory on its critical path.  Score/move columns are streamed to HBM fire-and-forget.
+// handed out with v_readlane, the previous column stays in registers, per-column metadata is captured in lane
+// registers and stored once per block, so the common chain step touches no memory on its critical path and
+// needs few scalar instructions (the kernel is scalar-issue bound).  Columns stream to HBM fire-and-forget.
 struct PoaSlot {
-    int4 *vrec, *vdp;
-    int32_t *predx, *M, *rank, *order0, *order1, *loK, *ppK, *bestK, *bpK, *pathv;
+    int4 *vrec, *kinfo;
+    int32_t *predx, *M, *rank, *order0, *order1, *bestK, *bpK, *pathv;
     uint8_t *mvK;
 };
 
@@ -206,14 +207,12 @@ __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
     uint8_t *p = P.poa_scratch + (size_t)slot * P.poa_slot_bytes;
     s.M = (int32_t *)p;       p += vc * 64 * 4;
     s.vrec = (int4 *)p;       p += vc * 16;
-    s.vdp = (int4 *)p;        p += vc * 16;
+    s.kinfo = (int4 *)p;      p += vc * 16;
     s.mvK = p;                p += vc * 64;
     s.predx = (int32_t *)p;   p += vc * 5 * 4;
     s.rank = (int32_t *)p;    p += vc * 4;
     s.order0 = (int32_t *)p;  p += vc * 4;
     s.order1 = (int32_t *)p;  p += vc * 4;
-    s.loK = (int32_t *)p;     p += vc * 4;
-    s.ppK = (int32_t *)p;     p += vc * 4;
     s.bestK = (int32_t *)p;   p += vc * 4;      // also the run-count / shift array while threading a read
     s.bpK = (int32_t *)p;     p += vc * 4;
     s.pathv = (int32_t *)p;
@@ -241,7 +240,7 @@ __device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to
 
 extern __shared__ uint32_t dyn_lds[];
 
-__global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_poa(KParams P, int z0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sMv[64 * 64];
     __shared__ int sLo[64], sPp[64], sV[64], sMeta[64];
@@ -286,6 +285,8 @@ __global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
             const int n0 = n;
             int Mprev = NEGV, vprev = -2, lo_prev = 0, cm_prev = NEGV, br_prev = 0;
             int kend = -1, bs = NEGV;
+            const int hiI = I - (CCSX_BAND - 1) > 0 ? I - (CCSX_BAND - 1) : 0;
+            const int lane4 = 4 * lane;
             __threadfence_block();
             for (int kb = 0; kb < n0; kb += LANES) {
                 const int kkL = kb + lane;
@@ -293,36 +294,54 @@ __global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
                 int4 rL = make_int4(0, 0, 0, 0);
                 if (kkL < n0) rL = g.vrec[vL];
                 const int nblk = (n0 - kb) < LANES ? (n0 - kb) : LANES;
-                for (int j = 0; j < nblk; ++j) {
+                int4 myInfo = make_int4(0, NEGV, 0, -1);                   // (lo, colmax, bestrow, pp) of column kb + lane
+                int32_t *Mrow = g.M + (size_t)kb * 64 + lane;
+                uint8_t *mvrow = g.mvK + (size_t)kb * 64 + lane;
+                for (int j = 0; j < nblk; ++j, Mrow += 64, mvrow += 64) {
                     const int k = kb + j;
                     const int v = rl(vL, j);
-                    const int4 rec = make_int4(rl(rL.x, j), rl(rL.y, j), rl(rL.z, j), rl(rL.w, j));
-                    const int vb = rec.x & 255, np = (rec.x >> 8) & 255;
+                    const int meta = rl(rL.x, j), p0 = rl(rL.y, j);
+                    const int vb = meta & 255, np = (meta >> 8) & 255;
                     int lo, best = NEGV, bm = 0, pp, i, rbv;
-                    if (np == 1 && rec.y == vprev) {                       // chain step: everything in registers
-                        lo = rfl(band_lo(lo_prev, br_prev, I));
-                        const int sh = lo - lo_prev;
-                        int x, y;
-                        if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; }
-                        else if (sh == 1) { x = Mprev; y = wave_shl1_i32(Mprev, NEGV); }
-                        else { x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); }
+                    if (np == 1 && p0 == vprev) {                          // chain step: registers only, no branches
+                        int t = br_prev + 1 - CCSX_BAND / 2;
+                        t = t > lo_prev ? t : lo_prev;
+                        t = t < lo_prev + 2 ? t : lo_prev + 2;
+                        lo = rfl(t < hiI ? t : hiI);
+                        const int idx = lane + (lo - lo_prev);             // row i sits in lane idx of the previous column
+                        const int ys = __shfl(Mprev, idx & 63), xs = __shfl(Mprev, (idx - 1) & 63);
+                        const int y = idx < LANES ? ys : NEGV;
+                        const int x = (unsigned)(idx - 1) < (unsigned)LANES ? xs : NEGV;
                         i = lo + lane;
-                        rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
-                        if (i >= 1 && i <= I && x > NEGV / 2) { best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); bm = MV_DIAG; }
-                        if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; bm = MV_DEL; } }
+                        const int ib = i - 1 < 0 ? 0 : (i - 1 >= I ? I - 1 : i - 1);   // clamped: unconditional LDS read, no branch
+                        rbv = read_base_packed(sread, ib);
+                        const bool rowok = i <= I;
+                        const int cdiag = x + (vb == rbv ? SC_MATCH : SC_MISMATCH);
+                        const bool vdiag = rowok && i >= 1 && x > NEGV / 2;
+                        best = vdiag ? cdiag : NEGV;                       // bm = MV_DIAG = 0
+                        const int cdel = y + SC_DEL;
+                        const bool vdel = rowok && y > NEGV / 2 && cdel > best;
+                        best = vdel ? cdel : best; bm = vdel ? MV_DEL : MV_DIAG;
                         pp = k - 1;
                     } else {                                               // source vertex or several / far in-edges
+                        const int4 rec = make_int4(meta, p0, rl(rL.z, j), rl(rL.w, j));
                         int ulo = 0, ubr = 0;
+                        pp = -1;
                         if (np > 0) {
                             bool far = false;
                             for (int q = 0; q < np; ++q) far |= (rfl(poa_pred(g, rec, v, q)) != vprev);
                             if (far) __threadfence_block();                // far columns come back from HBM/L2
                             int bestcm = NEGV - 1;
-                            for (int q = 0; q < np; ++q) {
+                            for (int q = 0; q < np; ++q) {                 // pass 1: band placement from the best in-edge column
                                 const int u = rfl(poa_pred(g, rec, v, q));
-                                int l, cm, b;
-                                if (u == vprev) { l = lo_prev; cm = cm_prev; b = br_prev; }
-                                else { const int4 dpu = g.vdp[u]; l = rfl(dpu.x); cm = rfl(dpu.y); b = rfl(dpu.z); }
+                                int l, cm, b, pu;
+                                if (u == vprev) { l = lo_prev; cm = cm_prev; b = br_prev; pu = k - 1; }
+                                else {
+                                    pu = rfl(g.rank[u]);
+                                    if (pu >= kb) { l = rl(myInfo.x, pu - kb); cm = rl(myInfo.y, pu - kb); b = rl(myInfo.z, pu - kb); }
+                                    else { const int4 ki = g.kinfo[pu]; l = rfl(ki.x); cm = rfl(ki.y); b = rfl(ki.z); }
+                                }
+                                if (q == 0) pp = pu;
                                 if (cm > bestcm) { bestcm = cm; ulo = l; ubr = b; }
                             }
                         }
@@ -330,7 +349,7 @@ __global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
                         i = lo + lane;
                         rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
                         const int npp = np == 0 ? 1 : np;
-                        for (int q = 0; q < npp; ++q) {
+                        for (int q = 0; q < npp; ++q) {                    // pass 2: candidates (in-edge data is re-derived: no arrays)
                             int x, y;
                             if (np == 0) {
                                 const int o1 = i - 1, o0 = i;
@@ -338,15 +357,16 @@ __global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
                                 y = (o0 >= 0 && o0 < LANES && o0 <= I) ? o0 * SC_INS : NEGV;
                             } else {
                                 const int u = rfl(poa_pred(g, rec, v, q));
-                                if (u == vprev) {
+                                if (u == vprev) {                          // the previous column is still in registers
                                     const int o1 = i - 1 - lo_prev, o0 = i - lo_prev;
                                     const int xs = __shfl(Mprev, o1 & 63), ys = __shfl(Mprev, o0 & 63);
                                     x = (o1 >= 0 && o1 < LANES) ? xs : NEGV;
                                     y = (o0 >= 0 && o0 < LANES) ? ys : NEGV;
                                 } else {
-                                    const int plo = rfl(g.vdp[u].x);
+                                    const int pu = rfl(g.rank[u]);
+                                    const int plo = (pu >= kb) ? rl(myInfo.x, pu - kb) : rfl(g.kinfo[pu].x);
                                     const int o1 = i - 1 - plo, o0 = i - plo;
-                                    const int32_t *Mu = g.M + (size_t)u * 64;
+                                    const int32_t *Mu = g.M + (size_t)pu * 64;
                                     x = (o1 >= 0 && o1 < LANES) ? Mu[o1] : NEGV;
                                     y = (o0 >= 0 && o0 < LANES) ? Mu[o0] : NEGV;
                                 }
@@ -354,23 +374,23 @@ __global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
                             if (i >= 1 && i <= I && x > NEGV / 2) { int c = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); if (c > best) { best = c; bm = MV_DIAG | (q << 2); } }
                             if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; bm = MV_DEL | (q << 2); } }
                         }
-                        pp = (np == 0) ? -1 : ((rec.y == vprev) ? k - 1 : rfl(g.rank[rec.y]));
                     }
                     // insertion chain: x_l = max_k<=l (c_k + (l-k)*INS): exact integer max-plus prefix scan (7 DPP ops)
-                    const int d = wave_scan_max_i32(best + 4 * lane);
-                    const int xi = d - 4 * lane;
+                    const int d = wave_scan_max_i32(best + lane4);
+                    const int xi = d - lane4;
                     if (xi > best) { best = xi; bm = MV_INS; }
                     if (i > I || best < NEGV / 2) best = NEGV;
                     const int cm = wave_reduce_max_i32(best);
                     const unsigned long long bal = __ballot(best == cm);
                     const int br = lo + (__ffsll((long long)bal) - 1);
-                    g.M[(size_t)v * 64 + lane] = best;
-                    g.mvK[(size_t)k * 64 + lane] = (uint8_t)bm;
-                    if (lane == 0) { g.vdp[v] = make_int4(lo, cm, br, 0); g.loK[k] = lo; g.ppK[k] = pp; }
+                    *Mrow = best;
+                    *mvrow = (uint8_t)bm;
+                    if (lane == j) myInfo = make_int4(lo, cm, br, pp);
                     const int oe = I - lo;
-                    if (oe >= 0 && oe < LANES) { const int xe = rl(best, oe); if (xe > NEGV / 2 && xe > bs) { bs = xe; kend = k; } }
+                    if ((unsigned)oe < (unsigned)LANES) { const int xe = rl(best, oe); if (xe > NEGV / 2 && xe > bs) { bs = xe; kend = k; } }
                     Mprev = best; vprev = v; lo_prev = lo; cm_prev = cm; br_prev = br;
                 }
+                if (kkL < n0) g.kinfo[kkL] = myInfo;
             }
             __threadfence_block();
             if (kend >= 0) {                                // else: read not added
@@ -384,7 +404,9 @@ __global__ __launch_bounds__(64) void k_poa(KParams P, int z0)
                         const int kk = kb + lane;
                         const bool in = kk < n0;
                         const int v = in ? order[kk] : 0;
-                        sV[lane] = v; sLo[lane] = in ? g.loK[kk] : 0; sPp[lane] = in ? g.ppK[kk] : -1; sMeta[lane] = in ? g.vrec[v].x : 0;
+                        int4 ki = make_int4(0, 0, 0, -1);
+                        if (in) ki = g.kinfo[kk];
+                        sV[lane] = v; sLo[lane] = ki.x; sPp[lane] = ki.w; sMeta[lane] = in ? g.vrec[v].x : 0;
                         const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb * 64);
                         uint4 *dst = (uint4 *)sMv;
 #pragma unroll

@@ -121,3 +121,36 @@ def test_recovers_truth_at_full_size(handle):
         kt, ks = kmers(tpl), kmers(s)
         assert len(kt & ks) / len(kt) > 0.98
         assert res.rq[z] > 0.999
+
+
+@pytest.mark.parametrize("n,passes,length,seed", [
+    (2, 30, 20000, 31),               # BASELINE config 4 shape: deep coverage, long template
+    (6, (3, 50), (1000, 25000), 32),  # BASELINE config 5 shape: Sequel-II-like mix
+])
+def test_baseline_config_shapes_bit_exact(handle, n, passes, length, seed):
+    batch = api.synth(n, passes, length, seed=seed)
+    res = handle.consensus(batch)
+    ref = _oracle(handle, batch)
+    _compare(res, ref, batch)
+
+
+def test_top_passes_and_poa_coverage_options(built):
+    o = api.default_opts(); o.top_passes = 5; o.max_poa_cov = 3
+    h = api.Handle(0, opts=o)
+    batch = api.synth(3, 9, 600, seed=33)
+    res = h.consensus(batch)
+    ref = api.Results.allocate(batch)
+    O.consensus_batch(h.model, o, batch, ref)
+    _compare(res, ref, batch)
+    assert (res.np_ <= 5).all()
+    h.close()
+
+
+def test_empty_and_tiny_reads(handle):
+    """a zero-length read and a ZMW of very short reads must not crash and must match the oracle"""
+    batch = api.synth(2, 4, 60, seed=34)
+    # make read 1 of zmw 0 empty by moving its bases to read 2
+    bo = batch.base_off.copy(); bo[2] = bo[1]
+    batch.base_off = bo
+    res = handle.consensus(batch)
+    _compare(res, _oracle(handle, batch), batch)
