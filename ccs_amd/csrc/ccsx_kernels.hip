@@ -767,7 +767,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
     __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
     __shared__ float sDLJ[2][32];
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
-    __shared__ uint8_t sObs[PW_MAXREADS][64];
+    __shared__ uint8_t sObs[PW_MAXREADS][68];                // 63 codes + look-ahead slack
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
     __shared__ float sBase[PW_MAXREADS];
@@ -887,47 +887,54 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                 const int Ia = sI[task.x], Ib = paired ? sI[task.y] : -1;
                 const int Tmax = (Ia > Ib ? Ia : Ib) + J;
                 const int sd = sStrand[myr];
-                float *gam = sGB + sGoff[myr] + row * S, *bet = sGB + sBoff[myr] + row * S;
                 const float2 *MI = sMI[sd];
                 const float *DLJ = sDLJ[sd];
                 const bool rowok = row <= I;
                 const int op = (row >= 1 && rowok) ? sObs[myr][row - 1] : 0;            // o_{i-1}
                 const int oc = (row < I) ? sObs[myr][row] : 0;                           // o_i
+                // activity windows: alpha computes column j = t - row for t in [row, row+J]; beta computes column
+                // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step.
+                const int tA0 = rowok ? row : (1 << 20), tB0 = rowok ? I - row : (1 << 20);
+                const float one0 = (row == 0) ? 1.0f : 0.0f, oneI = (row == I) ? 1.0f : 0.0f;
+                const float2 *pA = MI + op - row * MI_STRIDE;
+                const float *dA = DLJ - row;
+                float *gA = sGB + sGoff[myr] + row * S - row;
+                const float2 *pB = MI + oc + (J + I - row) * MI_STRIDE;
+                const float *dB = DLJ + (J + I - row);
+                float *bB = sGB + sBoff[myr] + row * S + (J + I - row);
                 float acur = 0.0f, updiag = 0.0f, mePrev = 0.0f, dlPrev = 0.0f;
                 float bcur = 0.0f, dndiag = 0.0f;
-                for (int t = 0; t <= Tmax; ++t) {
+                for (int t = 0; t <= Tmax; ++t, pA += MI_STRIDE, ++dA, ++gA, pB -= MI_STRIDE, --dB, --bB) {
                     float up = wave_shr1_f32(acur, 0.0f);
                     if (row == 0) up = 0.0f;
                     float dn = wave_shl1_f32(bcur, 0.0f);
                     if (row >= I) dn = 0.0f;
-                    const int j = t - row;
-                    if (rowok && j >= 0 && j <= J) {
-                        float gmm;
-                        if (j == 0) gmm = (row == 0) ? 1.0f : 0.0f;
-                        else { const float m = updiag * mePrev; const float dl = acur * dlPrev; gmm = m + dl; }
+                    const unsigned ja = (unsigned)(t - tA0);                 // = column j when active
+                    if (ja <= (unsigned)J) {
+                        const float m = updiag * mePrev, dl = acur * dlPrev;
+                        float gmm = m + dl;
+                        if (ja == 0) gmm = one0;
                         float st = 0.0f;
-                        if (j < J) {
-                            const float2 pr = MI[j * MI_STRIDE + op];
-                            if (row > 0) st = up * pr.y;
-                            mePrev = pr.x; dlPrev = DLJ[j];
+                        if (ja < (unsigned)J) {
+                            const float2 pr = *pA;
+                            st = up * pr.y;                                  // row 0: up == 0 -> +0, same bits as the SPEC's "no stay"
+                            mePrev = pr.x; dlPrev = *dA;
                         }
-                        gam[j] = gmm;
+                        *gA = gmm;
                         acur = gmm + st;
                     }
                     updiag = up;
-                    const int jb = J - (t - (I - row));
-                    if (rowok && jb >= 0 && jb <= J) {
-                        float b;
-                        if (jb == J) b = (row == I) ? 1.0f : 0.0f;
-                        else {
-                            const float2 pr = MI[jb * MI_STRIDE + oc];
-                            const float t1 = (row < I) ? pr.x * dndiag : 0.0f;
-                            const float t2 = (row < I) ? pr.y * dn : 0.0f;
-                            const float t3 = DLJ[jb] * bcur;
-                            b = (t1 + t2) + t3;
+                    const unsigned jbk = (unsigned)(t - tB0);                // = J - jb when active
+                    if (jbk <= (unsigned)J) {
+                        float bv = oneI;
+                        if (jbk != 0) {
+                            const float2 pr = *pB;
+                            const float t1 = pr.x * dndiag, t2 = pr.y * dn;  // last row: dn == dndiag == 0 -> +0
+                            const float t3 = *dB * bcur;
+                            bv = (t1 + t2) + t3;
                         }
-                        bet[jb] = b;
-                        bcur = b;
+                        *bB = bv;
+                        bcur = bv;
                     }
                     dndiag = dn;
                 }
@@ -966,12 +973,21 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                 cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f); cb.bq = betB[0];
                 const int Imin = two ? (Ia < Ib ? Ia : Ib) : -1;
                 int i = 0;
+                int oa = obA[0], ob = obB[0];                               // obs codes are fetched one row ahead
                 for (; i < Imin; ++i) {                                    // both chains, neither at its last row
-                    score_step(ca, La, sCTX, gamA, betA, S, i, obA[i], false);
-                    score_step(cb, Lb, sCTX, gamB, betB, S, i, obB[i], false);
+                    const int oan = obA[i + 1], obn = obB[i + 1];
+                    score_step(ca, La, sCTX, gamA, betA, S, i, oa, false);
+                    score_step(cb, Lb, sCTX, gamB, betB, S, i, ob, false);
+                    oa = oan; ob = obn;
                 }
-                for (int ia = i; ia <= Ia; ++ia) score_step(ca, La, sCTX, gamA, betA, S, ia, ia < Ia ? obA[ia] : 0, ia == Ia);
-                if (two) for (int ib = i; ib <= Ib; ++ib) score_step(cb, Lb, sCTX, gamB, betB, S, ib, ib < Ib ? obB[ib] : 0, ib == Ib);
+                {
+                    int o = oa;
+                    for (int ia = i; ia <= Ia; ++ia) { const int on = obA[ia + 1]; score_step(ca, La, sCTX, gamA, betA, S, ia, o, ia == Ia); o = on; }
+                }
+                if (two) {
+                    int o = ob;
+                    for (int ib = i; ib <= Ib; ++ib) { const int on = obB[ib + 1]; score_step(cb, Lb, sCTX, gamB, betB, S, ib, o, ib == Ib); o = on; }
+                }
                 {
                     const float res = La.fin ? ca.b : ca.acc;
                     const float dd = det_log2f(res) - sBase[ra];
