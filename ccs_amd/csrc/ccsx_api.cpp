@@ -53,7 +53,7 @@ struct ccsx_handle_s {
     // inputs
     DevBuf d_snr, d_read_off, d_base_off, d_bases, d_pw, d_flags;
     // layout
-    DevBuf d_read_zmw, d_vcap, d_dcap, d_seq_off, d_wb_off, d_ent_off;
+    DevBuf d_read_zmw, d_vcap, d_dcap, d_seq_off, d_wb_off, d_ent_off, d_wslot;
     // state
     DevBuf d_tabME, d_tabINS, d_tabDL, d_draft, d_zmw_i32 /* 6 x n int32 */, d_wbounds, d_ticket;
     DevBuf d_poa, d_align, d_avalid, d_ascore, d_ent;
@@ -111,7 +111,7 @@ int ccsx_destroy(ccsx_handle h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_model, &h->d_snr, &h->d_read_off, &h->d_base_off, &h->d_bases, &h->d_pw, &h->d_flags, &h->d_read_zmw,
-                      &h->d_vcap, &h->d_dcap, &h->d_seq_off, &h->d_wb_off, &h->d_ent_off, &h->d_tabME, &h->d_tabINS, &h->d_tabDL,
+                      &h->d_vcap, &h->d_dcap, &h->d_seq_off, &h->d_wb_off, &h->d_ent_off, &h->d_wslot, &h->d_tabME, &h->d_tabINS, &h->d_tabDL,
                       &h->d_draft, &h->d_zmw_i32, &h->d_wbounds, &h->d_ticket, &h->d_poa, &h->d_align, &h->d_avalid, &h->d_ascore,
                       &h->d_ent, &h->d_wseq, &h->d_wqv, &h->d_wsum, &h->d_wmeta, &h->d_out_seq, &h->d_out_qual, &h->d_out_raw,
                       &h->d_out_i32, &h->d_out_f32};
@@ -170,6 +170,8 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     h->read_off.assign(b->read_off, b->read_off + n + 1);
     h->base_off.assign(b->base_off, b->base_off + R + 1);
     const int64_t total_wslots = (int64_t)h->wb_off[n] - n;
+    std::vector<int32_t> wslot(total_wslots > 0 ? total_wslots : 1);
+    for (int z = 0; z < n; ++z) std::fill(wslot.begin() + (h->wb_off[z] - z), wslot.begin() + (h->wb_off[z + 1] - (z + 1)), z);
 
 #define UP(buf, src, bytes)                                                                                    \
     do {                                                                                                       \
@@ -188,6 +190,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     UP(h->d_seq_off, h->seq_off.data(), (size_t)(n + 1) * 8);
     UP(h->d_wb_off, h->wb_off.data(), (size_t)(n + 1) * 4);
     UP(h->d_ent_off, h->ent_off.data(), (size_t)(R + 1) * 8);
+    UP(h->d_wslot, wslot.data(), wslot.size() * 4);
 #undef UP
     HIPTRY(hipStreamSynchronize(h->stream));   // host staging vectors go out of scope
 
@@ -197,7 +200,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     RES(h->d_draft, (size_t)cap_total);
     RES(h->d_zmw_i32, (size_t)n * 4 * 6);
     RES(h->d_wbounds, (size_t)h->wb_off[n] * 4);
-    RES(h->d_ticket, 64);
+    RES(h->d_ticket, 256);
     RES(h->d_avalid, (size_t)R); RES(h->d_ascore, (size_t)R * 4);
     RES(h->d_ent, (size_t)h->ent_off[R] * 4);
     RES(h->d_wseq, (size_t)total_wslots * 32); RES(h->d_wqv, (size_t)total_wslots * 32 * 4);
@@ -229,13 +232,13 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     P.snr = (const float *)h->d_snr.p; P.read_off = (const int32_t *)h->d_read_off.p; P.base_off = (const int64_t *)h->d_base_off.p;
     P.bases = (const uint8_t *)h->d_bases.p; P.pw = (const uint8_t *)h->d_pw.p; P.flags = (const uint8_t *)h->d_flags.p;
     P.read_zmw = (const int32_t *)h->d_read_zmw.p; P.vcap = (const int32_t *)h->d_vcap.p; P.dcap = (const int32_t *)h->d_dcap.p;
-    P.seq_off = (const int64_t *)h->d_seq_off.p; P.wb_off = (const int32_t *)h->d_wb_off.p; P.ent_off = (const int64_t *)h->d_ent_off.p;
+    P.seq_off = (const int64_t *)h->d_seq_off.p; P.wb_off = (const int32_t *)h->d_wb_off.p; P.ent_off = (const int64_t *)h->d_ent_off.p; P.wslot_zmw = (const int32_t *)h->d_wslot.p;
     P.tabME = (float *)h->d_tabME.p; P.tabINS = (float *)h->d_tabINS.p; P.tabDL = (float *)h->d_tabDL.p;
     P.draft = (uint8_t *)h->d_draft.p;
     int32_t *zi = (int32_t *)h->d_zmw_i32.p;
     P.draft_len = zi; P.nwin = zi + n; P.zstat = zi + 2 * (size_t)n; P.nreads_used = zi + 3 * (size_t)n; P.np = zi + 4 * (size_t)n;
     P.wbounds = (int32_t *)h->d_wbounds.p;
-    P.ticket_poa = (int32_t *)h->d_ticket.p; P.ticket_align = P.ticket_poa + 1; P.debug = P.ticket_poa + 4;
+    P.ticket_poa = (int32_t *)h->d_ticket.p; P.ticket_align = P.ticket_poa + 1; P.debug = P.ticket_poa + 4; P.phase = (unsigned long long *)(P.ticket_poa + 16);
     P.poa_scratch = (uint8_t *)h->d_poa.p; P.poa_slot_bytes = poa_slot_bytes; P.poa_slots = poa_slots;
     P.align_scratch = (int32_t *)h->d_align.p; P.align_slot_i32 = align_slot_i32; P.align_slots = align_slots;
     P.avalid = (uint8_t *)h->d_avalid.p; P.ascore = (int32_t *)h->d_ascore.p; P.ent = (int32_t *)h->d_ent.p;
@@ -265,6 +268,16 @@ int ccsx_sync(ccsx_handle h)
     if (!h) return -1;
     HIPTRY(hipSetDevice(h->device));
     HIPTRY(hipStreamSynchronize(h->stream));
+#ifdef CCSX_PROFILE_PHASES
+    if (h->uploaded && h->ran) {
+        unsigned long long ph[16];
+        HIPTRY(hipMemcpy(ph, h->P.phase, sizeof(ph), hipMemcpyDeviceToHost));
+        static const char *nm[7] = {"prologue", "tables+lanes", "chunk plan", "fill", "score", "select/apply", "qv+store"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 7; ++i) tot += ph[i];
+        for (int i = 0; i < 7; ++i) std::fprintf(stderr, "[ccsx phase] %-14s %6.2f %%  (%llu cycles)\n", nm[i], tot ? 100.0 * ph[i] / tot : 0.0, ph[i]);
+    }
+#endif
 #ifdef CCSX_DEBUG_CHECKS
     if (h->uploaded) {
         int32_t dbg[2] = {0, 0};

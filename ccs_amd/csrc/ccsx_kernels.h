@@ -24,12 +24,14 @@ struct KParams {
     const int64_t *seq_off;    // [n+1] offsets of draft and outputs (capacity layout)
     const int32_t *wb_off;     // [n+1] offsets into wbounds; window slots of z = wb_off[z+1]-wb_off[z]-1
     const int64_t *ent_off;    // [R] offsets into ent
+    const int32_t *wslot_zmw;  // [total window slots] owning ZMW of every polish workgroup slot
     // ---- per-ZMW state
     float *tabME, *tabINS, *tabDL;
     uint8_t *draft;
     int32_t *draft_len, *nwin, *zstat, *nreads_used, *wbounds, *np;
     int32_t *ticket_poa, *ticket_align;   // adjacent
     int32_t *debug;            // [4] first failed bounds check (CCSX_DEBUG_CHECKS builds)
+    unsigned long long *phase; // [16] per-phase cycle sums (CCSX_PROFILE_PHASES builds)
     // ---- POA / alignment scratch (per resident slot)
     uint8_t *poa_scratch;
     size_t poa_slot_bytes;

@@ -22,6 +22,13 @@
 #include "wave_ops.h"
 
 #define LANES 64
+#ifdef CCSX_PROFILE_PHASES
+#define PHASE_T0() unsigned long long ph_t = __builtin_readcyclecounter(); (void)ph_t
+#define PHASE(idx) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd((unsigned long long *)P.phase + (idx), n_ - ph_t); ph_t = n_; } } while (0)
+#else
+#define PHASE_T0() do { } while (0)
+#define PHASE(idx) do { } while (0)
+#endif
 #ifdef CCSX_DEBUG_CHECKS
 #ifndef CCSX_CHK_MASK
 #define CCSX_CHK_MASK 0xff
@@ -743,6 +750,7 @@ struct ScoreChain {                  // running state of one (lane, read) mutati
     float2 pA, pB;
 };
 
+// one row of the extend+link recursion
 __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, const float2 *sCTX, const float *gam, const float *bet,
                                            int S, int i, int o, bool last)
 {
@@ -777,13 +785,14 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
     __shared__ uint8_t sMvalid[256];
     __shared__ int sAcc[32];
     __shared__ int sCtl[8];                                  // 0:J 1:cs 2:ce 3:nacc 5:chunk_end 6:ntasks
+    __shared__ int sCnt[4];
+    __shared__ short sList[256];                             // compacted valid mutation lanes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    PHASE_T0();
     // ---- locate (zmw, window)
-    int lo_ = 0, hi_ = P.n_zmw;
     const int bid = blockIdx.x;
-    while (hi_ - lo_ > 1) { int mid = (lo_ + hi_) >> 1; if (P.wb_off[mid] - mid <= bid) lo_ = mid; else hi_ = mid; }
-    const int z = lo_;
+    const int z = P.wslot_zmw[bid];                         // host-built map: no dependent search
     const int w = bid - (P.wb_off[z] - z);
     if (w >= P.nwin[z]) return;
     const int nw = P.nwin[z], Ld = P.draft_len[z];
@@ -816,14 +825,17 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
             na = st ? L - b : a;
         }
         if (lane == 0) { sI[r] = n; sStrand[r] = (uint8_t)st; }
+        uint8_t ov = 0;                                       // rows beyond the segment read as obs 0 (look-ahead loads stay finite)
         if (lane < n) {
             const int64_t p = P.base_off[rr] + na + lane;
-            sObs[r][lane] = (uint8_t)obs_of(P.bases[p], P.pw[p]);
+            ov = (uint8_t)obs_of(P.bases[p], P.pw[p]);
         }
+        sObs[r][lane] = ov;
+        if (lane < 4) sObs[r][64 + lane] = 0;
     }
 
-    const int slot = tid >> 5, cpos = tid & 31;            // my mutation lane m = tid
     const int half = lane >> 5, hrow = lane & 31;          // fill: which read of the pair, row within it
+    PHASE(0);
     int iters = 0, nonconv = 0, nvalid_last = 0;
     for (int it = 0; it < CCSX_MAX_ITER; ++it) {
         __syncthreads();
@@ -841,19 +853,41 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                 if (o == 0) sDLJ[sd][j] = sDL[k];
             }
         }
-        // my mutation on both strands
-        int type, x = 0, mval;
+        // valid mutation lanes of this round, compacted: lane m = slot*32 + c is valid iff the SPEC enumerates it;
+        // thread t then scores the t-th valid lane, so the ~30 % of unused lanes cost (almost) a whole wave less
         {
             const uint8_t *t = sT[0];
-            if (slot < 3) { type = 0; mval = cpos < J; if (mval) x = (t[cpos] + 1 + slot) & 3; }
-            else if (slot == 3) { type = 1; mval = cpos < J && !(cpos > 0 && t[cpos - 1] == t[cpos]); }
-            else { type = 2; x = slot - 4; mval = cpos <= J && !(cpos > 0 && t[cpos - 1] == x); }
+            const int sl0 = tid >> 5, c0 = tid & 31;
+            int v0;
+            if (sl0 < 3) v0 = c0 < J;
+            else if (sl0 == 3) v0 = c0 < J && !(c0 > 0 && t[c0 - 1] == t[c0]);
+            else v0 = c0 <= J && !(c0 > 0 && t[c0 - 1] == sl0 - 4);
+            const unsigned long long bal = __ballot(v0);
+            if (lane == 0) sCnt[wave] = __popcll(bal);
+            sMvalid[tid] = (uint8_t)v0; sDelta[tid] = 0.0f;
+            __syncthreads();
+            int basew = 0;
+            for (int q = 0; q < wave; ++q) basew += sCnt[q];
+            if (v0) sList[basew + __popcll(bal & ((1ull << lane) - 1ull))] = (short)tid;
+            __syncthreads();
+        }
+        const int nvm = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
+        const int mval = tid < nvm;
+        const int myM = mval ? sList[tid] : 0;
+        const int slot = myM >> 5, cpos = myM & 31;
+        int type, x = 0;
+        {
+            const uint8_t *t = sT[0];
+            if (slot < 3) { type = 0; x = (t[cpos < J ? cpos : 0] + 1 + slot) & 3; }
+            else if (slot == 3) type = 1;
+            else { type = 2; x = slot - 4; }
         }
         LaneMut LF, LR;
         if (mval) {
             LF = lane_mut(type, cpos, x, sT[0], J, lf, sDL);
             LR = lane_mut(type, (type == 2) ? J - cpos : J - 1 - cpos, 3 - x, sT[1], J, lfr, sDL);
         } else { LF = lane_mut(0, 0, 0, sT[0], J, lf, sDL); LR = LF; }
+        PHASE(1);
         float delta = 0.0f;
         int nvalid = 0;
         // ---- chunks of reads whose gamma/beta fit the LDS budget
@@ -877,6 +911,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
             }
             __syncthreads();
             const int rend = sCtl[5], ntask = sCtl[6];
+            PHASE(2);
             // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals
             for (int tk = wave; tk < ntask; tk += 4) {
                 const short2 task = sTask[tk];
@@ -954,9 +989,11 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                 }
             }
             __syncthreads();
+            PHASE(3);
             // ---- A3/A4: every lane scores its mutation against the reads of the chunk, two reads per loop
             int ra = rbeg;
-            while (ra < rend) {
+            const bool wave_has_work = (wave << 6) < nvm;            // wave-uniform: idle waves skip the scoring loops
+            while (wave_has_work && ra < rend) {
                 while (ra < rend && !sValid[ra]) ++ra;
                 if (ra >= rend) break;
                 int rb = ra + 1;
@@ -1003,11 +1040,11 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                 ra = two ? rb + 1 : rend;
             }
             rbeg = rend;
+            PHASE(4);
         }
         ++iters;
-        nvalid_last = nvalid;
-        if (!mval) delta = 0.0f;
-        sDelta[tid] = delta; sMvalid[tid] = (uint8_t)mval;
+        if (wave == 0) nvalid_last = nvalid;
+        if (mval) sDelta[myM] = delta;
         const int fav = (mval && delta > MUT_EPS) ? 1 : 0;
         const int anyfav = __syncthreads_or(fav);
         if (!anyfav) break;
@@ -1060,6 +1097,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
         if (sCtl[3] == 0) break;
     }
     __syncthreads();
+    PHASE(5);
     // ---- A6: QVs of the core positions from the last scoring round
     const int J = sCtl[0], cs = sCtl[1], ce = sCtl[2];
     const size_t wi = (size_t)(P.wb_off[z] - z) + w;
@@ -1091,6 +1129,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
         P.wsum[wi] = wsum;
         P.wmeta[wi] = make_int4(ce - cs, nvalid_last, nonconv, iters);
     }
+    PHASE(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1159,7 +1198,7 @@ static void trace_sync(hipStream_t st, const char *what)
 void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or NULL */)
 {
     if (ev) (void)hipEventRecord(ev[0], st);
-    (void)hipMemsetAsync(P.ticket_poa, 0, 32, st);                // ticket_poa and ticket_align are adjacent
+    (void)hipMemsetAsync(P.ticket_poa, 0, 256, st);                // ticket_poa and ticket_align are adjacent
     {
         int n = P.n_zmw * CCSX_NCTX;
         hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, P);
