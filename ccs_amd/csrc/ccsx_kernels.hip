@@ -247,7 +247,7 @@ __device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to
 
 extern __shared__ uint32_t dyn_lds[];
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_poa(KParams P, int z0)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_poa(KParams P, int z0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sMv[64 * 64];
     __shared__ int sLo[64], sPp[64], sV[64], sMeta[64];
@@ -302,6 +302,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
                 if (kkL < n0) rL = g.vrec[vL];
                 const int nblk = (n0 - kb) < LANES ? (n0 - kb) : LANES;
                 int4 myInfo = make_int4(0, NEGV, 0, -1);                   // (lo, colmax, bestrow, pp) of column kb + lane
+                // consume the block loads here, so the compiler waits for them once per block and not at the top of
+                // every column (a vmcnt(0) there would also drain each column's streaming stores)
+                asm volatile("" :: "v"(vL), "v"(rL.x), "v"(rL.y), "v"(rL.z), "v"(rL.w));
                 int32_t *Mrow = g.M + (size_t)kb * 64 + lane;
                 uint8_t *mvrow = g.mvK + (size_t)kb * 64 + lane;
                 for (int j = 0; j < nblk; ++j, Mrow += 64, mvrow += 64) {
@@ -643,6 +646,7 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
     int lo = 0, br = 0;
     for (int jb = 0; jb < Ld; jb += LANES) {            // draft bases: one coalesced load per 64 columns
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
+        asm volatile("" :: "v"(dL));                     // wait for the block load here, not inside the column loop
         const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
         for (int jj = 0; jj < nblk; ++jj) {
             const int j = jb + jj + 1;
