@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--handles", type=int, default=1, help="engine handles (HIP streams) per GPU; the batch is split between them "
                     "so kernels with different bottlenecks (POA: scalar issue, polish: VALU/LDS) overlap")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL; gloo for CPU-side tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -59,8 +60,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        local_rank = int(os.environ.get("CCSX_BENCH_DEVICE", local_rank))   # test hook: several ranks on one GPU (gloo)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -106,7 +111,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     t0 = time.time()
@@ -128,8 +133,18 @@ def main():
         alg_bytes = batch.algorithmic_bytes()               # 3*sum(len) + 48 + 2*L_out per ZMW
         # dominant kernel: algorithmic bytes of the whole step / summed launch duration of that kernel over the handles
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        # measured HBM traffic of that kernel (PMC FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 passes,
+        # profiles/r01_traffic.json, per ZMW at the same 10 x 10 kb workload) scaled to the ZMWs of one launch
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            kz = tj["kernels"][names[dom]]
+            if args.passes == 10 and args.length == 10000:
+                traffic = int((kz["fetch_size_kb_per_zmw"] + kz["write_size_kb_per_zmw"]) * 1024 * args.zmws)
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 6), "traffic": None,
+                    "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                     "avg_launch_ms": round(stage_ms[dom], 3), "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d)"}
         out = {
