@@ -153,7 +153,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     for (int z = 0; z < n; ++z) {
         int64_t maxL = 0;
         int nr = b->read_off[z + 1] - b->read_off[z];
-        if (h->opts.top_passes > 0 && nr > h->opts.top_passes) nr = h->opts.top_passes;
+        { const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > 64) ? 64 : h->opts.top_passes; if (nr > top) nr = top; }
         for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) {
             read_zmw[r] = z;
             const int64_t L = b->base_off[r + 1] - b->base_off[r];

@@ -22,6 +22,7 @@
 #include "wave_ops.h"
 
 #define LANES 64
+#define PW_MAXREADS_SPEC 64
 #ifdef CCSX_PROFILE_PHASES
 #define PHASE_T0() unsigned long long ph_t = __builtin_readcyclecounter(); (void)ph_t
 #define PHASE(idx) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd((unsigned long long *)P.phase + (idx), n_ - ph_t); ph_t = n_; } } while (0)
@@ -259,7 +260,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     {
         const int r0 = rfl(P.read_off[z]);
         int nreads = rfl(P.read_off[z + 1]) - r0;
-        if (P.opts.top_passes > 0 && nreads > P.opts.top_passes) nreads = P.opts.top_passes;
+        {   // SPEC: at most 64 passes are used (the polish kernel keeps per-read state for 64 reads)
+            const int top = (P.opts.top_passes <= 0 || P.opts.top_passes > PW_MAXREADS_SPEC) ? PW_MAXREADS_SPEC : P.opts.top_passes;
+            if (nreads > top) nreads = top;
+        }
         if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; }
         const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
         if (!enough && lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES;

@@ -73,7 +73,7 @@ typedef struct ccsx_model {
 typedef struct ccsx_opts {
     int32_t max_poa_cov;     /* --maxPoaCoverage (docs/changelog.md:114): subreads threaded into the POA */
     int32_t min_passes;      /* --min-passes                                                    */
-    int32_t top_passes;      /* --top-passes (0 = unlimited)                                    */
+    int32_t top_passes;      /* --top-passes; at most 64 passes are ever used (0 or >64 = 64)   */
     int32_t min_length;      /* --min-length                                                    */
     int32_t max_length;      /* --max-length                                                    */
     float   min_rq;          /* --min-rq                                                        */

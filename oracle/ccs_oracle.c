@@ -700,7 +700,10 @@ int orc_consensus_zmw(const orc_model *model, const orc_opts *opts, const float 
 {
     memset(out, 0, sizeof(*out));
     int nreads = nreads_in;
-    if (opts->top_passes > 0 && nreads > opts->top_passes) nreads = opts->top_passes;
+    {   /* SPEC: at most 64 passes are used (--top-passes 0 = "all" means the first 64) */
+        int top = (opts->top_passes <= 0 || opts->top_passes > 64) ? 64 : opts->top_passes;
+        if (nreads > top) nreads = top;
+    }
     if (nreads < opts->min_passes || nreads < 1) { out->status = ST_TOO_FEW; return 0; }
     int maxL = 0;
     for (int r = 0; r < nreads; ++r) { int L = (int)(base_off[r + 1] - base_off[r]); if (L > maxL) maxL = L; }

@@ -154,3 +154,38 @@ def test_empty_and_tiny_reads(handle):
     batch.base_off = bo
     res = handle.consensus(batch)
     _compare(res, _oracle(handle, batch), batch)
+
+
+def test_more_than_64_passes_are_capped(built):
+    """SPEC: at most 64 passes are used (--top-passes 0 / >64 = 64); 70 passes must not overrun anything"""
+    o = api.default_opts(); o.top_passes = 0
+    h = api.Handle(0, opts=o)
+    batch = api.synth(1, 70, 300, seed=35)
+    res = h.consensus(batch)
+    ref = api.Results.allocate(batch)
+    O.consensus_batch(h.model, o, batch, ref)
+    _compare(res, ref, batch)
+    assert res.np_[0] == 64
+    h.close()
+
+
+def test_api_misuse_is_reported_not_fatal(built):
+    import ctypes as C
+    L = api.lib()
+    h = api.Handle(0)
+    with pytest.raises(RuntimeError, match="no batch uploaded"):
+        h.run()
+    batch = api.synth(2, 3, 150, seed=36)
+    bad = api.Batch(batch.zmw_id, batch.snr, batch.read_off.copy(), batch.base_off, batch.bases, batch.pw, batch.ipd, batch.flags)
+    bad.read_off[1] = 99                                    # not monotone / inconsistent
+    with pytest.raises(RuntimeError, match="read_off|n_reads"):
+        h.upload(bad)
+    h.upload(batch); h.run(); h.sync()
+    small = api.Results.allocate(batch)
+    cr = small.c_struct(); cr.seq_capacity = 10             # too small
+    assert L.ccsx_download(h._h, C.byref(cr)) != 0 and b"too small" in L.ccsx_last_error()
+    good = h.download()                                     # the handle stays usable
+    assert (good.status >= 0).all()
+    hp = C.c_void_p()
+    assert L.ccsx_create(99, C.byref(h.model), C.byref(h.opts), C.byref(hp)) != 0
+    h.close()
