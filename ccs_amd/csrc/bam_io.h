@@ -279,14 +279,9 @@ inline size_t tag_value_size(char t)
     switch (t) { case 'c': case 'C': case 'A': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; }
 }
 
-inline bool read_subread(BgzfReader &in, std::vector<uint8_t> &buf, Subread &r)
+// decode one record body (the bytes after block_size)
+inline void parse_subread(const uint8_t *p, uint32_t bs, Subread &r)
 {
-    uint8_t b4[4];
-    if (!in.read(b4, 4)) return false;
-    const uint32_t bs = rd32(b4);
-    buf.resize(bs);
-    if (!in.read(buf.data(), bs)) throw std::runtime_error("truncated BAM record");
-    const uint8_t *p = buf.data();
     const uint32_t l_name = p[8], n_cig = p[12] | (p[13] << 8), l_seq = rd32(p + 16);
     r = Subread();
     r.name.assign((const char *)p + 32, l_name ? l_name - 1 : 0);
@@ -298,7 +293,7 @@ inline bool read_subread(BgzfReader &in, std::vector<uint8_t> &buf, Subread &r)
         const int c = nib2code[nib];
         if (c < 0) { r.has_n = true; r.bases[i] = 0; } else r.bases[i] = (uint8_t)c;
     }
-    const uint8_t *t = seq + (l_seq + 1) / 2 + l_seq, *end = buf.data() + bs;
+    const uint8_t *t = seq + (l_seq + 1) / 2 + l_seq, *end = p + bs;
     while (t + 3 <= end) {
         const char t0 = (char)t[0], t1 = (char)t[1], ty = (char)t[2];
         t += 3;
@@ -334,7 +329,34 @@ inline bool read_subread(BgzfReader &in, std::vector<uint8_t> &buf, Subread &r)
         else if (t0 == 'c' && t1 == 'x') r.cx = (int32_t)rdint(ty, t);
         t += vs;
     }
-    return true;
+}
+
+// a run of raw records (framed by the reader thread, decoded on the pool)
+struct RawChunk {
+    std::vector<uint8_t> data;
+    std::vector<std::pair<uint32_t, uint32_t>> recs;   // (offset, size) of every record body
+};
+
+inline bool read_raw_chunk(BgzfReader &in, RawChunk &c, size_t target_bytes)
+{
+    c.data.clear(); c.recs.clear();
+    uint8_t b4[4];
+    while (c.data.size() < target_bytes) {
+        if (!in.read(b4, 4)) break;
+        const uint32_t bs = rd32(b4);
+        const size_t off = c.data.size();
+        c.data.resize(off + bs);
+        if (!in.read(c.data.data() + off, bs)) throw std::runtime_error("truncated BAM record");
+        c.recs.emplace_back((uint32_t)off, bs);
+    }
+    return !c.recs.empty();
+}
+
+inline std::vector<Subread> decode_chunk(const RawChunk &c)
+{
+    std::vector<Subread> out(c.recs.size());
+    for (size_t i = 0; i < c.recs.size(); ++i) parse_subread(c.data.data() + c.recs[i].first, c.recs[i].second, out[i]);
+    return out;
 }
 
 // ---- record builders -------------------------------------------------------------------------------

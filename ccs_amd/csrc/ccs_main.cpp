@@ -37,6 +37,7 @@ struct Options {
     double min_snr = 2.5;
     int batch = 2048;
     int chunk_i = 1, chunk_n = 1;
+    int workers_per_gpu = 3;      // handles (streams) per device: packing/upload of one batch overlaps the kernels of another
     std::vector<int> gpus;
     ccsx_opts o;
     bool all_gpus = false;
@@ -116,6 +117,7 @@ void usage()
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
                  "      --batch-size N        ZMWs per GPU batch [2048]\n"
                  "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"
+                 "      --workers-per-gpu N   engine handles per device, overlapping upload and compute [3]\n"
                  "      --report-file F       ccs_report.txt path [<OUT prefix>.ccs_report.txt]\n"
                  "      --log-level L         ERROR|WARN|INFO [WARN]\n"
                  "  test helpers (not in the reference):\n"
@@ -141,6 +143,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--maxPoaCoverage") o.o.max_poa_cov = std::atoi(need(a.c_str()).c_str());
         else if (a == "--batch-size") o.batch = std::atoi(need(a.c_str()).c_str());
         else if (a == "--report-file") o.report = need(a.c_str());
+        else if (a == "--workers-per-gpu") o.workers_per_gpu = std::max(1, std::atoi(need(a.c_str()).c_str()));
         else if (a == "--chunk") { if (std::sscanf(need(a.c_str()).c_str(), "%d/%d", &o.chunk_i, &o.chunk_n) != 2 || o.chunk_i < 1 || o.chunk_i > o.chunk_n) { std::fprintf(stderr, "bad --chunk\n"); return false; } }
         else if (a == "--gpus") { std::string v = need(a.c_str()); if (v == "all") o.all_gpus = true; else { size_t p = 0; while (p < v.size()) { o.gpus.push_back(std::atoi(v.c_str() + p)); p = v.find(',', p); if (p == std::string::npos) break; ++p; } } }
         else if (a == "--log-level") { std::string v = need(a.c_str()); o.log_level = v == "INFO" ? 2 : (v == "ERROR" ? 0 : 1); }
@@ -329,7 +332,7 @@ int main(int argc, char **argv)
             if (ndev <= 0) { std::fprintf(stderr, "ccs: no gfx950 GPU available (this build has no CPU consensus path)\n"); return 1; }
             if (opt.all_gpus) for (int d = 0; d < ndev; ++d) opt.gpus.push_back(d);
             if (opt.gpus.empty()) opt.gpus.push_back(0);
-            for (int d : opt.gpus) {
+            for (int d : opt.gpus) for (int wk = 0; wk < opt.workers_per_gpu; ++wk) {
                 ccsx_handle h = nullptr;
                 if (ccsx_create(d, &model, &opt.o, &h)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); return 1; }
                 handles.push_back(h);
@@ -344,8 +347,6 @@ int main(int argc, char **argv)
 
         // ---- reader
         std::thread reader([&] {
-            std::vector<uint8_t> buf;
-            Subread rec;
             ZmwIn cur; bool have = false;
             int64_t nz = 0, nb = 0;
             auto batch = std::make_shared<Batch>();
@@ -358,19 +359,30 @@ int main(int argc, char **argv)
                     if (opt.dump) std::printf("%d\t%d\t%zu\t%.2f,%.2f,%.2f,%.2f\n", cur.zm, cur.host_status, cur.reads.size(), cur.snr[0], cur.snr[1], cur.snr[2], cur.snr[3]);
                     else {
                         batch->zmws.push_back(std::move(cur));
-                        if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; pack(*batch); to_gpu.push(batch); batch = std::make_shared<Batch>(); }
+                        if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_gpu.push(batch); batch = std::make_shared<Batch>(); }
                     }
                 }
                 cur = ZmwIn(); have = false;
             };
-            while (read_subread(in, buf, rec)) {
-                if (movie.empty()) movie = movie_of(rec.name);
-                if (!have || rec.zm != cur.zm) { flush_zmw(); cur.zm = rec.zm; have = true; }
-                if (rec.has_snr) std::memcpy(cur.snr, rec.snr, 16);
-                cur.reads.push_back(std::move(rec));
+            // this thread only frames records; decoding runs on the pool, results are consumed in order
+            std::deque<std::future<std::vector<Subread>>> pending;
+            auto consume = [&](std::vector<Subread> recs) {
+                for (Subread &rec : recs) {
+                    if (movie.empty()) movie = movie_of(rec.name);
+                    if (!have || rec.zm != cur.zm) { flush_zmw(); cur.zm = rec.zm; have = true; }
+                    if (rec.has_snr) std::memcpy(cur.snr, rec.snr, 16);
+                    cur.reads.push_back(std::move(rec));
+                }
+            };
+            for (;;) {
+                auto raw = std::make_shared<RawChunk>();
+                const bool more = read_raw_chunk(in, *raw, 4u << 20);
+                if (more) pending.push_back(pool.submit([raw] { return decode_chunk(*raw); }));
+                while (!pending.empty() && (!more || pending.size() > (size_t)(2 * pool.size() + 4))) { consume(pending.front().get()); pending.pop_front(); }
+                if (!more) break;
             }
             flush_zmw();
-            if (!opt.dump && !batch->zmws.empty()) { batch->index = nb++; pack(*batch); to_gpu.push(batch); }
+            if (!opt.dump && !batch->zmws.empty()) { batch->index = nb++; to_gpu.push(batch); }
             to_gpu.close();
         });
         if (opt.dump) { reader.join(); return 0; }
@@ -381,6 +393,7 @@ int main(int argc, char **argv)
         for (ccsx_handle h : handles) workers.emplace_back([&, h] {
             std::shared_ptr<Batch> b;
             while (to_gpu.pop(b)) {
+                pack(*b);                                       // SoA packing off the reader thread
                 const int n = (int)b->zmw_id.size();
                 if (n > 0) {
                     ccsx_batch cb{n, (int32_t)b->flags.size(), (int64_t)b->bases.size(), b->zmw_id.data(), b->snr.data(), b->read_off.data(),
@@ -454,7 +467,7 @@ int main(int argc, char **argv)
         write_report(opt, rep);
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         if (opt.log_level >= 1)
-            std::fprintf(stderr, "ccs: %" PRId64 " ZMWs in, %" PRId64 " HiFi reads out, %.2f s (%.1f ZMWs/s, %d host threads, %zu GPU%s)\n", rep.input, rep.pass, el,
+            std::fprintf(stderr, "ccs: %" PRId64 " ZMWs in, %" PRId64 " HiFi reads out, %.2f s (%.1f ZMWs/s, %d host threads, %zu GPU worker%s)\n", rep.input, rep.pass, el,
                          rep.input / el, nthreads, handles.size(), handles.size() == 1 ? "" : "s");
         return failed ? 1 : 0;
     } catch (const std::exception &e) {
