@@ -113,7 +113,7 @@ void usage()
                  "      --min-length N        minimum draft length [10]\n"
                  "      --max-length N        maximum draft length [50000]\n"
                  "      --min-rq F            minimum predicted accuracy [0.99]\n"
-                 "      --maxPoaCoverage N    subreads used for the draft [10]\n"
+                 "      --maxPoaCoverage N    subreads used for the draft [5]\n"
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
                  "      --batch-size N        ZMWs per GPU batch [2048]\n"
                  "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"

@@ -56,7 +56,7 @@ void ccsx_model_default(ccsx_model *m)
 void ccsx_opts_default(ccsx_opts *o)
 {
     std::memset(o, 0, sizeof(*o));
-    o->max_poa_cov = 10;
+    o->max_poa_cov = 5;      // "an approximate draft consensus from a few subreads" (docs/how-does-ccs-work.md:15); DESIGN.md §4 sweep
     o->min_passes = 3;
     o->top_passes = 60;      // docs/faq/accuracy-vs-passes.md:49-52
     o->min_length = 10;

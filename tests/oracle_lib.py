@@ -54,7 +54,7 @@ def tables(model, snr):
     return ME, INS, DL
 
 
-def poa_draft(batch, z, max_poa_cov=10):
+def poa_draft(batch, z, max_poa_cov=5):
     r0, r1 = int(batch.read_off[z]), int(batch.read_off[z + 1])
     b0 = int(batch.base_off[r0])
     rel = (batch.base_off[r0:r1 + 1] - b0).astype(np.int64)

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header(built):
     m = api.default_model()
     assert m.name == b"SYN-1" and m.snr_lo == 4.0 and m.snr_hi == 20.0
     o = api.default_opts()
-    assert (o.max_poa_cov, o.min_passes, o.top_passes, o.min_length, o.max_length) == (10, 3, 60, 10, 50000)
+    assert (o.max_poa_cov, o.min_passes, o.top_passes, o.min_length, o.max_length) == (5, 3, 60, 10, 50000)
     assert abs(o.min_rq - 0.99) < 1e-7
 
 
