@@ -167,6 +167,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
         for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) h->ent_off[r + 1] = h->ent_off[r] + 2 * (wcap - 1);
         maxL_max = std::max(maxL_max, maxL); vcap_max = std::max<int64_t>(vcap_max, vcap[z]); need_max = std::max(need_max, 2 * (wcap - 1));
     }
+    if (maxL_max > 65535) { ccsx_set_error("ccsx_upload: subreads longer than 65535 bases are not supported"); return -1; }
     h->read_off.assign(b->read_off, b->read_off + n + 1);
     h->base_off.assign(b->base_off, b->base_off + R + 1);
     const int64_t total_wslots = (int64_t)h->wb_off[n] - n;

@@ -673,10 +673,14 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
                 if (lane == 0) lo_need[kk] = lo;
                 org = i;                                // reset: this column is the new edge
             }
-            int dd = best + 4 * lane, od = org;
-            wave_scan_max_pair(dd, od);
+            // insertion chain with origin: (1) prefix max of d = c + 4*lane; (2) the winner of lane l is the highest
+            // lane k <= l that attains its own running maximum ("record holder": ties keep the higher lane, as the
+            // SPEC's serial chain does); a second prefix max over (k << 16 | origin_k) of the record holders finds it.
+            const int d0 = best + 4 * lane;
+            const int dd = wave_scan_max_i32(d0);
+            const int key = wave_scan_max_i32(d0 == dd ? ((lane << 16) | org) : -1);
             const int xi = dd - 4 * lane;
-            if (xi > best) { best = xi; org = od; }
+            if (xi > best) { best = xi; org = key & 0xffff; }
             if (i > I || best < NEGV / 2) best = NEGV;
             const int cm = wave_reduce_max_i32(best);
             const unsigned long long bal = __ballot(best == cm);
@@ -728,12 +732,12 @@ __global__ void k_post(KParams P)
 // reads per loop (two chains), serial over read rows exactly as the SPEC orders the operations.
 #define PW_THREADS 256
 #define PW_MAXREADS 64
-#define GB_FLOATS 9216               // 36 KB of LDS for gamma/beta of one chunk of reads (3 workgroups per CU)
+#define GB_FLOATS 8448               // 33 KB of LDS for gamma/beta of one chunk of reads (3 workgroups per CU with allocation-granularity slack)
 #define MI_STRIDE 13
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
-    int c, q, kA, kB, isdel, fin;
-    float dlA, dlL, fA, fB;
+    int c, q, kA, kB, isdel, fin;    // kA / kB index sCTX; +16 selects the copy whose INS component is zero
+    float dlA, dlL;
 };
 
 __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_t *t, int J, int lf, const float *sDL)
@@ -746,10 +750,12 @@ __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_
     else                { fin = (c + 1 == J); xA = fin ? 0 : t[c + 1]; q = c + 2; }
     if (pA > 3) pA = (xA + 2) & 3;
     const int kA = pA * 4 + xA, kB = (type == 1) ? kA : xA * 4 + nB;
-    L.c = c; L.q = q > J ? J : q; L.kA = kA; L.kB = kB; L.isdel = (type == 1); L.fin = fin;
+    L.c = c; L.q = q > J ? J : q; L.isdel = (type == 1); L.fin = fin;
     L.dlA = sDL[kA]; L.dlL = sDL[kB];
-    L.fA = (type == 1 && fin) ? 0.0f : 1.0f;
-    L.fB = fin ? 0.0f : 1.0f;
+    // the SPEC's "no stay move" cases (a deletion whose extension is the final column: INS[kA] unused; any extension
+    // that reaches the final column: INS[kB] unused) read the table copy whose INS component is an exact zero
+    L.kA = kA + ((type == 1 && fin) ? 16 : 0);
+    L.kB = kB + (fin ? 16 : 0);
     return L;
 }
 
@@ -764,9 +770,9 @@ __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, cons
 {
     const float gmm = gam[i * S];
     float2 nA = make_float2(0.f, 0.f), nB = make_float2(0.f, 0.f);
-    if (!last) { nA = sCTX[o * 16 + L.kA]; nB = sCTX[o * 16 + L.kB]; }
+    if (!last) { nA = sCTX[o * 32 + L.kA]; nB = sCTX[o * 32 + L.kB]; }
     const float bqn = bet[(i + 1) * S];
-    const float insA = s.pA.y * L.fA, meA = s.pA.x, insB = s.pB.y * L.fB;
+    const float insA = s.pA.y, meA = s.pA.x, insB = s.pB.y;
     const float a = gmm + s.ap * insA;
     float b;
     if (L.isdel) b = a;
@@ -778,7 +784,7 @@ __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, cons
 
 __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
 {
-    __shared__ float2 sCTX[CCSX_NOBS * 16];                  // [obs][ctx] = (ME, INS)
+    __shared__ float2 sCTX[CCSX_NOBS * 32];                  // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0)
     __shared__ float sDL[16];
     __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
     __shared__ float sDLJ[2][32];
@@ -812,9 +818,9 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
     const int r0 = P.read_off[z], nreads = P.nreads_used[z];
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
 
-    for (int e = tid; e < CCSX_NOBS * 16; e += PW_THREADS) {
-        const int o = e >> 4, k = e & 15;
-        sCTX[e] = make_float2(P.tabME[(size_t)z * 192 + k * CCSX_NOBS + o], P.tabINS[(size_t)z * 192 + k * CCSX_NOBS + o]);
+    for (int e = tid; e < CCSX_NOBS * 32; e += PW_THREADS) {
+        const int o = e >> 5, k = e & 15;
+        sCTX[e] = make_float2(P.tabME[(size_t)z * 192 + k * CCSX_NOBS + o], (e & 16) ? 0.0f : P.tabINS[(size_t)z * 192 + k * CCSX_NOBS + o]);
     }
     if (tid < 16) sDL[tid] = P.tabDL[(size_t)z * 16 + tid];
     if (tid < we - ws) sT[0][tid] = draft[ws + tid];
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
             if (j < J) {
                 const int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
                 const int k = ctx_of(prev, sT[sd][j]);
-                sMI[sd][j * MI_STRIDE + o] = sCTX[o * 16 + k];
+                sMI[sd][j * MI_STRIDE + o] = sCTX[o * 32 + k];
                 if (o == 0) sDLJ[sd][j] = sDL[k];
             }
         }
