@@ -2,9 +2,9 @@ import sys, os, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
 from ccs_amd import api
-n = 2048
+n = 4096
 b = api.synth(n, 10, 10000, seed=5)
-for cov in (3, 4, 6, 8, 10):
+for cov in (4, 5, 6, 7, 8):
     o = api.default_opts(); o.max_poa_cov = cov
     h = api.Handle(0, opts=o)
     h.upload(b); h.run(); h.sync(); h.run(); h.sync()
