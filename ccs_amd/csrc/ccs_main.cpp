@@ -46,7 +46,7 @@ struct Options {
     int log_level = 1;
 };
 
-enum HostStatus { HS_OK = 0, HS_POOR_SNR = 100, HS_NO_SUBREADS = 101, HS_TOO_FEW = 102 };
+enum HostStatus { HS_OK = 0, HS_POOR_SNR = 100, HS_NO_SUBREADS = 101, HS_TOO_FEW = 102, HS_TOO_LONG = 103 };
 
 struct ZmwIn {
     int32_t zm = 0;
@@ -225,6 +225,8 @@ void finish_zmw(ZmwIn &z, const Options &o)
     }
     z.reads.swap(keep);
     if (!any_len_ok) { z.host_status = HS_NO_SUBREADS; z.reads.clear(); return; }
+    // the engine handles subreads up to 65535 bases; longer inserts cannot pass --max-length (<= 50000) anyway
+    for (auto &r : z.reads) if (r.bases.size() > 65535 || (double)r.bases.size() > 1.3 * (double)o.o.max_length + 1000.0) { z.host_status = HS_TOO_LONG; z.reads.clear(); return; }
     if ((int)z.reads.size() < o.o.min_passes) { z.host_status = HS_TOO_FEW; z.reads.clear(); return; }
 }
 
@@ -271,7 +273,7 @@ const char *fail_label(int st)
         case CCSX_TOO_MANY_UNUSABLE: return "Reads failed polishing";
         case CCSX_NON_CONVERGENT: return "CCS did not converge";
         case CCSX_TOO_SHORT: return "Draft below --min-length";
-        case CCSX_TOO_LONG: return "Draft above --max-length";
+        case CCSX_TOO_LONG: case HS_TOO_LONG: return "Draft above --max-length";
         case CCSX_LOW_RQ: return "CCS below minimum RQ";
         case CCSX_EMPTY_WINDOW: return "Empty coverage windows";
         default: return "Unknown error";

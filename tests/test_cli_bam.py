@@ -44,6 +44,10 @@ def test_step1_filters_without_gpu(built, tmp_path):
     # --min-passes above the pass count -> "Lacking full passes" (TOO_FEW_PASSES); --min-snr above the SNR -> POOR_SNR
     assert all(l.split("\t")[1] == "102" for l in _run("--dump-zmws", "--min-passes", 5, bam).stdout.strip().split("\n"))
     assert all(l.split("\t")[1] == "100" for l in _run("--dump-zmws", "--min-snr", 30, bam).stdout.strip().split("\n"))
+    # a 70 kb insert is rejected on the host (status 103) instead of failing the batch upload
+    long_bam = tmp_path / "long.subreads.bam"
+    _run("--write-synthetic", "1,3,70000,4", long_bam)
+    assert _run("--dump-zmws", long_bam).stdout.split("\t")[1] == "103"
     # --chunk i/N partitions the ZMWs
     a = _run("--dump-zmws", "--chunk", "1/2", bam).stdout.strip().split("\n")
     c = _run("--dump-zmws", "--chunk", "2/2", bam).stdout.strip().split("\n")
