@@ -236,6 +236,7 @@ struct Subread {
     int32_t cx = -1;            // -1: tag absent
     float snr[4] = {0, 0, 0, 0};
     bool has_snr = false, has_n = false;
+    uint8_t strand = 0;         // 0 forward / 1 reverse pass (set by the driver: cx direction bits, else alternation)
     std::vector<uint8_t> bases;  // 0..3
     std::vector<uint8_t> pw, ipd;
 };

@@ -43,6 +43,7 @@ struct Options {
     bool all_gpus = false;
     std::string write_synth;      // "N,P,L[,seed]" -> write a synthetic subreads.bam to `out`
     bool dump = false;            // print one line per ZMW after the step-1 filters, no GPU
+    bool by_strand = false;       // --by-strand: one consensus per strand (docs/faq/mode-by-strand.md:8-23)
     int log_level = 1;
 };
 
@@ -54,6 +55,7 @@ struct ZmwIn {
     std::vector<Subread> reads;   // after filters: full-length passes only
     int host_status = HS_OK;
     int64_t order = 0;
+    int strand_tag = 0;           // --by-strand: 1 = /fwd, 2 = /rev
 };
 
 struct Batch {
@@ -114,6 +116,7 @@ void usage()
                  "      --max-length N        maximum draft length [50000]\n"
                  "      --min-rq F            minimum predicted accuracy [0.99]\n"
                  "      --maxPoaCoverage N    subreads used for the draft [5]\n"
+                 "      --by-strand           one consensus per strand, read names end in /fwd or /rev\n"
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
                  "      --batch-size N        ZMWs per GPU batch [2048]\n"
                  "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"
@@ -149,6 +152,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--log-level") { std::string v = need(a.c_str()); o.log_level = v == "INFO" ? 2 : (v == "ERROR" ? 0 : 1); }
         else if (a == "--write-synthetic") o.write_synth = need(a.c_str());
         else if (a == "--dump-zmws") o.dump = true;
+        else if (a == "--by-strand") o.by_strand = true;
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
         else pos.push_back(a);
     }
@@ -240,16 +244,12 @@ void pack(Batch &b)
         b.slot[i] = (int)b.zmw_id.size();
         b.zmw_id.push_back(z.zm);
         b.snr.insert(b.snr.end(), z.snr, z.snr + 4);
-        bool alt = false;
         for (size_t k = 0; k < z.reads.size(); ++k) {
             Subread &r = z.reads[k];
             b.bases.insert(b.bases.end(), r.bases.begin(), r.bases.end());
             b.pw.insert(b.pw.end(), r.pw.begin(), r.pw.end());
             b.ipd.insert(b.ipd.end(), r.ipd.begin(), r.ipd.end());
-            // strand: cx REVERSE_PASS (32) / FORWARD_PASS (16) when present, else consecutive passes alternate
-            uint8_t f = (r.cx >= 0 && (r.cx & 48)) ? (uint8_t)((r.cx & 32) ? 1 : 0) : (uint8_t)(alt ? 1 : 0);
-            alt = !alt;
-            b.flags.push_back(f);
+            b.flags.push_back(r.strand);
             b.base_off.push_back((int64_t)b.bases.size());
             std::vector<uint8_t>().swap(r.bases); std::vector<uint8_t>().swap(r.pw); std::vector<uint8_t>().swap(r.ipd);
         }
@@ -352,16 +352,32 @@ int main(int argc, char **argv)
             ZmwIn cur; bool have = false;
             int64_t nz = 0, nb = 0;
             auto batch = std::make_shared<Batch>();
+            auto emit_zmw = [&](ZmwIn &zin) {
+                finish_zmw(zin, opt);
+                if (opt.dump) std::printf("%d%s\t%d\t%zu\t%.2f,%.2f,%.2f,%.2f\n", zin.zm, zin.strand_tag == 1 ? "/fwd" : (zin.strand_tag == 2 ? "/rev" : ""), zin.host_status,
+                                          zin.reads.size(), zin.snr[0], zin.snr[1], zin.snr[2], zin.snr[3]);
+                else {
+                    batch->zmws.push_back(std::move(zin));
+                    if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_gpu.push(batch); batch = std::make_shared<Batch>(); }
+                }
+            };
             auto flush_zmw = [&] {
                 if (!have) return;
                 const bool mine = ((nz % opt.chunk_n) == (opt.chunk_i - 1));     // --chunk i/N (round-robin over ZMWs; needs no .pbi)
                 cur.order = nz++;
                 if (mine) {
-                    finish_zmw(cur, opt);
-                    if (opt.dump) std::printf("%d\t%d\t%zu\t%.2f,%.2f,%.2f,%.2f\n", cur.zm, cur.host_status, cur.reads.size(), cur.snr[0], cur.snr[1], cur.snr[2], cur.snr[3]);
-                    else {
-                        batch->zmws.push_back(std::move(cur));
-                        if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_gpu.push(batch); batch = std::make_shared<Batch>(); }
+                    // strand of every pass: cx REVERSE_PASS (32) / FORWARD_PASS (16) when present, else consecutive subreads alternate
+                    for (size_t k = 0; k < cur.reads.size(); ++k) {
+                        Subread &r = cur.reads[k];
+                        r.strand = (r.cx >= 0 && (r.cx & 48)) ? (uint8_t)((r.cx & 32) ? 1 : 0) : (uint8_t)(k & 1);
+                    }
+                    if (!opt.by_strand) emit_zmw(cur);
+                    else {                                   // each strand is treated as an individual entity (mode-by-strand.md:16-23)
+                        ZmwIn f, rv;
+                        f.zm = rv.zm = cur.zm; f.order = rv.order = cur.order; f.strand_tag = 1; rv.strand_tag = 2;
+                        std::memcpy(f.snr, cur.snr, 16); std::memcpy(rv.snr, cur.snr, 16);
+                        for (Subread &r : cur.reads) (r.strand ? rv : f).reads.push_back(std::move(r));
+                        emit_zmw(f); emit_zmw(rv);
                     }
                 }
                 cur = ZmwIn(); have = false;
@@ -437,7 +453,7 @@ int main(int argc, char **argv)
                     if (st != CCSX_SUCCESS) { rep.fail[fail_label(st)]++; continue; }
                     ++rep.pass;
                     const int64_t o = bt.seq_off[s]; const int32_t len = bt.seq_len[s];
-                    rb.begin(movie + "/" + std::to_string(z.zm) + "/ccs", bt.seq.data() + o, bt.qual.data() + o, (uint32_t)len);
+                    rb.begin(movie + "/" + std::to_string(z.zm) + "/ccs" + (z.strand_tag == 1 ? "/fwd" : (z.strand_tag == 2 ? "/rev" : "")), bt.seq.data() + o, bt.qual.data() + o, (uint32_t)len);
                     rb.tagZ("RG", "ccsamd01");
                     rb.tagf("ec", bt.ec[s]);
                     rb.tagi("np", bt.np[s]);

@@ -48,6 +48,10 @@ def test_step1_filters_without_gpu(built, tmp_path):
     long_bam = tmp_path / "long.subreads.bam"
     _run("--write-synthetic", "1,3,70000,4", long_bam)
     assert _run("--dump-zmws", long_bam).stdout.split("\t")[1] == "103"
+    # --by-strand: each strand is its own entity with its own pass count (4 passes -> 2 + 2 < --min-passes 3)
+    bs = _run("--dump-zmws", "--by-strand", "--min-passes", 2, bam).stdout.strip().split("\n")
+    assert [l.split("\t")[:3] for l in bs] == [[f"{1000 + z}/{s}", "0", "2"] for z in range(4) for s in ("fwd", "rev")]
+    assert all(l.split("\t")[1] == "102" for l in _run("--dump-zmws", "--by-strand", bam).stdout.strip().split("\n"))
     # --chunk i/N partitions the ZMWs
     a = _run("--dump-zmws", "--chunk", "1/2", bam).stdout.strip().split("\n")
     c = _run("--dump-zmws", "--chunk", "2/2", bam).stdout.strip().split("\n")
@@ -86,3 +90,23 @@ def test_cli_matches_library(built, tmp_path):
         assert np.allclose(t["sn"], batch.snr[z])
     rep = open(tmp_path / "o.hifi.ccs_report.txt").read()
     assert f"ZMWs input                    : 7" in rep and f"ZMWs pass filters             : {len(ok)}" in rep
+
+
+@pytest.mark.gpu
+def test_cli_by_strand(built, tmp_path):
+    bam, out = tmp_path / "s.subreads.bam", tmp_path / "o.hifi.bam"
+    _run("--write-synthetic", "3,8,500,23", bam)
+    _run(bam, out, "--by-strand", "--min-rq", 0.9)
+    _, recs = bam_util.read_bam(out)
+    names = [r["name"] for r in recs]
+    assert names == [f"m64000_synth/{1000 + z}/ccs/{s}" for z in range(3) for s in ("fwd", "rev")]
+    batch = api.synth(3, 8, 500, seed=23, first_zmw_id=1000)
+    for z in range(3):
+        tpl = batch.tpl[batch.tpl_off[z]:batch.tpl_off[z + 1]]
+        fwd, rev = recs[2 * z]["seq"], recs[2 * z + 1]["seq"]
+        assert recs[2 * z]["tags"]["np"] == 4 and recs[2 * z + 1]["tags"]["np"] == 4
+        assert abs(len(fwd) - 500) <= 25 and abs(len(rev) - 500) <= 25   # 4 passes per strand (~Q15): residual indels
+        # the reverse-strand consensus is the reverse complement of the forward one (up to a few residual errors)
+        rc = (3 - rev[::-1]).astype(np.uint8)
+        n = min(len(rc), len(fwd), len(tpl))
+        assert (rc[:50] == fwd[:50]).mean() > 0.9 and (fwd[:50] == tpl[:50]).mean() > 0.9
