@@ -106,7 +106,9 @@ def test_cli_by_strand(built, tmp_path):
         fwd, rev = recs[2 * z]["seq"], recs[2 * z + 1]["seq"]
         assert recs[2 * z]["tags"]["np"] == 4 and recs[2 * z + 1]["tags"]["np"] == 4
         assert abs(len(fwd) - 500) <= 25 and abs(len(rev) - 500) <= 25   # 4 passes per strand (~Q15): residual indels
-        # the reverse-strand consensus is the reverse complement of the forward one (up to a few residual errors)
+        # both strand consensi describe the same molecule: the reverse one is the reverse complement of the template
+        def kmers(x, k=12):
+            return {bytes(x[i:i + k]) for i in range(len(x) - k + 1)}
         rc = (3 - rev[::-1]).astype(np.uint8)
-        n = min(len(rc), len(fwd), len(tpl))
-        assert (rc[:50] == fwd[:50]).mean() > 0.9 and (fwd[:50] == tpl[:50]).mean() > 0.9
+        kt = kmers(tpl)
+        assert len(kmers(fwd) & kt) / len(kt) > 0.6 and len(kmers(rc) & kt) / len(kt) > 0.6
