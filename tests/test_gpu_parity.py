@@ -189,3 +189,59 @@ def test_api_misuse_is_reported_not_fatal(built):
     hp = C.c_void_p()
     assert L.ccsx_create(99, C.byref(h.model), C.byref(h.opts), C.byref(hp)) != 0
     h.close()
+
+
+def test_fuzz_ragged_batch_bit_exact(handle):
+    """200 ragged ZMWs (3-24 passes, 40-1800 bp), with corrupted reads, truncated reads, all-forward ZMWs,
+    constant-base reads and flipped strand flags mixed in: every output must equal the oracle's."""
+    batch = api.synth(200, (3, 24), (40, 1800), seed=4242)
+    rng = np.random.default_rng(7)
+    bases, flags = batch.bases, batch.flags
+    for z in range(0, 200, 7):                      # junk read
+        r = int(batch.read_off[z]) + int(rng.integers(0, batch.read_off[z + 1] - batch.read_off[z]))
+        a, b = int(batch.base_off[r]), int(batch.base_off[r + 1])
+        bases[a:b] = rng.integers(0, 4, b - a, dtype=np.uint8)
+    for z in range(3, 200, 11):                     # homopolymer read
+        r = int(batch.read_off[z]) + 1
+        a, b = int(batch.base_off[r]), int(batch.base_off[r + 1])
+        bases[a:b] = 2
+    for z in range(5, 200, 13):                     # wrong strand flag on one read
+        r = int(batch.read_off[z + 1]) - 1
+        flags[r] ^= 1
+    for z in range(1, 200, 17):                     # a block of the read replaced by junk (large insertion-like)
+        r = int(batch.read_off[z]) + 2
+        a, b = int(batch.base_off[r]), int(batch.base_off[r + 1])
+        if b - a > 200:
+            m = a + (b - a) // 2
+            bases[m:m + 90] = rng.integers(0, 4, 90, dtype=np.uint8)
+    res = handle.consensus(batch)
+    ref = _oracle(handle, batch)
+    _compare(res, ref, batch)
+    assert len(set(res.status.tolist())) >= 2       # the batch exercises more than one status
+
+
+def test_full_size_determinism_and_sharding(handle):
+    """BASELINE config-2 shape at a bench-sized batch: two runs are byte-identical, and so is the same batch
+    processed as two independent shards on two handles (what multi-GPU sharding does)."""
+    import hashlib
+    batch = api.synth(512, 10, 10000, seed=99)
+
+    def digest(results, parts):
+        h = hashlib.sha256()
+        for res, n in zip(results, parts):
+            for z in range(n):
+                h.update(res.sequence(z).tobytes()); h.update(res.raw(z).tobytes()); h.update(res.rq[z].tobytes())
+        return h.hexdigest()
+
+    a = handle.consensus(batch)
+    b = handle.consensus(batch)
+    d1, d2 = digest([a], [512]), digest([b], [512])
+    assert d1 == d2
+    h2 = api.Handle(0)
+    p0, p1 = batch.slice(0, 200), batch.slice(200, 512)
+    handle.upload(p0); h2.upload(p1)
+    handle.run(); h2.run(); handle.sync(); h2.sync()
+    d3 = digest([handle.download(), h2.download()], [200, 312])
+    h2.close()
+    assert d3 == d1
+    assert (a.status == 0).mean() > 0.99 and a.rq[a.status == 0].mean() > 0.9995
