@@ -825,29 +825,34 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
     if (tid < 16) sDL[tid] = P.tabDL[(size_t)z * 16 + tid];
     if (tid < we - ws) sT[0][tid] = draft[ws + tid];
     if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb[w] - ws; sCtl[2] = wb[w + 1] - ws; }
-    // read segments (native orientation)
-    for (int r = wave; r < nreads; r += 4) {
-        int n = -1, na = 0;
-        const int rr = r0 + r;
-        const int L = (int)(P.base_off[rr + 1] - P.base_off[rr]);
+    // read segments (native orientation).  Metadata of all reads is fetched in parallel, one lane per read
+    // (one dependent chain for the whole window instead of one per read), then the segments are loaded coalesced.
+    if (tid < nreads) {
+        const int rr = r0 + tid;
+        const int64_t bo0 = P.base_off[rr];
+        const int L = (int)(P.base_off[rr + 1] - bo0);
         const int st = ((P.flags[rr] & 1) != (P.flags[r0] & 1)) ? 1 : 0;
+        int n = -1, na = 0;
         if (P.avalid[rr]) {
             const int32_t *ent = P.ent + P.ent_off[rr];
-            int a = ent[idx_ws], b = ent[idx_we];
+            const int a = ent[idx_ws], b = ent[idx_we];
             n = b - a;
             if (n < 0 || n > CCSX_IMAX) n = -1;
             na = st ? L - b : a;
         }
-        if (lane == 0) { sI[r] = n; sStrand[r] = (uint8_t)st; }
+        sI[tid] = n; sStrand[tid] = (uint8_t)st; sGoff[tid] = na;          // sGoff doubles as scratch for the segment start
+    }
+    __syncthreads();
+    for (int r = wave; r < nreads; r += 4) {
+        const int n = sI[r];
         uint8_t ov = 0;                                       // rows beyond the segment read as obs 0 (look-ahead loads stay finite)
         if (lane < n) {
-            const int64_t p = P.base_off[rr] + na + lane;
+            const int64_t p = P.base_off[r0 + r] + sGoff[r] + lane;
             ov = (uint8_t)obs_of(P.bases[p], P.pw[p]);
         }
         sObs[r][lane] = ov;
         if (lane < 4) sObs[r][64 + lane] = 0;
     }
-
     const int half = lane >> 5, hrow = lane & 31;          // fill: which read of the pair, row within it
     PHASE(0);
     int iters = 0, nonconv = 0, nvalid_last = 0;
