@@ -24,11 +24,12 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 #define WAVE_IMIN ((int)0x80000000)
 __device__ __forceinline__ int wave_scan_max_i32(int v)
 {
+    // Hillis-Steele inside each 16-lane row (every step reads the running value, so each one is a single fused
+    // v_max_i32_dpp), then the two cross-row broadcasts: 6 VALU ops.
     int s = imax(v, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_SHR(2), 0xf, 0xf, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_SHR(3), 0xf, 0xf, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(4), 0xf, 0xe, false));
-    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(8), 0xf, 0xc, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(2), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(4), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(8), 0xf, 0xf, false));
     s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_BCAST15, 0xa, 0xf, false));
     s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_BCAST31, 0xc, 0xf, false));
     return s;
