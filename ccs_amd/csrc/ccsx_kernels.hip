@@ -251,12 +251,12 @@ extern __shared__ uint32_t dyn_lds[];
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_poa(KParams P, int z0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sMv[64 * 64];
-    __shared__ int sLo[64], sPp[64], sV[64], sMeta[64];
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
     PoaSlot g = poa_slot(P, blockIdx.x);                   // launched in chunks of poa_slots ZMWs: slot = block
     const int z = z0 + blockIdx.x;
     if (z >= P.n_zmw) return;
+    PHASE_T0();
     {
         const int r0 = rfl(P.read_off[z]);
         int nreads = rfl(P.read_off[z + 1]) - r0;
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 __threadfence_block();
                 }
             } else {
+            PHASE(8);
             // ---- DP over the graph in topological order
             const int n0 = n;
             int Mprev = NEGV, vprev = -2, lo_prev = 0, cm_prev = NEGV, br_prev = 0;
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 if (kkL < n0) g.kinfo[kkL] = myInfo;
             }
             __threadfence_block();
+            PHASE(9);
             if (kend >= 0) {                                // else: read not added
             // ---- traceback: lane 0 walks, the block of 64 positions it is in is cached in LDS
             {
@@ -414,34 +416,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 while (k >= 0) {
                     const int kb = (k >> 6) << 6;
                     __syncthreads();
+                    // block cache: the 64 move rows go to LDS, the per-position words (band start, position of in-edge 0,
+                    // vertex id, record word) stay in lane registers and are handed out with v_readlane
+                    int4 kiL = make_int4(0, 0, 0, -1);
+                    int vLt = 0, metaL = 0;
                     {
                         const int kk = kb + lane;
-                        const bool in = kk < n0;
-                        const int v = in ? order[kk] : 0;
-                        int4 ki = make_int4(0, 0, 0, -1);
-                        if (in) ki = g.kinfo[kk];
-                        sV[lane] = v; sLo[lane] = ki.x; sPp[lane] = ki.w; sMeta[lane] = in ? g.vrec[v].x : 0;
+                        if (kk < n0) { kiL = g.kinfo[kk]; vLt = order[kk]; metaL = g.vrec[vLt].x; }
                         const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb * 64);
                         uint4 *dst = (uint4 *)sMv;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) dst[q * 64 + lane] = src[q * 64 + lane];
                     }
+                    asm volatile("" :: "v"(kiL.x), "v"(kiL.w), "v"(vLt), "v"(metaL));
                     __syncthreads();
                     while (k >= kb) {                                  // uniform walk: every lane follows the same (k, i)
                         const int kl = k - kb;
-                        CHK(i - sLo[kl] >= 0 && i - sLo[kl] < 64 && i >= 0, 101);
-                        const int m = rfl(sMv[kl * 64 + (i - sLo[kl])]);
+                        const int lo_k = rl(kiL.x, kl);
+                        CHK(i - lo_k >= 0 && i - lo_k < 64 && i >= 0, 101);
+                        const int m = rfl(sMv[kl * 64 + (i - lo_k)]);
                         const int t = m & 3, slot = m >> 2;
                         CHK(i >= 1 || t == MV_DEL, 102);
                         if (t == MV_INS) { if (lane == 0) g.pathv[i - 1] = -1; --i; continue; }
-                        const int meta = rfl(sMeta[kl]);
+                        const int meta = rl(metaL, kl);
                         const int np = (meta >> 8) & 255;
                         int up;
                         if (np == 0) up = -1;
-                        else if (slot == 0) up = rfl(sPp[kl]);
-                        else { const int v = rfl(sV[kl]); const int4 rec = g.vrec[v]; up = rfl(g.rank[poa_pred(g, rec, v, slot)]); }
+                        else if (slot == 0) up = rl(kiL.w, kl);
+                        else { const int v = rl(vLt, kl); const int4 rec = g.vrec[v]; up = rfl(g.rank[poa_pred(g, rec, v, slot)]); }
                         if (t == MV_DIAG) {
-                            if (lane == 0) g.pathv[i - 1] = ((meta & 255) == read_base_packed(sread, i - 1)) ? sV[kl] : -1;
+                            if (lane == 0) g.pathv[i - 1] = ((meta & 255) == read_base_packed(sread, i - 1)) ? rl(vLt, kl) : -1;
                             --i;
                         }
                         CHK(up < k && up >= -1, 103);
@@ -452,6 +456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 for (int q = lane; q < i; q += LANES) g.pathv[q] = -1;     // leading insertions at START
             }
             __threadfence_block();
+            PHASE(10);
             // ---- thread the read into the graph (wave-parallel; identical result to the serial list insertion)
             int32_t *cnt = g.bestK;
             int carry = 0;
@@ -535,10 +540,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             n = n0 + nnew;
             nadded += 1;
             __threadfence_block();
+            PHASE(11);
             }   // capacity ok
             }   // kend >= 0
             }   // not the first read
         }
+        PHASE(12);
         // ---- consensus: heaviest path (uniform walk, block records via readlane)
         int Ld = 0, nw = 0, stat = -1;
         if (ok && n > 0) {
@@ -613,6 +620,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             }
             P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat;
         }
+        PHASE(13);
         }   // enough
     }
 }
