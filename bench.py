@@ -143,8 +143,16 @@ def main():
                 traffic = int((kz["fetch_size_kb_per_zmw"] + kz["write_size_kb_per_zmw"]) * 1024 * args.zmws)
         except Exception:
             traffic = None
+        valu_busy = None
+        try:
+            valu_busy = tj["kernels"][names[dom]].get("valu_busy_frac")
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 6), "traffic": traffic,
+                    # the interpretable ceiling of this integer/f32 stencil work is VALU issue, not HBM: measured occupancy of the
+                    # vector ALUs by that kernel (rocprofv3 SQ_THREAD_CYCLES_VALU, committed under profiles/)
+                    "valu_busy_frac": valu_busy,
                     "avg_launch_ms": round(stage_ms[dom], 3), "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d)"}
         out = {
