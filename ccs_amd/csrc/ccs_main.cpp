@@ -44,6 +44,9 @@ struct Options {
     std::string write_synth;      // "N,P,L[,seed]" -> write a synthetic subreads.bam to `out`
     bool dump = false;            // print one line per ZMW after the step-1 filters, no GPU
     bool by_strand = false;       // --by-strand: one consensus per strand (docs/faq/mode-by-strand.md:8-23)
+    bool qv_binning = false;      // --qv-binning: 7-bin per-base QVs after rq is computed (docs/faq/qv-binning.md:19-31)
+    bool suppress_reports = false;
+    std::string metrics;          // --metrics-json (default <prefix>.zmw_metrics.json.gz)
     int log_level = 1;
 };
 
@@ -56,6 +59,8 @@ struct ZmwIn {
     int host_status = HS_OK;
     int64_t order = 0;
     int strand_tag = 0;           // --by-strand: 1 = /fwd, 2 = /rev
+    int64_t polymerase_len = 0;   // zmw_metrics: bases of all subreads of the ZMW
+    int32_t median_len = 0, n_full = 0;
 };
 
 struct Batch {
@@ -117,6 +122,9 @@ void usage()
                  "      --min-rq F            minimum predicted accuracy [0.99]\n"
                  "      --maxPoaCoverage N    subreads used for the draft [5]\n"
                  "      --by-strand           one consensus per strand, read names end in /fwd or /rev\n"
+                 "      --qv-binning          write 7-bin per-base QVs (Q3 Q10 Q17 Q22 Q27 Q35 Q40)\n"
+                 "      --metrics-json F      per-ZMW metrics [<OUT prefix>.zmw_metrics.json.gz]\n"
+                 "      --suppress-reports    do not write ccs_report.txt / zmw_metrics.json.gz\n"
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
                  "      --batch-size N        ZMWs per GPU batch [2048]\n"
                  "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"
@@ -153,6 +161,9 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--write-synthetic") o.write_synth = need(a.c_str());
         else if (a == "--dump-zmws") o.dump = true;
         else if (a == "--by-strand") o.by_strand = true;
+        else if (a == "--qv-binning") o.qv_binning = true;
+        else if (a == "--suppress-reports") o.suppress_reports = true;
+        else if (a == "--metrics-json") o.metrics = need(a.c_str());
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
         else pos.push_back(a);
     }
@@ -160,7 +171,11 @@ bool parse(int argc, char **argv, Options &o)
     if (o.dump) { if (pos.size() != 1) return false; o.in = pos[0]; return true; }
     if (pos.size() != 2) return false;
     o.in = pos[0]; o.out = pos[1];
-    if (o.report.empty()) { std::string p = o.out; const size_t d = p.rfind(".bam"); if (d != std::string::npos) p = p.substr(0, d); o.report = p + ".ccs_report.txt"; }
+    {
+        std::string p = o.out; const size_t d = p.rfind(".bam"); if (d != std::string::npos) p = p.substr(0, d);
+        if (o.report.empty()) o.report = p + ".ccs_report.txt";
+        if (o.metrics.empty()) o.metrics = p + ".zmw_metrics.json.gz";
+    }
     if (o.batch < 1) o.batch = 1;
     return true;
 }
@@ -206,7 +221,15 @@ int write_synthetic(const Options &o, ThreadPool &pool)
 // ---- step-1 filters (docs/how-does-ccs-work.md:19-32) ----------------------------------------------
 void finish_zmw(ZmwIn &z, const Options &o)
 {
+    for (auto &r : z.reads) z.polymerase_len += (int64_t)r.bases.size() + 45;   // + adapter between consecutive subreads
     if (z.reads.empty()) { z.host_status = HS_NO_SUBREADS; return; }
+    {
+        std::vector<size_t> s0;
+        for (auto &r : z.reads) s0.push_back(r.bases.size());
+        std::nth_element(s0.begin(), s0.begin() + s0.size() / 2, s0.end());
+        z.median_len = (int32_t)s0[s0.size() / 2];
+        for (auto &r : z.reads) z.n_full += ((r.cx < 0) || ((r.cx & 3) == 3)) ? 1 : 0;
+    }
     float mn = z.snr[0];
     for (int c = 1; c < 4; ++c) mn = std::min(mn, z.snr[c]);
     if (mn < (float)o.min_snr) { z.host_status = HS_POOR_SNR; z.reads.clear(); return; }
@@ -277,6 +300,24 @@ const char *fail_label(int st)
         case CCSX_LOW_RQ: return "CCS below minimum RQ";
         case CCSX_EMPTY_WINDOW: return "Empty coverage windows";
         default: return "Unknown error";
+    }
+}
+
+const char *status_name(int st)
+{
+    switch (st) {   // docs/faq/reports-aux-files.md:143-159
+        case CCSX_SUCCESS: return "SUCCESS";
+        case HS_POOR_SNR: return "POOR_SNR";
+        case HS_NO_SUBREADS: return "NO_SUBREADS";
+        case HS_TOO_FEW: case CCSX_TOO_FEW_PASSES: return "TOO_FEW_PASSES";
+        case CCSX_DRAFT_FAILURE: return "DRAFT_FAILURE";
+        case CCSX_TOO_MANY_UNUSABLE: return "TOO_MANY_UNUSABLE";
+        case CCSX_NON_CONVERGENT: return "NON_CONVERGENT";
+        case CCSX_TOO_SHORT: return "TOO_SHORT";
+        case CCSX_TOO_LONG: case HS_TOO_LONG: return "TOO_LONG";
+        case CCSX_LOW_RQ: return "POOR_QUALITY";
+        case CCSX_EMPTY_WINDOW: return "EMPTY_WINDOW_DURING_POLISHING";
+        default: return "EXCEPTION_THROWN";
     }
 }
 
@@ -438,6 +479,15 @@ int main(int argc, char **argv)
             int64_t next = 0;
             RecordBuilder rb;
             std::shared_ptr<Batch> b;
+            std::string metrics = "{\n  \"zmws\": [\n";
+            bool first_metric = true;
+            gzFile gzm = opt.suppress_reports ? nullptr : gzopen(opt.metrics.c_str(), "wb");
+            auto flush_metrics = [&](bool force) {
+                if (gzm && (force || metrics.size() > (1u << 20))) { gzwrite(gzm, metrics.data(), (unsigned)metrics.size()); metrics.clear(); }
+            };
+            static const uint8_t qvbin[94] = {3,3,3,3,3,3,3, 10,10,10,10,10,10,10, 17,17,17,17,17,17, 22,22,22,22,22, 27,27,27,27,27,
+                                              35,35,35,35,35,35,35,35,35,35, 40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,
+                                              40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40};
             auto emit = [&](Batch &bt) {
                 if (!header_done) {
                     write_header(out, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:" + movie +
@@ -450,9 +500,22 @@ int main(int argc, char **argv)
                     int st = z.host_status;
                     const int s = bt.slot[i];
                     if (st == HS_OK) st = bt.status.empty() ? CCSX_DRAFT_FAILURE : bt.status[s];
+                    if (!opt.suppress_reports) {
+                        const bool have = (s >= 0 && !bt.status.empty());
+                        const int32_t isz = (have && bt.seq_len[s] > 0) ? bt.seq_len[s] : z.median_len;
+                        char line[512];
+                        std::snprintf(line, sizeof(line), "%s    {\"effective_coverage\": %.2f, \"has_tandem_repeat\": false, \"insert_size\": %d, \"num_full_passes\": %d, "
+                                      "\"polymerase_length\": %" PRId64 ", \"predicted_accuracy\": %.6f, \"status\": \"%s\", \"zmw\": \"%s/%d%s\"}",
+                                      first_metric ? "" : ",\n", have ? bt.ec[s] : 0.0f, isz, have ? bt.np[s] : z.n_full, z.polymerase_len,
+                                      (have && bt.seq_len[s] > 0) ? bt.rq[s] : -1.0f, status_name(st), movie.c_str(), z.zm,
+                                      z.strand_tag == 1 ? "/fwd" : (z.strand_tag == 2 ? "/rev" : ""));
+                        metrics += line; first_metric = false;
+                        flush_metrics(false);
+                    }
                     if (st != CCSX_SUCCESS) { rep.fail[fail_label(st)]++; continue; }
                     ++rep.pass;
                     const int64_t o = bt.seq_off[s]; const int32_t len = bt.seq_len[s];
+                    if (opt.qv_binning) for (int32_t q = 0; q < len; ++q) { uint8_t &v = bt.qual[o + q]; v = qvbin[v > 93 ? 93 : v]; }   // after rq (qv-binning.md:19-21)
                     rb.begin(movie + "/" + std::to_string(z.zm) + "/ccs" + (z.strand_tag == 1 ? "/fwd" : (z.strand_tag == 2 ? "/rev" : "")), bt.seq.data() + o, bt.qual.data() + o, (uint32_t)len);
                     rb.tagZ("RG", "ccsamd01");
                     rb.tagf("ec", bt.ec[s]);
@@ -475,6 +538,7 @@ int main(int argc, char **argv)
             for (auto &kv : hold) emit(*kv.second);
             if (!header_done) write_header(out, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:unknown\n");
             out.close();
+            if (gzm) { metrics += "\n  ]\n}\n"; flush_metrics(true); gzclose(gzm); }
         });
 
         reader.join();
@@ -482,7 +546,7 @@ int main(int argc, char **argv)
         to_writer.close();
         writer.join();
         for (ccsx_handle h : handles) ccsx_destroy(h);
-        write_report(opt, rep);
+        if (!opt.suppress_reports) write_report(opt, rep);
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         if (opt.log_level >= 1)
             std::fprintf(stderr, "ccs: %" PRId64 " ZMWs in, %" PRId64 " HiFi reads out, %.2f s (%.1f ZMWs/s, %d host threads, %zu GPU worker%s)\n", rep.input, rep.pass, el,

@@ -112,3 +112,27 @@ def test_cli_by_strand(built, tmp_path):
         rc = (3 - rev[::-1]).astype(np.uint8)
         kt = kmers(tpl)
         assert len(kmers(fwd) & kt) / len(kt) > 0.6 and len(kmers(rc) & kt) / len(kt) > 0.6
+
+
+@pytest.mark.gpu
+def test_cli_reports_and_qv_binning(built, tmp_path):
+    import gzip, json
+    bam, out, out2 = tmp_path / "s.subreads.bam", tmp_path / "o.hifi.bam", tmp_path / "b.hifi.bam"
+    _run("--write-synthetic", "5,8,600,29", bam)
+    _run(bam, out)
+    _run(bam, out2, "--qv-binning", "--suppress-reports")
+    _, recs = bam_util.read_bam(out)
+    _, recs2 = bam_util.read_bam(out2)
+    bins = np.array([3] * 7 + [10] * 7 + [17] * 6 + [22] * 5 + [27] * 5 + [35] * 10 + [40] * 54, np.uint8)   # docs/faq/qv-binning.md:23-31
+    assert len(recs) == len(recs2) > 0
+    for a, b in zip(recs, recs2):
+        assert np.array_equal(a["seq"], b["seq"]) and a["tags"]["rq"] == b["tags"]["rq"]      # binning happens after rq
+        assert np.array_equal(b["qual"], bins[a["qual"]]) and set(b["qual"].tolist()) <= {3, 10, 17, 22, 27, 35, 40}
+    assert not (tmp_path / "b.hifi.ccs_report.txt").exists() and not (tmp_path / "b.hifi.zmw_metrics.json.gz").exists()
+    mt = json.load(gzip.open(tmp_path / "o.hifi.zmw_metrics.json.gz"))["zmws"]
+    assert len(mt) == 5 and [m["zmw"] for m in mt] == [f"m64000_synth/{1000 + z}" for z in range(5)]
+    ok = [m for m in mt if m["status"] == "SUCCESS"]
+    assert len(ok) == len(recs)
+    for m, r in zip(ok, recs):
+        assert m["insert_size"] == len(r["seq"]) and m["num_full_passes"] == 8 and abs(m["predicted_accuracy"] - r["tags"]["rq"]) < 1e-5
+        assert m["polymerase_length"] > 8 * 500 and abs(m["effective_coverage"] - r["tags"]["ec"]) < 0.01
