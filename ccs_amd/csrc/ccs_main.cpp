@@ -112,7 +112,7 @@ void usage()
 {
     std::fprintf(stderr,
                  "ccs (MI355X) - generate HiFi reads from PacBio subreads\n"
-                 "usage: ccs [options] IN.subreads.bam OUT.bam\n"
+                 "usage: ccs [options] IN.subreads.bam OUT.{bam,fastq.gz}\n"
                  "  -j, --num-threads N       host threads for BAM (de)compression [all]\n"
                  "      --min-passes N        minimum full-length passes [3]\n"
                  "      --top-passes N        use at most N passes, 0 = all [60]\n"
@@ -172,7 +172,7 @@ bool parse(int argc, char **argv, Options &o)
     if (pos.size() != 2) return false;
     o.in = pos[0]; o.out = pos[1];
     {
-        std::string p = o.out; const size_t d = p.rfind(".bam"); if (d != std::string::npos) p = p.substr(0, d);
+        std::string p = o.out; size_t d = p.rfind(".bam"); if (d == std::string::npos) d = p.rfind(".fastq.gz"); if (d != std::string::npos) p = p.substr(0, d);
         if (o.report.empty()) o.report = p + ".ccs_report.txt";
         if (o.metrics.empty()) o.metrics = p + ".zmw_metrics.json.gz";
     }
@@ -472,8 +472,13 @@ int main(int argc, char **argv)
 
         // ---- writer (restores batch order)
         Report rep;
+        const bool fastq = opt.out.size() > 9 && opt.out.compare(opt.out.size() - 9, 9, ".fastq.gz") == 0;   // OUT.fastq.gz (docs/index.md:55-58)
         std::thread writer([&] {
-            BgzfWriter out(opt.out, pool);
+            std::unique_ptr<BgzfWriter> outp;
+            gzFile gzq = nullptr;
+            if (fastq) { gzq = gzopen(opt.out.c_str(), "wb4"); if (!gzq) throw std::runtime_error("cannot create " + opt.out); }
+            else outp.reset(new BgzfWriter(opt.out, pool));
+            std::string fq;
             bool header_done = false;
             std::map<int64_t, std::shared_ptr<Batch>> hold;
             int64_t next = 0;
@@ -489,11 +494,11 @@ int main(int argc, char **argv)
                                               35,35,35,35,35,35,35,35,35,35, 40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,
                                               40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40};
             auto emit = [&](Batch &bt) {
-                if (!header_done) {
-                    write_header(out, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:" + movie +
+                if (!header_done && !fastq) {
+                    write_header(*outp, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:" + movie +
                                           "\tPM:SEQUELII\n@PG\tID:ccs\tPN:ccs\tVN:amd-mi355x-r1\tDS:Generate circular consensus sequences (ccs) from subreads.\n");
-                    header_done = true;
                 }
+                header_done = true;
                 for (size_t i = 0; i < bt.zmws.size(); ++i) {
                     ++rep.input;
                     const ZmwIn &z = bt.zmws[i];
@@ -516,14 +521,25 @@ int main(int argc, char **argv)
                     ++rep.pass;
                     const int64_t o = bt.seq_off[s]; const int32_t len = bt.seq_len[s];
                     if (opt.qv_binning) for (int32_t q = 0; q < len; ++q) { uint8_t &v = bt.qual[o + q]; v = qvbin[v > 93 ? 93 : v]; }   // after rq (qv-binning.md:19-21)
-                    rb.begin(movie + "/" + std::to_string(z.zm) + "/ccs" + (z.strand_tag == 1 ? "/fwd" : (z.strand_tag == 2 ? "/rev" : "")), bt.seq.data() + o, bt.qual.data() + o, (uint32_t)len);
+                    const std::string qname = movie + "/" + std::to_string(z.zm) + "/ccs" + (z.strand_tag == 1 ? "/fwd" : (z.strand_tag == 2 ? "/rev" : ""));
+                    if (fastq) {
+                        fq.clear(); fq += '@'; fq += qname; fq += '\n';
+                        for (int32_t q = 0; q < len; ++q) fq += "ACGT"[bt.seq[o + q] & 3];
+                        fq += "\n+\n";
+                        for (int32_t q = 0; q < len; ++q) fq += (char)(33 + (bt.qual[o + q] > 93 ? 93 : bt.qual[o + q]));
+                        fq += '\n';
+                        gzwrite(gzq, fq.data(), (unsigned)fq.size());
+                        rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.np_sum += bt.np[s];
+                        continue;
+                    }
+                    rb.begin(qname, bt.seq.data() + o, bt.qual.data() + o, (uint32_t)len);
                     rb.tagZ("RG", "ccsamd01");
                     rb.tagf("ec", bt.ec[s]);
                     rb.tagi("np", bt.np[s]);
                     rb.tagf("rq", bt.rq[s]);
                     rb.tagBf("sn", z.snr, 4);
                     rb.tagi("zm", z.zm);
-                    rb.finish(out);
+                    rb.finish(*outp);
                     rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.np_sum += bt.np[s];
                 }
             };
@@ -536,8 +552,11 @@ int main(int argc, char **argv)
                 }
             }
             for (auto &kv : hold) emit(*kv.second);
-            if (!header_done) write_header(out, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:unknown\n");
-            out.close();
+            if (fastq) gzclose(gzq);
+            else {
+                if (!header_done) write_header(*outp, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:unknown\n");
+                outp->close();
+            }
             if (gzm) { metrics += "\n  ]\n}\n"; flush_metrics(true); gzclose(gzm); }
         });
 

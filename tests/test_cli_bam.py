@@ -129,6 +129,13 @@ def test_cli_reports_and_qv_binning(built, tmp_path):
         assert np.array_equal(a["seq"], b["seq"]) and a["tags"]["rq"] == b["tags"]["rq"]      # binning happens after rq
         assert np.array_equal(b["qual"], bins[a["qual"]]) and set(b["qual"].tolist()) <= {3, 10, 17, 22, 27, 35, 40}
     assert not (tmp_path / "b.hifi.ccs_report.txt").exists() and not (tmp_path / "b.hifi.zmw_metrics.json.gz").exists()
+    fq = tmp_path / "o.fastq.gz"                                                        # OUT.fastq.gz (docs/index.md:55-58)
+    _run(bam, fq, "--suppress-reports")
+    lines = gzip.open(fq, "rt").read().split("\n")
+    assert len(lines) == 4 * len(recs) + 1
+    for k, r in enumerate(recs):
+        assert lines[4 * k] == "@" + r["name"] and lines[4 * k + 1] == "".join("ACGT"[b] for b in r["seq"])
+        assert lines[4 * k + 3] == "".join(chr(33 + q) for q in r["qual"])
     mt = json.load(gzip.open(tmp_path / "o.hifi.zmw_metrics.json.gz"))["zmws"]
     assert len(mt) == 5 and [m["zmw"] for m in mt] == [f"m64000_synth/{1000 + z}" for z in range(5)]
     ok = [m for m in mt if m["status"] == "SUCCESS"]
