@@ -3,7 +3,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 import numpy as np
 from ccs_amd import api
 import oracle_lib as O
-o = api.default_opts(); o.reserved[0] = int(os.environ.get('GATE', '0')); h = api.Handle(0, opts=o)
+h = api.Handle(0)
 for (n, P, L, seed) in [(2, 3, 200, 1), (4, 6, 900, 11), (3, 10, 2000, 2)]:
     batch = api.synth(n, P, L, seed=seed)
     h.upload(batch); h.run(); h.sync()
