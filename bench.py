@@ -168,7 +168,7 @@ def main():
             "host": {"synth_s": round(gen_s, 2), "upload_s": round(upload_s, 3), "download_s": round(download_s, 3),
                      "pcie_inclusive_zmws_per_s": round(args.zmws / (elapsed / args.steps + upload_s + download_s), 2)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             import oracle_lib
             cores = effective_cores()
             probe = batch.slice(0, 1)
