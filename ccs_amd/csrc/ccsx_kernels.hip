@@ -247,10 +247,11 @@ __device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to
 }
 
 extern __shared__ uint32_t dyn_lds[];
+#define TB_BLOCK 32                   // positions cached per traceback block (LDS per wave bounds the POA occupancy)
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_poa(KParams P, int z0)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sMv[64 * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t sMv[TB_BLOCK * 64];   // move rows of the traceback's current block
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
     PoaSlot g = poa_slot(P, blockIdx.x);                   // launched in chunks of poa_slots ZMWs: slot = block
@@ -414,19 +415,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             {
                 int k = kend, i = I;
                 while (k >= 0) {
-                    const int kb = (k >> 6) << 6;
+                    const int kb = (k / TB_BLOCK) * TB_BLOCK;
                     __syncthreads();
-                    // block cache: the 64 move rows go to LDS, the per-position words (band start, position of in-edge 0,
+                    // block cache: the TB_BLOCK move rows go to LDS, the per-position words (band start, position of in-edge 0,
                     // vertex id, record word) stay in lane registers and are handed out with v_readlane
                     int4 kiL = make_int4(0, 0, 0, -1);
                     int vLt = 0, metaL = 0;
                     {
                         const int kk = kb + lane;
-                        if (kk < n0) { kiL = g.kinfo[kk]; vLt = order[kk]; metaL = g.vrec[vLt].x; }
+                        if (lane < TB_BLOCK && kk < n0) { kiL = g.kinfo[kk]; vLt = order[kk]; metaL = g.vrec[vLt].x; }
                         const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb * 64);
                         uint4 *dst = (uint4 *)sMv;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) dst[q * 64 + lane] = src[q * 64 + lane];
+                        for (int q = 0; q < TB_BLOCK / 16; ++q) dst[q * 64 + lane] = src[q * 64 + lane];
                     }
                     asm volatile("" :: "v"(kiL.x), "v"(kiL.w), "v"(vLt), "v"(metaL));
                     __syncthreads();
