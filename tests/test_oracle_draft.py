@@ -115,3 +115,31 @@ def test_status_taxonomy(built):
         b.bases[a:e] = rng.integers(0, 4, e - a, dtype=np.uint8)
     r = api.Results.allocate(b); O.consensus_batch(m, o, b, r)
     assert r.status[0] == 3 and r.np_[0] <= 2
+
+
+def test_accuracy_rises_with_passes(built):
+    """[DOC] docs/img/ccs-acc.png via docs/faq/accuracy-vs-passes.md:13 — about Q20 at 4-5 passes, about Q30 at 10,
+    higher beyond; subreads ~90 % accurate (docs/how-does-ccs-work.md:46).  Statistical acceptance on synthetic
+    data: empirical quality is monotone in the pass count and lands in broad bands around those figures, and the
+    predicted accuracy (rq) tracks the empirical one."""
+    import difflib
+    m, o = api.default_model(), api.default_opts()
+    o.min_rq = 0.0
+    emp = {}
+    for passes in (4, 10, 20):
+        batch = api.synth(16, passes, 1000, seed=500 + passes)
+        res = api.Results.allocate(batch)
+        O.consensus_batch(m, o, batch, res, nthreads=4)
+        errs = bases = 0
+        for z in range(batch.n_zmw):
+            tpl = batch.tpl[batch.tpl_off[z]:batch.tpl_off[z + 1]]
+            s = res.sequence(z)
+            sm = difflib.SequenceMatcher(None, bytes(s + 65), bytes(tpl + 65), autojunk=False)
+            errs += sum(max(i2 - i1, j2 - j1) for tag, i1, i2, j1, j2 in sm.get_opcodes() if tag != "equal")
+            bases += len(tpl)
+        emp[passes] = (errs / bases, float(1.0 - res.rq.mean()))
+    q = {p: -10 * np.log10(max(e[0], 1e-6)) for p, e in emp.items()}
+    assert q[4] < q[10] <= q[20] + 1e-9
+    assert 12 <= q[4] <= 28 and 25 <= q[10] <= 45 and q[20] >= 30
+    for p, (e_emp, e_pred) in emp.items():                     # rq is calibrated within a factor ~4 of the truth
+        assert e_pred < 4 * max(e_emp, 2e-4) + 1e-4 and e_emp < 4 * e_pred + 2e-3, (p, e_emp, e_pred)
