@@ -41,7 +41,7 @@ class Opts(C.Structure):
     _fields_ = [
         ("max_poa_cov", C.c_int32), ("min_passes", C.c_int32), ("top_passes", C.c_int32),
         ("min_length", C.c_int32), ("max_length", C.c_int32), ("min_rq", C.c_float),
-        ("poa_slots", C.c_int32), ("reserved", C.c_int32 * 8),
+        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -62,6 +62,8 @@ class CResults(C.Structure):
         ("seq", C.POINTER(C.c_uint8)), ("qual", C.POINTER(C.c_uint8)), ("raw_qv", C.POINTER(C.c_float)),
         ("rq", C.POINTER(C.c_float)), ("np", C.POINTER(C.c_int32)), ("ec", C.POINTER(C.c_float)),
         ("iters", C.POINTER(C.c_int32)), ("n_windows", C.POINTER(C.c_int32)),
+        ("fi", C.POINTER(C.c_uint8)), ("fp", C.POINTER(C.c_uint8)), ("ri", C.POINTER(C.c_uint8)), ("rp", C.POINTER(C.c_uint8)),
+        ("fn", C.POINTER(C.c_int32)), ("rn", C.POINTER(C.c_int32)),
     ]
 
 
@@ -228,16 +230,20 @@ class Results:
     ec: np.ndarray
     iters: np.ndarray
     n_windows: np.ndarray
+    fn: np.ndarray = None
+    rn: np.ndarray = None
+    kin: np.ndarray | None = None        # [4, capacity] planes fi, fp, ri, rp (CodecV1 codes); None without kinetics
 
     @staticmethod
-    def allocate(batch: Batch) -> "Results":
+    def allocate(batch: Batch, kinetics: bool = False) -> "Results":
         n = batch.n_zmw
         cb = batch.c_struct()
         off = np.zeros(n + 1, np.int64)
         cap = lib().ccsx_result_layout(C.byref(cb), _ptr(off, C.c_int64))
         return Results(off, np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(cap, np.uint8), np.zeros(cap, np.uint8),
                        np.zeros(cap, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.float32),
-                       np.zeros(n, np.int32), np.zeros(n, np.int32))
+                       np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32),
+                       np.zeros((4, cap), np.uint8) if kinetics else None)
 
     def c_struct(self) -> CResults:
         r = CResults()
@@ -254,6 +260,10 @@ class Results:
         r.ec = _ptr(self.ec, C.c_float)
         r.iters = _ptr(self.iters, C.c_int32)
         r.n_windows = _ptr(self.n_windows, C.c_int32)
+        r.fn = _ptr(self.fn, C.c_int32)
+        r.rn = _ptr(self.rn, C.c_int32)
+        if self.kin is not None:
+            r.fi, r.fp, r.ri, r.rp = (_ptr(self.kin[k], C.c_uint8) for k in range(4))
         return r
 
     def sequence(self, z: int) -> np.ndarray:
@@ -267,6 +277,11 @@ class Results:
     def raw(self, z: int) -> np.ndarray:
         o = int(self.seq_off[z])
         return self.raw_qv[o:o + int(self.seq_len[z])]
+
+    def kinetics(self, z: int) -> np.ndarray:
+        """[4, seq_len] CodecV1 codes (fi, fp, ri, rp) of ZMW z, orientation of SEQ."""
+        o = int(self.seq_off[z])
+        return self.kin[:, o:o + int(self.seq_len[z])]
 
 
 class Handle:
@@ -287,7 +302,7 @@ class Handle:
             raise RuntimeError(f"{what} failed: " + self._L.ccsx_last_error().decode())
 
     def consensus(self, batch: Batch) -> Results:
-        res = Results.allocate(batch)
+        res = Results.allocate(batch, kinetics=bool(self.opts.hifi_kinetics))
         cb, cr = batch.c_struct(), res.c_struct()
         self._check(self._L.ccsx_consensus_batch(self._h, C.byref(cb), C.byref(cr)), "ccsx_consensus_batch")
         return res
@@ -304,7 +319,7 @@ class Handle:
         self._check(self._L.ccsx_sync(self._h), "ccsx_sync")
 
     def download(self) -> Results:
-        res = Results.allocate(self._keep)
+        res = Results.allocate(self._keep, kinetics=bool(self.opts.hifi_kinetics))
         cr = res.c_struct()
         self._check(self._L.ccsx_download(self._h, C.byref(cr)), "ccsx_download")
         return res

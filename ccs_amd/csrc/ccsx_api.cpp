@@ -51,14 +51,15 @@ struct ccsx_handle_s {
     ccsx_opts opts;
     DevBuf d_model;
     // inputs
-    DevBuf d_snr, d_read_off, d_base_off, d_bases, d_pw, d_flags;
+    DevBuf d_snr, d_read_off, d_base_off, d_bases, d_pw, d_ipd, d_flags;
     // layout
     DevBuf d_read_zmw, d_vcap, d_dcap, d_seq_off, d_wb_off, d_ent_off, d_wslot;
     // state
     DevBuf d_tabME, d_tabINS, d_tabDL, d_draft, d_zmw_i32 /* 6 x n int32 */, d_wbounds, d_ticket;
     DevBuf d_poa, d_align, d_avalid, d_ascore, d_ent;
     DevBuf d_wseq, d_wqv, d_wsum, d_wmeta;
-    DevBuf d_out_seq, d_out_qual, d_out_raw, d_out_i32 /* 4 x n */, d_out_f32 /* 2 x n */;
+    DevBuf d_out_seq, d_out_qual, d_out_raw, d_out_i32 /* 6 x n */, d_out_f32 /* 2 x n */;
+    DevBuf d_wtpl, d_wtmeta, d_wkin, d_out_kin;   // HiFi kinetics only
     // host copies of the layout
     std::vector<int64_t> seq_off, ent_off;
     std::vector<int32_t> wb_off, read_off;
@@ -114,7 +115,7 @@ int ccsx_destroy(ccsx_handle h)
                       &h->d_vcap, &h->d_dcap, &h->d_seq_off, &h->d_wb_off, &h->d_ent_off, &h->d_wslot, &h->d_tabME, &h->d_tabINS, &h->d_tabDL,
                       &h->d_draft, &h->d_zmw_i32, &h->d_wbounds, &h->d_ticket, &h->d_poa, &h->d_align, &h->d_avalid, &h->d_ascore,
                       &h->d_ent, &h->d_wseq, &h->d_wqv, &h->d_wsum, &h->d_wmeta, &h->d_out_seq, &h->d_out_qual, &h->d_out_raw,
-                      &h->d_out_i32, &h->d_out_f32};
+                      &h->d_out_i32, &h->d_out_f32, &h->d_ipd, &h->d_wtpl, &h->d_wtmeta, &h->d_wkin, &h->d_out_kin};
     for (auto *b : bufs) b->release();
     for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -143,6 +144,8 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
 {
     if (!h) { ccsx_set_error("ccsx_upload: null handle"); return -1; }
     if (validate(b)) return -1;
+    const bool kin = h->opts.hifi_kinetics != 0;
+    if (kin && !b->ipd) { ccsx_set_error("ccsx_upload: opts.hifi_kinetics needs batch.ipd"); return -1; }
     HIPTRY(hipSetDevice(h->device));
     const int n = b->n_zmw, R = b->n_reads;
     const int64_t NB = b->n_bases;
@@ -184,6 +187,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     UP(h->d_base_off, b->base_off, (size_t)(R + 1) * 8);
     UP(h->d_bases, b->bases, (size_t)NB);
     UP(h->d_pw, b->pw, (size_t)NB);
+    if (kin) UP(h->d_ipd, b->ipd, (size_t)NB);
     UP(h->d_flags, b->flags, (size_t)R);
     UP(h->d_read_zmw, read_zmw.data(), (size_t)R * 4);
     UP(h->d_vcap, vcap.data(), (size_t)n * 4);
@@ -207,7 +211,11 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     RES(h->d_wseq, (size_t)total_wslots * 32); RES(h->d_wqv, (size_t)total_wslots * 32 * 4);
     RES(h->d_wsum, (size_t)total_wslots * 4); RES(h->d_wmeta, (size_t)total_wslots * 16);
     RES(h->d_out_seq, (size_t)cap_total); RES(h->d_out_qual, (size_t)cap_total); RES(h->d_out_raw, (size_t)cap_total * 4);
-    RES(h->d_out_i32, (size_t)n * 4 * 4); RES(h->d_out_f32, (size_t)n * 4 * 2);
+    RES(h->d_out_i32, (size_t)n * 4 * 6); RES(h->d_out_f32, (size_t)n * 4 * 2);
+    if (kin) {
+        RES(h->d_wtpl, (size_t)total_wslots * 32); RES(h->d_wtmeta, (size_t)total_wslots * 4);
+        RES(h->d_wkin, (size_t)total_wslots * 32 * 4); RES(h->d_out_kin, (size_t)cap_total * 4);
+    }
 
     // ---- resident POA graphs / alignment slots: as many as fit a memory budget, never more than the work
     const size_t poa_slot_bytes = (((size_t)vcap_max + 64) * 392 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
@@ -248,6 +256,12 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     P.out_seq = (uint8_t *)h->d_out_seq.p; P.out_qual = (uint8_t *)h->d_out_qual.p; P.out_raw = (float *)h->d_out_raw.p;
     int32_t *oi = (int32_t *)h->d_out_i32.p;
     P.out_status = oi; P.out_len = oi + n; P.out_iters = oi + 2 * (size_t)n; P.out_nwin = oi + 3 * (size_t)n;
+    P.out_fn = oi + 4 * (size_t)n; P.out_rn = oi + 5 * (size_t)n;
+    if (kin) {
+        P.ipd = (const uint8_t *)h->d_ipd.p;
+        P.wtpl = (uint8_t *)h->d_wtpl.p; P.wtmeta = (short2 *)h->d_wtmeta.p; P.wkin = (uchar4 *)h->d_wkin.p;
+        P.out_kin = (uint8_t *)h->d_out_kin.p; P.kin_plane = cap_total;
+    }
     float *of = (float *)h->d_out_f32.p;
     P.out_rq = of; P.out_ec = of + n;
     h->uploaded = true; h->ran = false;
@@ -298,6 +312,10 @@ int ccsx_download(ccsx_handle h, ccsx_results *res)
     if (!h || !h->ran || !res) { ccsx_set_error("ccsx_download: nothing to download"); return -1; }
     const int n = h->P.n_zmw;
     if (res->n_zmw != n || res->seq_capacity < h->seq_off[n]) { ccsx_set_error("ccsx_download: result buffers too small"); return -1; }
+    if (!h->P.out_kin && (res->fi || res->fp || res->ri || res->rp)) {
+        ccsx_set_error("ccsx_download: kinetics buffers given but the handle was created without opts.hifi_kinetics");
+        return -1;
+    }
     HIPTRY(hipSetDevice(h->device));
     hipStream_t s = h->stream;
 #define DOWN(dst, src, bytes) do { if (dst) HIPTRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, s)); } while (0)
@@ -311,6 +329,13 @@ int ccsx_download(ccsx_handle h, ccsx_results *res)
     DOWN(res->seq, h->P.out_seq, (size_t)h->seq_off[n]);
     DOWN(res->qual, h->P.out_qual, (size_t)h->seq_off[n]);
     DOWN(res->raw_qv, h->P.out_raw, (size_t)h->seq_off[n] * 4);
+    DOWN(res->fn, h->P.out_fn, (size_t)n * 4);
+    DOWN(res->rn, h->P.out_rn, (size_t)n * 4);
+    if (h->P.out_kin) {
+        const size_t pl = (size_t)h->seq_off[n];
+        DOWN(res->fi, h->P.out_kin, pl); DOWN(res->fp, h->P.out_kin + pl, pl);
+        DOWN(res->ri, h->P.out_kin + 2 * pl, pl); DOWN(res->rp, h->P.out_kin + 3 * pl, pl);
+    }
 #undef DOWN
     HIPTRY(hipStreamSynchronize(s));
     if (res->seq_off) std::memcpy(res->seq_off, h->seq_off.data(), (size_t)(n + 1) * 8);

@@ -723,10 +723,14 @@ __global__ void k_post(KParams P)
 {
     int z = blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= P.n_zmw) return;
-    if (P.zstat[z] != CCSX_SUCCESS) { P.np[z] = 0; return; }
-    int r0 = P.read_off[z], nr = P.nreads_used[z], np = 0;
-    for (int r = 0; r < nr; ++r) np += P.avalid[r0 + r];
-    P.np[z] = np;
+    if (P.zstat[z] != CCSX_SUCCESS) { P.np[z] = 0; P.out_fn[z] = 0; P.out_rn[z] = 0; return; }
+    int r0 = P.read_off[z], nr = P.nreads_used[z], np = 0, rn = 0;
+    for (int r = 0; r < nr; ++r) {
+        const int v = P.avalid[r0 + r];
+        np += v;
+        if (v && ((P.flags[r0 + r] ^ P.flags[r0]) & 1)) ++rn;
+    }
+    P.np[z] = np; P.out_fn[z] = np - rn; P.out_rn[z] = rn;
     if (2 * np <= nr) { P.zstat[z] = CCSX_TOO_MANY_UNUSABLE; P.nwin[z] = 0; }
 }
 
@@ -1156,8 +1160,113 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
         for (int k = 0; k < ce - cs; ++k) wsum = wsum + sPerr[k];
         P.wsum[wi] = wsum;
         P.wmeta[wi] = make_int4(ce - cs, nvalid_last, nonconv, iters);
+        if (P.wtmeta) P.wtmeta[wi] = make_short2((short)J, (short)cs);
     }
+    if (P.wtpl && tid < J) P.wtpl[wi * 32 + tid] = sT[0][tid];
     PHASE(6);
+}
+
+// ------------------------------------------------------------------------------------------------
+// N4: HiFi kinetics (docs/faq/kinetics.md:8-18; SPEC DESIGN.md §2.9).  One workgroup per window, one wave per read:
+// lane = read row of a global alignment of the read's segment to the CONVERGED window template (read orientation),
+// the insertion chain of a column is one fused DPP max-scan, the 2-bit moves of a row stay in the lane's registers
+// (31 columns = 62 bits) and the traceback walks them with v_readlane on wave-uniform scalars — no DP matrix in
+// memory at all.  Matching DIAG cells add the read base's decoded IPD / PW frames to integer LDS sums (order
+// independent, so atomics keep the result deterministic); means are re-encoded with CodecV1.
+__device__ __forceinline__ int codec_v1_decode(int c)
+{
+    return c < 64 ? c : (c < 128 ? 64 + (c - 64) * 2 : (c < 192 ? 192 + (c - 128) * 4 : 448 + (c - 192) * 8));
+}
+__device__ __forceinline__ int codec_v1_encode(int f)
+{
+    if (f < 64) return f;
+    if (f < 192) return 64 + (f - 64 + 1) / 2;
+    if (f < 448) return 128 + (f - 192 + 2) / 4;
+    const int c = 192 + (f - 448 + 4) / 8;
+    return c > 255 ? 255 : c;
+}
+__device__ __forceinline__ int kin_mean_code(unsigned sum, unsigned cnt)
+{
+    return cnt ? codec_v1_encode((int)((2u * sum + cnt) / (2u * cnt))) : 0;
+}
+
+__global__ __launch_bounds__(256) void k_kinetics(KParams P)
+{
+    __shared__ uint8_t sT[2][32];
+    __shared__ unsigned sK[2][3][32];                       // [strand][ipd, pw, count][forward column]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x;
+    const int z = P.wslot_zmw[bid];
+    const int w = bid - (P.wb_off[z] - z);
+    if (w >= P.nwin[z]) return;
+    const int nw = P.nwin[z];
+    const size_t wi = (size_t)(P.wb_off[z] - z) + w;
+    const short2 tm = P.wtmeta[wi];
+    const int J = tm.x, cs = tm.y, ce = cs + P.wmeta[wi].x;
+    const int r0 = P.read_off[z], nreads = P.nreads_used[z];
+    const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
+    if (tid < J) { const uint8_t b = P.wtpl[wi * 32 + tid]; sT[0][tid] = b; sT[1][J - 1 - tid] = (uint8_t)(3 - b); }
+    if (tid < 192) (&sK[0][0][0])[tid] = 0u;
+    __syncthreads();
+    for (int r = wave; r < nreads; r += 4) {
+        const int rr = r0 + r;
+        if (!P.avalid[rr]) continue;
+        const int32_t *ent = P.ent + P.ent_off[rr];
+        const int a = rfl(ent[idx_ws]), b = rfl(ent[idx_we]);
+        const int n = b - a;
+        if (n < 0 || n > CCSX_IMAX) continue;
+        const int64_t bo0 = P.base_off[rr];
+        const int L = (int)(P.base_off[rr + 1] - bo0);
+        const int st = rfl(((P.flags[rr] ^ P.flags[r0]) & 1) ? 1 : 0);
+        const int64_t p0 = bo0 + (st ? L - b : a);
+        const bool rowok = lane >= 1 && lane <= n;
+        const int rbv = rowok ? P.bases[p0 + lane - 1] : 4;   // lane i holds read base i-1
+        const uint8_t *t = sT[st];
+        int Hprev = (lane <= n) ? lane * SC_INS : NEGV;
+        unsigned long long mvmask = 0ull;                    // 2 bits per column: 0 DIAG, 1 LEFT, 2 UP
+        for (int j = 1; j <= J; ++j) {
+            const int tb = t[j - 1];
+            const int x = wave_shr1_i32(Hprev, NEGV);
+            const int diag = rowok ? x + (rbv == tb ? SC_MATCH : SC_MISMATCH) : NEGV;
+            const int left = (lane <= n) ? Hprev + SC_DEL : NEGV;
+            const int h = diag >= left ? diag : left;
+            const int v = wave_scan_max_i32(h + 4 * lane) - 4 * lane;      // insertion chain: v(i) = max_k<=i h(k) + (i-k)*SC_INS
+            const unsigned long long mv = (v > h) ? 2ull : (diag >= left ? 0ull : 1ull);
+            mvmask |= mv << (2 * (j - 1));
+            Hprev = (lane <= n) ? v : NEGV;
+        }
+        const int mlo = (int)(unsigned)mvmask, mhi = (int)(unsigned)(mvmask >> 32);
+        int i = n, j = J, myrow = -1;
+        while (i > 0 || j > 0) {
+            int mv;
+            if (j == 0) mv = 2;
+            else if (i == 0) mv = 1;
+            else {
+                const unsigned long long rm = ((unsigned long long)(unsigned)rl(mhi, i) << 32) | (unsigned)rl(mlo, i);
+                mv = (int)((rm >> (2 * (j - 1))) & 3ull);
+            }
+            if (mv == 0) { if (lane == j - 1) myrow = i - 1; --i; --j; }
+            else if (mv == 1) --j;
+            else --i;
+        }
+        if (lane < J && myrow >= 0) {
+            const int jf = st ? J - 1 - lane : lane;
+            const int64_t p = p0 + myrow;
+            if (jf >= cs && jf < ce && P.bases[p] == t[lane]) {
+                atomicAdd(&sK[st][0][jf], (unsigned)codec_v1_decode(P.ipd[p]));
+                atomicAdd(&sK[st][1][jf], (unsigned)codec_v1_decode(P.pw[p]));
+                atomicAdd(&sK[st][2][jf], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < ce - cs) {
+        const int c = cs + tid;
+        uchar4 k;
+        k.x = (uint8_t)kin_mean_code(sK[0][0][c], sK[0][2][c]); k.y = (uint8_t)kin_mean_code(sK[0][1][c], sK[0][2][c]);
+        k.z = (uint8_t)kin_mean_code(sK[1][0][c], sK[1][2][c]); k.w = (uint8_t)kin_mean_code(sK[1][1][c], sK[1][2][c]);
+        P.wkin[wi * 32 + tid] = k;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1186,6 +1295,11 @@ __global__ __launch_bounds__(64) void k_stitch(KParams P)
                 P.out_seq[so + off + k] = P.wseq[(w0 + w) * 32 + k];
                 P.out_raw[so + off + k] = qv;
                 P.out_qual[so + off + k] = (uint8_t)(qv + 0.5f);
+                if (P.out_kin) {
+                    const uchar4 kk = P.wkin[(w0 + w) * 32 + k];
+                    uint8_t *o = P.out_kin + so + off + k;
+                    o[0] = kk.x; o[P.kin_plane] = kk.y; o[2 * P.kin_plane] = kk.z; o[3 * P.kin_plane] = kk.w;
+                }
             }
         }
         run += __shfl(pre, 63);
@@ -1249,6 +1363,10 @@ void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or 
     if (ev) (void)hipEventRecord(ev[3], st);
     if (P.total_wslots > 0) hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), 0, st, P);
     trace_sync(st, "k_polish");
+    if (P.opts.hifi_kinetics && P.total_wslots > 0) {
+        hipLaunchKernelGGL(k_kinetics, dim3((unsigned)P.total_wslots), dim3(256), 0, st, P);
+        trace_sync(st, "k_kinetics");
+    }
     if (ev) (void)hipEventRecord(ev[4], st);
     hipLaunchKernelGGL(k_stitch, dim3(P.n_zmw), dim3(64), 0, st, P);
     if (ev) (void)hipEventRecord(ev[5], st);

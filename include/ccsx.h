@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCSX_ABI_VERSION 1
+#define CCSX_ABI_VERSION 2
 
 /* ---- fixed constants of the algorithm specification ---- */
 #define CCSX_BAND          64   /* DP band rows of the POA / alignment kernels (one wave64)      */
@@ -78,7 +78,8 @@ typedef struct ccsx_opts {
     int32_t max_length;      /* --max-length                                                    */
     float   min_rq;          /* --min-rq                                                        */
     int32_t poa_slots;       /* concurrent POA graphs resident on the device (0 = auto)          */
-    int32_t reserved[8];
+    int32_t hifi_kinetics;   /* --hifi-kinetics (docs/faq/kinetics.md:8-18): per-strand averaged IPD / PW; needs batch.ipd */
+    int32_t reserved[7];
 } ccsx_opts;
 
 /* ---- input batch: SoA + CSR ---- */
@@ -91,8 +92,10 @@ typedef struct ccsx_batch {
     const int32_t *read_off;     /* [n_zmw+1] first read of each ZMW                            */
     const int64_t *base_off;     /* [R+1] first base of each read                               */
     const uint8_t *bases;        /* [n_bases] codes 0..3 = A,C,G,T, native (sequenced) orientation */
-    const uint8_t *pw;           /* [n_bases] pulse width in frames (pw tag, decoded)           */
-    const uint8_t *ipd;          /* [n_bases] inter-pulse duration (ip tag); may be NULL (unused by the HMM) */
+    const uint8_t *pw;           /* [n_bases] pulse width, CodecV1 code as stored in the pw:B,C tag (codes < 64 ARE the
+                                    frame count, so the HMM's pulse-width bin min(pw,3) needs no decoding)        */
+    const uint8_t *ipd;          /* [n_bases] inter-pulse duration, CodecV1 code (ip:B,C tag).  Unused by the HMM;
+                                    may be NULL unless opts.hifi_kinetics is set                                   */
     const uint8_t *flags;        /* [R] bit0: pass is on the reverse strand (cx REVERSE_PASS)   */
 } ccsx_batch;
 
@@ -112,6 +115,12 @@ typedef struct ccsx_results {
     float   *ec;                 /* [n_zmw] effective coverage (ec tag)                         */
     int32_t *iters;              /* [n_zmw] total polish iterations over all windows            */
     int32_t *n_windows;          /* [n_zmw]                                                     */
+    /* HiFi kinetics (opts.hifi_kinetics; any of these may be NULL).  CodecV1 codes, indexed like seq (orientation of
+     * SEQ; a BAM writer that stores ri/rp in the reverse strand's own orientation reverses them).  Tags fi fp ri rp
+     * fn rn of docs/faq/bam-output.md:13-23; with --by-strand the forward pair is the record's ip / pw.           */
+    uint8_t *fi, *fp;            /* [seq_capacity] mean IPD / pulse width of the passes on SEQ's strand         */
+    uint8_t *ri, *rp;            /* [seq_capacity] same for the passes on the opposite strand                   */
+    int32_t *fn, *rn;            /* [n_zmw] passes used per strand (fn + rn = np); filled with or without kinetics */
 } ccsx_results;
 
 /* ---- per-kernel device timings of the last run, HIP events on the handle's stream (ms) ---- */

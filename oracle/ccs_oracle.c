@@ -549,11 +549,12 @@ static void revcomp_tpl(const wtpl_t *w, uint8_t *tr, int *lfr)
 /* Polish one window.  obs[r] = native-orientation observation codes of read r's segment, I[r] its length
  * (I[r] < 0 or > IMAX: read unusable in this window), strand[r] = 1 if the read is reverse to the draft.
  * Outputs the core sequence, per-base error probability and raw QV.  Returns number of scoring rounds.     */
-int orc_polish_window(const float *ME, const float *INS, const float *DL,
+static int polish_window_impl(const float *ME, const float *INS, const float *DL,
                       const uint8_t *tpl, int J0, int cs, int ce, int lf, int rf,
                       int nreads, const uint8_t *const *obs, const int32_t *I, const uint8_t *strand,
                       uint8_t *out_seq, float *out_perr, float *out_qv, int32_t *out_len,
-                      int32_t *out_nvalid, int32_t *out_nonconv, float *out_delta /* [256] optional */)
+                      int32_t *out_nvalid, int32_t *out_nonconv, float *out_delta /* [256] optional */,
+                      wtpl_t *wfinal /* optional: the converged window template incl. overhangs */)
 {
     wtpl_t w; w.J = J0; w.cs = cs; w.ce = ce; w.lf = lf; w.rf = rf; memcpy(w.t, tpl, J0);
     float *gam = (float *)malloc(sizeof(float) * (size_t)nreads * (IMAX + 2) * GS);
@@ -642,8 +643,82 @@ int orc_polish_window(const float *ME, const float *INS, const float *DL,
     }
     *out_len = len; *out_nvalid = nvalid; *out_nonconv = nonconv;
     if (out_delta) memcpy(out_delta, delta, sizeof(delta));
+    if (wfinal) *wfinal = w;
     free(gam); free(bet); free(base); free(valid);
     return iters;
+}
+
+int orc_polish_window(const float *ME, const float *INS, const float *DL,
+                      const uint8_t *tpl, int J0, int cs, int ce, int lf, int rf,
+                      int nreads, const uint8_t *const *obs, const int32_t *I, const uint8_t *strand,
+                      uint8_t *out_seq, float *out_perr, float *out_qv, int32_t *out_len,
+                      int32_t *out_nvalid, int32_t *out_nonconv, float *out_delta /* [256] optional */)
+{
+    return polish_window_impl(ME, INS, DL, tpl, J0, cs, ce, lf, rf, nreads, obs, I, strand, out_seq, out_perr, out_qv,
+                              out_len, out_nvalid, out_nonconv, out_delta, NULL);
+}
+
+/* ---------------- N4: HiFi kinetics (docs/faq/kinetics.md:8-18, tags docs/faq/bam-output.md:13-23) ------------
+ * SPEC.  pw / ipd inputs are CodecV1 codes (the u8 stored in the BAM ip/pw tags).  For every
+ * window, every read with a usable segment (0 <= I <= IMAX) is aligned globally to the CONVERGED window template in
+ * the read's own orientation (reverse-strand reads against the reverse complement) with the integer scores of the
+ * draft stage; a DIAG move whose bases agree attributes that read base's decoded IPD / PW frames to the template
+ * column.  Per strand and per core position the frames are averaged (integer, round half up) and re-encoded.      */
+int orc_codec_v1_decode(int c)
+{
+    return c < 64 ? c : (c < 128 ? 64 + (c - 64) * 2 : (c < 192 ? 192 + (c - 128) * 4 : 448 + (c - 192) * 8));
+}
+int orc_codec_v1_encode(int f)          /* nearest representable value, ties up, clamp at 952 */
+{
+    if (f < 0) f = 0;
+    if (f < 64) return f;
+    if (f < 192) return 64 + (f - 64 + 1) / 2;
+    if (f < 448) return 128 + (f - 192 + 2) / 4;
+    int c = 192 + (f - 448 + 4) / 8;
+    return c > 255 ? 255 : c;
+}
+
+/* one read on one window.  t = template in the READ's orientation (J columns), rb/ipd/pwc = the read segment
+ * (native orientation, I bases).  sums are indexed by FORWARD window column: jf = strand ? J-1-j : j.
+ * Alignment: H[i][0] = i*INS, H[0][j] = j*DEL;  h = max(diag, left), cell = max(h, up);
+ * move = UP iff up > h, else DIAG iff diag >= left, else LEFT.  Traceback from (I,J).                              */
+void orc_kinetics_read(const uint8_t *t, int J, const uint8_t *rb, const uint8_t *ipd, const uint8_t *pwc, int I,
+                       int strand, uint32_t *sum_ipd /* [JMAX+1] */, uint32_t *sum_pw, uint32_t *cnt)
+{
+    static const int MV_D = 0, MV_L = 1, MV_U = 2;
+    int32_t H[IMAX + 1][JMAX + 1]; uint8_t mv[IMAX + 1][JMAX + 1];
+    for (int i = 0; i <= I; ++i) { H[i][0] = i * SC_INS; mv[i][0] = (uint8_t)MV_U; }
+    for (int j = 1; j <= J; ++j) {
+        H[0][j] = H[0][j - 1] + SC_DEL; mv[0][j] = (uint8_t)MV_L;
+        for (int i = 1; i <= I; ++i) {
+            int diag = H[i - 1][j - 1] + (rb[i - 1] == t[j - 1] ? SC_MATCH : SC_MISMATCH);
+            int left = H[i][j - 1] + SC_DEL;
+            int h = diag >= left ? diag : left;
+            int up = H[i - 1][j] + SC_INS;
+            if (up > h) { H[i][j] = up; mv[i][j] = (uint8_t)MV_U; }
+            else { H[i][j] = h; mv[i][j] = (uint8_t)(diag >= left ? MV_D : MV_L); }
+        }
+    }
+    int i = I, j = J;
+    while (i > 0 || j > 0) {
+        int m = mv[i][j];
+        if (m == MV_D) {
+            if (rb[i - 1] == t[j - 1]) {
+                int jf = strand ? J - j : j - 1;
+                sum_ipd[jf] += (uint32_t)orc_codec_v1_decode(ipd[i - 1]);
+                sum_pw[jf] += (uint32_t)orc_codec_v1_decode(pwc[i - 1]);
+                cnt[jf] += 1;
+            }
+            --i; --j;
+        } else if (m == MV_L) --j;
+        else --i;
+    }
+}
+
+static inline uint8_t kin_mean_code(uint32_t sum, uint32_t cnt)
+{
+    if (!cnt) return 0;
+    return (uint8_t)orc_codec_v1_encode((int)((2u * sum + cnt) / (2u * cnt)));
 }
 
 /* ---------------- first-principles helpers for tests/test_oracle_hmm.py ---------------------------------- */
@@ -689,14 +764,16 @@ double orc_bruteforce_likelihood(const float *ME, const float *INS, const float 
 typedef struct {
     int32_t status, seq_len, np, iters, n_windows;
     float rq, ec;
+    int32_t fn, rn;             /* passes used on the strand of SEQ / on the other strand (fn + rn = np) */
 } orc_zmw_out;
 
 enum { ST_SUCCESS = 0, ST_TOO_FEW = 1, ST_DRAFT_FAIL = 2, ST_UNUSABLE = 3, ST_NONCONV = 4, ST_SHORT = 5, ST_LONG = 6, ST_LOWRQ = 7, ST_EMPTY = 8 };
 
-int orc_consensus_zmw(const orc_model *model, const orc_opts *opts, const float *snr, int nreads_in,
+int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const float *snr, int nreads_in,
                       const int64_t *base_off /* [nreads+1], relative to bases */, const uint8_t *bases, const uint8_t *pw,
                       const uint8_t *flags, uint8_t *seq, uint8_t *qual, float *raw_qv, int64_t cap, orc_zmw_out *out,
-                      uint8_t *draft_out, int32_t *draft_len_out)
+                      uint8_t *draft_out, int32_t *draft_len_out,
+                      const uint8_t *ipd /* NULL = no kinetics */, uint8_t *fi, uint8_t *fp, uint8_t *ri, uint8_t *rp)
 {
     memset(out, 0, sizeof(*out));
     int nreads = nreads_in;
@@ -730,6 +807,7 @@ int orc_consensus_zmw(const orc_model *model, const orc_opts *opts, const float 
         int32_t sc;
         avalid[r] = (uint8_t)orc_align(ob, L, draft, Ld, rstart[r], &sc);
         np += avalid[r];
+        if (avalid[r]) { if (strand[r]) out->rn += 1; else out->fn += 1; }
     }
     free(ob);
     out->np = np;
@@ -765,12 +843,34 @@ int orc_consensus_zmw(const orc_model *model, const orc_opts *opts, const float 
                 for (int i = 0; i < n; ++i) oo[i] = (uint8_t)obs_of(bb[i], pp[i]);
             }
             uint8_t wseq[JMAX + 1]; float wperr[JMAX + 1], wqv[JMAX + 1]; int32_t wlen, wnv, wnc;
-            int it = orc_polish_window(ME, INS, DL, draft + ws, J, cs, ce, lf, rf, nreads, obs, Iw, strand,
-                                       wseq, wperr, wqv, &wlen, &wnv, &wnc, NULL);
+            wtpl_t wf;
+            int it = polish_window_impl(ME, INS, DL, draft + ws, J, cs, ce, lf, rf, nreads, obs, Iw, strand,
+                                        wseq, wperr, wqv, &wlen, &wnv, &wnc, NULL, &wf);
             out->iters += it; nvalid_sum += wnv; nonconv_any |= wnc;
+            uint32_t ks[2][3][JMAX + 1];                          /* [strand][ipd, pw, count][forward column] */
+            if (ipd) {
+                memset(ks, 0, sizeof(ks));
+                uint8_t tr[JMAX + 1]; int lfr; revcomp_tpl(&wf, tr, &lfr);
+                for (int r = 0; r < nreads; ++r) {
+                    if (Iw[r] < 0) continue;
+                    int a = rstart[r][ws], b = rstart[r][we], L = (int)(base_off[r + 1] - base_off[r]);
+                    int na = strand[r] ? L - b : a;
+                    int64_t p0 = base_off[r] + na;
+                    (void)a;
+                    orc_kinetics_read(strand[r] ? tr : wf.t, wf.J, bases + p0, ipd + p0, pw + p0, Iw[r], strand[r],
+                                      ks[strand[r]][0], ks[strand[r]][1], ks[strand[r]][2]);
+                }
+            }
             float wsum = 0.0f;
             for (int i = 0; i < wlen; ++i) {
-                if (len < cap) { seq[len] = wseq[i]; qual[len] = (uint8_t)(wqv[i] + 0.5f); if (raw_qv) raw_qv[len] = wqv[i]; } else overflow = 1;
+                if (len < cap) {
+                    seq[len] = wseq[i]; qual[len] = (uint8_t)(wqv[i] + 0.5f); if (raw_qv) raw_qv[len] = wqv[i];
+                    if (ipd) {
+                        const int c = wf.cs + i;
+                        fi[len] = kin_mean_code(ks[0][0][c], ks[0][2][c]); fp[len] = kin_mean_code(ks[0][1][c], ks[0][2][c]);
+                        ri[len] = kin_mean_code(ks[1][0][c], ks[1][2][c]); rp[len] = kin_mean_code(ks[1][1][c], ks[1][2][c]);
+                    }
+                } else overflow = 1;
                 wsum = wsum + wperr[i]; ++len;
             }
             perr_sum += (double)wsum;
@@ -792,11 +892,21 @@ done:
     return ret;
 }
 
+int orc_consensus_zmw(const orc_model *model, const orc_opts *opts, const float *snr, int nreads_in,
+                      const int64_t *base_off /* [nreads+1], relative to bases */, const uint8_t *bases, const uint8_t *pw,
+                      const uint8_t *flags, uint8_t *seq, uint8_t *qual, float *raw_qv, int64_t cap, orc_zmw_out *out,
+                      uint8_t *draft_out, int32_t *draft_len_out)
+{
+    return orc_consensus_zmw_kin(model, opts, snr, nreads_in, base_off, bases, pw, flags, seq, qual, raw_qv, cap, out,
+                                 draft_out, draft_len_out, NULL, NULL, NULL, NULL, NULL);
+}
+
 /* batch driver over the ccsx SoA/CSR layout; nthreads > 1 uses OpenMP over ZMWs (cpu_baseline leg of bench.py) */
-int orc_consensus_batch(const orc_model *model, const orc_opts *opts, int n_zmw, const float *snr, const int32_t *read_off,
+int orc_consensus_batch_kin(const orc_model *model, const orc_opts *opts, int n_zmw, const float *snr, const int32_t *read_off,
                         const int64_t *base_off, const uint8_t *bases, const uint8_t *pw, const uint8_t *flags,
                         const int64_t *seq_off, int32_t *status, int32_t *seq_len, uint8_t *seq, uint8_t *qual, float *raw_qv,
-                        float *rq, int32_t *np, float *ec, int32_t *iters, int32_t *n_windows, int nthreads)
+                        float *rq, int32_t *np, float *ec, int32_t *iters, int32_t *n_windows, int nthreads,
+                        const uint8_t *ipd, uint8_t *fi, uint8_t *fp, uint8_t *ri, uint8_t *rp, int32_t *fn, int32_t *rn)
 {
     /* keep per-window / per-read scratch on the (per-thread) malloc arenas instead of mmap/munmap per call */
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
@@ -811,11 +921,24 @@ int orc_consensus_batch(const orc_model *model, const orc_opts *opts, int n_zmw,
         int64_t *rel = (int64_t *)malloc(sizeof(int64_t) * (nr + 1));
         for (int r = 0; r <= nr; ++r) rel[r] = base_off[r0 + r] - b0;
         orc_zmw_out o;
-        orc_consensus_zmw(model, opts, snr + 4 * z, nr, rel, bases + b0, pw + b0, flags + r0,
+        orc_consensus_zmw_kin(model, opts, snr + 4 * z, nr, rel, bases + b0, pw + b0, flags + r0,
                           seq + seq_off[z], qual + seq_off[z], raw_qv ? raw_qv + seq_off[z] : NULL,
-                          seq_off[z + 1] - seq_off[z], &o, NULL, NULL);
+                          seq_off[z + 1] - seq_off[z], &o, NULL, NULL,
+                          ipd ? ipd + b0 : NULL, ipd ? fi + seq_off[z] : NULL, ipd ? fp + seq_off[z] : NULL,
+                          ipd ? ri + seq_off[z] : NULL, ipd ? rp + seq_off[z] : NULL);
         status[z] = o.status; seq_len[z] = o.seq_len; rq[z] = o.rq; np[z] = o.np; ec[z] = o.ec; iters[z] = o.iters; n_windows[z] = o.n_windows;
+        if (fn) fn[z] = o.fn;
+        if (rn) rn[z] = o.rn;
         free(rel);
     }
     return 0;
+}
+
+int orc_consensus_batch(const orc_model *model, const orc_opts *opts, int n_zmw, const float *snr, const int32_t *read_off,
+                        const int64_t *base_off, const uint8_t *bases, const uint8_t *pw, const uint8_t *flags,
+                        const int64_t *seq_off, int32_t *status, int32_t *seq_len, uint8_t *seq, uint8_t *qual, float *raw_qv,
+                        float *rq, int32_t *np, float *ec, int32_t *iters, int32_t *n_windows, int nthreads)
+{
+    return orc_consensus_batch_kin(model, opts, n_zmw, snr, read_off, base_off, bases, pw, flags, seq_off, status, seq_len, seq,
+                                   qual, raw_qv, rq, np, ec, iters, n_windows, nthreads, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
 }

@@ -139,13 +139,39 @@ def bruteforce_likelihood(ME, INS, DL, tpl, lf, obs):
 
 
 def consensus_batch(model, opts, batch, results, nthreads=1):
-    """Whole-path oracle over a ccs_amd.api.Batch into a ccs_amd.api.Results (same layout as the product)."""
+    """Whole-path oracle over a ccs_amd.api.Batch into a ccs_amd.api.Results (same layout as the product).
+    HiFi kinetics (fi/fp/ri/rp planes) are computed iff `results` was allocated with kinetics=True."""
     L = lib()
-    L.orc_consensus_batch(C.byref(model), C.byref(opts), batch.n_zmw, _p(batch.snr, C.c_float),
-                          _p(batch.read_off, C.c_int32), _p(batch.base_off, C.c_int64), _p(batch.bases, C.c_uint8),
-                          _p(batch.pw, C.c_uint8), _p(batch.flags, C.c_uint8), _p(results.seq_off, C.c_int64),
-                          _p(results.status, C.c_int32), _p(results.seq_len, C.c_int32), _p(results.seq, C.c_uint8),
-                          _p(results.qual, C.c_uint8), _p(results.raw_qv, C.c_float), _p(results.rq, C.c_float),
-                          _p(results.np_, C.c_int32), _p(results.ec, C.c_float), _p(results.iters, C.c_int32),
-                          _p(results.n_windows, C.c_int32), int(nthreads))
+    kin = results.kin is not None
+    nullp = C.POINTER(C.c_uint8)()
+    planes = [_p(results.kin[k], C.c_uint8) for k in range(4)] if kin else [nullp] * 4
+    L.orc_consensus_batch_kin(C.byref(model), C.byref(opts), batch.n_zmw, _p(batch.snr, C.c_float),
+                              _p(batch.read_off, C.c_int32), _p(batch.base_off, C.c_int64), _p(batch.bases, C.c_uint8),
+                              _p(batch.pw, C.c_uint8), _p(batch.flags, C.c_uint8), _p(results.seq_off, C.c_int64),
+                              _p(results.status, C.c_int32), _p(results.seq_len, C.c_int32), _p(results.seq, C.c_uint8),
+                              _p(results.qual, C.c_uint8), _p(results.raw_qv, C.c_float), _p(results.rq, C.c_float),
+                              _p(results.np_, C.c_int32), _p(results.ec, C.c_float), _p(results.iters, C.c_int32),
+                              _p(results.n_windows, C.c_int32), int(nthreads),
+                              _p(batch.ipd, C.c_uint8) if kin else nullp, *planes,
+                              _p(results.fn, C.c_int32), _p(results.rn, C.c_int32))
     return results
+
+
+def codec_decode(c):
+    return lib().orc_codec_v1_decode(int(c))
+
+
+def codec_encode(f):
+    return lib().orc_codec_v1_encode(int(f))
+
+
+def kinetics_read(tpl_read_orient, read_bases, ipd, pw, strand):
+    """orc_kinetics_read on one read: returns (sum_ipd, sum_pw, cnt) indexed by FORWARD window column."""
+    t = np.ascontiguousarray(tpl_read_orient, np.uint8)
+    rb = np.ascontiguousarray(read_bases, np.uint8)
+    ip = np.ascontiguousarray(ipd, np.uint8)
+    pwc = np.ascontiguousarray(pw, np.uint8)
+    si, sp, cn = (np.zeros(JMAX + 1, np.uint32) for _ in range(3))
+    lib().orc_kinetics_read(_p(t, C.c_uint8), len(t), _p(rb, C.c_uint8), _p(ip, C.c_uint8), _p(pwc, C.c_uint8), len(rb),
+                            int(strand), _p(si, C.c_uint32), _p(sp, C.c_uint32), _p(cn, C.c_uint32))
+    return si[: len(t)], sp[: len(t)], cn[: len(t)]

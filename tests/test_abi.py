@@ -23,7 +23,7 @@ def test_header_and_exports_agree(built):
     L = C.CDLL(api.LIB_PATH)
     for name in decl:
         assert hasattr(L, name), f"{name} declared in include/ccsx.h but not exported by libccsx.so"
-    assert L.ccsx_abi_version() == 1
+    assert L.ccsx_abi_version() == 2
 
 
 def test_struct_layouts_match_header(built):
@@ -31,12 +31,12 @@ def test_struct_layouts_match_header(built):
     assert C.sizeof(api.Model) == 32 + 8 + 16 * 3 * 4 * 4 + 16 * 12 * 4 + 16 * 3 * 4 * 2
     assert C.sizeof(api.Opts) == 4 * 7 + 4 * 8
     assert C.sizeof(api.CBatch) == 16 + 8 * 8
-    assert C.sizeof(api.CResults) == 16 + 11 * 8
+    assert C.sizeof(api.CResults) == 16 + 17 * 8
     m = api.default_model()
     assert m.name == b"SYN-1" and m.snr_lo == 4.0 and m.snr_hi == 20.0
     o = api.default_opts()
     assert (o.max_poa_cov, o.min_passes, o.top_passes, o.min_length, o.max_length) == (5, 3, 60, 10, 50000)
-    assert abs(o.min_rq - 0.99) < 1e-7
+    assert abs(o.min_rq - 0.99) < 1e-7 and o.hifi_kinetics == 0
 
 
 def test_no_silent_cpu_fallback(built):

@@ -245,3 +245,80 @@ def test_full_size_determinism_and_sharding(handle):
     h2.close()
     assert d3 == d1
     assert (a.status == 0).mean() > 0.99 and a.rq[a.status == 0].mean() > 0.9995
+
+
+# ---- N4: HiFi kinetics (docs/faq/kinetics.md:8-18; SPEC DESIGN.md §2.9) ----------------------------------------
+def _kin_handle():
+    opts = api.default_opts()
+    opts.hifi_kinetics = 1
+    return api.Handle(0, opts=opts)
+
+
+@pytest.mark.parametrize("n,passes,length,seed", [
+    (6, 10, 2000, 21),
+    (12, (3, 14), (150, 1500), 22),     # ragged; some ZMWs fail (too few passes) and must stay empty
+    (2, 40, 500, 23),                   # deep coverage
+])
+def test_kinetics_bit_exact(built, n, passes, length, seed):
+    batch = api.synth(n, passes, length, seed=seed)
+    rng = np.random.default_rng(seed)
+    batch.ipd = rng.integers(0, 256, len(batch.bases)).astype(np.uint8)          # the whole CodecV1 range
+    batch.pw = np.where(rng.random(len(batch.bases)) < 0.9, batch.pw, rng.integers(0, 256, len(batch.bases))).astype(np.uint8)
+    h = _kin_handle()
+    try:
+        res = h.consensus(batch)
+        ref = api.Results.allocate(batch, kinetics=True)
+        O.consensus_batch(h.model, h.opts, batch, ref, nthreads=8)
+        _compare(res, ref, batch)
+        assert np.array_equal(res.fn, ref.fn) and np.array_equal(res.rn, ref.rn)
+        assert np.array_equal(res.fn + res.rn, res.np_)
+        seen = 0
+        for z in range(batch.n_zmw):
+            assert np.array_equal(res.kinetics(z), ref.kinetics(z)), f"zmw {z}: kinetics differ"
+            seen += int((res.kinetics(z) > 0).sum())
+        assert seen > 0
+    finally:
+        h.close()
+
+
+def test_kinetics_do_not_change_the_consensus(handle):
+    batch = api.synth(5, 8, 1200, seed=41)
+    plain = handle.consensus(batch)
+    assert plain.kin is None and np.array_equal(plain.fn + plain.rn, plain.np_)  # pass counts come with every run
+    h = _kin_handle()
+    try:
+        res = h.consensus(batch)
+        _compare(res, plain, batch)
+        # split form + base-coded kinetics: forward planes follow SEQ, reverse planes its complement
+        batch.ipd = (10 + 10 * batch.bases).astype(np.uint8)
+        h.upload(batch); h.run(); h.sync()
+        r2 = h.download()
+        for z in range(batch.n_zmw):
+            s = r2.sequence(z).astype(int)
+            fi, _, ri, _ = r2.kinetics(z).astype(int)
+            assert (fi[fi > 0] == 10 + 10 * s[fi > 0]).all() and (ri[ri > 0] == 10 + 10 * (3 - s[ri > 0])).all()
+            assert (fi > 0).mean() > 0.99 and (ri > 0).mean() > 0.99
+    finally:
+        h.close()
+
+
+def test_kinetics_need_ipd(built):
+    import ctypes as C
+    batch = api.synth(2, 4, 200, seed=3)
+    h = _kin_handle()
+    try:
+        cb = batch.c_struct()
+        cb.ipd = C.POINTER(C.c_uint8)()
+        assert h._L.ccsx_upload(h._h, C.byref(cb)) != 0
+        assert b"ipd" in h._L.ccsx_last_error()
+    finally:
+        h.close()
+    # and a handle without the option refuses kinetics buffers instead of leaving them unwritten
+    h2 = api.Handle(0)
+    try:
+        h2.upload(batch); h2.run(); h2.sync()
+        res = api.Results.allocate(batch, kinetics=True)
+        cr = res.c_struct()
+        assert h2._L.ccsx_download(h2._h, C.byref(cr)) != 0
+    finally:
+        h2.close()
