@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--handles", type=int, default=1, help="engine handles (HIP streams) per GPU; the batch is split between them "
                     "so kernels with different bottlenecks (POA: scalar issue, polish: VALU/LDS) overlap")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL; gloo for CPU-side tests)")
+    ap.add_argument("--hifi-kinetics", action="store_true", help="also run the N4 kinetics kernel (not part of the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -80,7 +81,9 @@ def main():
     gen_s = time.time() - t0
     nh = max(1, min(args.handles, args.zmws))
     parts = [batch.slice(i * args.zmws // nh, (i + 1) * args.zmws // nh) for i in range(nh)] if nh > 1 else [batch]
-    hs = [api.Handle(local_rank) for _ in range(nh)]
+    opts = api.default_opts()
+    opts.hifi_kinetics = 1 if args.hifi_kinetics else 0
+    hs = [api.Handle(local_rank, opts=opts) for _ in range(nh)]
     h = hs[0]
     t0 = time.time()
     for hh, part in zip(hs, parts):
@@ -161,7 +164,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.passes} passes x {args.length} bp synthetic subreads (BASELINE configs[1] shape), "
                                    f"{args.zmws} ZMWs per GPU per step", "zmws_per_gpu": args.zmws, "handles_per_gpu": nh, "passes": args.passes,
-                       "template_len": args.length, "parallelism": f"zmw-shard x{world}", "model": "SYN-1"},
+                       "template_len": args.length, "parallelism": f"zmw-shard x{world}", "model": "SYN-1",
+                       "hifi_kinetics": bool(args.hifi_kinetics)},
             "roofline": roofline,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "success_frac": ok / args.zmws, "mean_rq": float(rq_ok.mean()) if ok else None,

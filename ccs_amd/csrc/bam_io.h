@@ -268,11 +268,16 @@ inline bool read_header(BgzfReader &in, BamHeader &h)
     return true;
 }
 
-// CodecV1 frames -> pulse-width / IPD value (only min(pw,3) matters to the HMM; clamp to 255)
-inline uint8_t codec_v1(uint8_t c)
+// pw / ip travel as CodecV1 codes (include/ccsx.h ccsx_batch): B,C tags are passed through untouched, raw-frame
+// B,S tags are encoded (nearest representable value, ties up, clamp at 952 frames)
+inline uint8_t codec_v1_encode(int64_t f)
 {
-    unsigned v = c < 64 ? c : (c < 128 ? 64 + (c - 64) * 2 : (c < 192 ? 192 + (c - 128) * 4 : 448 + (c - 192) * 8));
-    return (uint8_t)(v > 255 ? 255 : v);
+    if (f < 0) f = 0;
+    if (f < 64) return (uint8_t)f;
+    if (f < 192) return (uint8_t)(64 + (f - 64 + 1) / 2);
+    if (f < 448) return (uint8_t)(128 + (f - 192 + 2) / 4);
+    const int64_t c = 192 + (f - 448 + 4) / 8;
+    return (uint8_t)(c > 255 ? 255 : c);
 }
 
 inline size_t tag_value_size(char t)
@@ -317,8 +322,8 @@ inline void parse_subread(const uint8_t *p, uint32_t bs, Subread &r)
                 std::vector<uint8_t> &dst = (t0 == 'p') ? r.pw : r.ipd;
                 dst.resize(n);
                 for (uint32_t i = 0; i < n; ++i) {
-                    if (es == 1) dst[i] = codec_v1(q[i]);
-                    else { const int64_t v = rdint(st, q + i * es); dst[i] = (uint8_t)(v > 255 ? 255 : (v < 0 ? 0 : v)); }
+                    if (es == 1) dst[i] = q[i];
+                    else dst[i] = codec_v1_encode(rdint(st, q + i * es));
                 }
             }
             t = q + (size_t)n * es;

@@ -74,8 +74,8 @@ struct Batch {
     std::vector<int> slot;        // per zmws[]: index into the SoA or -1
     // results
     std::vector<int64_t> seq_off;
-    std::vector<int32_t> status, seq_len, np, iters, n_windows;
-    std::vector<uint8_t> seq, qual;
+    std::vector<int32_t> status, seq_len, np, iters, n_windows, fn, rn;
+    std::vector<uint8_t> seq, qual, kin;   // kin: 4 planes (fi, fp, ri, rp) of seq.size() bytes each (--hifi-kinetics)
     std::vector<float> rq, ec;
 };
 
@@ -123,6 +123,7 @@ void usage()
                  "      --maxPoaCoverage N    subreads used for the draft [5]\n"
                  "      --by-strand           one consensus per strand, read names end in /fwd or /rev\n"
                  "      --qv-binning          write 7-bin per-base QVs (Q3 Q10 Q17 Q22 Q27 Q35 Q40)\n"
+                 "      --hifi-kinetics       averaged per-strand kinetics: tags fi fp fn ri rp rn (ip pw with --by-strand)\n"
                  "      --metrics-json F      per-ZMW metrics [<OUT prefix>.zmw_metrics.json.gz]\n"
                  "      --suppress-reports    do not write ccs_report.txt / zmw_metrics.json.gz\n"
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
@@ -162,6 +163,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--dump-zmws") o.dump = true;
         else if (a == "--by-strand") o.by_strand = true;
         else if (a == "--qv-binning") o.qv_binning = true;
+        else if (a == "--hifi-kinetics") o.o.hifi_kinetics = 1;
         else if (a == "--suppress-reports") o.suppress_reports = true;
         else if (a == "--metrics-json") o.metrics = need(a.c_str());
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
@@ -463,6 +465,11 @@ int main(int argc, char **argv)
                     b->rq.resize(n); b->ec.resize(n); b->seq.resize(cap); b->qual.resize(cap);
                     ccsx_results r{n, cap, b->seq_off.data(), b->status.data(), b->seq_len.data(), b->seq.data(), b->qual.data(), nullptr,
                                    b->rq.data(), b->np.data(), b->ec.data(), b->iters.data(), b->n_windows.data()};
+                    if (opt.o.hifi_kinetics) {
+                        b->kin.resize((size_t)4 * cap); b->fn.resize(n); b->rn.resize(n);
+                        r.fi = b->kin.data(); r.fp = r.fi + cap; r.ri = r.fp + cap; r.rp = r.ri + cap;
+                        r.fn = b->fn.data(); r.rn = b->rn.data();
+                    }
                     if (ccsx_consensus_batch(h, &cb, &r)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); failed = 1; }
                     std::vector<uint8_t>().swap(b->bases); std::vector<uint8_t>().swap(b->pw); std::vector<uint8_t>().swap(b->ipd);
                 }
@@ -483,6 +490,7 @@ int main(int argc, char **argv)
             std::map<int64_t, std::shared_ptr<Batch>> hold;
             int64_t next = 0;
             RecordBuilder rb;
+            std::vector<uint8_t> kin_rev;
             std::shared_ptr<Batch> b;
             std::string metrics = "{\n  \"zmws\": [\n";
             bool first_metric = true;
@@ -495,7 +503,8 @@ int main(int argc, char **argv)
                                               40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40};
             auto emit = [&](Batch &bt) {
                 if (!header_done && !fastq) {
-                    write_header(*outp, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:" + movie +
+                    write_header(*outp, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS" +
+                                          std::string(opt.o.hifi_kinetics && opt.by_strand ? ";Ipd:CodecV1=ip;PulseWidth:CodecV1=pw" : "") + "\tPU:" + movie +
                                           "\tPM:SEQUELII\n@PG\tID:ccs\tPN:ccs\tVN:amd-mi355x-r1\tDS:Generate circular consensus sequences (ccs) from subreads.\n");
                 }
                 header_done = true;
@@ -539,6 +548,20 @@ int main(int argc, char **argv)
                     rb.tagf("rq", bt.rq[s]);
                     rb.tagBf("sn", z.snr, 4);
                     rb.tagi("zm", z.zm);
+                    if (opt.o.hifi_kinetics) {                      // docs/faq/kinetics.md:8-18, tag table docs/faq/bam-output.md:13-23
+                        const size_t cap = bt.seq.size();
+                        const uint8_t *fi = bt.kin.data() + o, *fp = fi + cap, *ri = fp + cap, *rp = ri + cap;
+                        const uint32_t nf = bt.fn[s] > 0 ? (uint32_t)len : 0, nr = bt.rn[s] > 0 ? (uint32_t)len : 0;   // a strand without passes: empty lists
+                        if (z.strand_tag) {                         // single-strand record: its own strand is the forward pair
+                            rb.tagBC("ip", fi, nf); rb.tagBC("pw", fp, nf);
+                        } else {
+                            rb.tagBC("fi", fi, nf); rb.tagBC("fp", fp, nf); rb.tagi("fn", bt.fn[s]);
+                            kin_rev.assign(ri, ri + nr); std::reverse(kin_rev.begin(), kin_rev.end());   // reverse strand: its own orientation
+                            rb.tagBC("ri", kin_rev.data(), nr);
+                            kin_rev.assign(rp, rp + nr); std::reverse(kin_rev.begin(), kin_rev.end());
+                            rb.tagBC("rp", kin_rev.data(), nr); rb.tagi("rn", bt.rn[s]);
+                        }
+                    }
                     rb.finish(*outp);
                     rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.np_sum += bt.np[s];
                 }

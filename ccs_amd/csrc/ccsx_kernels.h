@@ -17,7 +17,6 @@ struct KParams {
     const int32_t *read_off;
     const int64_t *base_off;
     const uint8_t *bases, *pw, *flags;
-    const uint8_t *ipd;        // NULL unless opts.hifi_kinetics
     // ---- host-derived layout
     const int32_t *read_zmw;   // [R] owning ZMW of each read
     const int32_t *vcap;       // [n] POA vertex capacity
@@ -49,17 +48,19 @@ struct KParams {
     float *wqv;                // [wslots][32]
     float *wsum;               // [wslots] sum of p_err over the core
     int4 *wmeta;               // [wslots] (core length, usable reads, non-convergent, iterations)
-    // ---- HiFi kinetics (NULL unless opts.hifi_kinetics)
+    // ---- results
+    uint8_t *out_seq, *out_qual;
+    float *out_raw;
+    int32_t *out_status, *out_len, *out_iters, *out_nwin;
+    float *out_rq, *out_ec;
+    int32_t *out_fn, *out_rn;  // passes used per strand
+    // ---- HiFi kinetics (NULL unless opts.hifi_kinetics); kept at the end so the hot kernels' kernarg offsets do not move
+    const uint8_t *ipd;
     uint8_t *wtpl;             // [wslots][32] converged window template incl. overhangs
     short2 *wtmeta;            // [wslots] (J, core start)
     uchar4 *wkin;              // [wslots][32] (fi, fp, ri, rp) codes of the core positions
     uint8_t *out_kin;          // 4 planes (fi, fp, ri, rp) of seq_off[n] bytes each
     long long kin_plane;       // plane stride = seq_off[n]
-    // ---- results
-    uint8_t *out_seq, *out_qual;
-    float *out_raw;
-    int32_t *out_status, *out_len, *out_iters, *out_nwin, *out_fn, *out_rn;
-    float *out_rq, *out_ec;
 };
 
 void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev);

@@ -1190,10 +1190,54 @@ __device__ __forceinline__ int kin_mean_code(unsigned sum, unsigned cnt)
     return cnt ? codec_v1_encode((int)((2u * sum + cnt) / (2u * cnt))) : 0;
 }
 
+// scalar traceback of one read: rows live in lanes base..base+n; bit c of (upm, lfm) in the lane of row i says the
+// move of cell (i, c+1) is UP / LEFT (neither = DIAG).  Returns, for lane base+c, the read row matched (DIAG) to
+// column c of the read-oriented template, or -1.
+__device__ __forceinline__ int kin_traceback(int upm, int lfm, int n, int J, int base, int lane)
+{
+    int i = n, j = J, myrow = -1;
+    while (i > 0 && j > 0) {                                 // DIAG needs both; the rest of the path is a straight edge
+        const unsigned su = (unsigned)rl(upm, base + i) >> (j - 1), sl = (unsigned)rl(lfm, base + i) >> (j - 1);
+        const int up = su & 1u, lf = sl & 1u;
+        if (!(up | lf) && lane == base + j - 1) myrow = i - 1;
+        i -= 1 - lf;
+        j -= 1 - up;
+    }
+    return myrow;
+}
+
+// the same walk for segments of <= 31 bases, one iteration per DIAG RUN instead of per cell: nd = (up | left) << (32 - row)
+// puts the cells of one diagonal (i - j constant) at the same bit position in every lane, so a single
+// ballot lists the non-DIAG cells of the current diagonal and the highest one at or below row i ends the run.  A
+// typical window has ~3 indels per read: ~4 iterations instead of ~30 steps.
+__device__ __forceinline__ int kin_traceback_runs(int upm, unsigned long long nd, int n, int J, int base, int lane)
+{
+    int i = n, j = J, myrow = -1;
+    const int c = lane - base;
+    while (i > 0 && j > 0) {
+        const int p = j + 31 - i;                            // bit of cell (i', j') on this diagonal: (j'-1) + 32 - i'
+        const unsigned rows = (unsigned)(__ballot((int)((nd >> p) & 1ull)) >> base);
+        const unsigned below = rows & (unsigned)((2ull << i) - 1ull);         // non-DIAG cells at rows <= i (row 0 always is one)
+        const int istar = 31 - __builtin_clz(below | 1u);
+        int run = i - istar;
+        if (run > j) run = j;
+        if (c >= j - run && c < j) myrow = c + i - j;        // DIAG cell (c + 1 + i - j, c + 1) matches read row c + i - j
+        i -= run; j -= run;
+        if (i > 0 && j > 0) {                                // (i, j) is UP or LEFT
+            if (((unsigned)rl(upm, base + i) >> (j - 1)) & 1u) --i; else --j;
+        }
+    }
+    return myrow;
+}
+
 __global__ __launch_bounds__(256) void k_kinetics(KParams P)
 {
     __shared__ uint8_t sT[2][32];
     __shared__ unsigned sK[2][3][32];                       // [strand][ipd, pw, count][forward column]
+    __shared__ int sN[PW_MAXREADS], sOff[PW_MAXREADS];      // segment length (-1 = unusable), offset of the segment in the read
+    __shared__ uint8_t sSt[PW_MAXREADS];
+    __shared__ short2 sTask[PW_MAXREADS];
+    __shared__ int sNT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = blockIdx.x;
     const int z = P.wslot_zmw[bid];
@@ -1207,52 +1251,84 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
     if (tid < J) { const uint8_t b = P.wtpl[wi * 32 + tid]; sT[0][tid] = b; sT[1][J - 1 - tid] = (uint8_t)(3 - b); }
     if (tid < 192) (&sK[0][0][0])[tid] = 0u;
+    if (tid < nreads) {                                      // one lane per read: segment of the read inside this window
+        const int rr = r0 + tid;
+        int n = -1, off = 0;
+        const int st = ((P.flags[rr] ^ P.flags[r0]) & 1) ? 1 : 0;
+        if (P.avalid[rr]) {
+            const int32_t *ent = P.ent + P.ent_off[rr];
+            const int a = ent[idx_ws], b = ent[idx_we];
+            n = b - a;
+            if (n < 0 || n > CCSX_IMAX) n = -1;
+            off = st ? (int)(P.base_off[rr + 1] - P.base_off[rr]) - b : a;
+        }
+        sN[tid] = n; sOff[tid] = off; sSt[tid] = (uint8_t)st;
+    }
     __syncthreads();
-    for (int r = wave; r < nreads; r += 4) {
-        const int rr = r0 + r;
-        if (!P.avalid[rr]) continue;
-        const int32_t *ent = P.ent + P.ent_off[rr];
-        const int a = rfl(ent[idx_ws]), b = rfl(ent[idx_we]);
-        const int n = b - a;
-        if (n < 0 || n > CCSX_IMAX) continue;
-        const int64_t bo0 = P.base_off[rr];
-        const int L = (int)(P.base_off[rr + 1] - bo0);
-        const int st = rfl(((P.flags[rr] ^ P.flags[r0]) & 1) ? 1 : 0);
-        const int64_t p0 = bo0 + (st ? L - b : a);
-        const bool rowok = lane >= 1 && lane <= n;
-        const int rbv = rowok ? P.bases[p0 + lane - 1] : 4;   // lane i holds read base i-1
+    if (tid == 0) {                                          // tasks: two short segments share a wave (32 lanes each)
+        int nt = 0, pend = -1;
+        for (int r = 0; r < nreads; ++r) {
+            const int n = sN[r];
+            if (n < 0) continue;
+            if (n > 31) sTask[nt++] = make_short2((short)r, (short)-1);
+            else if (pend < 0) pend = r;
+            else { sTask[nt++] = make_short2((short)pend, (short)r); pend = -1; }
+        }
+        if (pend >= 0) sTask[nt++] = make_short2((short)pend, (short)-1);
+        sNT = nt;
+    }
+    __syncthreads();
+    const int ntask = sNT;
+    unsigned tlo[2], thi[2];                                 // template bit planes per strand: bit c = column c (wave-uniform)
+    for (int sd = 0; sd < 2; ++sd) {
+        const int b = lane < J ? sT[sd][lane] : 0;
+        tlo[sd] = (unsigned)__ballot(b & 1); thi[sd] = (unsigned)__ballot(b & 2);
+    }
+    for (int tk = wave; tk < ntask; tk += 4) {
+        const short2 task = sTask[tk];
+        const bool paired = rfl((int)task.y) >= 0;
+        const int half = (paired && lane >= 32) ? 1 : 0;
+        const int base = half * 32, row = lane - base;
+        const int myr = half ? task.y : task.x;
+        const int n = sN[myr], st = sSt[myr];
+        const int64_t p0 = P.base_off[r0 + myr] + sOff[myr];
+        const int rbv = (row >= 1 && row <= n) ? P.bases[p0 + row - 1] : 0;   // lane of row i holds read base i-1
         const uint8_t *t = sT[st];
-        int Hprev = (lane <= n) ? lane * SC_INS : NEGV;
-        unsigned long long mvmask = 0ull;                    // 2 bits per column: 0 DIAG, 1 LEFT, 2 UP
+        // bit c of mt: read base of this row == template column c (the two bit planes of the template come as ballots)
+        const unsigned mt = ~((tlo[st] ^ ((rbv & 1) ? ~0u : 0u)) | (thi[st] ^ ((rbv & 2) ? ~0u : 0u)));
+        // scores are kept shifted by +5 inside a column (h5 = h + 5): diag5 = x + 8*match, left5 = H + 1.  Rows beyond
+        // the read compute garbage that no lower lane and no traceback step ever reads.
+        const int c1 = 4 * row - 5;
+        int H = row * SC_INS;
+        int upm = 0, lfm = 0;
         for (int j = 1; j <= J; ++j) {
-            const int tb = t[j - 1];
-            const int x = wave_shr1_i32(Hprev, NEGV);
-            const int diag = rowok ? x + (rbv == tb ? SC_MATCH : SC_MISMATCH) : NEGV;
-            const int left = (lane <= n) ? Hprev + SC_DEL : NEGV;
-            const int h = diag >= left ? diag : left;
-            const int v = wave_scan_max_i32(h + 4 * lane) - 4 * lane;      // insertion chain: v(i) = max_k<=i h(k) + (i-k)*SC_INS
-            const unsigned long long mv = (v > h) ? 2ull : (diag >= left ? 0ull : 1ull);
-            mvmask |= mv << (2 * (j - 1));
-            Hprev = (lane <= n) ? v : NEGV;
+            int x = wave_shr1_i32(H, NEGV);
+            if (row == 0) x = NEGV;                          // (lane 32 of a pair would otherwise see the other read)
+            const int diag5 = x + (int)(((mt >> (j - 1)) & 1u) << 3);
+            const int left5 = H + 1;
+            const int h5 = diag5 >= left5 ? diag5 : left5;
+            // insertion chain: v(i) = max_k<=i h(k) + (i-k)*SC_INS, one fused DPP max-scan (per half when paired)
+            const int d0 = h5 + c1;
+            const int v = (paired ? half_scan_max_i32(d0) : wave_scan_max_i32(d0)) - 4 * row;     // = v(i) exactly
+            const unsigned bit = 1u << (j - 1);
+            if (v + 5 > h5) upm |= bit;
+            else if (diag5 < left5) lfm |= bit;
+            H = v;
         }
-        const int mlo = (int)(unsigned)mvmask, mhi = (int)(unsigned)(mvmask >> 32);
-        int i = n, j = J, myrow = -1;
-        while (i > 0 || j > 0) {
-            int mv;
-            if (j == 0) mv = 2;
-            else if (i == 0) mv = 1;
-            else {
-                const unsigned long long rm = ((unsigned long long)(unsigned)rl(mhi, i) << 32) | (unsigned)rl(mlo, i);
-                mv = (int)((rm >> (2 * (j - 1))) & 3ull);
+        int myrow;
+        const int nA = rfl(sN[task.x]);
+        if (nA <= 31) {
+            const unsigned long long nd = (unsigned long long)(unsigned)(upm | lfm) << (32 - (row & 31));
+            myrow = kin_traceback_runs(upm, nd, nA, J, 0, lane);
+            if (paired) {
+                const int rowB = kin_traceback_runs(upm, nd, rfl(sN[task.y]), J, 32, lane);
+                if (half) myrow = rowB;
             }
-            if (mv == 0) { if (lane == j - 1) myrow = i - 1; --i; --j; }
-            else if (mv == 1) --j;
-            else --i;
-        }
-        if (lane < J && myrow >= 0) {
-            const int jf = st ? J - 1 - lane : lane;
+        } else myrow = kin_traceback(upm, lfm, nA, J, 0, lane);
+        if (row < J && myrow >= 0) {
+            const int jf = st ? J - 1 - row : row;
             const int64_t p = p0 + myrow;
-            if (jf >= cs && jf < ce && P.bases[p] == t[lane]) {
+            if (jf >= cs && jf < ce && P.bases[p] == t[row]) {
                 atomicAdd(&sK[st][0][jf], (unsigned)codec_v1_decode(P.ipd[p]));
                 atomicAdd(&sK[st][1][jf], (unsigned)codec_v1_decode(P.pw[p]));
                 atomicAdd(&sK[st][2][jf], 1u);

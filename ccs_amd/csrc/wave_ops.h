@@ -34,6 +34,17 @@ __device__ __forceinline__ int wave_scan_max_i32(int v)
     s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_BCAST31, 0xc, 0xf, false));
     return s;
 }
+// inclusive prefix maximum inside each 32-lane half (two independent scans per wave): the same ladder without the last
+// cross-half broadcast, 5 VALU ops
+__device__ __forceinline__ int half_scan_max_i32(int v)
+{
+    int s = imax(v, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(2), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(4), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(8), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_BCAST15, 0xa, 0xf, false));
+    return s;
+}
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ int wave_scan_add_i32(int v)
 {

@@ -143,3 +143,40 @@ def test_cli_reports_and_qv_binning(built, tmp_path):
     for m, r in zip(ok, recs):
         assert m["insert_size"] == len(r["seq"]) and m["num_full_passes"] == 8 and abs(m["predicted_accuracy"] - r["tags"]["rq"]) < 1e-5
         assert m["polymerase_length"] > 8 * 500 and abs(m["effective_coverage"] - r["tags"]["ec"]) < 0.01
+
+
+@pytest.mark.gpu
+def test_cli_hifi_kinetics(built, tmp_path):
+    """--hifi-kinetics: fi fp fn ri rp rn on double-strand records, ip pw on --by-strand records
+    (docs/faq/kinetics.md:8-18,29-33; tag table docs/faq/bam-output.md:13-23)."""
+    bam, out, out2 = tmp_path / "s.subreads.bam", tmp_path / "k.hifi.bam", tmp_path / "ks.hifi.bam"
+    _run("--write-synthetic", "5,8,700,37", bam)
+    _run(bam, out, "--hifi-kinetics", "--suppress-reports")
+    _, recs = bam_util.read_bam(out)
+    batch = api.synth(5, 8, 700, seed=37, first_zmw_id=1000)
+    opts = api.default_opts(); opts.hifi_kinetics = 1
+    h = api.Handle(0, opts=opts)
+    res = h.consensus(batch)
+    h.close()
+    ok = [z for z in range(5) if res.status[z] == 0]
+    assert len(recs) == len(ok) > 0
+    for rec, z in zip(recs, ok):
+        t = rec["tags"]
+        fi, fp, ri, rp = res.kinetics(z)
+        assert np.array_equal(rec["seq"], res.sequence(z))
+        assert np.array_equal(t["fi"], fi) and np.array_equal(t["fp"], fp)
+        assert np.array_equal(t["ri"], ri[::-1]) and np.array_equal(t["rp"], rp[::-1])     # reverse strand in its own orientation
+        assert t["fn"] == res.fn[z] == 4 and t["rn"] == res.rn[z] == 4 and t["np"] == 8
+        assert (np.asarray(t["fi"]) > 0).mean() > 0.99 and set(np.unique(t["fp"]).tolist()) <= {0, 1, 2, 3}
+    # without the option none of the kinetics tags is written
+    plain = tmp_path / "p.hifi.bam"
+    _run(bam, plain, "--suppress-reports")
+    assert not ({"fi", "fp", "ri", "rp", "fn", "rn", "ip", "pw"} & set(bam_util.read_bam(plain)[1][0]["tags"]))
+    # single-strand records carry their own strand's kinetics as ip / pw
+    _run(bam, out2, "--hifi-kinetics", "--by-strand", "--min-rq", 0.9, "--suppress-reports")
+    text, recs2 = bam_util.read_bam(out2)
+    assert "Ipd:CodecV1=ip" in text and len(recs2) == 10
+    for r in recs2:
+        t = r["tags"]
+        assert len(t["ip"]) == len(t["pw"]) == len(r["seq"]) and "fi" not in t and "ri" not in t
+        assert (np.asarray(t["ip"]) > 0).mean() > 0.99
