@@ -36,14 +36,25 @@ def effective_cores() -> int:
     return n
 
 
+# BASELINE.json configs (SURVEY.md §8 sizes): (passes, template length, ZMWs per GPU per step in the default run)
+WORKLOADS = {"c1": (3, 1000, 65536), "c2": (10, 10000, 8192), "c4": (30, 20000, 1024), "c5": ((3, 50), (1000, 25000), 4096)}
+
+
+def _span(v):
+    a = [int(x) for x in str(v).split("-")]
+    return a[0] if len(a) == 1 else (a[0], a[1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--zmws", type=int, default=4096, help="ZMWs per GPU per step")
-    ap.add_argument("--passes", type=int, default=10)
-    ap.add_argument("--length", type=int, default=10000)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="BASELINE.json config shape: c2 (default, the "
+                    "one the metric is quoted on) 10 x 10 kb; c1 3 x 1 kb; c4 30 x 20 kb; c5 3-50 passes x 1-25 kb (log-uniform)")
+    ap.add_argument("--zmws", type=int, default=0, help="ZMWs per GPU per step [workload default]")
+    ap.add_argument("--passes", type=_span, default=None, help="passes per ZMW, N or LO-HI [workload default]")
+    ap.add_argument("--length", type=_span, default=None, help="template length, N or LO-HI (log-uniform) [workload default]")
     ap.add_argument("--handles", type=int, default=1, help="engine handles (HIP streams) per GPU; the batch is split between them "
                     "so kernels with different bottlenecks (POA: scalar issue, polish: VALU/LDS) overlap")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL; gloo for CPU-side tests)")
@@ -51,6 +62,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.passes = wl[0] if args.passes is None else args.passes
+    args.length = wl[1] if args.length is None else args.length
+    args.zmws = wl[2] if args.zmws <= 0 else args.zmws
 
     import numpy as np
     import torch
@@ -142,7 +157,7 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             kz = tj["kernels"][names[dom]]
-            if args.passes == 10 and args.length == 10000:
+            if args.passes == 10 and args.length == 10000 and not args.hifi_kinetics:
                 traffic = int((kz["fetch_size_kb_per_zmw"] + kz["write_size_kb_per_zmw"]) * 1024 * args.zmws)
         except Exception:
             traffic = None
@@ -159,11 +174,12 @@ def main():
                     "avg_launch_ms": round(stage_ms[dom], 3), "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d)"}
         out = {
-            "metric": "ZMWs/sec (HiFi reads/sec), 10-pass x 10 kb synthetic", "value": round(value, 2), "unit": "ZMWs/s",
+            "metric": "ZMWs/sec (HiFi reads/sec), 10-pass x 10 kb synthetic" if args.workload == "c2" and args.passes == 10 and args.length == 10000
+                      else f"ZMWs/sec, {args.passes} passes x {args.length} bp synthetic", "value": round(value, 2), "unit": "ZMWs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.passes} passes x {args.length} bp synthetic subreads (BASELINE configs[1] shape), "
-                                   f"{args.zmws} ZMWs per GPU per step", "zmws_per_gpu": args.zmws, "handles_per_gpu": nh, "passes": args.passes,
+            "config": {"workload": f"{args.passes} passes x {args.length} bp synthetic subreads (BASELINE configs[{int(args.workload[1]) - 1}] shape), "
+                                   f"{args.zmws} ZMWs per GPU per step", "preset": args.workload, "zmws_per_gpu": args.zmws, "handles_per_gpu": nh, "passes": args.passes,
                        "template_len": args.length, "parallelism": f"zmw-shard x{world}", "model": "SYN-1",
                        "hifi_kinetics": bool(args.hifi_kinetics)},
             "roofline": roofline,

@@ -53,7 +53,7 @@ struct ccsx_handle_s {
     // inputs
     DevBuf d_snr, d_read_off, d_base_off, d_bases, d_pw, d_ipd, d_flags;
     // layout
-    DevBuf d_read_zmw, d_vcap, d_dcap, d_seq_off, d_wb_off, d_ent_off, d_wslot;
+    DevBuf d_read_zmw, d_vcap, d_dcap, d_seq_off, d_wb_off, d_ent_off, d_wslot, d_zperm, d_rperm;
     // state
     DevBuf d_tabME, d_tabINS, d_tabDL, d_draft, d_zmw_i32 /* 6 x n int32 */, d_wbounds, d_ticket;
     DevBuf d_poa, d_align, d_avalid, d_ascore, d_ent;
@@ -115,7 +115,7 @@ int ccsx_destroy(ccsx_handle h)
                       &h->d_vcap, &h->d_dcap, &h->d_seq_off, &h->d_wb_off, &h->d_ent_off, &h->d_wslot, &h->d_tabME, &h->d_tabINS, &h->d_tabDL,
                       &h->d_draft, &h->d_zmw_i32, &h->d_wbounds, &h->d_ticket, &h->d_poa, &h->d_align, &h->d_avalid, &h->d_ascore,
                       &h->d_ent, &h->d_wseq, &h->d_wqv, &h->d_wsum, &h->d_wmeta, &h->d_out_seq, &h->d_out_qual, &h->d_out_raw,
-                      &h->d_out_i32, &h->d_out_f32, &h->d_ipd, &h->d_wtpl, &h->d_wtmeta, &h->d_wkin, &h->d_out_kin};
+                      &h->d_out_i32, &h->d_out_f32, &h->d_zperm, &h->d_rperm, &h->d_ipd, &h->d_wtpl, &h->d_wtmeta, &h->d_wkin, &h->d_out_kin};
     for (auto *b : bufs) b->release();
     for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -173,6 +173,24 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     if (maxL_max > 65535) { ccsx_set_error("ccsx_upload: subreads longer than 65535 bases are not supported"); return -1; }
     h->read_off.assign(b->read_off, b->read_off + n + 1);
     h->base_off.assign(b->base_off, b->base_off + R + 1);
+    // launch order: longest first (stable within 256-base classes, so a uniform batch keeps its input order and its
+    // locality).  Mixed batches (BASELINE configs[4]: 1-25 kb, 3-50 passes) otherwise end on a few long stragglers.
+    std::vector<int32_t> zperm(n), rperm(R > 0 ? R : 1);
+    {
+        auto order_by = [](std::vector<int32_t> &perm, const std::vector<int64_t> &len) {
+            const int NB = 258;
+            std::vector<int32_t> cnt(NB + 1, 0);
+            auto cls = [&](int64_t l) { int c = (int)(l >> 8); return NB - 1 - (c > NB - 1 ? NB - 1 : c); };   // descending length
+            for (int64_t l : len) ++cnt[cls(l) + 1];
+            for (int i = 0; i < NB; ++i) cnt[i + 1] += cnt[i];
+            for (size_t i = 0; i < len.size(); ++i) perm[cnt[cls(len[i])]++] = (int32_t)i;
+        };
+        std::vector<int64_t> zl(n), rl(R);
+        for (int z = 0; z < n; ++z) zl[z] = dcap[z];
+        for (int r = 0; r < R; ++r) rl[r] = b->base_off[r + 1] - b->base_off[r];
+        order_by(zperm, zl);
+        if (R > 0) order_by(rperm, rl);
+    }
     const int64_t total_wslots = (int64_t)h->wb_off[n] - n;
     std::vector<int32_t> wslot(total_wslots > 0 ? total_wslots : 1);
     for (int z = 0; z < n; ++z) std::fill(wslot.begin() + (h->wb_off[z] - z), wslot.begin() + (h->wb_off[z + 1] - (z + 1)), z);
@@ -196,6 +214,8 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     UP(h->d_wb_off, h->wb_off.data(), (size_t)(n + 1) * 4);
     UP(h->d_ent_off, h->ent_off.data(), (size_t)(R + 1) * 8);
     UP(h->d_wslot, wslot.data(), wslot.size() * 4);
+    UP(h->d_zperm, zperm.data(), zperm.size() * 4);
+    UP(h->d_rperm, rperm.data(), rperm.size() * 4);
 #undef UP
     HIPTRY(hipStreamSynchronize(h->stream));   // host staging vectors go out of scope
 
@@ -242,6 +262,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     P.bases = (const uint8_t *)h->d_bases.p; P.pw = (const uint8_t *)h->d_pw.p; P.flags = (const uint8_t *)h->d_flags.p;
     P.read_zmw = (const int32_t *)h->d_read_zmw.p; P.vcap = (const int32_t *)h->d_vcap.p; P.dcap = (const int32_t *)h->d_dcap.p;
     P.seq_off = (const int64_t *)h->d_seq_off.p; P.wb_off = (const int32_t *)h->d_wb_off.p; P.ent_off = (const int64_t *)h->d_ent_off.p; P.wslot_zmw = (const int32_t *)h->d_wslot.p;
+    P.zmw_perm = (const int32_t *)h->d_zperm.p; P.read_perm = (const int32_t *)h->d_rperm.p;
     P.tabME = (float *)h->d_tabME.p; P.tabINS = (float *)h->d_tabINS.p; P.tabDL = (float *)h->d_tabDL.p;
     P.draft = (uint8_t *)h->d_draft.p;
     int32_t *zi = (int32_t *)h->d_zmw_i32.p;

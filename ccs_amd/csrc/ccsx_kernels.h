@@ -54,6 +54,9 @@ struct KParams {
     int32_t *out_status, *out_len, *out_iters, *out_nwin;
     float *out_rq, *out_ec;
     int32_t *out_fn, *out_rn;  // passes used per strand
+    // ---- launch order (cost-sorted, longest first: the one-wave-per-ZMW / per-read kernels finish together)
+    const int32_t *zmw_perm;   // [n_zmw]
+    const int32_t *read_perm;  // [n_reads]
     // ---- HiFi kinetics (NULL unless opts.hifi_kinetics); kept at the end so the hot kernels' kernarg offsets do not move
     const uint8_t *ipd;
     uint8_t *wtpl;             // [wslots][32] converged window template incl. overhangs

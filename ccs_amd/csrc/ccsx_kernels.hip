@@ -255,8 +255,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
     PoaSlot g = poa_slot(P, blockIdx.x);                   // launched in chunks of poa_slots ZMWs: slot = block
-    const int z = z0 + blockIdx.x;
-    if (z >= P.n_zmw) return;
+    if (z0 + (int)blockIdx.x >= P.n_zmw) return;
+    const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);     // longest ZMWs first
     PHASE_T0();
     {
         const int r0 = rfl(P.read_off[z]);
@@ -296,7 +296,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             PHASE(8);
             // ---- DP over the graph in topological order
             const int n0 = n;
-            int Mprev = NEGV, vprev = -2, lo_prev = 0, cm_prev = NEGV, br_prev = 0;
+            int Mprev = NEGV, lo_prev = 0, cm_prev = NEGV, br_prev = 0;
+            int M2 = NEGV, M3 = NEGV, lo2 = 0, lo3 = 0;             // columns k-2, k-3: most branch in-edges end there
             int kend = -1, bs = NEGV;
             const int hiI = I - (CCSX_BAND - 1) > 0 ? I - (CCSX_BAND - 1) : 0;
             const int lane4 = 4 * lane;
@@ -306,20 +307,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 const int vL = kkL < n0 ? order[kkL] : 0;
                 int4 rL = make_int4(0, 0, 0, 0);
                 if (kkL < n0) rL = g.vrec[vL];
+                // topological positions of in-edges 0..2 of the block's columns (ranks are fixed during a DP pass): gathered
+                // once per block, so a branch column needs no dependent rank[] load on its critical path
+                int pLx = -1, pLy = -1, pLz = -1;
+                {
+                    const int npL = (rL.x >> 8) & 255;
+                    if (npL >= 1) pLx = g.rank[rL.y];
+                    if (npL >= 2) pLy = g.rank[rL.z];
+                    if (npL >= 3) pLz = g.rank[rL.w];
+                }
                 const int nblk = (n0 - kb) < LANES ? (n0 - kb) : LANES;
                 int4 myInfo = make_int4(0, NEGV, 0, -1);                   // (lo, colmax, bestrow, pp) of column kb + lane
                 // consume the block loads here, so the compiler waits for them once per block and not at the top of
                 // every column (a vmcnt(0) there would also drain each column's streaming stores)
-                asm volatile("" :: "v"(vL), "v"(rL.x), "v"(rL.y), "v"(rL.z), "v"(rL.w));
+                asm volatile("" :: "v"(vL), "v"(rL.x), "v"(rL.y), "v"(rL.z), "v"(rL.w), "v"(pLx), "v"(pLy), "v"(pLz));
                 int32_t *Mrow = g.M + (size_t)kb * 64 + lane;
                 uint8_t *mvrow = g.mvK + (size_t)kb * 64 + lane;
                 for (int j = 0; j < nblk; ++j, Mrow += 64, mvrow += 64) {
                     const int k = kb + j;
                     const int v = rl(vL, j);
-                    const int meta = rl(rL.x, j), p0 = rl(rL.y, j);
+                    const int meta = rl(rL.x, j), q0 = rl(pLx, j);         // q0: position of in-edge 0
                     const int vb = meta & 255, np = (meta >> 8) & 255;
                     int lo, best = NEGV, bm = 0, pp, i, rbv;
-                    if (np == 1 && p0 == vprev) {                          // chain step: registers only, no branches
+                    if (np == 1 && q0 == k - 1) {                          // chain step: registers only, no branches
                         int t = br_prev + 1 - CCSX_BAND / 2;
                         t = t > lo_prev ? t : lo_prev;
                         t = t < lo_prev + 2 ? t : lo_prev + 2;
@@ -340,24 +350,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         best = vdel ? cdel : best; bm = vdel ? MV_DEL : MV_DIAG;
                         pp = k - 1;
                     } else {                                               // source vertex or several / far in-edges
-                        const int4 rec = make_int4(meta, p0, rl(rL.z, j), rl(rL.w, j));
+                        // in-edge positions: 0..2 from the block prefetch, 3..7 (rare) through predx + rank
+                        const int q1 = rl(pLy, j), q2 = rl(pLz, j);
                         int ulo = 0, ubr = 0;
-                        pp = -1;
+                        pp = np > 0 ? q0 : -1;
                         if (np > 0) {
-                            bool far = false;
-                            for (int q = 0; q < np; ++q) far |= (rfl(poa_pred(g, rec, v, q)) != vprev);
-                            if (far) __threadfence_block();                // far columns come back from HBM/L2
+                            bool far = false;                              // some column comes back from HBM/L2: order our stores first
+                            for (int q = 0; q < np; ++q) {
+                                const int pu = q == 0 ? q0 : (q == 1 ? q1 : (q == 2 ? q2 : rfl(g.rank[g.predx[v * 5 + (q - 3)]])));
+                                far |= (pu < k - 3) || (pu < kb);
+                            }
+                            if (far) __threadfence_block();
                             int bestcm = NEGV - 1;
                             for (int q = 0; q < np; ++q) {                 // pass 1: band placement from the best in-edge column
-                                const int u = rfl(poa_pred(g, rec, v, q));
-                                int l, cm, b, pu;
-                                if (u == vprev) { l = lo_prev; cm = cm_prev; b = br_prev; pu = k - 1; }
-                                else {
-                                    pu = rfl(g.rank[u]);
-                                    if (pu >= kb) { l = rl(myInfo.x, pu - kb); cm = rl(myInfo.y, pu - kb); b = rl(myInfo.z, pu - kb); }
-                                    else { const int4 ki = g.kinfo[pu]; l = rfl(ki.x); cm = rfl(ki.y); b = rfl(ki.z); }
-                                }
-                                if (q == 0) pp = pu;
+                                const int pu = q == 0 ? q0 : (q == 1 ? q1 : (q == 2 ? q2 : rfl(g.rank[g.predx[v * 5 + (q - 3)]])));
+                                int l, cm, b;
+                                if (pu == k - 1) { l = lo_prev; cm = cm_prev; b = br_prev; }
+                                else if (pu >= kb) { l = rl(myInfo.x, pu - kb); cm = rl(myInfo.y, pu - kb); b = rl(myInfo.z, pu - kb); }
+                                else { const int4 ki = g.kinfo[pu]; l = rfl(ki.x); cm = rfl(ki.y); b = rfl(ki.z); }
                                 if (cm > bestcm) { bestcm = cm; ulo = l; ubr = b; }
                             }
                         }
@@ -372,14 +382,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                                 x = (o1 >= 0 && o1 < LANES && o1 <= I) ? o1 * SC_INS : NEGV;
                                 y = (o0 >= 0 && o0 < LANES && o0 <= I) ? o0 * SC_INS : NEGV;
                             } else {
-                                const int u = rfl(poa_pred(g, rec, v, q));
-                                if (u == vprev) {                          // the previous column is still in registers
-                                    const int o1 = i - 1 - lo_prev, o0 = i - lo_prev;
-                                    const int xs = __shfl(Mprev, o1 & 63), ys = __shfl(Mprev, o0 & 63);
+                                const int pu = q == 0 ? q0 : (q == 1 ? q1 : (q == 2 ? q2 : rfl(g.rank[g.predx[v * 5 + (q - 3)]])));
+                                if (pu >= k - 3) {                         // the last three columns are still in registers
+                                    const int plo = pu == k - 1 ? lo_prev : (pu == k - 2 ? lo2 : lo3);
+                                    const int srcM = pu == k - 1 ? Mprev : (pu == k - 2 ? M2 : M3);
+                                    const int o1 = i - 1 - plo, o0 = i - plo;
+                                    const int xs = __shfl(srcM, o1 & 63), ys = __shfl(srcM, o0 & 63);
                                     x = (o1 >= 0 && o1 < LANES) ? xs : NEGV;
                                     y = (o0 >= 0 && o0 < LANES) ? ys : NEGV;
                                 } else {
-                                    const int pu = rfl(g.rank[u]);
                                     const int plo = (pu >= kb) ? rl(myInfo.x, pu - kb) : rfl(g.kinfo[pu].x);
                                     const int o1 = i - 1 - plo, o0 = i - plo;
                                     const int32_t *Mu = g.M + (size_t)pu * 64;
@@ -404,7 +415,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                     if (lane == j) myInfo = make_int4(lo, cm, br, pp);
                     const int oe = I - lo;
                     if ((unsigned)oe < (unsigned)LANES) { const int xe = rl(best, oe); if (xe > NEGV / 2 && xe > bs) { bs = xe; kend = k; } }
-                    Mprev = best; vprev = v; lo_prev = lo; cm_prev = cm; br_prev = br;
+                    M3 = M2; lo3 = lo2; M2 = Mprev; lo2 = lo_prev;
+                    Mprev = best; lo_prev = lo; cm_prev = cm; br_prev = br;
                 }
                 if (kkL < n0) g.kinfo[kkL] = myInfo;
             }
@@ -433,6 +445,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                     __syncthreads();
                     while (k >= kb) {                                  // uniform walk: every lane follows the same (k, i)
                         const int kl = k - kb;
+                        {
+                            // a run of plain DIAG steps along the chain (in-edge 0 is the previous position): lane s tests
+                            // step s of the run, one ballot gives its length, the path entries are stored by the lanes
+                            const int kls = kl - lane;
+                            const int src = kls & 63;
+                            const int lo_s = __shfl(kiL.x, src), pp_s = __shfl(kiL.w, src);
+                            const int off = i - lane - lo_s;
+                            const bool inb = kls >= 0 && i - lane >= 1 && (unsigned)off < 64u;
+                            const int m_s = inb ? sMv[kls * 64 + off] : 255;
+                            const unsigned long long simple = __ballot(m_s == 0 && pp_s == k - lane - 1);
+                            const int R = (simple == ~0ull) ? 64 : __ffsll((long long)~simple) - 1;
+                            if (R > 0) {
+                                const int meta_s = __shfl(metaL, src), v_s = __shfl(vLt, src);
+                                if (lane < R) {
+                                    const int ir = i - lane - 1;
+                                    g.pathv[ir] = ((meta_s & 255) == read_base_packed(sread, ir)) ? v_s : -1;
+                                }
+                                k -= R; i -= R;
+                                continue;
+                            }
+                        }
                         const int lo_k = rl(kiL.x, kl);
                         CHK(i - lo_k >= 0 && i - lo_k < 64 && i >= 0, 101);
                         const int m = rfl(sMv[kl * 64 + (i - lo_k)]);
@@ -636,8 +669,8 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
     int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] then lo_need[need]
-    const int r = rbase + blockIdx.x;                   // launched in chunks of align_slots reads: slot = block
-    if (r >= P.n_reads) return;
+    if (rbase + (int)blockIdx.x >= P.n_reads) return;   // launched in chunks of align_slots reads: slot = block
+    const int r = rfl(P.read_perm[rbase + blockIdx.x]); // longest reads first
     const int z = rfl(P.read_zmw[r]);
     const int r0 = rfl(P.read_off[z]);
     if (lane == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
@@ -817,54 +850,79 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     PHASE_T0();
-    // ---- locate (zmw, window)
+    // ---- locate (zmw, window).  The prologue is a chain of dependent global loads; every level issues all of its
+    // loads before the first use (clamped indices instead of branches), so the chain is 4 round trips deep
+    // (z-level scalars -> window bounds + per-read metadata + tables -> entry rows -> segments), not one per array.
     const int bid = blockIdx.x;
     const int z = P.wslot_zmw[bid];                         // host-built map: no dependent search
-    const int w = bid - (P.wb_off[z] - z);
-    if (w >= P.nwin[z]) return;
-    const int nw = P.nwin[z], Ld = P.draft_len[z];
-    const int32_t *wb = P.wbounds + P.wb_off[z];
-    const uint8_t *draft = P.draft + P.seq_off[z];
-    int ws = wb[w] - CCSX_WIN_OVERHANG; if (ws < 0) ws = 0;
-    int we = wb[w + 1] + CCSX_WIN_OVERHANG; if (we > Ld) we = Ld;
-    const int lf = ws > 0 ? draft[ws - 1] : 4, rf = we < Ld ? draft[we] : 4;
+    const int wbo = P.wb_off[z], nw = P.nwin[z], Ld = P.draft_len[z];
     const int r0 = P.read_off[z], nreads = P.nreads_used[z];
+    const int64_t so = P.seq_off[z];
+    const int w = bid - (wbo - z);
+    if (w >= nw) return;
+    const int32_t *wb = P.wbounds + wbo;
+    const uint8_t *draft = P.draft + so;
+    const int wb0 = wb[w], wb1 = wb[w + 1];
+    const int64_t bo_r0 = P.base_off[r0];
+    const int fl0 = P.flags[r0] & 1;
+    int ws = wb0 - CCSX_WIN_OVERHANG; if (ws < 0) ws = 0;
+    int we = wb1 + CCSX_WIN_OVERHANG; if (we > Ld) we = Ld;
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
-
-    for (int e = tid; e < CCSX_NOBS * 32; e += PW_THREADS) {
-        const int o = e >> 5, k = e & 15;
-        sCTX[e] = make_float2(P.tabME[(size_t)z * 192 + k * CCSX_NOBS + o], (e & 16) ? 0.0f : P.tabINS[(size_t)z * 192 + k * CCSX_NOBS + o]);
-    }
-    if (tid < 16) sDL[tid] = P.tabDL[(size_t)z * 16 + tid];
-    if (tid < we - ws) sT[0][tid] = draft[ws + tid];
-    if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb[w] - ws; sCtl[2] = wb[w + 1] - ws; }
-    // read segments (native orientation).  Metadata of all reads is fetched in parallel, one lane per read
-    // (one dependent chain for the whole window instead of one per read), then the segments are loaded coalesced.
-    if (tid < nreads) {
-        const int rr = r0 + tid;
-        const int64_t bo0 = P.base_off[rr];
-        const int L = (int)(P.base_off[rr + 1] - bo0);
-        const int st = ((P.flags[rr] & 1) != (P.flags[r0] & 1)) ? 1 : 0;
-        int n = -1, na = 0;
-        if (P.avalid[rr]) {
-            const int32_t *ent = P.ent + P.ent_off[rr];
-            const int a = ent[idx_ws], b = ent[idx_we];
-            n = b - a;
-            if (n < 0 || n > CCSX_IMAX) n = -1;
-            na = st ? L - b : a;
+    const int lfv = draft[ws > 0 ? ws - 1 : 0], rfv = draft[we < Ld ? we : Ld - 1];
+    const int lf = ws > 0 ? lfv : 4, rf = we < Ld ? rfv : 4;
+    {
+        // level 2: everything that needs only z / r0 / the window bounds
+        const int e0 = tid, e1 = tid + PW_THREADS < CCSX_NOBS * 32 ? tid + PW_THREADS : tid;
+        const size_t tz = (size_t)z * 192;
+        const int i0 = (e0 & 15) * CCSX_NOBS + (e0 >> 5), i1 = (e1 & 15) * CCSX_NOBS + (e1 >> 5);
+        const float me0 = P.tabME[tz + i0], in0 = P.tabINS[tz + i0], me1 = P.tabME[tz + i1], in1 = P.tabINS[tz + i1];
+        const float dl = P.tabDL[(size_t)z * 16 + (tid & 15)];
+        const int tcl = tid < we - ws ? tid : we - ws - 1;
+        const uint8_t dr = draft[ws + tcl];
+        const int rcl = tid < nreads ? tid : nreads - 1;
+        const int rr = r0 + rcl;
+        const int64_t bo0 = P.base_off[rr], bo1 = P.base_off[rr + 1], eo = P.ent_off[rr];
+        const int flr = P.flags[rr] & 1, av = P.avalid[rr];
+        // level 3: entry rows of the window's two edge columns (in bounds for every read; ignored unless the read mapped)
+        const int a = P.ent[eo + idx_ws], b = P.ent[eo + idx_we];
+        sCTX[e0] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
+        if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[e1] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
+        if (tid < 16) sDL[tid] = dl;
+        if (tid < we - ws) sT[0][tid] = dr;
+        if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb0 - ws; sCtl[2] = wb1 - ws; }
+        if (tid < nreads) {
+            const int L = (int)(bo1 - bo0);
+            const int st = flr != fl0 ? 1 : 0;
+            int n = -1, na = 0;
+            if (av) {
+                n = b - a;
+                if (n < 0 || n > CCSX_IMAX) n = -1;
+                na = st ? L - b : a;
+            }
+            sI[tid] = n; sStrand[tid] = (uint8_t)st;
+            sGoff[tid] = (int)(bo0 - bo_r0) + na;            // segment start relative to the ZMW's first base (sGoff is re-planned later)
         }
-        sI[tid] = n; sStrand[tid] = (uint8_t)st; sGoff[tid] = na;          // sGoff doubles as scratch for the segment start
     }
     __syncthreads();
-    for (int r = wave; r < nreads; r += 4) {
-        const int n = sI[r];
-        uint8_t ov = 0;                                       // rows beyond the segment read as obs 0 (look-ahead loads stay finite)
-        if (lane < n) {
-            const int64_t p = P.base_off[r0 + r] + sGoff[r] + lane;
-            ov = (uint8_t)obs_of(P.bases[p], P.pw[p]);
+    // level 4: the read segments (native orientation), four reads per wave in flight
+    for (int rb = 0; rb < nreads; rb += 16) {
+        uint8_t bq[4], pq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = rb + 4 * q + wave;
+            const int n = r < nreads ? sI[r] : -1;
+            const int64_t p = bo_r0 + ((lane < n) ? sGoff[r] + lane : 0);
+            bq[q] = P.bases[p]; pq[q] = P.pw[p];
         }
-        sObs[r][lane] = ov;
-        if (lane < 4) sObs[r][64 + lane] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = rb + 4 * q + wave;
+            if (r < nreads) {
+                const int n = sI[r];
+                sObs[r][lane] = (lane < n) ? (uint8_t)obs_of(bq[q], pq[q]) : (uint8_t)0;   // rows beyond the segment read as obs 0
+                if (lane < 4) sObs[r][64 + lane] = 0;
+            }
+        }
     }
     const int half = lane >> 5, hrow = lane & 31;          // fill: which read of the pair, row within it
     PHASE(0);
