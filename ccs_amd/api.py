@@ -83,7 +83,7 @@ EXPORTS = [
     "ccsx_abi_version", "ccsx_last_error", "ccsx_device_count", "ccsx_model_default", "ccsx_opts_default",
     "ccsx_create", "ccsx_destroy", "ccsx_result_layout", "ccsx_consensus_batch", "ccsx_upload", "ccsx_run",
     "ccsx_sync", "ccsx_download", "ccsx_get_timings", "ccsx_stage_draft", "ccsx_stage_align",
-    "ccsx_stage_windows", "ccsx_synth_generate", "ccsx_synth_free",
+    "ccsx_stage_windows", "ccsx_synth_generate", "ccsx_synth_free", "ccsx_alloc_pinned", "ccsx_free_pinned",
 ]
 
 _lib = None
@@ -113,6 +113,9 @@ def lib() -> C.CDLL:
         L.ccsx_synth_generate.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_uint64, C.POINTER(C.POINTER(CSynth))]
         L.ccsx_synth_free.argtypes = [C.POINTER(CSynth)]
+        L.ccsx_alloc_pinned.restype = C.c_void_p
+        L.ccsx_alloc_pinned.argtypes = [C.c_size_t]
+        L.ccsx_free_pinned.argtypes = [C.c_void_p]
         L.ccsx_model_default.argtypes = [C.POINTER(Model)]
         L.ccsx_opts_default.argtypes = [C.POINTER(Opts)]
         _lib = L

@@ -7,6 +7,10 @@
 // (docs/faq/bam-output.md:9-30, docs/faq/missing-adapters.md:11-12).  htslib/pbbam are not in the image;
 // zlib is.
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -71,24 +75,6 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------- BGZF
-inline std::vector<uint8_t> inflate_block(const std::vector<uint8_t> &blk)
-{
-    // blk = one whole gzip member; payload starts after the 12-byte header + XLEN extra, ends 8 bytes before the end
-    const size_t xlen = blk[10] | (blk[11] << 8);
-    const size_t off = 12 + xlen;
-    const uint32_t isize = blk[blk.size() - 4] | (blk[blk.size() - 3] << 8) | (blk[blk.size() - 2] << 16) | ((uint32_t)blk[blk.size() - 1] << 24);
-    std::vector<uint8_t> out(isize);
-    if (isize == 0) return out;
-    z_stream zs; std::memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
-    zs.next_in = const_cast<Bytef *>(blk.data() + off); zs.avail_in = (uInt)(blk.size() - off - 8);
-    zs.next_out = out.data(); zs.avail_out = isize;
-    const int rc = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
-    if (rc != Z_STREAM_END) throw std::runtime_error("BGZF block does not inflate");
-    return out;
-}
-
 inline std::vector<uint8_t> deflate_block(const uint8_t *data, size_t n, int level)
 {
     std::vector<uint8_t> out(18 + compressBound((uLong)n) + 8);
@@ -113,67 +99,116 @@ inline std::vector<uint8_t> deflate_block(const uint8_t *data, size_t n, int lev
     return out;
 }
 
-class BgzfReader {   // sequential compressed read, pooled inflate, in-order byte stream
+// Sequential BGZF input.  The file is memory-mapped; the reader thread only hops from block header to block header and hands
+// runs of ~1 MB of compressed blocks ("slabs") to the pool, each of which inflates into ONE contiguous buffer.  Consumers
+// either copy bytes out (read) or walk the inflated slab in place (take_slab / the record framer below), so the byte stream is
+// never copied by the reader thread.
+class BgzfReader {
 public:
-    BgzfReader(const std::string &path, ThreadPool &pool, int lookahead = 64) : pool_(pool), lookahead_(lookahead)
+    typedef std::shared_ptr<std::vector<uint8_t>> Slab;
+    BgzfReader(const std::string &path, ThreadPool &pool, int depth = 0) : pool_(pool), depth_(depth > 0 ? depth : 2 * pool.size() + 4)
     {
-        f_ = std::fopen(path.c_str(), "rb");
-        if (!f_) throw std::runtime_error("cannot open " + path);
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (fstat(fd_, &st) != 0) throw std::runtime_error("cannot stat " + path);
+        size_ = (size_t)st.st_size;
+        if (size_ > 0) {
+            void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+            if (m == MAP_FAILED) throw std::runtime_error("cannot mmap " + path + " (regular files only)");
+            map_ = (const uint8_t *)m;
+            (void)madvise(m, size_, MADV_SEQUENTIAL);
+        }
     }
-    ~BgzfReader() { if (f_) std::fclose(f_); }
+    ~BgzfReader()
+    {
+        for (auto &f : pending_) { try { f.get(); } catch (...) {} }       // tasks reference the mapping
+        if (map_) munmap((void *)map_, size_);
+        if (fd_ >= 0) ::close(fd_);
+    }
     // read exactly n bytes; returns false on clean EOF at a record boundary (n bytes not available)
     bool read(void *dst, size_t n)
     {
         uint8_t *d = (uint8_t *)dst;
         while (n > 0) {
-            if (pos_ == cur_.size()) { if (!next_block()) return false; continue; }
-            const size_t k = std::min(n, cur_.size() - pos_);
-            std::memcpy(d, cur_.data() + pos_, k);
+            if (!cur_ || pos_ == cur_->size()) { if (!next_slab()) return false; continue; }
+            const size_t k = std::min(n, cur_->size() - pos_);
+            std::memcpy(d, cur_->data() + pos_, k);
             d += k; pos_ += k; n -= k;
         }
         return true;
     }
+    // the inflated slab the stream is currently in (fetches the next one when the current is used up); null at EOF
+    Slab current() { while (!cur_ || pos_ == cur_->size()) if (!next_slab()) return Slab(); return cur_; }
+    size_t pos() const { return pos_; }
+    void advance(size_t n) { pos_ += n; }
 
 private:
-    bool next_block()
+    struct Blk { size_t off, size; };
+    void schedule()
     {
-        while (!eof_ && (int)pending_.size() < lookahead_) {
-            uint8_t h[18];
-            const size_t got = std::fread(h, 1, 18, f_);
-            if (got == 0) { eof_ = true; break; }
-            if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) throw std::runtime_error("not a BGZF file");
-            // find the BC subfield
-            const size_t xlen = h[10] | (h[11] << 8);
-            std::vector<uint8_t> blk(18);
-            std::memcpy(blk.data(), h, 18);
-            size_t bsize = 0;
-            if (h[12] == 'B' && h[13] == 'C') bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
-            else {   // BC is not the first extra subfield: read the whole extra area
-                blk.resize(12 + xlen);
-                if (std::fread(blk.data() + 18, 1, 12 + xlen - 18, f_) != 12 + xlen - 18) throw std::runtime_error("truncated BGZF header");
-                for (size_t p = 12; p + 4 <= 12 + xlen;) {
-                    const size_t sl = blk[p + 2] | (blk[p + 3] << 8);
-                    if (blk[p] == 'B' && blk[p + 1] == 'C') bsize = (size_t)(blk[p + 4] | (blk[p + 5] << 8)) + 1;
+        while (foff_ < size_ && (int)pending_.size() < depth_) {
+            std::vector<Blk> blks;
+            size_t comp = 0, raw = 0;
+            while (foff_ < size_ && comp < (1u << 20)) {
+                if (size_ - foff_ < 18) throw std::runtime_error("truncated BGZF header");
+                const uint8_t *h = map_ + foff_;
+                if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) throw std::runtime_error("not a BGZF file");
+                const size_t xlen = h[10] | (h[11] << 8);
+                if (size_ - foff_ < 12 + xlen) throw std::runtime_error("truncated BGZF header");
+                size_t bsize = 0;
+                for (size_t p = 12; p + 4 <= 12 + xlen;) {                  // find the BC subfield
+                    const size_t sl = h[p + 2] | (h[p + 3] << 8);
+                    if (h[p] == 'B' && h[p + 1] == 'C' && p + 6 <= 12 + xlen) bsize = (size_t)(h[p + 4] | (h[p + 5] << 8)) + 1;
                     p += 4 + sl;
                 }
                 if (!bsize) throw std::runtime_error("BGZF block without BC field");
+                if (size_ - foff_ < bsize || bsize < 12 + xlen + 8) throw std::runtime_error("truncated BGZF block");
+                const uint8_t *t = h + bsize - 4;
+                raw += (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+                blks.push_back({foff_, bsize});
+                foff_ += bsize; comp += bsize;
             }
-            const size_t have = blk.size();
-            blk.resize(bsize);
-            if (std::fread(blk.data() + have, 1, bsize - have, f_) != bsize - have) throw std::runtime_error("truncated BGZF block");
-            auto sp = std::make_shared<std::vector<uint8_t>>(std::move(blk));
-            pending_.push_back(pool_.submit([sp] { return inflate_block(*sp); }));
+            const uint8_t *map = map_;
+            pending_.push_back(pool_.submit([map, blks, raw]() -> Slab {
+                Slab out = std::make_shared<std::vector<uint8_t>>(raw);
+                size_t at = 0;
+                z_stream zs; std::memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+                for (const Blk &b : blks) {
+                    const uint8_t *h = map + b.off;
+                    const size_t xlen = h[10] | (h[11] << 8), off = 12 + xlen;
+                    const uint8_t *t = h + b.size - 4;
+                    const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+                    if (isize == 0) continue;
+                    if (at + isize > out->size()) { inflateEnd(&zs); throw std::runtime_error("BGZF block sizes are inconsistent"); }
+                    if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); throw std::runtime_error("inflateReset failed"); }
+                    zs.next_in = const_cast<Bytef *>(h + off); zs.avail_in = (uInt)(b.size - off - 8);
+                    zs.next_out = out->data() + at; zs.avail_out = (uInt)isize;
+                    const int rc = inflate(&zs, Z_FINISH);
+                    if (rc != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); throw std::runtime_error("BGZF block does not inflate"); }
+                    at += isize;
+                }
+                inflateEnd(&zs);
+                return out;
+            }));
         }
+    }
+    bool next_slab()
+    {
+        schedule();
         if (pending_.empty()) return false;
         cur_ = pending_.front().get(); pending_.pop_front(); pos_ = 0;
+        schedule();
         return true;
     }
     ThreadPool &pool_;
-    int lookahead_;
-    FILE *f_ = nullptr;
-    bool eof_ = false;
-    std::deque<std::future<std::vector<uint8_t>>> pending_;
-    std::vector<uint8_t> cur_;
+    int depth_;
+    int fd_ = -1;
+    const uint8_t *map_ = nullptr;
+    size_t size_ = 0, foff_ = 0;
+    std::deque<std::future<Slab>> pending_;
+    Slab cur_;
     size_t pos_ = 0;
 };
 
@@ -337,23 +372,40 @@ inline void parse_subread(const uint8_t *p, uint32_t bs, Subread &r)
     }
 }
 
-// a run of raw records (framed by the reader thread, decoded on the pool)
+// a run of raw records: framed by the reader thread (pointer hops inside one inflated slab, no copy), decoded on the pool.
+// Only a record that straddles two slabs is copied (into `carry`).
 struct RawChunk {
-    std::vector<uint8_t> data;
-    std::vector<std::pair<uint32_t, uint32_t>> recs;   // (offset, size) of every record body
+    BgzfReader::Slab slab;                                    // keeps the referenced bytes alive
+    std::deque<std::vector<uint8_t>> carry;
+    std::vector<std::pair<const uint8_t *, uint32_t>> recs;   // (body, size) of every record
 };
 
-inline bool read_raw_chunk(BgzfReader &in, RawChunk &c, size_t target_bytes)
+inline bool read_raw_chunk(BgzfReader &in, RawChunk &c)
 {
-    c.data.clear(); c.recs.clear();
-    uint8_t b4[4];
-    while (c.data.size() < target_bytes) {
-        if (!in.read(b4, 4)) break;
+    c.slab.reset(); c.carry.clear(); c.recs.clear();
+    c.slab = in.current();
+    if (!c.slab) return false;
+    const BgzfReader::Slab slab = c.slab;
+    for (;;) {
+        const size_t pos = in.pos(), left = slab->size() - pos;
+        if (left >= 4) {
+            const uint32_t bs = rd32(slab->data() + pos);
+            if (left >= 4 + (size_t)bs) {                      // whole record inside this slab
+                c.recs.emplace_back(slab->data() + pos + 4, bs);
+                in.advance(4 + (size_t)bs);
+                if (in.pos() == slab->size()) break;
+                continue;
+            }
+        }
+        if (left == 0) break;
+        // the record continues in the next slab(s): copy it out, then end the chunk (the stream has moved on)
+        uint8_t b4[4];
+        if (!in.read(b4, 4)) throw std::runtime_error("truncated BAM record");
         const uint32_t bs = rd32(b4);
-        const size_t off = c.data.size();
-        c.data.resize(off + bs);
-        if (!in.read(c.data.data() + off, bs)) throw std::runtime_error("truncated BAM record");
-        c.recs.emplace_back((uint32_t)off, bs);
+        c.carry.emplace_back(bs);
+        if (bs && !in.read(c.carry.back().data(), bs)) throw std::runtime_error("truncated BAM record");
+        c.recs.emplace_back(c.carry.back().data(), bs);
+        break;
     }
     return !c.recs.empty();
 }
@@ -361,7 +413,7 @@ inline bool read_raw_chunk(BgzfReader &in, RawChunk &c, size_t target_bytes)
 inline std::vector<Subread> decode_chunk(const RawChunk &c)
 {
     std::vector<Subread> out(c.recs.size());
-    for (size_t i = 0; i < c.recs.size(); ++i) parse_subread(c.data.data() + c.recs[i].first, c.recs[i].second, out[i]);
+    for (size_t i = 0; i < c.recs.size(); ++i) parse_subread(c.recs[i].first, c.recs[i].second, out[i]);
     return out;
 }
 

@@ -9,7 +9,11 @@
 //                   (docs/faq/bam-output.md:9-30), BGZF deflate on the pool, ccs_report.txt
 //                   (docs/faq/reports-aux-files.md:16-72)
 // There is no CPU consensus fallback: without a gfx950 device the program exits with an error.
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cstring>
 #include <chrono>
 #include <cinttypes>
 #include <cmath>
@@ -70,7 +74,9 @@ struct Batch {
     std::vector<int32_t> zmw_id, read_off;
     std::vector<float> snr;
     std::vector<int64_t> base_off;
-    std::vector<uint8_t> bases, pw, ipd, flags;
+    std::vector<uint8_t> flags;
+    const uint8_t *bases = nullptr, *pw = nullptr, *ipd = nullptr;   // in the packing worker's pinned arena, valid during its engine call
+    int64_t n_bases = 0;
     std::vector<int> slot;        // per zmws[]: index into the SoA or -1
     // results
     std::vector<int64_t> seq_off;
@@ -113,7 +119,7 @@ void usage()
     std::fprintf(stderr,
                  "ccs (MI355X) - generate HiFi reads from PacBio subreads\n"
                  "usage: ccs [options] IN.subreads.bam OUT.{bam,fastq.gz}\n"
-                 "  -j, --num-threads N       host threads for BAM (de)compression [all]\n"
+                 "  -j, --num-threads N       host threads for BAM (de)compression [all usable: affinity / cgroup quota]\n"
                  "      --min-passes N        minimum full-length passes [3]\n"
                  "      --top-passes N        use at most N passes, 0 = all [60]\n"
                  "      --min-snr F           minimum SNR of a ZMW [2.5]\n"
@@ -180,6 +186,33 @@ bool parse(int argc, char **argv, Options &o)
     }
     if (o.batch < 1) o.batch = 1;
     return true;
+}
+
+// host threads the process may actually use: affinity mask and cgroup CPU quota (a container can expose 256 logical CPUs
+// with a 16-CPU quota; over-subscribing the quota makes the BGZF pool slower, not faster)
+int effective_cores()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && c < n) n = c; }
+    auto quota = [](const char *path, bool v2) -> double {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return 0.0;
+        char a[64] = {0}; long long per = 100000, q = -1;
+        double r = 0.0;
+        if (v2) { if (std::fscanf(f, "%63s %lld", a, &per) >= 1 && std::strcmp(a, "max") != 0) r = std::atof(a) / (double)(per > 0 ? per : 100000); }
+        else if (std::fscanf(f, "%lld", &q) == 1 && q > 0) {
+            FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            if (g) { if (std::fscanf(g, "%lld", &per) != 1) per = 100000; std::fclose(g); }
+            r = (double)q / (double)(per > 0 ? per : 100000);
+        }
+        std::fclose(f);
+        return r;
+    };
+    double q = quota("/sys/fs/cgroup/cpu.max", true);
+    if (q <= 0.0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+    if (q > 0.0) { const int c = (int)std::ceil(q); if (c < n) n = c; }
+    return n < 1 ? 1 : n;
 }
 
 std::string movie_of(const std::string &qname) { const size_t p = qname.find('/'); return p == std::string::npos ? qname : qname.substr(0, p); }
@@ -259,10 +292,32 @@ void finish_zmw(ZmwIn &z, const Options &o)
     if ((int)z.reads.size() < o.o.min_passes) { z.host_status = HS_TOO_FEW; z.reads.clear(); return; }
 }
 
-void pack(Batch &b)
+// page-locked staging of one GPU worker (bases / pw / ipd of the batch in flight), grown geometrically and reused
+struct Arena {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    uint8_t *reserve(size_t bytes)
+    {
+        if (bytes > cap) {
+            ccsx_free_pinned(p);
+            cap = bytes + bytes / 4 + (1u << 20);
+            p = (uint8_t *)ccsx_alloc_pinned(cap);
+            if (!p) { cap = 0; throw std::runtime_error(std::string("pinned staging: ") + ccsx_last_error()); }
+        }
+        return p;
+    }
+    ~Arena() { ccsx_free_pinned(p); }
+};
+
+void pack(Batch &b, Arena &arena)
 {
     b.read_off.assign(1, 0); b.base_off.assign(1, 0);
     b.slot.assign(b.zmws.size(), -1);
+    int64_t total = 0;
+    for (const ZmwIn &z : b.zmws) if (z.host_status == HS_OK) for (const Subread &r : z.reads) total += (int64_t)r.bases.size();
+    uint8_t *base = arena.reserve((size_t)3 * (size_t)total);
+    uint8_t *bases = base, *pw = base + total, *ipd = base + 2 * total;
+    int64_t at = 0;
     for (size_t i = 0; i < b.zmws.size(); ++i) {
         ZmwIn &z = b.zmws[i];
         if (z.host_status != HS_OK) continue;
@@ -271,15 +326,16 @@ void pack(Batch &b)
         b.snr.insert(b.snr.end(), z.snr, z.snr + 4);
         for (size_t k = 0; k < z.reads.size(); ++k) {
             Subread &r = z.reads[k];
-            b.bases.insert(b.bases.end(), r.bases.begin(), r.bases.end());
-            b.pw.insert(b.pw.end(), r.pw.begin(), r.pw.end());
-            b.ipd.insert(b.ipd.end(), r.ipd.begin(), r.ipd.end());
+            const size_t L = r.bases.size();
+            std::memcpy(bases + at, r.bases.data(), L); std::memcpy(pw + at, r.pw.data(), L); std::memcpy(ipd + at, r.ipd.data(), L);
+            at += (int64_t)L;
             b.flags.push_back(r.strand);
-            b.base_off.push_back((int64_t)b.bases.size());
+            b.base_off.push_back(at);
             std::vector<uint8_t>().swap(r.bases); std::vector<uint8_t>().swap(r.pw); std::vector<uint8_t>().swap(r.ipd);
         }
         b.read_off.push_back((int32_t)b.flags.size());
     }
+    b.bases = bases; b.pw = pw; b.ipd = ipd; b.n_bases = total;
 }
 
 struct Report {
@@ -363,7 +419,7 @@ int main(int argc, char **argv)
 {
     Options opt;
     if (!parse(argc, argv, opt)) { usage(); return 2; }
-    int nthreads = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();
+    int nthreads = opt.threads > 0 ? opt.threads : effective_cores();
     if (nthreads < 1) nthreads = 1;
     try {
         ThreadPool pool(nthreads);
@@ -391,14 +447,19 @@ int main(int argc, char **argv)
         const auto t_start = std::chrono::steady_clock::now();
 
         // ---- reader
+        long long rd_us[3] = {0, 0, 0};                  // framing (BGZF inflate wait), waiting for record decode, grouping + filters + queue
         std::thread reader([&] {
             ZmwIn cur; bool have = false;
             int64_t nz = 0, nb = 0;
             auto batch = std::make_shared<Batch>();
             auto emit_zmw = [&](ZmwIn &zin) {
                 finish_zmw(zin, opt);
-                if (opt.dump) std::printf("%d%s\t%d\t%zu\t%.2f,%.2f,%.2f,%.2f\n", zin.zm, zin.strand_tag == 1 ? "/fwd" : (zin.strand_tag == 2 ? "/rev" : ""), zin.host_status,
-                                          zin.reads.size(), zin.snr[0], zin.snr[1], zin.snr[2], zin.snr[3]);
+                if (opt.dump) {
+                    unsigned long long hsh = 1469598103934665603ull;       // FNV-1a over bases, pw, ip of the kept passes (reader self-check)
+                    for (const Subread &r : zin.reads) for (const std::vector<uint8_t> *v : {&r.bases, &r.pw, &r.ipd}) for (uint8_t x : *v) { hsh ^= x; hsh *= 1099511628211ull; }
+                    std::printf("%d%s\t%d\t%zu\t%.2f,%.2f,%.2f,%.2f\t%016llx\n", zin.zm, zin.strand_tag == 1 ? "/fwd" : (zin.strand_tag == 2 ? "/rev" : ""), zin.host_status,
+                                zin.reads.size(), zin.snr[0], zin.snr[1], zin.snr[2], zin.snr[3], hsh);
+                }
                 else {
                     batch->zmws.push_back(std::move(zin));
                     if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_gpu.push(batch); batch = std::make_shared<Batch>(); }
@@ -437,9 +498,18 @@ int main(int argc, char **argv)
             };
             for (;;) {
                 auto raw = std::make_shared<RawChunk>();
-                const bool more = read_raw_chunk(in, *raw, 4u << 20);
+                auto t0 = std::chrono::steady_clock::now();
+                const bool more = read_raw_chunk(in, *raw);
+                rd_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
                 if (more) pending.push_back(pool.submit([raw] { return decode_chunk(*raw); }));
-                while (!pending.empty() && (!more || pending.size() > (size_t)(2 * pool.size() + 4))) { consume(pending.front().get()); pending.pop_front(); }
+                while (!pending.empty() && (!more || pending.size() > (size_t)(2 * pool.size() + 4))) {
+                    t0 = std::chrono::steady_clock::now();
+                    auto recs = pending.front().get();
+                    auto t1 = std::chrono::steady_clock::now();
+                    consume(std::move(recs)); pending.pop_front();
+                    rd_us[1] += std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+                    rd_us[2] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
+                }
                 if (!more) break;
             }
             flush_zmw();
@@ -451,14 +521,23 @@ int main(int argc, char **argv)
         // ---- GPU workers
         std::vector<std::thread> workers;
         std::atomic<int> failed{0};
+        std::atomic<long long> us_pack{0}, us_engine{0}, us_wait{0};       // summed over workers (--log-level INFO)
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto us_since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
         for (ccsx_handle h : handles) workers.emplace_back([&, h] {
             std::shared_ptr<Batch> b;
-            while (to_gpu.pop(b)) {
-                pack(*b);                                       // SoA packing off the reader thread
+            Arena arena;
+            for (;;) {
+                auto t0 = now();
+                if (!to_gpu.pop(b)) break;
+                us_wait += us_since(t0); t0 = now();
+                try { pack(*b, arena); }                        // SoA packing off the reader thread, straight into pinned memory
+                catch (const std::exception &e) { std::fprintf(stderr, "ccs: %s\n", e.what()); failed = 1; b->zmw_id.clear(); }
+                us_pack += us_since(t0); t0 = now();
                 const int n = (int)b->zmw_id.size();
                 if (n > 0) {
-                    ccsx_batch cb{n, (int32_t)b->flags.size(), (int64_t)b->bases.size(), b->zmw_id.data(), b->snr.data(), b->read_off.data(),
-                                  b->base_off.data(), b->bases.data(), b->pw.data(), b->ipd.data(), b->flags.data()};
+                    ccsx_batch cb{n, (int32_t)b->flags.size(), b->n_bases, b->zmw_id.data(), b->snr.data(), b->read_off.data(),
+                                  b->base_off.data(), b->bases, b->pw, b->ipd, b->flags.data()};
                     b->seq_off.resize(n + 1);
                     const int64_t cap = ccsx_result_layout(&cb, b->seq_off.data());
                     b->status.resize(n); b->seq_len.resize(n); b->np.resize(n); b->iters.resize(n); b->n_windows.resize(n);
@@ -471,8 +550,9 @@ int main(int argc, char **argv)
                         r.fn = b->fn.data(); r.rn = b->rn.data();
                     }
                     if (ccsx_consensus_batch(h, &cb, &r)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); failed = 1; }
-                    std::vector<uint8_t>().swap(b->bases); std::vector<uint8_t>().swap(b->pw); std::vector<uint8_t>().swap(b->ipd);
+                    b->bases = b->pw = b->ipd = nullptr;        // the arena is reused for the next batch
                 }
+                us_engine += us_since(t0);
                 to_writer.push(b);
             }
         });
@@ -590,6 +670,12 @@ int main(int argc, char **argv)
         for (ccsx_handle h : handles) ccsx_destroy(h);
         if (!opt.suppress_reports) write_report(opt, rep);
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        if (opt.log_level >= 2)
+            std::fprintf(stderr, "ccs: reader thread: framing/inflate %.2f s, waiting for record decode %.2f s, grouping+filters+queue %.2f s\n",
+                         rd_us[0] * 1e-6, rd_us[1] * 1e-6, rd_us[2] * 1e-6);
+        if (opt.log_level >= 2)
+            std::fprintf(stderr, "ccs: GPU workers (sum over %zu): waiting for input %.2f s, packing %.2f s, upload+kernels+download %.2f s\n", handles.size(),
+                         us_wait.load() * 1e-6, us_pack.load() * 1e-6, us_engine.load() * 1e-6);
         if (opt.log_level >= 1)
             std::fprintf(stderr, "ccs: %" PRId64 " ZMWs in, %" PRId64 " HiFi reads out, %.2f s (%.1f ZMWs/s, %d host threads, %zu GPU worker%s)\n", rep.input, rep.pass, el,
                          rep.input / el, nthreads, handles.size(), handles.size() == 1 ? "" : "s");

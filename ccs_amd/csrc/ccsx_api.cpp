@@ -78,6 +78,19 @@ int ccsx_device_count(void)
     return n;
 }
 
+void *ccsx_alloc_pinned(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { ccsx_set_error(std::string("hipHostMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+void ccsx_free_pinned(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int ccsx_create(int device_ordinal, const ccsx_model *model, const ccsx_opts *opts, ccsx_handle *out)
 {
     if (!model || !opts || !out) { ccsx_set_error("ccsx_create: null argument"); return -1; }

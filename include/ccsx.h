@@ -144,6 +144,11 @@ void        ccsx_opts_default(ccsx_opts *o);
 int         ccsx_create(int device_ordinal, const ccsx_model *model, const ccsx_opts *opts, ccsx_handle *out);
 int         ccsx_destroy(ccsx_handle h);
 
+/* page-locked host memory for batch arrays (optional: any host memory works; pinned buffers upload by DMA at PCIe
+ * rate instead of through the runtime's staging copy).  NULL on failure (ccsx_last_error). */
+void       *ccsx_alloc_pinned(size_t bytes);
+void        ccsx_free_pinned(void *p);
+
 /* result sizing: fills res->seq_off[0..n] and returns the total capacity needed (elements) */
 int64_t     ccsx_result_layout(const ccsx_batch *b, int64_t *seq_off);
 

@@ -180,3 +180,29 @@ def test_cli_hifi_kinetics(built, tmp_path):
         t = r["tags"]
         assert len(t["ip"]) == len(t["pw"]) == len(r["seq"]) and "fi" not in t and "ri" not in t
         assert (np.asarray(t["ip"]) > 0).mean() > 0.99
+
+
+def test_reader_multi_slab_content(built, tmp_path):
+    """The BGZF reader inflates ~1 MB slabs on the pool and frames records in place; records that straddle two slabs take
+    the copy path.  A file of many slabs must decode to exactly the generator's bytes (FNV-1a per ZMW via --dump-zmws)."""
+    bam = tmp_path / "big.subreads.bam"
+    _run("--write-synthetic", "120,6,4000,13", bam)
+    assert os.path.getsize(bam) > 3 * (1 << 20)                    # several slabs
+    b = api.synth(120, 6, 4000, seed=13, first_zmw_id=1000)
+
+    def fnv(z):
+        h = 1469598103934665603
+        for r in range(int(b.read_off[z]), int(b.read_off[z + 1])):
+            a, e = int(b.base_off[r]), int(b.base_off[r + 1])
+            for arr in (b.bases, b.pw, b.ipd):
+                for x in arr[a:e].tolist():
+                    h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return f"{h:016x}"
+
+    for threads in (1, 5):
+        lines = _run("--dump-zmws", "-j", threads, bam).stdout.strip().split("\n")
+        assert len(lines) == 120
+        for z in (0, 1, 17, 59, 118, 119):
+            f = lines[z].split("\t")
+            assert f[0] == str(1000 + z) and f[1] == "0" and f[2] == "6" and f[4] == fnv(z)
+        assert len({l.split("\t")[4] for l in lines}) == 120
