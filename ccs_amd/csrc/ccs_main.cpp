@@ -446,9 +446,16 @@ int main(int argc, char **argv)
         std::string movie;
         const auto t_start = std::chrono::steady_clock::now();
 
+        // an exception on any pipeline thread ends the run with a message and exit code 1 (the other threads are drained, not killed)
+        std::atomic<int> failed{0};
+        std::mutex err_m;
+        std::string err_msg;
+        auto fail = [&](const std::string &m) { std::lock_guard<std::mutex> l(err_m); if (!failed.exchange(1)) err_msg = m; };
+
         // ---- reader
         long long rd_us[3] = {0, 0, 0};                  // framing (BGZF inflate wait), waiting for record decode, grouping + filters + queue
         std::thread reader([&] {
+            try {
             ZmwIn cur; bool have = false;
             int64_t nz = 0, nb = 0;
             auto batch = std::make_shared<Batch>();
@@ -514,13 +521,17 @@ int main(int argc, char **argv)
             }
             flush_zmw();
             if (!opt.dump && !batch->zmws.empty()) { batch->index = nb++; to_gpu.push(batch); }
+            } catch (const std::exception &e) { fail(std::string("reading ") + opt.in + ": " + e.what()); }
             to_gpu.close();
         });
-        if (opt.dump) { reader.join(); return 0; }
+        if (opt.dump) {
+            reader.join();
+            if (failed) std::fprintf(stderr, "ccs: %s\n", err_msg.c_str());
+            return failed ? 1 : 0;
+        }
 
         // ---- GPU workers
         std::vector<std::thread> workers;
-        std::atomic<int> failed{0};
         std::atomic<long long> us_pack{0}, us_engine{0}, us_wait{0};       // summed over workers (--log-level INFO)
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto us_since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
@@ -561,6 +572,7 @@ int main(int argc, char **argv)
         Report rep;
         const bool fastq = opt.out.size() > 9 && opt.out.compare(opt.out.size() - 9, 9, ".fastq.gz") == 0;   // OUT.fastq.gz (docs/index.md:55-58)
         std::thread writer([&] {
+            try {
             std::unique_ptr<BgzfWriter> outp;
             gzFile gzq = nullptr;
             if (fastq) { gzq = gzopen(opt.out.c_str(), "wb4"); if (!gzq) throw std::runtime_error("cannot create " + opt.out); }
@@ -661,6 +673,11 @@ int main(int argc, char **argv)
                 outp->close();
             }
             if (gzm) { metrics += "\n  ]\n}\n"; flush_metrics(true); gzclose(gzm); }
+            } catch (const std::exception &e) {
+                fail(std::string("writing ") + opt.out + ": " + e.what());
+                std::shared_ptr<Batch> drop;
+                while (to_writer.pop(drop)) {}                   // keep the workers from blocking on a full queue
+            }
         });
 
         reader.join();
@@ -679,6 +696,7 @@ int main(int argc, char **argv)
         if (opt.log_level >= 1)
             std::fprintf(stderr, "ccs: %" PRId64 " ZMWs in, %" PRId64 " HiFi reads out, %.2f s (%.1f ZMWs/s, %d host threads, %zu GPU worker%s)\n", rep.input, rep.pass, el,
                          rep.input / el, nthreads, handles.size(), handles.size() == 1 ? "" : "s");
+        if (failed && !err_msg.empty()) std::fprintf(stderr, "ccs: %s\n", err_msg.c_str());
         return failed ? 1 : 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "ccs: %s\n", e.what());

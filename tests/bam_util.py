@@ -43,3 +43,50 @@ def read_bam(path):
                 tags[tag], = struct.unpack_from(fmt, r, q); q += struct.calcsize(fmt)
         recs.append(dict(name=name, flag=flag, seq=seq, qual=qual, tags=tags))
     return text, recs
+
+
+# ---- tiny writer (adversarial inputs for the C++ reader) ------------------------------------------------------------
+def _bgzf_block(payload: bytes, extra_first: bytes = b"") -> bytes:
+    import zlib
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(payload) + co.flush()
+    extra = extra_first + b"BC" + struct.pack("<H", 2) + b"\0\0"
+    total = 12 + len(extra) + len(comp) + 8
+    extra = extra_first + b"BC" + struct.pack("<H", 2) + struct.pack("<H", total - 1)
+    hdr = b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", len(extra))
+    return hdr + extra + comp + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload))
+
+
+BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def record(name: str, seq: str, tags: list, raw_tail: bytes = b"") -> bytes:
+    """tags: list of (tag, type, value); type in 'i','f','Z','BC','BS','Bf'; raw_tail: bytes appended after the tags."""
+    nib = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15}
+    n = len(seq)
+    packed = bytearray((n + 1) // 2)
+    for i, ch in enumerate(seq):
+        packed[i >> 1] |= nib[ch] << (0 if (i & 1) else 4)
+    body = struct.pack("<iiBBHHHiiii", -1, -1, len(name) + 1, 255, 4680, 0, 4, n, -1, -1, 0) + name.encode() + b"\0" + bytes(packed) + b"\xff" * n
+    for tag, ty, v in tags:
+        body += tag.encode()
+        if ty == "i": body += b"i" + struct.pack("<i", v)
+        elif ty == "f": body += b"f" + struct.pack("<f", v)
+        elif ty == "Z": body += b"Z" + v.encode() + b"\0"
+        elif ty == "BC": body += b"BC" + struct.pack("<i", len(v)) + np.asarray(v, np.uint8).tobytes()
+        elif ty == "BS": body += b"BS" + struct.pack("<i", len(v)) + np.asarray(v, "<u2").tobytes()
+        elif ty == "Bf": body += b"Bf" + struct.pack("<i", len(v)) + np.asarray(v, "<f4").tobytes()
+        else: raise ValueError(ty)
+    body += raw_tail
+    return struct.pack("<i", len(body)) + body
+
+
+def write_bam(path, text: str, records: list, block: int = 0xff00, extra_first: bytes = b"", empty_blocks: bool = False, eof: bool = True):
+    data = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 0) + b"".join(records)
+    with open(path, "wb") as f:
+        for k, a in enumerate(range(0, len(data), block)):
+            f.write(_bgzf_block(data[a:a + block], extra_first))
+            if empty_blocks and k % 3 == 1:
+                f.write(_bgzf_block(b"", extra_first))
+        if eof:
+            f.write(BGZF_EOF)

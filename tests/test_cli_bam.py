@@ -206,3 +206,70 @@ def test_reader_multi_slab_content(built, tmp_path):
             f = lines[z].split("\t")
             assert f[0] == str(1000 + z) and f[1] == "0" and f[2] == "6" and f[4] == fnv(z)
         assert len({l.split("\t")[4] for l in lines}) == 120
+
+
+def _v1enc(f):
+    f = max(0, int(f))
+    if f < 64: return f
+    if f < 192: return 64 + (f - 64 + 1) // 2
+    if f < 448: return 128 + (f - 192 + 2) // 4
+    return min(255, 192 + (f - 448 + 4) // 8)
+
+
+def _fnv(parts):
+    h = 1469598103934665603
+    for arr in parts:
+        for x in arr:
+            h = ((h ^ int(x)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:016x}"
+
+
+def test_reader_handles_odd_but_valid_bams(built, tmp_path):
+    """Hand-built inputs: tiny BGZF blocks (every record straddles many), empty blocks, a gzip extra field in which BC is not
+    the first subfield, raw-frame B,S kinetics, missing pw/ip, reads with N, no cx tag, header-only files, truncation."""
+    rng = np.random.default_rng(2)
+    hdr = "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:x\tPL:PACBIO\tDS:READTYPE=SUBREAD\tPU:m1\n"
+    recs, expect = [], {}
+    for zm in (7, 8, 9):
+        parts = []
+        for k in range(4):
+            n = 180 + 10 * k
+            codes = rng.integers(0, 4, n)
+            seq = "".join("ACGT"[c] for c in codes)
+            tags = [("zm", "i", zm), ("sn", "Bf", [9.0, 15.0, 8.0, 12.0]), ("RG", "Z", "x")]
+            if zm == 7:                                  # raw frames as uint16: encoded with CodecV1 by the reader
+                pw = rng.integers(0, 1200, n); ip = rng.integers(0, 1200, n)
+                tags += [("pw", "BS", pw), ("ip", "BS", ip), ("cx", "i", 3 | (32 if k & 1 else 16))]
+                parts += [codes, [_v1enc(x) for x in pw], [_v1enc(x) for x in ip]]
+            elif zm == 8:                                # no kinetics at all, no cx: defaults pw = 2, ip = 1, strands alternate
+                parts += [codes, [2] * n, [1] * n]
+            else:                                        # codec bytes pass through untouched; one pass contains an N and is dropped
+                pw = rng.integers(0, 256, n); ip = rng.integers(0, 256, n)
+                tags += [("pw", "BC", pw), ("ip", "BC", ip), ("cx", "i", 3)]
+                if k == 2:
+                    seq = seq[:50] + "N" + seq[51:]
+                else:
+                    parts += [codes, pw, ip]
+            recs.append(bam_util.record(f"m1/{zm}/{k * 300}_{k * 300 + n}", seq, tags))
+        expect[zm] = _fnv(parts)
+    for name, kw in (("tiny.bam", dict(block=97)), ("extra.bam", dict(block=5000, extra_first=b"XY\x03\x00abc")),
+                     ("holes.bam", dict(block=700, empty_blocks=True)), ("noeof.bam", dict(block=3000, eof=False))):
+        p = tmp_path / name
+        bam_util.write_bam(p, hdr, recs, **kw)
+        lines = [l.split("\t") for l in _run("--dump-zmws", "--min-passes", 1, "-j", 3, p).stdout.strip().split("\n")]
+        assert [l[0] for l in lines] == ["7", "8", "9"] and [l[2] for l in lines] == ["4", "4", "3"], name
+        assert [l[4] for l in lines] == [expect[7], expect[8], expect[9]], name
+    # header only: no ZMWs, clean exit
+    p = tmp_path / "empty.bam"
+    bam_util.write_bam(p, hdr, [])
+    r = _run("--dump-zmws", p)
+    assert r.returncode == 0 and r.stdout.strip() == ""
+    # truncated in the middle of a block / not BGZF at all: an error message and exit code 1, no crash
+    full = open(tmp_path / "extra.bam", "rb").read()
+    open(tmp_path / "cut.bam", "wb").write(full[: len(full) // 2])
+    open(tmp_path / "junk.bam", "wb").write(b"this is not a bam file" * 10)
+    # a record with an undefined tag type fails on a pool thread: still a message and exit code 1
+    bam_util.write_bam(tmp_path / "badtag.bam", hdr, recs[:2] + [bam_util.record("m1/7/9", "ACGT", [("zm", "i", 7)], raw_tail=b"xxQ\1")] + recs[2:])
+    for name in ("cut.bam", "junk.bam", "badtag.bam"):
+        r = _run("--dump-zmws", tmp_path / name, check=False)
+        assert r.returncode == 1 and "ccs:" in r.stderr, (name, r.stderr)
