@@ -102,7 +102,7 @@ __device__ __forceinline__ float det_exp2f(float x)
 }
 
 __device__ __forceinline__ int ctx_of(int prev, int cur) { if (prev > 3) prev = (cur + 2) & 3; return prev * 4 + cur; }
-__device__ __forceinline__ int obs_of(int base, int pw) { int b = pw < 1 ? 1 : (pw > 3 ? 3 : pw); return base * 3 + (b - 1); }
+__device__ __forceinline__ int obs_of(int base, int pw) { int b = pw < 1 ? 1 : (pw > 3 ? 3 : pw); return (base & 3) * 3 + (b - 1); }   // only the low two bits of a base code count
 
 __device__ __forceinline__ int wave_max_i32(int v)
 {
@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
         const int myr = half ? task.y : task.x;
         const int n = sN[myr], st = sSt[myr];
         const int64_t p0 = P.base_off[r0 + myr] + sOff[myr];
-        const int rbv = (row >= 1 && row <= n) ? P.bases[p0 + row - 1] : 0;   // lane of row i holds read base i-1
+        const int rbv = (row >= 1 && row <= n) ? (P.bases[p0 + row - 1] & 3) : 0;   // lane of row i holds read base i-1
         const uint8_t *t = sT[st];
         // bit c of mt: read base of this row == template column c (the two bit planes of the template come as ballots)
         const unsigned mt = ~((tlo[st] ^ ((rbv & 1) ? ~0u : 0u)) | (thi[st] ^ ((rbv & 2) ? ~0u : 0u)));
@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
         if (row < J && myrow >= 0) {
             const int jf = st ? J - 1 - row : row;
             const int64_t p = p0 + myrow;
-            if (jf >= cs && jf < ce && P.bases[p] == t[row]) {
+            if (jf >= cs && jf < ce && (P.bases[p] & 3) == t[row]) {
                 atomicAdd(&sK[st][0][jf], (unsigned)codec_v1_decode(P.ipd[p]));
                 atomicAdd(&sK[st][1][jf], (unsigned)codec_v1_decode(P.pw[p]));
                 atomicAdd(&sK[st][2][jf], 1u);

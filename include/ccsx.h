@@ -91,7 +91,8 @@ typedef struct ccsx_batch {
     const float   *snr;          /* [n_zmw][4] A,C,G,T (sn tag)                                 */
     const int32_t *read_off;     /* [n_zmw+1] first read of each ZMW                            */
     const int64_t *base_off;     /* [R+1] first base of each read                               */
-    const uint8_t *bases;        /* [n_bases] codes 0..3 = A,C,G,T, native (sequenced) orientation */
+    const uint8_t *bases;        /* [n_bases] codes 0..3 = A,C,G,T, native (sequenced) orientation; only the low two bits of
+                                    a byte are used, so no input byte can index out of range on the device */
     const uint8_t *pw;           /* [n_bases] pulse width, CodecV1 code as stored in the pw:B,C tag (codes < 64 ARE the
                                     frame count, so the HMM's pulse-width bin min(pw,3) needs no decoding)        */
     const uint8_t *ipd;          /* [n_bases] inter-pulse duration, CodecV1 code (ip:B,C tag).  Unused by the HMM;

@@ -159,7 +159,7 @@ void orc_tables(const orc_model *m, const float *snr, float *ME, float *INS, flo
 }
 
 static inline int ctx_of(int prev, int cur) { if (prev > 3) prev = (cur + 2) & 3; return prev * 4 + cur; }
-static inline int obs_of(int base, int pw) { int b = pw; if (b < 1) b = 1; if (b > 3) b = 3; return base * 3 + (b - 1); }
+static inline int obs_of(int base, int pw) { int b = pw; if (b < 1) b = 1; if (b > 3) b = 3; return (base & 3) * 3 + (b - 1); }   /* only the low two bits of a base code count */
 
 /* ---------------- steps 2+3: banded DP column shared by POA and alignment ------------------------------- */
 typedef struct {
@@ -363,8 +363,8 @@ static int poa_consensus(poa_t *g, uint8_t *draft, int cap)
 
 static void orient(const uint8_t *b, const uint8_t *pw, int L, int rev, uint8_t *ob, uint8_t *opw)
 {
-    if (!rev) { memcpy(ob, b, L); if (opw) memcpy(opw, pw, L); }
-    else for (int i = 0; i < L; ++i) { ob[i] = (uint8_t)(3 - b[L - 1 - i]); if (opw) opw[i] = pw[L - 1 - i]; }
+    if (!rev) { for (int i = 0; i < L; ++i) ob[i] = (uint8_t)(b[i] & 3); if (opw) memcpy(opw, pw, L); }
+    else for (int i = 0; i < L; ++i) { ob[i] = (uint8_t)((3 - b[L - 1 - i]) & 3); if (opw) opw[i] = pw[L - 1 - i]; }
 }
 
 /* step 2: draft from the first min(nreads, max_poa_cov) reads.  Orientation = that of read 0.
@@ -691,7 +691,7 @@ void orc_kinetics_read(const uint8_t *t, int J, const uint8_t *rb, const uint8_t
     for (int j = 1; j <= J; ++j) {
         H[0][j] = H[0][j - 1] + SC_DEL; mv[0][j] = (uint8_t)MV_L;
         for (int i = 1; i <= I; ++i) {
-            int diag = H[i - 1][j - 1] + (rb[i - 1] == t[j - 1] ? SC_MATCH : SC_MISMATCH);
+            int diag = H[i - 1][j - 1] + ((rb[i - 1] & 3) == t[j - 1] ? SC_MATCH : SC_MISMATCH);
             int left = H[i][j - 1] + SC_DEL;
             int h = diag >= left ? diag : left;
             int up = H[i - 1][j] + SC_INS;
@@ -703,7 +703,7 @@ void orc_kinetics_read(const uint8_t *t, int J, const uint8_t *rb, const uint8_t
     while (i > 0 || j > 0) {
         int m = mv[i][j];
         if (m == MV_D) {
-            if (rb[i - 1] == t[j - 1]) {
+            if ((rb[i - 1] & 3) == t[j - 1]) {
                 int jf = strand ? J - j : j - 1;
                 sum_ipd[jf] += (uint32_t)orc_codec_v1_decode(ipd[i - 1]);
                 sum_pw[jf] += (uint32_t)orc_codec_v1_decode(pwc[i - 1]);

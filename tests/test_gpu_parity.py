@@ -322,3 +322,17 @@ def test_kinetics_need_ipd(built):
         assert h2._L.ccsx_download(h2._h, C.byref(cr)) != 0
     finally:
         h2.close()
+
+
+def test_dirty_base_bytes_are_memory_safe(handle):
+    """Only the low two bits of a base byte count (include/ccsx.h): garbage in the high bits must neither fault nor change
+    the result; arbitrary pw bytes only select the pulse-width bin."""
+    batch = api.synth(6, 7, 900, seed=91)
+    clean = handle.consensus(batch)
+    rng = np.random.default_rng(9)
+    batch.bases = (batch.bases | (rng.integers(0, 64, len(batch.bases)) << 2)).astype(np.uint8)
+    dirty = handle.consensus(batch)
+    _compare(dirty, clean, batch)
+    _compare(dirty, _oracle(handle, batch), batch)
+    batch.pw = rng.integers(0, 256, len(batch.bases)).astype(np.uint8)
+    _compare(handle.consensus(batch), _oracle(handle, batch), batch)
