@@ -336,3 +336,39 @@ def test_dirty_base_bytes_are_memory_safe(handle):
     _compare(dirty, _oracle(handle, batch), batch)
     batch.pw = rng.integers(0, 256, len(batch.bases)).astype(np.uint8)
     _compare(handle.consensus(batch), _oracle(handle, batch), batch)
+
+
+def test_hostile_metadata(built):
+    """NaN / inf / negative / zero SNR, a ZMW without reads and a ZMW whose reads are all empty: same statuses and bytes as
+    the oracle, nothing faults (one status per ZMW, the run continues: docs/faq/reports-aux-files.md:10-12)."""
+    b = api.synth(8, 6, 400, seed=3)
+    b.snr[1] = np.nan; b.snr[2] = np.inf; b.snr[3] = -5.0; b.snr[4] = 0.0
+    ro, bo = b.read_off, b.base_off
+    bases, pw, ipd, flags, nbo, nro = [], [], [], [], [0], [0]
+    for z in range(8):
+        for r in range(ro[z], ro[z + 1]):
+            if z == 5:
+                continue                                     # ZMW 5: no reads at all
+            a, e = int(bo[r]), int(bo[r + 1])
+            if z == 6:
+                e = a                                        # ZMW 6: six empty reads
+            bases.append(b.bases[a:e]); pw.append(b.pw[a:e]); ipd.append(b.ipd[a:e]); flags.append(b.flags[r]); nbo.append(nbo[-1] + e - a)
+        nro.append(len(flags))
+    nb = api.Batch(b.zmw_id.copy(), b.snr.copy(), np.array(nro, np.int32), np.array(nbo, np.int64), np.concatenate(bases).astype(np.uint8),
+                   np.concatenate(pw).astype(np.uint8), np.concatenate(ipd).astype(np.uint8), np.array(flags, np.uint8))
+    for kin in (0, 1):
+        o = api.default_opts(); o.hifi_kinetics = kin; o.min_passes = 1
+        h = api.Handle(0, opts=o)
+        try:
+            res = h.consensus(nb)
+            ref = api.Results.allocate(nb, kinetics=bool(kin))
+            O.consensus_batch(h.model, o, nb, ref, nthreads=4)
+            assert res.status.tolist() == ref.status.tolist() == [0, 7, 0, 0, 0, 1, 2, 0]
+            assert np.array_equal(res.seq_len, ref.seq_len)
+            for z in range(8):
+                assert np.array_equal(res.sequence(z), ref.sequence(z)) and np.array_equal(res.quals(z), ref.quals(z))
+                if kin:
+                    assert np.array_equal(res.kinetics(z), ref.kinetics(z))
+            assert np.array_equal(np.nan_to_num(res.rq, nan=-1), np.nan_to_num(ref.rq, nan=-1))
+        finally:
+            h.close()
