@@ -273,3 +273,23 @@ def test_reader_handles_odd_but_valid_bams(built, tmp_path):
     for name in ("cut.bam", "junk.bam", "badtag.bam"):
         r = _run("--dump-zmws", tmp_path / name, check=False)
         assert r.returncode == 1 and "ccs:" in r.stderr, (name, r.stderr)
+
+
+@pytest.mark.gpu
+def test_cli_output_is_independent_of_workers_and_batching(built, tmp_path):
+    """Batches are handed to whichever engine is free (several devices, several handles per device) and the writer restores
+    input order: the hifi.bam must not depend on --gpus / --workers-per-gpu / --batch-size / -j (docs/faq/parallelize.md)."""
+    bam = tmp_path / "s.subreads.bam"
+    _run("--write-synthetic", "40,6,700,5", bam)
+    outs = []
+    for k, args in enumerate((("--batch-size", 40, "--workers-per-gpu", 1), ("--batch-size", 3, "--gpus", "0,0", "--workers-per-gpu", 2, "-j", 2),
+                              ("--batch-size", 7, "--workers-per-gpu", 3, "-j", 9))):
+        out = tmp_path / f"o{k}.bam"
+        _run(bam, out, "--suppress-reports", *args)
+        outs.append(bam_util.read_bam(out)[1])
+    assert len(outs[0]) > 30
+    for other in outs[1:]:
+        assert len(other) == len(outs[0])
+        for a, b in zip(outs[0], other):
+            assert a["name"] == b["name"] and np.array_equal(a["seq"], b["seq"]) and np.array_equal(a["qual"], b["qual"])
+            assert a["tags"]["rq"] == b["tags"]["rq"] and a["tags"]["np"] == b["tags"]["np"] and a["tags"]["ec"] == b["tags"]["ec"]
