@@ -126,6 +126,21 @@ def _ptr(a: np.ndarray, ty):
     return a.ctypes.data_as(C.POINTER(ty))
 
 
+class _Pinned:
+    """Owner of one ccsx_alloc_pinned block."""
+
+    def __init__(self, p):
+        self.p = p
+
+    def __del__(self):
+        try:
+            if self.p:
+                lib().ccsx_free_pinned(self.p)
+                self.p = None
+        except Exception:
+            pass
+
+
 @dataclass
 class Batch:
     """Input batch, SoA + CSR (include/ccsx.h ccsx_batch).  All arrays are C-contiguous numpy."""
@@ -171,6 +186,25 @@ class Batch:
         else:
             lout = int(self.base_off[-1]) // max(1, int(self.read_off[-1])) * n
         return 3 * int(self.base_off[-1]) + 48 * n + 2 * lout
+
+    def pinned(self) -> "Batch":
+        """Copy of this batch whose per-base arrays live in page-locked host memory (ccsx_alloc_pinned): uploads run at PCIe
+        rate instead of through the runtime's pageable staging.  The buffers are released with the returned object."""
+        L = lib()
+        out = Batch(self.zmw_id, self.snr, self.read_off, self.base_off, None, None, None, self.flags, self.tpl_off, self.tpl)
+        keep = []
+        for name in ("bases", "pw", "ipd"):
+            src = getattr(self, name)
+            n = max(1, src.nbytes)
+            p = L.ccsx_alloc_pinned(n)
+            if not p:
+                raise RuntimeError("ccsx_alloc_pinned failed: " + L.ccsx_last_error().decode())
+            keep.append(_Pinned(p))
+            arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,))[: len(src)]
+            arr[:] = src
+            setattr(out, name, arr)
+        out._pinned = keep
+        return out
 
     def slice(self, z0: int, z1: int) -> "Batch":
         r0, r1 = int(self.read_off[z0]), int(self.read_off[z1])

@@ -372,3 +372,12 @@ def test_hostile_metadata(built):
             assert np.array_equal(np.nan_to_num(res.rq, nan=-1), np.nan_to_num(ref.rq, nan=-1))
         finally:
             h.close()
+
+
+def test_pinned_batch_gives_identical_results(handle):
+    batch = api.synth(5, 6, 800, seed=61)
+    a = handle.consensus(batch)
+    pb = batch.pinned()
+    assert np.array_equal(pb.bases, batch.bases) and np.array_equal(pb.pw, batch.pw) and np.array_equal(pb.ipd, batch.ipd)
+    b = handle.consensus(pb)
+    _compare(b, a, batch)
