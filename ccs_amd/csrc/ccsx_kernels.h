@@ -29,7 +29,7 @@ struct KParams {
     float *tabME, *tabINS, *tabDL;
     uint8_t *draft;
     int32_t *draft_len, *nwin, *zstat, *nreads_used, *wbounds, *np;
-    int32_t *ticket_poa, *ticket_align;   // adjacent
+    int32_t *ticket_poa, *ticket_align;   // 256-byte scratch block that also holds debug[] and phase[] (no tickets since the chunked launch)
     int32_t *debug;            // [4] first failed bounds check (CCSX_DEBUG_CHECKS builds)
     unsigned long long *phase; // [16] per-phase cycle sums (CCSX_PROFILE_PHASES builds)
     // ---- POA / alignment scratch (per resident slot)

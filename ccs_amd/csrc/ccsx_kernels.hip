@@ -193,7 +193,7 @@ __device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t 
 __device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { return (int)((sread[i >> 4] >> (2 * (i & 15))) & 3u); }
 
 // ------------------------------------------------------------------------------------------------
-// D2/D3: sparse POA.  One wave per resident graph ("slot"); slots pull ZMWs from an atomic ticket.
+// D2/D3: sparse POA.  One wave per resident graph ("slot"); the kernel is launched per chunk of poa_slots ZMWs, longest first.
 //
 // v2 layout.  By vertex id: vrec {base | npred<<8 | reads<<16, pred0, pred1, pred2}, predx (in-edges 3..7),
 // rank (topological position).  By topological position: order (ping-pong), the score column Mk[64] and move
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                             if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; bm = MV_DEL | (q << 2); } }
                         }
                     }
-                    // insertion chain: x_l = max_k<=l (c_k + (l-k)*INS): exact integer max-plus prefix scan (7 DPP ops)
+                    // insertion chain: x_l = max_k<=l (c_k + (l-k)*INS): exact integer max-plus prefix scan (6 fused DPP ops)
                     const int d = wave_scan_max_i32(best + lane4);
                     const int xi = d - lane4;
                     if (xi > best) { best = xi; bm = MV_INS; }
@@ -1474,7 +1474,7 @@ static void trace_sync(hipStream_t st, const char *what)
 void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or NULL */)
 {
     if (ev) (void)hipEventRecord(ev[0], st);
-    (void)hipMemsetAsync(P.ticket_poa, 0, 256, st);                // ticket_poa and ticket_align are adjacent
+    (void)hipMemsetAsync(P.ticket_poa, 0, 256, st);                // debug / phase-profile words (CCSX_DEBUG_CHECKS, CCSX_PROFILE_PHASES builds)
     {
         int n = P.n_zmw * CCSX_NCTX;
         hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, P);

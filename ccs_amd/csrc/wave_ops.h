@@ -20,7 +20,7 @@ __device__ __forceinline__ float wave_shl1_f32(float x, float fill) { return __i
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 // inclusive prefix maximum over the 64 lanes.  `old` = INT_MIN (the identity of max) lets the DPP combiner
-// fold every move into its v_max_i32_dpp: 7 VALU ops in total.
+// fold every move into its v_max_i32_dpp.
 #define WAVE_IMIN ((int)0x80000000)
 __device__ __forceinline__ int wave_scan_max_i32(int v)
 {
