@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             const int n0 = n;
             int Mprev = NEGV, lo_prev = 0, cm_prev = NEGV, br_prev = 0;
             int M2 = NEGV, M3 = NEGV, lo2 = 0, lo3 = 0;             // columns k-2, k-3: most branch in-edges end there
+            int rbK = 4;                                            // read base of row lo + lane - 1 of the current band position
             int kend = -1, bs = NEGV;
             const int hiI = I - (CCSX_BAND - 1) > 0 ? I - (CCSX_BAND - 1) : 0;
             const int lane4 = 4 * lane;
@@ -334,19 +335,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         t = t > lo_prev ? t : lo_prev;
                         t = t < lo_prev + 2 ? t : lo_prev + 2;
                         lo = rfl(t < hiI ? t : hiI);
-                        const int idx = lane + (lo - lo_prev);             // row i sits in lane idx of the previous column
-                        const int ys = __shfl(Mprev, idx & 63), xs = __shfl(Mprev, (idx - 1) & 63);
-                        const int y = idx < LANES ? ys : NEGV;
-                        const int x = (unsigned)(idx - 1) < (unsigned)LANES ? xs : NEGV;
+                        const int sh = lo - lo_prev;                       // 0..2: the band follows the best row of the previous column
+                        // rows of the previous column by wave shifts (no LDS crossbar on the chain); the read base of row i-1
+                        // travels with the band, only the top lane(s) fetch a new one.  Invalid cells carry NEGV, lose every
+                        // comparison and are reset at the end of the column.
+                        int x, y;
+                        if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; }
+                        else {
+                            const int top = lo + 62;
+                            int tc = top >= I ? I - 1 : top; tc = tc < 0 ? 0 : tc;   // clamped: the value only matters for valid rows
+                            const int nb = read_base_packed(sread, tc);
+                            if (sh == 1) { x = Mprev; y = wave_shl1_i32(Mprev, NEGV); rbK = wave_shl1_i32(rbK, nb); }
+                            else {
+                                x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV);
+                                int tc1 = top - 1 >= I ? I - 1 : top - 1; tc1 = tc1 < 0 ? 0 : tc1;
+                                const int nb1 = read_base_packed(sread, tc1);
+                                rbK = wave_shl1_i32(wave_shl1_i32(rbK, nb1), nb);
+                            }
+                        }
                         i = lo + lane;
-                        const int ib = i - 1 < 0 ? 0 : (i - 1 >= I ? I - 1 : i - 1);   // clamped: unconditional LDS read, no branch
-                        rbv = read_base_packed(sread, ib);
-                        const bool rowok = i <= I;
-                        const int cdiag = x + (vb == rbv ? SC_MATCH : SC_MISMATCH);
-                        const bool vdiag = rowok && i >= 1 && x > NEGV / 2;
-                        best = vdiag ? cdiag : NEGV;                       // bm = MV_DIAG = 0
+                        rbv = rbK;
+                        best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH);   // bm = MV_DIAG = 0
                         const int cdel = y + SC_DEL;
-                        const bool vdel = rowok && y > NEGV / 2 && cdel > best;
+                        const bool vdel = cdel > best;
                         best = vdel ? cdel : best; bm = vdel ? MV_DEL : MV_DIAG;
                         pp = k - 1;
                     } else {                                               // source vertex or several / far in-edges
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         lo = rfl(band_lo(ulo, ubr, I));
                         i = lo + lane;
                         rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
+                        rbK = rbv;                                         // the chain step continues from this band position
                         const int npp = np == 0 ? 1 : np;
                         for (int q = 0; q < npp; ++q) {                    // pass 2: candidates (in-edge data is re-derived: no arrays)
                             int x, y;
@@ -690,6 +702,7 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
     int Mprev = (lane <= I) ? lane * SC_INS : NEGV;
     int Oprev = 0;                                      // entry row at column 0 is 0 for every cell
     int lo = 0, br = 0;
+    int rbv = (lane >= 1 && lane <= I) ? read_base_packed(sread, lane - 1) : 4;   // base of row lo + lane (minus one), band at lo = 0
     for (int jb = 0; jb < Ld; jb += LANES) {            // draft bases: one coalesced load per 64 columns
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
         asm volatile("" :: "v"(dL));                     // wait for the block load here, not inside the column loop
@@ -701,14 +714,26 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
             const int sh = lo - plo;                    // 0..2
             const int i = lo + lane;
             const int vb = rl(dL, jj);
-            const int rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
+            // the read base of row i-1 travels with the band: a band shift moves it one lane down and only the top lane(s)
+            // fetch a new base (4 = no base: rows 0 and > I)
             int x, y, ox, oy;
             if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; ox = wave_shr1_i32(Oprev, 0); oy = Oprev; }
-            else if (sh == 1) { x = Mprev; y = wave_shl1_i32(Mprev, NEGV); ox = Oprev; oy = wave_shl1_i32(Oprev, 0); }
-            else { x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); ox = wave_shl1_i32(Oprev, 0); oy = wave_shl1_i32(ox, 0); }
-            int best = NEGV, org = 0;
-            if (i >= 1 && i <= I && x > NEGV / 2) { best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); org = ox; }
-            if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; org = oy; } }
+            else {
+                const int top = lo + 62;                                // read index of lane 63's base
+                const int nb = top < I ? read_base_packed(sread, top < 0 ? 0 : top) : 4;
+                if (sh == 1) {
+                    x = Mprev; y = wave_shl1_i32(Mprev, NEGV); ox = Oprev; oy = wave_shl1_i32(Oprev, 0);
+                    rbv = wave_shl1_i32(rbv, nb);
+                } else {
+                    x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); ox = wave_shl1_i32(Oprev, 0); oy = wave_shl1_i32(ox, 0);
+                    const int nb1 = top - 1 < I ? read_base_packed(sread, top - 1 < 0 ? 0 : top - 1) : 4;
+                    rbv = wave_shl1_i32(wave_shl1_i32(rbv, nb1), nb);
+                }
+            }
+            // invalid cells (outside the band, row 0 for the diagonal) carry NEGV and simply lose every comparison; rows > I and
+            // anything below NEGV/2 are reset to NEGV at the end of the column, so nothing accumulates
+            int best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH), org = ox;
+            { const int c = y + SC_DEL; if (c > best) { best = c; org = oy; } }
             const bool need = (j == next_need);
             if (need) {
                 Osave[(size_t)kk * 64 + lane] = org;    // origin (previous edge) of the cell's entry move
