@@ -158,14 +158,14 @@ def main():
         alg_bytes = batch.algorithmic_bytes()               # 3*sum(len) + 48 + 2*L_out per ZMW
         # dominant kernel: algorithmic bytes of the whole step / summed launch duration of that kernel over the handles
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-        # measured HBM traffic of that kernel (PMC FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 passes,
+        # measured HBM traffic of that kernel (PMC 2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 passes,
         # profiles/r01_traffic.json, per ZMW at the same 10 x 10 kb workload) scaled to the ZMWs of one launch
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             kz = tj["kernels"][names[dom]]
             if args.passes == 10 and args.length == 10000 and not args.hifi_kinetics:
-                traffic = int((kz["fetch_size_kb_per_zmw"] + kz["write_size_kb_per_zmw"]) * 1024 * args.zmws)
+                traffic = int((2 * kz["fetch_size_kb_per_zmw"] + kz["write_size_kb_per_zmw"]) * 1024 * args.zmws)   # calibrated: FETCH_SIZE = bytes / 2
         except Exception:
             traffic = None
         valu_busy = None
