@@ -28,3 +28,44 @@ def test_gpu_reproduces_golden(built, case):
     G.check(res, exp)
     assert np.array_equal(h.stage_draft(0), draft0)
     h.close()
+
+
+# ---- HiFi kinetics (tests/golden/golden_kin_v1.npz, made by tests/golden/make_golden_kinetics.py) --------------------
+KIN_CASES = ["p5_l700", "mix"]
+
+
+def _kin_case(case):
+    import os
+    batch, exp, _, _ = G.load(case)
+    g = np.load(os.path.join(os.path.dirname(G.GOLDEN), "golden_kin_v1.npz"))
+    batch.ipd = np.ascontiguousarray(g[f"{case}/ipd"])
+    return batch, exp, g[f"{case}/kin"], g[f"{case}/fn"], g[f"{case}/rn"]
+
+
+def _check_kin(res, exp, kin, fn, rn):
+    G.check(res, exp)
+    assert np.array_equal(res.fn, fn) and np.array_equal(res.rn, rn)
+    for z in range(len(fn)):
+        o, n = int(exp["seq_off"][z]), int(exp["seq_len"][z])
+        assert np.array_equal(res.kinetics(z), kin[:, o:o + n]), f"zmw {z} kinetics"
+
+
+@pytest.mark.parametrize("case", KIN_CASES)
+def test_oracle_reproduces_golden_kinetics(built, case):
+    batch, exp, kin, fn, rn = _kin_case(case)
+    opts = api.default_opts(); opts.hifi_kinetics = 1
+    res = api.Results.allocate(batch, kinetics=True)
+    O.consensus_batch(api.default_model(), opts, batch, res, nthreads=2)
+    _check_kin(res, exp, kin, fn, rn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", KIN_CASES)
+def test_gpu_reproduces_golden_kinetics(built, case):
+    batch, exp, kin, fn, rn = _kin_case(case)
+    opts = api.default_opts(); opts.hifi_kinetics = 1
+    h = api.Handle(0, opts=opts)
+    try:
+        _check_kin(h.consensus(batch), exp, kin, fn, rn)
+    finally:
+        h.close()
