@@ -249,7 +249,7 @@ __device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to
 extern __shared__ uint32_t dyn_lds[];
 #define TB_BLOCK 32                   // positions cached per traceback block (LDS per wave bounds the POA occupancy)
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_poa(KParams P, int z0)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa(KParams P, int z0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sMv[TB_BLOCK * 64];   // move rows of the traceback's current block
     const int lane = threadIdx.x;
