@@ -55,7 +55,7 @@ struct ccsx_handle_s {
     // layout
     DevBuf d_read_zmw, d_vcap, d_dcap, d_seq_off, d_wb_off, d_ent_off, d_wslot, d_zperm, d_rperm;
     // state
-    DevBuf d_tabME, d_tabINS, d_tabDL, d_draft, d_zmw_i32 /* 6 x n int32 */, d_wbounds, d_ticket;
+    DevBuf d_tabME, d_tabINS, d_tabDL, d_tabZ, d_dmask, d_draft, d_zmw_i32 /* 6 x n int32 */, d_wbounds, d_ticket;
     DevBuf d_poa, d_align, d_avalid, d_ascore, d_ent;
     DevBuf d_wseq, d_wqv, d_wsum, d_wmeta;
     DevBuf d_out_seq, d_out_qual, d_out_raw, d_out_i32 /* 6 x n */, d_out_f32 /* 2 x n */;
@@ -125,7 +125,7 @@ int ccsx_destroy(ccsx_handle h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_model, &h->d_snr, &h->d_read_off, &h->d_base_off, &h->d_bases, &h->d_pw, &h->d_flags, &h->d_read_zmw,
-                      &h->d_vcap, &h->d_dcap, &h->d_seq_off, &h->d_wb_off, &h->d_ent_off, &h->d_wslot, &h->d_tabME, &h->d_tabINS, &h->d_tabDL,
+                      &h->d_vcap, &h->d_dcap, &h->d_seq_off, &h->d_wb_off, &h->d_ent_off, &h->d_wslot, &h->d_tabME, &h->d_tabINS, &h->d_tabDL, &h->d_tabZ, &h->d_dmask,
                       &h->d_draft, &h->d_zmw_i32, &h->d_wbounds, &h->d_ticket, &h->d_poa, &h->d_align, &h->d_avalid, &h->d_ascore,
                       &h->d_ent, &h->d_wseq, &h->d_wqv, &h->d_wsum, &h->d_wmeta, &h->d_out_seq, &h->d_out_qual, &h->d_out_raw,
                       &h->d_out_i32, &h->d_out_f32, &h->d_zperm, &h->d_rperm, &h->d_ipd, &h->d_wtpl, &h->d_wtmeta, &h->d_wkin, &h->d_out_kin};
@@ -177,7 +177,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
         }
         dcap[z] = (int32_t)ccsx_draft_cap(maxL);
         vcap[z] = (int32_t)ccsx_vertex_cap(maxL);
-        const int wcap = dcap[z] / CCSX_WIN_CORE + 4;
+        const int wcap = dcap[z] / (CCSX_WIN_CORE - 3) + 4;   // cores are 19..25 columns (SPEC windows)
         h->seq_off[z + 1] = h->seq_off[z] + dcap[z];
         h->wb_off[z + 1] = h->wb_off[z] + wcap;
         for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) h->ent_off[r + 1] = h->ent_off[r] + 2 * (wcap - 1);
@@ -234,13 +234,13 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
 
     const int64_t cap_total = h->seq_off[n];
 #define RES(buf, bytes) do { if ((buf).reserve(bytes)) return -2; } while (0)
-    RES(h->d_tabME, (size_t)n * 192 * 4); RES(h->d_tabINS, (size_t)n * 192 * 4); RES(h->d_tabDL, (size_t)n * 16 * 4);
+    RES(h->d_tabME, (size_t)n * 192 * 4); RES(h->d_tabINS, (size_t)n * 192 * 4); RES(h->d_tabDL, (size_t)n * 16 * 4); RES(h->d_tabZ, (size_t)n * 32 * 4);
     RES(h->d_draft, (size_t)cap_total);
     RES(h->d_zmw_i32, (size_t)n * 4 * 6);
     RES(h->d_wbounds, (size_t)h->wb_off[n] * 4);
     RES(h->d_ticket, 256);
     RES(h->d_avalid, (size_t)R); RES(h->d_ascore, (size_t)R * 4);
-    RES(h->d_ent, (size_t)h->ent_off[R] * 4);
+    RES(h->d_ent, (size_t)h->ent_off[R] * 4); RES(h->d_dmask, (size_t)h->ent_off[R] * 4);
     RES(h->d_wseq, (size_t)total_wslots * 32); RES(h->d_wqv, (size_t)total_wslots * 32 * 4);
     RES(h->d_wsum, (size_t)total_wslots * 4); RES(h->d_wmeta, (size_t)total_wslots * 16);
     RES(h->d_out_seq, (size_t)cap_total); RES(h->d_out_qual, (size_t)cap_total); RES(h->d_out_raw, (size_t)cap_total * 4);
@@ -252,7 +252,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
 
     // ---- resident POA graphs / alignment slots: as many as fit a memory budget, never more than the work
     const size_t poa_slot_bytes = (((size_t)vcap_max + 64) * 392 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
-    const size_t align_slot_i32 = (size_t)need_max * 64 + need_max + 64;
+    const size_t align_slot_i32 = (size_t)need_max * 128 + need_max + 64;   // (origin, dirty bits) per cell and edge + band starts
     size_t freeb = 0, totalb = 0;
     HIPTRY(hipMemGetInfo(&freeb, &totalb));
     freeb += h->d_poa.cap + h->d_align.cap;                      // what we already hold is reusable
@@ -276,7 +276,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     P.read_zmw = (const int32_t *)h->d_read_zmw.p; P.vcap = (const int32_t *)h->d_vcap.p; P.dcap = (const int32_t *)h->d_dcap.p;
     P.seq_off = (const int64_t *)h->d_seq_off.p; P.wb_off = (const int32_t *)h->d_wb_off.p; P.ent_off = (const int64_t *)h->d_ent_off.p; P.wslot_zmw = (const int32_t *)h->d_wslot.p;
     P.zmw_perm = (const int32_t *)h->d_zperm.p; P.read_perm = (const int32_t *)h->d_rperm.p;
-    P.tabME = (float *)h->d_tabME.p; P.tabINS = (float *)h->d_tabINS.p; P.tabDL = (float *)h->d_tabDL.p;
+    P.tabME = (float *)h->d_tabME.p; P.tabINS = (float *)h->d_tabINS.p; P.tabDL = (float *)h->d_tabDL.p; P.tabZ = (float *)h->d_tabZ.p;
     P.draft = (uint8_t *)h->d_draft.p;
     int32_t *zi = (int32_t *)h->d_zmw_i32.p;
     P.draft_len = zi; P.nwin = zi + n; P.zstat = zi + 2 * (size_t)n; P.nreads_used = zi + 3 * (size_t)n; P.np = zi + 4 * (size_t)n;
@@ -284,7 +284,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     P.ticket_poa = (int32_t *)h->d_ticket.p; P.ticket_align = P.ticket_poa + 1; P.debug = P.ticket_poa + 4; P.phase = (unsigned long long *)(P.ticket_poa + 16);
     P.poa_scratch = (uint8_t *)h->d_poa.p; P.poa_slot_bytes = poa_slot_bytes; P.poa_slots = poa_slots;
     P.align_scratch = (int32_t *)h->d_align.p; P.align_slot_i32 = align_slot_i32; P.align_slots = align_slots;
-    P.avalid = (uint8_t *)h->d_avalid.p; P.ascore = (int32_t *)h->d_ascore.p; P.ent = (int32_t *)h->d_ent.p;
+    P.avalid = (uint8_t *)h->d_avalid.p; P.ascore = (int32_t *)h->d_ascore.p; P.ent = (int32_t *)h->d_ent.p; P.dmask = (uint32_t *)h->d_dmask.p;
     P.total_wslots = total_wslots;
     P.wseq = (uint8_t *)h->d_wseq.p; P.wqv = (float *)h->d_wqv.p; P.wsum = (float *)h->d_wsum.p; P.wmeta = (int4 *)h->d_wmeta.p;
     P.out_seq = (uint8_t *)h->d_out_seq.p; P.out_qual = (uint8_t *)h->d_out_qual.p; P.out_raw = (float *)h->d_out_raw.p;

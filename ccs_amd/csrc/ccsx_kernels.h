@@ -27,6 +27,7 @@ struct KParams {
     const int32_t *wslot_zmw;  // [total window slots] owning ZMW of every polish workgroup slot
     // ---- per-ZMW state
     float *tabME, *tabINS, *tabDL;
+    float *tabZ;               // [n][32] z-score parameters per context: MU[16], VAR[16]
     uint8_t *draft;
     int32_t *draft_len, *nwin, *zstat, *nreads_used, *wbounds, *np;
     int32_t *ticket_poa, *ticket_align;   // 256-byte scratch block that also holds debug[] and phase[] (no tickets since the chunked launch)
@@ -42,6 +43,7 @@ struct KParams {
     uint8_t *avalid;
     int32_t *ascore;
     int32_t *ent;              // entry rows of every window-edge column, per read
+    uint32_t *dmask;           // same indexing: pile-up dirty bits of the draft positions between two window-edge columns
     // ---- per-window polish outputs
     long long total_wslots;
     uint8_t *wseq;             // [wslots][32]

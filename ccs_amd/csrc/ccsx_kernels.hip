@@ -52,6 +52,10 @@
 #define JMIN_DEL 4
 #define AB_TOL 0.01f
 #define TINY_P 1e-30f
+#define SKIP_MARGIN 6
+#define SKIP_SPREAD 3
+#define DQ_SCALE 65536.0f
+#define DQ_CLAMP 100.0f
 
 // ------------------------------------------------------------------------------------------------
 // deterministic log2 / exp2 (DESIGN.md §SPEC "det math"): only +, *, / (IEEE, correctly rounded) and bit ops
@@ -172,6 +176,23 @@ __global__ void k_setup(KParams P)
         else          INS[k * CCSX_NOBS + o] = ((pS * m->em_stick[k][pwb]) * 0.333333333f) * 4.0f;
     }
     P.tabDL[(size_t)z * 16 + k] = pD;
+    // A7 z-score parameters (SPEC "z-score gate"; oracle orc_zparams, same operation order)
+    {
+        const float pA = pM + pD, pI = pB + pS;
+        const float lM = det_log2f(pM), lD = det_log2f(pD), lB = det_log2f(pB), lS = det_log2f(pS * 0.333333333f);
+        float e1m = 0.0f, e2m = 0.0f, e1b = 0.0f, e2b = 0.0f, e1s = 0.0f, e2s = 0.0f;
+        for (int o = 0; o < CCSX_NOBS; ++o) { const float p = m->em_match[k][o], l = det_log2f(p), t = p * l; e1m = e1m + t; e2m = e2m + t * l; }
+        for (int b = 0; b < 3; ++b) { const float p = m->em_branch[k][b], l = det_log2f(p), t = p * l; e1b = e1b + t; e2b = e2b + t * l; }
+        for (int b = 0; b < 3; ++b) { const float p = m->em_stick[k][b], l = det_log2f(p), t = p * l; e1s = e1s + t; e2s = e2s + t * l; }
+        const float a1 = __fdiv_rn(pM * (lM + e1m) + pD * lD, pA);
+        const float a2 = __fdiv_rn(pM * ((lM * lM + (2.0f * lM) * e1m) + e2m) + pD * (lD * lD), pA);
+        const float s1 = __fdiv_rn(pB * (lB + e1b) + pS * (lS + e1s), pI);
+        const float s2 = __fdiv_rn(pB * ((lB * lB + (2.0f * lB) * e1b) + e2b) + pS * ((lS * lS + (2.0f * lS) * e1s) + e2s), pI);
+        const float vA = a2 - a1 * a1, vS = s2 - s1 * s1;
+        const float EN = __fdiv_rn(pI, pA), VN = __fdiv_rn(pI, pA * pA);
+        P.tabZ[(size_t)z * 32 + k] = EN * s1 + a1;
+        P.tabZ[(size_t)z * 32 + 16 + k] = (EN * vS + VN * (s1 * s1)) + vA;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,23 +670,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             }
             __threadfence_block();
         }
-        if (lane == 0) {
-            if (Ld <= 0) stat = CCSX_DRAFT_FAILURE;
-            else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
-            else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
-            else {
-                const uint8_t *d = P.draft + P.seq_off[z];
-                int32_t *b = P.wbounds + P.wb_off[z];
-                int cur = 0; b[0] = 0;
-                while (cur < Ld) {
-                    int nb;
-                    if (Ld - cur <= CCSX_WIN_CORE + 6) nb = Ld;
-                    else { nb = cur + CCSX_WIN_CORE; int sh = 0; while (sh < 3 && d[nb] == d[nb - 1]) { ++nb; ++sh; } }
-                    b[++nw] = nb; cur = nb;
+        if (Ld <= 0) stat = CCSX_DRAFT_FAILURE;
+        else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
+        else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
+        else {
+            // step 4 windows.  SPEC: a break nb is bad when for some period p in 1..4 the p-mer before it equals the p-mer
+            // after it ("avoid breaking windows at simple repeats", docs/how-does-ccs-work.md:58-60); the target cur+22 moves by
+            // 0,+1,-1,+2,-2,+3,-3 to the first good position.  Lane l holds draft[cur+14+l]; E_p = ballot(d[i] == d[i+p]).
+            const uint8_t *d = P.draft + P.seq_off[z];
+            int32_t *b = P.wbounds + P.wb_off[z];
+            int cur = 0;
+            if (lane == 0) b[0] = 0;
+            while (cur < Ld) {
+                int nb;
+                if (Ld - cur <= CCSX_WIN_CORE + 6) nb = Ld;
+                else {
+                    const int base = cur + CCSX_WIN_CORE - 8;                 // positions base .. base+15 cover every p-mer examined
+                    const int pos = base + lane;
+                    const int x = (lane < 16 && pos < Ld) ? (int)d[pos] : 8 + lane;
+                    unsigned e[4];
+#pragma unroll
+                    for (int p = 1; p <= 4; ++p) e[p - 1] = (unsigned)__ballot(x == __shfl(x, (lane + p) & 63)) & 0xffffu;
+                    nb = cur + CCSX_WIN_CORE;
+                    const int offs[7] = {0, 1, -1, 2, -2, 3, -3};
+#pragma unroll
+                    for (int k = 6; k >= 0; --k) {                            // last assignment wins: scan the preference order backwards
+                        const int c = 8 + offs[k];                            // bit index of the candidate break
+                        bool bad = false;
+#pragma unroll
+                        for (int p = 1; p <= 4; ++p) bad |= ((e[p - 1] >> (c - p)) & ((1u << p) - 1u)) == ((1u << p) - 1u);
+                        if (!bad) nb = cur + CCSX_WIN_CORE + offs[k];
+                    }
                 }
+                ++nw;
+                if (lane == 0) b[nw] = nb;
+                cur = nb;
             }
-            P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat;
         }
+        if (lane == 0) { P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat; }
         PHASE(13);
         }   // enough
     }
@@ -695,12 +737,19 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
     load_read_packed(sread, P.bases + P.base_off[r], I, rev, lane);
     __syncthreads();
     const int nneed = 2 * nw;                           // needed columns: 0, b1-2, b1+2, ..., Ld
-    int32_t *lo_need = Osave + (size_t)P.need_max * 64;
+    int32_t *lo_need = Osave + (size_t)P.need_max * 128;
+    int2 *OMsave = (int2 *)Osave;                      // per window-edge column and cell: (origin row at the previous edge, dirty bits)
     int kk = 1;                                         // next needed column index
     int next_need = (nw == 1) ? Ld : rfl(wb[1]) - CCSX_WIN_OVERHANG;
     // column 0 = START
     int Mprev = (lane <= I) ? lane * SC_INS : NEGV;
     int Oprev = 0;                                      // entry row at column 0 is 0 for every cell
+    // candidate-filter pile-up (SPEC "dirty masks"): every cell carries the dirty bits of the draft positions its best path has
+    // passed since the last window-edge column e: bit (j - e - 1) = position j-1 (column j) was not passed by a matching DIAG
+    // step.  Leading insertions dirty position 0.  Bit 31: an insertion right at the edge column (dirties the LAST position of
+    // the previous interval, patched in the epilogue).
+    unsigned Kprev = (lane >= 1) ? 1u : 0u;
+    int ecol = 0;                                       // last window-edge column
     int lo = 0, br = 0;
     int rbv = (lane >= 1 && lane <= I) ? read_base_packed(sread, lane - 1) : 4;   // base of row lo + lane (minus one), band at lo = 0
     for (int jb = 0; jb < Ld; jb += LANES) {            // draft bases: one coalesced load per 64 columns
@@ -717,28 +766,37 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
             // the read base of row i-1 travels with the band: a band shift moves it one lane down and only the top lane(s)
             // fetch a new base (4 = no base: rows 0 and > I)
             int x, y, ox, oy;
-            if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; ox = wave_shr1_i32(Oprev, 0); oy = Oprev; }
+            unsigned kx, ky;
+            if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; ox = wave_shr1_i32(Oprev, 0); oy = Oprev; kx = (unsigned)wave_shr1_i32((int)Kprev, 0); ky = Kprev; }
             else {
                 const int top = lo + 62;                                // read index of lane 63's base
                 const int nb = top < I ? read_base_packed(sread, top < 0 ? 0 : top) : 4;
                 if (sh == 1) {
                     x = Mprev; y = wave_shl1_i32(Mprev, NEGV); ox = Oprev; oy = wave_shl1_i32(Oprev, 0);
+                    kx = Kprev; ky = (unsigned)wave_shl1_i32((int)Kprev, 0);
                     rbv = wave_shl1_i32(rbv, nb);
                 } else {
                     x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); ox = wave_shl1_i32(Oprev, 0); oy = wave_shl1_i32(ox, 0);
+                    kx = (unsigned)wave_shl1_i32((int)Kprev, 0); ky = (unsigned)wave_shl1_i32((int)kx, 0);
                     const int nb1 = top - 1 < I ? read_base_packed(sread, top - 1 < 0 ? 0 : top - 1) : 4;
                     rbv = wave_shl1_i32(wave_shl1_i32(rbv, nb1), nb);
                 }
             }
             // invalid cells (outside the band, row 0 for the diagonal) carry NEGV and simply lose every comparison; rows > I and
             // anything below NEGV/2 are reset to NEGV at the end of the column, so nothing accumulates
-            int best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH), org = ox;
-            { const int c = y + SC_DEL; if (c > best) { best = c; org = oy; } }
+            const unsigned bitj = 1u << (j - ecol - 1);
+            const bool match = (vb == rbv);
+            int best = x + (match ? SC_MATCH : SC_MISMATCH), org = ox;
+            unsigned kd = match ? kx : (kx | bitj);
+            { const int c = y + SC_DEL; if (c > best) { best = c; org = oy; kd = ky | bitj; } }
             const bool need = (j == next_need);
+            unsigned insbits = bitj | (bitj << 1);      // an insertion in column j dirties positions j-1 and j
             if (need) {
-                Osave[(size_t)kk * 64 + lane] = org;    // origin (previous edge) of the cell's entry move
+                // origin (previous edge) of the cell's entry move + dirty bits of the interval that ends here
+                OMsave[(size_t)kk * 64 + lane] = make_int2(org, (int)kd);
                 if (lane == 0) lo_need[kk] = lo;
                 org = i;                                // reset: this column is the new edge
+                kd = 0u; insbits = 0x80000001u; ecol = j;
             }
             // insertion chain with origin: (1) prefix max of d = c + 4*lane; (2) the winner of lane l is the highest
             // lane k <= l that attains its own running maximum ("record holder": ties keep the higher lane, as the
@@ -747,12 +805,13 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
             const int dd = wave_scan_max_i32(d0);
             const int key = wave_scan_max_i32(d0 == dd ? ((lane << 16) | org) : -1);
             const int xi = dd - 4 * lane;
-            if (xi > best) { best = xi; org = key & 0xffff; }
+            const unsigned ksrc = (unsigned)__shfl((int)kd, (key >> 16) & 63);   // dirty bits of the cell the insertion run starts from
+            if (xi > best) { best = xi; org = key & 0xffff; kd = ksrc | insbits; }
             if (i > I || best < NEGV / 2) best = NEGV;
             const int cm = wave_reduce_max_i32(best);
             const unsigned long long bal = __ballot(best == cm);
             br = lo + (__ffsll((long long)bal) - 1);
-            Mprev = best; Oprev = org;
+            Mprev = best; Oprev = org; Kprev = kd;
             if (need) {
                 ++kk;
                 next_need = (kk >= nneed) ? -1 : ((kk == nneed - 1) ? Ld : rfl(wb[(kk + 1) >> 1]) + ((kk & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
@@ -761,17 +820,32 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
     }
     const int oe = I - lo;
     int sc = NEGV, eLast = 0;
-    if (oe >= 0 && oe < LANES) { sc = rl(Mprev, oe); eLast = rl(Oprev, oe); }
+    unsigned kLast = 0u;
+    if (oe >= 0 && oe < LANES) { sc = rl(Mprev, oe); eLast = rl(Oprev, oe); kLast = (unsigned)rl((int)Kprev, oe); }
     const int valid = (sc > NEGV / 2 && sc >= Ld) ? 1 : 0;
     __threadfence_block();
     if (lane == 0) {
         P.ascore[r] = sc; P.avalid[r] = (uint8_t)valid;
         if (valid) {
             int32_t *ent = P.ent + P.ent_off[r];
+            uint32_t *dm = P.dmask + P.ent_off[r];
             int e = eLast;
             ent[nneed - 1] = e;
-            for (int k2 = nneed - 1; k2 >= 2; --k2) { e = Osave[(size_t)k2 * 64 + (e - lo_need[k2])]; ent[k2 - 1] = e; }
-            ent[0] = 0;
+            // interval k2 = columns col(k2-1)+1 .. col(k2); a set bit 31 in interval k2+1 (insertion while sitting on edge k2)
+            // dirties the last position of interval k2
+            unsigned carry = kLast >> 31;               // trailing insertions after the last draft position
+            for (int k2 = nneed - 1; k2 >= 1; --k2) {
+                const int cell = e - lo_need[k2];
+                const int2 om = OMsave[(size_t)k2 * 64 + cell];
+                unsigned mk = (unsigned)om.y;
+                const int cend = (k2 == nneed - 1) ? Ld : wb[(k2 + 1) >> 1] + ((k2 & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG);
+                const int cbeg = (k2 == 1) ? 0 : wb[k2 >> 1] + (((k2 - 1) & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG);
+                if (carry) mk |= 1u << (cend - cbeg - 1);
+                carry = mk >> 31;
+                dm[k2] = mk & 0x7fffffffu;
+                if (k2 >= 2) { e = om.x; ent[k2 - 1] = e; }
+            }
+            ent[0] = 0; dm[0] = 0u;
         }
     }
 }
@@ -793,15 +867,20 @@ __global__ void k_post(KParams P)
 }
 
 // ------------------------------------------------------------------------------------------------
-// A1-A6: Arrow polish of one window per workgroup (256 threads = 4 waves).
+// A1-A7 + step 7: Arrow polish of one window per workgroup (PW_THREADS = 4 waves).
 //
-// v2.  LDS holds: sCTX[obs][ctx] = (ME, INS) as float2 — 16 contexts = 16 distinct 8-byte slots, so a wave's
+// v3.  LDS holds: sCTX[obs][ctx] = (ME, INS) as float2 — 16 contexts = 16 distinct 8-byte slots, so a wave's
 // ds_read_b64 with a uniform obs row is bank-conflict free by construction; per-column copies sMI[strand][j][obs]
-// (row stride 13) for the fill; gamma/beta of one chunk of reads (sGB).  Fill: two reads per wave (lanes 0-31 /
-// 32-63, lane = read row) when both have <= 31 bases, alpha and beta swept in the same anti-diagonal loop
-// (two independent dependency chains), neighbours via DPP wave shifts.  Scoring: one lane per mutation, two
-// reads per loop (two chains), serial over read rows exactly as the SPEC orders the operations.
+// (row stride 13) for the fill; gamma/beta of one chunk of reads (sGB, ODD row stride: the fill's lane = row stores and
+// the scoring's lane = column loads are both conflict free).  Fill: two reads per wave (lanes 0-31 / 32-63, lane = read
+// row) when both have <= 31 bases, alpha and beta swept in the same anti-diagonal loop (two independent dependency
+// chains), neighbours via DPP wave shifts.  Candidate filter (docs/how-does-ccs-work.md:80-83): the step-3 alignments'
+// dirty bits give a per-position pile-up margin; unambiguous non-homopolymer positions enumerate no mutations.
+// Scoring: a pool of (64 compacted mutation lanes) x (pair of usable reads) tasks over the waves, serial over read rows
+// exactly as the SPEC orders the operations; per-read gains are summed in 2^-16 fixed point with LDS integer atomics, so
+// the sum does not depend on which wave scored which read.
 #define PW_THREADS 256
+#define PW_WAVES (PW_THREADS / 64)
 #define PW_MAXREADS 64
 #define GB_FLOATS 8448               // 33 KB of LDS for gamma/beta of one chunk of reads (3 workgroups per CU with allocation-granularity slack)
 #define MI_STRIDE 13
@@ -853,24 +932,50 @@ __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, cons
     s.ap = a; s.bp = b; s.b = b; s.pA = nA; s.pB = nB; s.bq = bqn;
 }
 
+// fixed-point image of one read's log2-likelihood gain (SPEC "integer sum over reads")
+__device__ __forceinline__ int dq_fix(float d)
+{
+    if (d < -DQ_CLAMP) d = -DQ_CLAMP;
+    if (d > DQ_CLAMP) d = DQ_CLAMP;
+    return (int)floorf(d * DQ_SCALE + 0.5f);
+}
+
+// error probability reported for a position the candidate filter skipped (pile-up margin g = clean - dirty)
+__device__ __forceinline__ float skip_perr(int g)
+{
+    if (g < 0) g = 0;
+    if (g > 12) g = 12;
+    return 8.0f * det_exp2f(-3.0f * (float)g);
+}
+
+// window-edge column of needed-column index k (k_align's list: 0, b1-2, b1+2, b2-2, ..., Ld)
+__device__ __forceinline__ int need_col(const int32_t *wb, int nw, int Ld, int k)
+{
+    return k == 0 ? 0 : (k == 2 * nw - 1 ? Ld : wb[(k + 1) >> 1] + ((k & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
+}
+
 __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
 {
     __shared__ float2 sCTX[CCSX_NOBS * 32];                  // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0)
-    __shared__ float sDL[16];
+    __shared__ float sDL[16], sZP[32];                       // sZP: z-score MU[16], VAR[16]
     __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
     __shared__ float sDLJ[2][32];
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
     __shared__ uint8_t sObs[PW_MAXREADS][68];                // 63 codes + look-ahead slack
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
-    __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
+    __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
+    __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS], sVlist[PW_MAXREADS];
     __shared__ float sBase[PW_MAXREADS];
     __shared__ short2 sTask[PW_MAXREADS];                    // fill tasks: (read A, read B or -1)
     __shared__ float sGB[GB_FLOATS];
-    __shared__ float sDelta[256];
+    __shared__ int sDeltaI[256];                             // fixed-point sums of the per-read gains; converted in place to float
+    float *sDelta = (float *)sDeltaI;                        // (each thread converts its own entry after the scoring barrier)
     __shared__ uint8_t sMvalid[256];
     __shared__ int sAcc[32];
-    __shared__ int sCtl[8];                                  // 0:J 1:cs 2:ce 3:nacc 5:chunk_end 6:ntasks
-    __shared__ int sCnt[4];
+    __shared__ int sCtl[12];                                 // 0:J 1:cs 2:ce 3:nacc 5:chunk_end 6:ntasks 7:ev bits 8:usable valid reads of the chunk
+    __shared__ float sZS[4];                                 // z-score sums: M fwd, V fwd, M rev, V rev
+    __shared__ float sPskip[36];                             // error probability of a position if it is skipped (travels with the base)
+    __shared__ int sCnt[PW_WAVES];
     __shared__ short sList[256];                             // compacted valid mutation lanes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -895,6 +1000,8 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
     const int lfv = draft[ws > 0 ? ws - 1 : 0], rfv = draft[we < Ld ? we : Ld - 1];
     const int lf = ws > 0 ? lfv : 4, rf = we < Ld ? rfv : 4;
+    // the (at most three) alignment intervals this window spans: start columns relative to ws and lengths
+    const int c1 = need_col(wb, nw, Ld, idx_ws + 1), c2 = (idx_ws + 2 <= idx_we) ? need_col(wb, nw, Ld, idx_ws + 2) : we;
     {
         // level 2: everything that needs only z / r0 / the window bounds
         const int e0 = tid, e1 = tid + PW_THREADS < CCSX_NOBS * 32 ? tid + PW_THREADS : tid;
@@ -902,6 +1009,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
         const int i0 = (e0 & 15) * CCSX_NOBS + (e0 >> 5), i1 = (e1 & 15) * CCSX_NOBS + (e1 >> 5);
         const float me0 = P.tabME[tz + i0], in0 = P.tabINS[tz + i0], me1 = P.tabME[tz + i1], in1 = P.tabINS[tz + i1];
         const float dl = P.tabDL[(size_t)z * 16 + (tid & 15)];
+        const float zp = P.tabZ[(size_t)z * 32 + (tid & 31)];
         const int tcl = tid < we - ws ? tid : we - ws - 1;
         const uint8_t dr = draft[ws + tcl];
         const int rcl = tid < nreads ? tid : nreads - 1;
@@ -910,9 +1018,13 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
         const int flr = P.flags[rr] & 1, av = P.avalid[rr];
         // level 3: entry rows of the window's two edge columns (in bounds for every read; ignored unless the read mapped)
         const int a = P.ent[eo + idx_ws], b = P.ent[eo + idx_we];
+        const unsigned m1 = P.dmask[eo + idx_ws + 1];
+        const unsigned m2 = (idx_ws + 2 <= idx_we) ? P.dmask[eo + idx_ws + 2] : 0u;
+        const unsigned m3 = (idx_ws + 3 <= idx_we) ? P.dmask[eo + idx_ws + 3] : 0u;
         sCTX[e0] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
         if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[e1] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
         if (tid < 16) sDL[tid] = dl;
+        if (tid < 32) sZP[tid] = zp;
         if (tid < we - ws) sT[0][tid] = dr;
         if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb0 - ws; sCtl[2] = wb1 - ws; }
         if (tid < nreads) {
@@ -926,22 +1038,24 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
             }
             sI[tid] = n; sStrand[tid] = (uint8_t)st;
             sGoff[tid] = (int)(bo0 - bo_r0) + na;            // segment start relative to the ZMW's first base (sGoff is re-planned later)
+            // interval k covers draft positions col(k-1) .. col(k)-1: bit (p - col(k-1))
+            sDirty[tid] = av ? (m1 | (m2 << (c1 - ws)) | (m3 << (c2 - ws))) : 0u;
         }
     }
     __syncthreads();
     // level 4: the read segments (native orientation), four reads per wave in flight
-    for (int rb = 0; rb < nreads; rb += 16) {
+    for (int rb = 0; rb < nreads; rb += 4 * PW_WAVES) {
         uint8_t bq[4], pq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = rb + 4 * q + wave;
+            const int r = rb + PW_WAVES * q + wave;
             const int n = r < nreads ? sI[r] : -1;
             const int64_t p = bo_r0 + ((lane < n) ? sGoff[r] + lane : 0);
             bq[q] = P.bases[p]; pq[q] = P.pw[p];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = rb + 4 * q + wave;
+            const int r = rb + PW_WAVES * q + wave;
             if (r < nreads) {
                 const int n = sI[r];
                 sObs[r][lane] = (lane < n) ? (uint8_t)obs_of(bq[q], pq[q]) : (uint8_t)0;   // rows beyond the segment read as obs 0
@@ -949,13 +1063,30 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
             }
         }
     }
+    // ---- step 7, candidate filter: pile-up margin of every window position over the reads with a usable segment
+    if (wave == 0) {
+        const int J0 = we - ws;
+        int nuse = 0, nd = 0;
+        for (int r = 0; r < nreads; ++r) if (sI[r] >= 0) { ++nuse; nd += (int)((sDirty[r] >> (lane & 31)) & 1u); }
+        const int margin = nuse - 2 * nd;
+        const bool inw = lane < J0;
+        const unsigned neg = (unsigned)__ballot(inw && margin < 0);
+        // positions within SKIP_SPREAD of a dirty majority are polished too
+        const unsigned nearneg = neg | (neg << 1) | (neg << 2) | (neg << 3) | (neg >> 1) | (neg >> 2) | (neg >> 3);
+        const bool ok = inw && !P.opts.disable_heuristics && margin >= SKIP_MARGIN && !((nearneg >> lane) & 1u);
+        const unsigned ev = (unsigned)__ballot(ok);
+        if (lane == 0) sCtl[7] = (int)ev;
+        if (lane < 36) sPskip[lane] = inw ? skip_perr(margin) : 0.0f;
+    }
     const int half = lane >> 5, hrow = lane & 31;          // fill: which read of the pair, row within it
     PHASE(0);
-    int iters = 0, nonconv = 0, nvalid_last = 0;
+    int iters = 0, nonconv = 0;
+    unsigned skmask = 0;                                     // positions skipped in the current round (wave-uniform)
+    int nvalid_last = 0;
     for (int it = 0; it < CCSX_MAX_ITER; ++it) {
         __syncthreads();
         const int J = sCtl[0];
-        const int S = (J + 2) & ~1;                          // even row stride >= J+1
+        const int S = (J + 1) | 1;                           // odd row stride >= J+1
         if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
         __syncthreads();
         const int lfr = (rf < 4) ? 3 - rf : 4;
@@ -968,8 +1099,28 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                 if (o == 0) sDLJ[sd][j] = sDL[k];
             }
         }
+        // z-score expectation of the window template on each strand, summed in column order (SPEC)
+        if (lane == 0 && wave < 2) {
+            const uint8_t *t = sT[wave];
+            float M = 0.0f, V = 0.0f;
+            for (int j = 0; j < J; ++j) {
+                const int prev = j > 0 ? t[j - 1] : (wave ? lfr : lf);
+                const int k = ctx_of(prev, t[j]);
+                M = M + sZP[k]; V = V + sZP[16 + k];
+            }
+            sZS[2 * wave] = M; sZS[2 * wave + 1] = V;
+        }
+        // positions skipped this round: evidence bit set and not inside a homopolymer of the CURRENT template
+        {
+            const uint8_t *t = sT[0];
+            const int c = lane & 31;
+            const int tc = c < J ? t[c] : 9;
+            const int prev = c > 0 ? (c - 1 < J ? t[c - 1] : 8) : lf, next = c + 1 < J ? t[c + 1] : rf;
+            const bool hp = (prev == tc) || (next == tc);
+            skmask = (unsigned)__ballot(lane < J && (((unsigned)sCtl[7] >> c) & 1u) && !hp);
+        }
         // valid mutation lanes of this round, compacted: lane m = slot*32 + c is valid iff the SPEC enumerates it;
-        // thread t then scores the t-th valid lane, so the ~30 % of unused lanes cost (almost) a whole wave less
+        // thread t then scores the t-th valid lane, so unused lanes cost nothing
         {
             const uint8_t *t = sT[0];
             const int sl0 = tid >> 5, c0 = tid & 31;
@@ -977,33 +1128,21 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
             if (sl0 < 3) v0 = c0 < J;
             else if (sl0 == 3) v0 = c0 < J && !(c0 > 0 && t[c0 - 1] == t[c0]);
             else v0 = c0 <= J && !(c0 > 0 && t[c0 - 1] == sl0 - 4);
+            if (v0 && ((skmask >> (c0 < J ? c0 : J - 1)) & 1u)) v0 = 0;       // candidate filter (insertions after the last column follow J-1)
             const unsigned long long bal = __ballot(v0);
             if (lane == 0) sCnt[wave] = __popcll(bal);
-            sMvalid[tid] = (uint8_t)v0; sDelta[tid] = 0.0f;
+            sMvalid[tid] = (uint8_t)v0; sDeltaI[tid] = 0;
             __syncthreads();
             int basew = 0;
             for (int q = 0; q < wave; ++q) basew += sCnt[q];
             if (v0) sList[basew + __popcll(bal & ((1ull << lane) - 1ull))] = (short)tid;
             __syncthreads();
         }
-        const int nvm = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
-        const int mval = tid < nvm;
-        const int myM = mval ? sList[tid] : 0;
-        const int slot = myM >> 5, cpos = myM & 31;
-        int type, x = 0;
-        {
-            const uint8_t *t = sT[0];
-            if (slot < 3) { type = 0; x = (t[cpos < J ? cpos : 0] + 1 + slot) & 3; }
-            else if (slot == 3) type = 1;
-            else { type = 2; x = slot - 4; }
-        }
-        LaneMut LF, LR;
-        if (mval) {
-            LF = lane_mut(type, cpos, x, sT[0], J, lf, sDL);
-            LR = lane_mut(type, (type == 2) ? J - cpos : J - 1 - cpos, 3 - x, sT[1], J, lfr, sDL);
-        } else { LF = lane_mut(0, 0, 0, sT[0], J, lf, sDL); LR = LF; }
+        int nvm = 0;
+#pragma unroll
+        for (int q = 0; q < PW_WAVES; ++q) nvm += sCnt[q];
+        const int nblk = (nvm + 63) >> 6;
         PHASE(1);
-        float delta = 0.0f;
         int nvalid = 0;
         // ---- chunks of reads whose gamma/beta fit the LDS budget
         int rbeg = 0;
@@ -1028,7 +1167,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
             const int rend = sCtl[5], ntask = sCtl[6];
             PHASE(2);
             // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals
-            for (int tk = wave; tk < ntask; tk += 4) {
+            for (int tk = wave; tk < ntask; tk += PW_WAVES) {
                 const short2 task = sTask[tk];
                 const bool paired = task.y >= 0;
                 const int myr = paired ? (half ? task.y : task.x) : task.x;
@@ -1090,6 +1229,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                 }
                 // zero row I+1 of beta, validity
                 if (row < S && (paired || lane < 32) ) sGB[sBoff[myr] + (I + 1) * S + row] = 0.0f;
+                if (!paired && lane >= 32 && lane < S) sGB[sBoff[myr] + (I + 1) * S + lane] = 0.0f;   // S can reach 33
                 const int basel = paired ? (half << 5) : 0;
                 const float aIJ = __shfl(acur, basel + I);
                 const float b00 = __shfl(bcur, basel);
@@ -1099,68 +1239,99 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                         la = det_log2f(aIJ); const float lb = det_log2f(b00);
                         float df = la - lb; if (df < 0.0f) df = -df;
                         v = !(df > AB_TOL);
+                        if (v && P.opts.min_zscore != 0.0f) {               // A7 z-score gate (x4 per emitted base = 2 bits per read base)
+                            const float zd = (la - (float)(2 * I)) - sZS[2 * sd];
+                            const float zm = P.opts.min_zscore;
+                            if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) v = 0;
+                        }
                     }
                     sValid[myr] = (uint8_t)v; sBase[myr] = la;
                 }
             }
             __syncthreads();
+            if (tid == 0) {                                                  // usable reads of the chunk, in read order
+                int nv = 0;
+                for (int r = rbeg; r < rend; ++r) if (sValid[r]) sVlist[nv++] = (uint8_t)r;
+                sCtl[8] = nv;
+            }
+            __syncthreads();
             PHASE(3);
-            // ---- A3/A4: every lane scores its mutation against the reads of the chunk, two reads per loop
-            int ra = rbeg;
-            const bool wave_has_work = (wave << 6) < nvm;            // wave-uniform: idle waves skip the scoring loops
-            while (wave_has_work && ra < rend) {
-                while (ra < rend && !sValid[ra]) ++ra;
-                if (ra >= rend) break;
-                int rb = ra + 1;
-                while (rb < rend && !sValid[rb]) ++rb;
-                const bool two = rb < rend;
-                const int Ia = sI[ra], Ib = two ? sI[rb] : -1;
-                const LaneMut La = sStrand[ra] ? LR : LF;
-                const LaneMut Lb = (two && sStrand[rb]) ? LR : LF;
-                const float *gamA = sGB + sGoff[ra] + La.c, *betA = sGB + sBoff[ra] + La.q;
-                const float *gamB = sGB + sGoff[two ? rb : ra] + Lb.c, *betB = sGB + sBoff[two ? rb : ra] + Lb.q;
-                const uint8_t *obA = sObs[ra], *obB = sObs[two ? rb : ra];
-                ScoreChain ca, cb;
-                ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f); ca.bq = betA[0];
-                cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f); cb.bq = betB[0];
-                const int Imin = two ? (Ia < Ib ? Ia : Ib) : -1;
-                int i = 0;
-                int oa = obA[0], ob = obB[0];                               // obs codes are fetched one row ahead
-                for (; i < Imin; ++i) {                                    // both chains, neither at its last row
-                    const int oan = obA[i + 1], obn = obB[i + 1];
-                    score_step(ca, La, sCTX, gamA, betA, S, i, oa, false);
-                    score_step(cb, Lb, sCTX, gamB, betB, S, i, ob, false);
-                    oa = oan; ob = obn;
+            // ---- A3/A4: task pool.  Task id = block * npairs + pair; a block is 64 compacted mutation lanes, a pair two usable
+            // reads (two independent chains per lane).  Gains are added to sDeltaI in fixed point (order independent).
+            {
+                const int nv = sCtl[8], npairs = (nv + 1) >> 1, ntk = nblk * npairs;
+                nvalid += nv;
+                int curblk = -1;
+                LaneMut LF, LR;
+                int myM = 0; bool mval = false;
+                for (int tk = wave; tk < ntk; tk += PW_WAVES) {
+                    const int blk = tk / npairs, pr = tk - blk * npairs;
+                    if (blk != curblk) {
+                        curblk = blk;
+                        const int li = blk * 64 + lane;
+                        mval = li < nvm;
+                        myM = mval ? sList[li] : 0;
+                        const int slot = myM >> 5, cpos = myM & 31;
+                        int type, x = 0;
+                        const uint8_t *t = sT[0];
+                        if (slot < 3) { type = 0; x = (t[cpos < J ? cpos : 0] + 1 + slot) & 3; }
+                        else if (slot == 3) type = 1;
+                        else { type = 2; x = slot - 4; }
+                        if (mval) {
+                            LF = lane_mut(type, cpos, x, sT[0], J, lf, sDL);
+                            LR = lane_mut(type, (type == 2) ? J - cpos : J - 1 - cpos, 3 - x, sT[1], J, lfr, sDL);
+                        } else { LF = lane_mut(0, 0, 0, sT[0], J, lf, sDL); LR = LF; }
+                    }
+                    const int ra = sVlist[2 * pr];
+                    const bool two = 2 * pr + 1 < nv;
+                    const int rb = two ? sVlist[2 * pr + 1] : ra;
+                    const int Ia = sI[ra], Ib = two ? sI[rb] : -1;
+                    const LaneMut La = sStrand[ra] ? LR : LF;
+                    const LaneMut Lb = (two && sStrand[rb]) ? LR : LF;
+                    const float *gamA = sGB + sGoff[ra] + La.c, *betA = sGB + sBoff[ra] + La.q;
+                    const float *gamB = sGB + sGoff[rb] + Lb.c, *betB = sGB + sBoff[rb] + Lb.q;
+                    const uint8_t *obA = sObs[ra], *obB = sObs[rb];
+                    ScoreChain ca, cb;
+                    ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f); ca.bq = betA[0];
+                    cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f); cb.bq = betB[0];
+                    const int Imin = two ? (Ia < Ib ? Ia : Ib) : -1;
+                    int i = 0;
+                    int oa = obA[0], ob = obB[0];                               // obs codes are fetched one row ahead
+                    for (; i < Imin; ++i) {                                    // both chains, neither at its last row
+                        const int oan = obA[i + 1], obn = obB[i + 1];
+                        score_step(ca, La, sCTX, gamA, betA, S, i, oa, false);
+                        score_step(cb, Lb, sCTX, gamB, betB, S, i, ob, false);
+                        oa = oan; ob = obn;
+                    }
+                    {
+                        int o = oa;
+                        for (int ia = i; ia <= Ia; ++ia) { const int on = obA[ia + 1]; score_step(ca, La, sCTX, gamA, betA, S, ia, o, ia == Ia); o = on; }
+                    }
+                    if (two) {
+                        int o = ob;
+                        for (int ib = i; ib <= Ib; ++ib) { const int on = obB[ib + 1]; score_step(cb, Lb, sCTX, gamB, betB, S, ib, o, ib == Ib); o = on; }
+                    }
+                    int dq;
+                    {
+                        const float res = La.fin ? ca.b : ca.acc;
+                        dq = dq_fix(det_log2f(res) - sBase[ra]);
+                    }
+                    if (two) {
+                        const float res = Lb.fin ? cb.b : cb.acc;
+                        dq += dq_fix(det_log2f(res) - sBase[rb]);
+                    }
+                    if (mval) atomicAdd(&sDeltaI[myM], dq);
                 }
-                {
-                    int o = oa;
-                    for (int ia = i; ia <= Ia; ++ia) { const int on = obA[ia + 1]; score_step(ca, La, sCTX, gamA, betA, S, ia, o, ia == Ia); o = on; }
-                }
-                if (two) {
-                    int o = ob;
-                    for (int ib = i; ib <= Ib; ++ib) { const int on = obB[ib + 1]; score_step(cb, Lb, sCTX, gamB, betB, S, ib, o, ib == Ib); o = on; }
-                }
-                {
-                    const float res = La.fin ? ca.b : ca.acc;
-                    const float dd = det_log2f(res) - sBase[ra];
-                    delta = delta + dd;
-                }
-                ++nvalid;
-                if (two) {
-                    const float res = Lb.fin ? cb.b : cb.acc;
-                    const float dd = det_log2f(res) - sBase[rb];
-                    delta = delta + dd;
-                    ++nvalid;
-                }
-                ra = two ? rb + 1 : rend;
             }
             rbeg = rend;
             PHASE(4);
         }
         ++iters;
-        if (wave == 0) nvalid_last = nvalid;
-        if (mval) sDelta[myM] = delta;
-        const int fav = (mval && delta > MUT_EPS) ? 1 : 0;
+        nvalid_last = nvalid;
+        __syncthreads();
+        const float delta = (float)sDeltaI[tid] * (1.0f / DQ_SCALE);
+        sDelta[tid] = delta;                                 // same slot, same thread
+        const int fav = (sMvalid[tid] && delta > MUT_EPS) ? 1 : 0;
         const int anyfav = __syncthreads_or(fav);
         if (!anyfav) break;
         if (it == CCSX_MAX_ITER - 1) { nonconv = 1; break; }
@@ -1191,6 +1362,7 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                 for (int a = 0; a < nacc; ++a) for (int b2 = a + 1; b2 < nacc; ++b2)
                     if ((sAcc[b2] & 31) > (sAcc[a] & 31)) { int tt = sAcc[a]; sAcc[a] = sAcc[b2]; sAcc[b2] = tt; }
                 int Jc = J, cs = sCtl[1], ce = sCtl[2];
+                unsigned ev = (unsigned)sCtl[7];
                 uint8_t *t = sT[0];
                 for (int a = 0; a < nacc; ++a) {
                     const int m = sAcc[a], sl = m >> 5, c = m & 31;
@@ -1199,13 +1371,23 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
                         for (int k = Jc; k > c; --k) t[k] = t[k - 1];
                         t[c] = (uint8_t)(sl - 4); ++Jc;
                         if (c < cs) { ++cs; ++ce; } else if (c < ce) ++ce;
+                        // the evidence bit and the skip probability travel with their base; an inserted base is a candidate
+                        const unsigned lowm = (1u << c) - 1u;
+                        ev = (ev & lowm) | ((ev & ~lowm) << 1);
+                        for (int k = CCSX_JMAX; k > c; --k) sPskip[k] = sPskip[k - 1];
+                        sPskip[c] = 0.0f;
                     } else {
                         for (int k = c; k + 1 < Jc; ++k) t[k] = t[k + 1];
                         --Jc;
                         if (c < cs) { --cs; --ce; } else if (c < ce) --ce;
+                        const unsigned lowm = (1u << c) - 1u;
+                        ev = (ev & lowm) | ((ev >> 1) & ~lowm);
+                        for (int k = c; k < CCSX_JMAX; ++k) sPskip[k] = sPskip[k + 1];
                     }
+                    // re-open the neighbourhood of the applied mutation for the following rounds
+                    for (int q = c - SKIP_SPREAD; q <= c + SKIP_SPREAD; ++q) if (q >= 0 && q < 32) ev &= ~(1u << q);
                 }
-                sCtl[0] = Jc; sCtl[1] = cs; sCtl[2] = ce; sCtl[3] = nacc;
+                sCtl[0] = Jc; sCtl[1] = cs; sCtl[2] = ce; sCtl[3] = nacc; sCtl[7] = (int)ev;
             }
         }
         __syncthreads();
@@ -1219,16 +1401,20 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
     float *sPerr = sGB;                                     // reuse
     if (tid < ce - cs) {
         const int c = cs + tid;
-        float s = 0.0f;
-        for (int sl = 0; sl < 8; ++sl) {
-            int m = sl * 32 + c;
-            if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }
+        float p;
+        if ((skmask >> c) & 1u) p = sPskip[c];              // skipped by the candidate filter: error probability from the pile-up margin
+        else {
+            float s = 0.0f;
+            for (int sl = 0; sl < 8; ++sl) {
+                int m = sl * 32 + c;
+                if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }
+            }
+            if (c == J - 1) for (int sl = 4; sl < 8; ++sl) {
+                int m = sl * 32 + J;
+                if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }
+            }
+            p = __fdiv_rn(s, 1.0f + s);
         }
-        if (c == J - 1) for (int sl = 4; sl < 8; ++sl) {
-            int m = sl * 32 + J;
-            if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }
-        }
-        float p = __fdiv_rn(s, 1.0f + s);
         if (p < 1e-10f) p = 1e-10f;
         float qv = -3.01029996f * det_log2f(p);
         if (qv < 0.0f) qv = 0.0f;
@@ -1433,17 +1619,20 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
 __global__ __launch_bounds__(64) void k_stitch(KParams P)
 {
     __shared__ double sSum;
+    __shared__ int sHist[65];                               // windows by number of passes used
     const int z = blockIdx.x, lane = threadIdx.x;
     int stat = P.zstat[z];
     const int nw = (stat == CCSX_SUCCESS) ? P.nwin[z] : 0;
     const size_t w0 = (size_t)(P.wb_off[z] - z);
     const int64_t so = P.seq_off[z], cap = P.seq_off[z + 1] - so;
     int run = 0, nvs = 0, its = 0, ncv = 0;
-    if (lane == 0) sSum = 0.0;
+    if (lane == 0) { sSum = 0.0; sHist[64] = 0; }
+    sHist[lane] = 0;
+    __syncthreads();
     for (int wbase = 0; wbase < nw; wbase += LANES) {
         const int w = wbase + lane;
         int4 mt = make_int4(0, 0, 0, 0);
-        if (w < nw) mt = P.wmeta[w0 + w];
+        if (w < nw) { mt = P.wmeta[w0 + w]; if ((unsigned)mt.y <= 64u) atomicAdd(&sHist[mt.y], 1); }
         int pre = mt.x;                                     // inclusive scan of lengths
 #pragma unroll
         for (int s = 1; s < LANES; s <<= 1) { int o = __shfl_up(pre, s); if (lane >= s) pre += o; }
@@ -1471,7 +1660,16 @@ __global__ __launch_bounds__(64) void k_stitch(KParams P)
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { nvs += __shfl_xor(nvs, s); its += __shfl_xor(its, s); ncv |= __shfl_xor(ncv, s); }
+    __syncthreads();
+    // np = mode over windows of the passes used for polishing (docs/faq/accuracy-vs-passes.md:18-24); ties: the smaller count
+    int npmode;
+    {
+        int key = (sHist[lane] << 7) | (127 - lane);
+        if (lane == 0) { const int k64 = (sHist[64] << 7) | (127 - 64); key = k64 > key ? k64 : key; }
+        npmode = 127 - (wave_max_i32(key) & 127);
+    }
     if (lane == 0) {
+        if (stat == CCSX_SUCCESS) P.np[z] = npmode;
         int64_t len = run; if (len > cap) len = cap;
         float rq = 0.0f, ec = 0.0f;
         if (stat == CCSX_SUCCESS) {

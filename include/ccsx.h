@@ -79,7 +79,10 @@ typedef struct ccsx_opts {
     float   min_rq;          /* --min-rq                                                        */
     int32_t poa_slots;       /* concurrent POA graphs resident on the device (0 = auto)          */
     int32_t hifi_kinetics;   /* --hifi-kinetics (docs/faq/kinetics.md:8-18): per-strand averaged IPD / PW; needs batch.ipd */
-    int32_t reserved[7];
+    int32_t disable_heuristics; /* --disable-heuristics (docs/faq/low-complexity.md:15): no candidate filter, every position is polished */
+    float   min_zscore;      /* a pass is dropped from a window when its z-score (log-likelihood vs the model's expectation for
+                                the window template) is below this; 0 = gate off                                   */
+    int32_t reserved[5];
 } ccsx_opts;
 
 /* ---- input batch: SoA + CSR ---- */

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <stdio.h>
 #include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -55,6 +56,11 @@
 #define JMIN_DEL  4         /* deletions are not applied when the window would shrink to <= JMIN_DEL */
 #define AB_TOL    0.01f     /* |log2 alpha(I,J) - log2 beta(0,0)| tolerance (alpha/beta agreement)   */
 #define TINY_P    1e-30f    /* a read whose scaled likelihood falls below this is unusable in the window */
+#define SKIP_MARGIN 6       /* candidate filter: a non-homopolymer position is skipped iff clean - dirty >= SKIP_MARGIN   */
+#define SKIP_SPREAD 3       /* ... and no position within SKIP_SPREAD of it has a dirty majority (clean - dirty < 0); the
+                               same neighbourhood of every applied mutation is polished in the following rounds           */
+#define DQ_SCALE  65536.0f  /* per-read log2-likelihood gains are summed as fixed point (2^-16): order independent      */
+#define DQ_CLAMP  100.0f
 
 typedef struct orc_model {
     char  name[32];
@@ -69,7 +75,10 @@ typedef struct orc_opts {
     int32_t max_poa_cov, min_passes, top_passes, min_length, max_length;
     float   min_rq;
     int32_t poa_slots;
-    int32_t reserved[8];
+    int32_t hifi_kinetics;
+    int32_t disable_heuristics;     /* --disable-heuristics: no candidate filter (every position is polished) */
+    float   min_zscore;             /* a pass is dropped from a window when its z-score is below this (0 = gate off) */
+    int32_t reserved[5];
 } orc_opts;
 
 /* ---------------- deterministic log2 / exp2 (DESIGN.md §SPEC "det math") -------------------------------- */
@@ -155,6 +164,51 @@ void orc_tables(const orc_model *m, const float *snr, float *ME, float *INS, flo
             else          INS[k * NOBS + o] = ((pS * m->em_stick[k][pwb]) * 0.333333333f) * 4.0f;
         }
         DL[k] = pD;
+    }
+}
+
+/* A7, z-score gate ([RECALL] unanimity AddRead: reads whose likelihood is improbably low under the model are not
+ * used; docs name the effect only: docs/faq/accuracy-vs-passes.md:22-24).  Per context k the mean MU[k] and variance
+ * VAR[k] of the log2-likelihood one template position contributes when a read is GENERATED by the model: a geometric
+ * number of stay events (branch / stick, each with its emission) followed by one advance (match with its emission, or
+ * deletion).  A read's z-score in a window is (log2 P(read | template) - sum_j MU[k_j]) / sqrt(sum_j VAR[k_j]).      */
+void orc_zparams(const orc_model *m, const float *snr, float *MU, float *VAR)
+{
+    for (int k = 0; k < NCTX; ++k) {
+        int cur = k & 3;
+        float s = snr[cur];
+        if (s < m->snr_lo) s = m->snr_lo;
+        if (s > m->snr_hi) s = m->snr_hi;
+        float w[3];
+        for (int mv = 0; mv < 3; ++mv) {
+            const float *c = m->trans_poly[k][mv];
+            float t = c[3] * s;
+            t = t + c[2];
+            t = t * s;
+            t = t + c[1];
+            t = t * s;
+            t = t + c[0];
+            if (t < 1e-6f) t = 1e-6f;
+            w[mv] = t;
+        }
+        float den = 1.0f + w[0];
+        den = den + w[1];
+        den = den + w[2];
+        float pM = 1.0f / den, pB = w[0] / den, pS = w[1] / den, pD = w[2] / den;
+        float pA = pM + pD, pI = pB + pS;
+        float lM = orc_log2f(pM), lD = orc_log2f(pD), lB = orc_log2f(pB), lS = orc_log2f(pS * 0.333333333f);
+        float e1m = 0.0f, e2m = 0.0f, e1b = 0.0f, e2b = 0.0f, e1s = 0.0f, e2s = 0.0f;
+        for (int o = 0; o < NOBS; ++o) { float p = m->em_match[k][o], l = orc_log2f(p), t = p * l; e1m = e1m + t; e2m = e2m + t * l; }
+        for (int b = 0; b < 3; ++b) { float p = m->em_branch[k][b], l = orc_log2f(p), t = p * l; e1b = e1b + t; e2b = e2b + t * l; }
+        for (int b = 0; b < 3; ++b) { float p = m->em_stick[k][b], l = orc_log2f(p), t = p * l; e1s = e1s + t; e2s = e2s + t * l; }
+        float a1 = (pM * (lM + e1m) + pD * lD) / pA;
+        float a2 = (pM * ((lM * lM + (2.0f * lM) * e1m) + e2m) + pD * (lD * lD)) / pA;
+        float s1 = (pB * (lB + e1b) + pS * (lS + e1s)) / pI;
+        float s2 = (pB * ((lB * lB + (2.0f * lB) * e1b) + e2b) + pS * ((lS * lS + (2.0f * lS) * e1s) + e2s)) / pI;
+        float vA = a2 - a1 * a1, vS = s2 - s1 * s1;
+        float EN = pI / pA, VN = pI / (pA * pA);
+        MU[k] = EN * s1 + a1;
+        VAR[k] = (EN * vS + VN * (s1 * s1)) + vA;
     }
 }
 
@@ -391,8 +445,11 @@ int orc_poa_draft(int nreads, const int64_t *base_off, const uint8_t *bases, con
     return len;
 }
 
-/* step 3: read (draft orientation) vs draft, global, adaptive band.  rstart[0..Ld]; returns 1 if valid. */
-int orc_align(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out)
+/* step 3: read (draft orientation) vs draft, global, adaptive band.  rstart[0..Ld]; returns 1 if valid.
+ * dirty (optional, [Ld]): the pile-up evidence of the candidate filter (docs/how-does-ccs-work.md:80-83) —
+ * dirty[p] = 1 iff the optimal path does not pass draft position p by a plain matching DIAG step: a mismatch or a
+ * deletion marks p; a read base inserted between positions p-1 and p marks both neighbours.                        */
+int orc_align_ev(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty)
 {
     int32_t *lo = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
     uint8_t *mv = (uint8_t *)malloc((size_t)(Ld + 1) * BAND);
@@ -414,29 +471,56 @@ int orc_align(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart
     if (valid) {
         /* rstart[j] = row at which the optimal path ENTERS column j (read bases consumed when draft
          * position j becomes the next one): insertions emitted while waiting at state j follow it. */
+        if (dirty) memset(dirty, 0, Ld);
         int i = I, j = Ld;
         while (j > 0) {
             int t = mv[(size_t)j * BAND + (i - lo[j])] & 3;
-            if (t == MV_INS) { --i; continue; }
+            if (t == MV_INS) {                              /* read base i-1 emitted while waiting in column j */
+                if (dirty) { dirty[j - 1] = 1; if (j < Ld) dirty[j] = 1; }
+                --i; continue;
+            }
             rstart[j] = i;
-            if (t == MV_DIAG) --i;
+            if (t == MV_DIAG) { if (dirty && d[j - 1] != r[i - 1]) dirty[j - 1] = 1; --i; }
+            else if (dirty) dirty[j - 1] = 1;               /* deletion of draft position j-1 */
             --j;
         }
+        if (i > 0 && dirty) dirty[0] = 1;                   /* leading insertions */
         rstart[0] = 0;
     }
     free(lo); free(mv);
     return valid;
 }
+int orc_align(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out)
+{
+    return orc_align_ev(r, I, d, Ld, rstart, score_out, NULL);
+}
 
-/* step 4: window core boundaries b[0]=0 < ... < b[n]=Ld ; returns n (docs/how-does-ccs-work.md:57-61) */
+/* step 4: window core boundaries b[0]=0 < ... < b[n]=Ld ; returns n (docs/how-does-ccs-work.md:57-61).
+ * "Avoid breaking windows at simple repeats (homopolymers to 4-mer repeats)": a boundary nb is bad when for some
+ * period p in 1..4 the p-mer before it equals the p-mer after it; the target boundary cur+22 is moved by
+ * 0,+1,-1,+2,-2,+3,-3 to the first good position (all bad: unmoved).                                              */
+static int win_bad_break(const uint8_t *d, int Ld, int cur, int nb)
+{
+    for (int p = 1; p <= 4; ++p) {
+        if (nb - p < cur || nb + p > Ld) continue;
+        int eq = 1;
+        for (int k = 0; k < p && eq; ++k) eq = (d[nb - p + k] == d[nb + k]);
+        if (eq) return 1;
+    }
+    return 0;
+}
 int orc_windows(const uint8_t *d, int Ld, int32_t *b, int cap)
 {
+    static const int off[7] = { 0, 1, -1, 2, -2, 3, -3 };
     int n = 0, cur = 0;
     b[0] = 0;
     while (cur < Ld) {
         int nb;
         if (Ld - cur <= WIN_CORE + 6) nb = Ld;
-        else { nb = cur + WIN_CORE; int sh = 0; while (sh < 3 && d[nb] == d[nb - 1]) { ++nb; ++sh; } }
+        else {
+            nb = cur + WIN_CORE;
+            for (int k = 0; k < 7; ++k) if (!win_bad_break(d, Ld, cur, cur + WIN_CORE + off[k])) { nb = cur + WIN_CORE + off[k]; break; }
+        }
         if (n + 1 >= cap) return -1;
         b[++n] = nb; cur = nb;
     }
@@ -546,15 +630,54 @@ static void revcomp_tpl(const wtpl_t *w, uint8_t *tr, int *lfr)
     *lfr = (w->rf < 4) ? 3 - w->rf : 4;
 }
 
+/* fixed-point image of one read's log2-likelihood gain (SPEC: the per-mutation sum over reads is an integer sum,
+ * so it does not depend on the order in which reads are visited)                                                   */
+static inline int32_t dq_fix(float d)
+{
+    if (d < -DQ_CLAMP) d = -DQ_CLAMP;
+    if (d > DQ_CLAMP) d = DQ_CLAMP;
+    return (int32_t)floorf(d * DQ_SCALE + 0.5f);
+}
+
+/* candidate filter state of a window: bit c of ev = "the pile-up allows skipping template position c"; the bit
+ * travels with its base when insertions / deletions are applied (an inserted base is always a candidate)            */
+static inline uint32_t ev_insert(uint32_t ev, int c) { uint32_t lowm = (c >= 32) ? 0xffffffffu : ((1u << c) - 1u); return (ev & lowm) | ((ev & ~lowm) << 1); }
+static inline uint32_t ev_delete(uint32_t ev, int c) { uint32_t lowm = (1u << c) - 1u; return (ev & lowm) | ((ev >> 1) & ~lowm); }
+/* positions skipped this round: evidence bit set and not part of a homopolymer run of the CURRENT template
+ * ("homopolymers are always polished", docs/how-does-ccs-work.md:82)                                               */
+static uint32_t skip_mask(const wtpl_t *w, uint32_t ev)
+{
+    uint32_t sk = 0;
+    for (int c = 0; c < w->J; ++c) {
+        int prev = c > 0 ? w->t[c - 1] : w->lf, next = c + 1 < w->J ? w->t[c + 1] : w->rf;
+        int hp = (prev == w->t[c]) || (next == w->t[c]);
+        if (((ev >> c) & 1u) && !hp) sk |= 1u << c;
+    }
+    return sk;
+}
+
+/* statistics / calibration hooks of the tests (never used by the product, which cannot link this file) */
+struct orc_dbg_s {
+    int32_t stats, calib;                 /* calib: run unfiltered and record the true p_err of skippable positions */
+    int64_t n_scored, n_windows, n_rounds, n_pos, n_evok;
+    int64_t cal_cnt[64]; double cal_sum[64]; float cal_max[64];
+} orc_dbg;
+
+static __thread uint32_t orc_dbg_calib_ev; static __thread int orc_dbg_margin[JMAX + 1];
 /* Polish one window.  obs[r] = native-orientation observation codes of read r's segment, I[r] its length
  * (I[r] < 0 or > IMAX: read unusable in this window), strand[r] = 1 if the read is reverse to the draft.
+ * ev0 = candidate-filter evidence of the draft window (bit c: position c may be skipped), skip_p = error
+ * probability reported for a skipped position.
  * Outputs the core sequence, per-base error probability and raw QV.  Returns number of scoring rounds.     */
 static int polish_window_impl(const float *ME, const float *INS, const float *DL,
                       const uint8_t *tpl, int J0, int cs, int ce, int lf, int rf,
                       int nreads, const uint8_t *const *obs, const int32_t *I, const uint8_t *strand,
+                      uint32_t ev0, const float *skip_p /* [J0] p_err of position c if it is skipped */,
+                      const float *MU, const float *VAR, float zmin /* z-score gate; MU == NULL or zmin == 0: off */,
                       uint8_t *out_seq, float *out_perr, float *out_qv, int32_t *out_len,
                       int32_t *out_nvalid, int32_t *out_nonconv, float *out_delta /* [256] optional */,
-                      wtpl_t *wfinal /* optional: the converged window template incl. overhangs */)
+                      wtpl_t *wfinal /* optional: the converged window template incl. overhangs */,
+                      int64_t *out_nscored /* optional: (mutation, read) evaluations */)
 {
     wtpl_t w; w.J = J0; w.cs = cs; w.ce = ce; w.lf = lf; w.rf = rf; memcpy(w.t, tpl, J0);
     float *gam = (float *)malloc(sizeof(float) * (size_t)nreads * (IMAX + 2) * GS);
@@ -562,9 +685,14 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
     float *base = (float *)malloc(sizeof(float) * nreads);
     uint8_t *valid = (uint8_t *)malloc(nreads);
     float delta[256]; uint8_t mvalid[256];
+    float pskip[JMAX + 2];                                   /* travels with the bases like ev */
+    for (int c = 0; c <= JMAX; ++c) pskip[c] = (skip_p && c < J0) ? skip_p[c] : 0.0f;
+    uint32_t ev = ev0, sk = 0;
     int iters = 0, nonconv = 0, nvalid = 0;
+    int64_t nscored = 0;
     for (int it = 0; it < MAX_ITER; ++it) {
         uint8_t tr[JMAX + 1]; int lfr; revcomp_tpl(&w, tr, &lfr);
+        sk = skip_mask(&w, ev);
         nvalid = 0;
         for (int r = 0; r < nreads; ++r) {
             valid[r] = 0;
@@ -576,13 +704,26 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
             if (!(a > TINY_P) || !(b > TINY_P)) continue;
             float la = orc_log2f(a), lb = orc_log2f(b);
             if (fabsf(la - lb) > AB_TOL) continue;
+            if (MU && zmin != 0.0f) {                        /* z-score gate; the x4 per emitted base is 2 bits per read base */
+                int kk[JMAX + 1]; tpl_ctx(strand[r] ? tr : w.t, w.J, strand[r] ? lfr : w.lf, kk);
+                float M = 0.0f, V = 0.0f;
+                for (int j = 0; j < w.J; ++j) { M = M + MU[kk[j]]; V = V + VAR[kk[j]]; }
+                float d = (la - (float)(2 * I[r])) - M;
+                if (orc_dbg.stats == 3) { float z = d / sqrtf(V); int bin = (int)floorf(z * 2.0f) + 32; if (bin < 0) bin = 0; if (bin > 63) bin = 63;
+                    _Pragma("omp atomic") orc_dbg.cal_cnt[bin] += 1; }
+                if (d < 0.0f && d * d > (zmin * zmin) * V) continue;
+            }
             base[r] = la; valid[r] = 1; ++nvalid;
         }
         for (int m = 0; m < 256; ++m) {
             int type, c, x; delta[m] = 0.0f;
             mvalid[m] = (uint8_t)mut_decode(m, w.t, w.J, &type, &c, &x);
+            if (mvalid[m]) {                                 /* candidate filter: insertions after the last column follow J-1 */
+                int cc = (c < w.J) ? c : w.J - 1;
+                if ((sk >> cc) & 1u) mvalid[m] = 0;
+            }
             if (!mvalid[m]) continue;
-            float dsum = 0.0f;
+            int32_t dsum = 0;
             for (int r = 0; r < nreads; ++r) {
                 if (!valid[r]) continue;
                 const float *g = gam + (size_t)r * (IMAX + 2) * GS, *be = bet + (size_t)r * (IMAX + 2) * GS;
@@ -592,9 +733,10 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
                     res = score_mut(ME, INS, DL, tr, w.J, lfr, obs[r], I[r], g, be, type, cr, 3 - x);
                 } else res = score_mut(ME, INS, DL, w.t, w.J, w.lf, obs[r], I[r], g, be, type, c, x);
                 float d = orc_log2f(res) - base[r];
-                dsum = dsum + d;
+                dsum += dq_fix(d);
+                ++nscored;
             }
-            delta[m] = dsum;
+            delta[m] = (float)dsum * (1.0f / DQ_SCALE);
         }
         ++iters;
         /* A5: greedy selection of favourable, well-separated mutations */
@@ -620,21 +762,47 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
         /* apply in descending position order */
         for (int a = 0; a < nacc; ++a) for (int b = a + 1; b < nacc; ++b)
             if ((acc_m[b] & 31) > (acc_m[a] & 31)) { int t = acc_m[a]; acc_m[a] = acc_m[b]; acc_m[b] = t; }
-        for (int a = 0; a < nacc; ++a) { int type = 0, c = 0, x = 0; mut_decode(acc_m[a], w.t, w.J, &type, &c, &x); tpl_apply(&w, type, c, x); }
+        for (int a = 0; a < nacc; ++a) {
+            int type = 0, c = 0, x = 0; mut_decode(acc_m[a], w.t, w.J, &type, &c, &x);
+            if (orc_dbg.stats == 2) {
+                fprintf(stderr, "  APPLY it %d type %d c %d x %d delta %.2f cs %d ce %d sk %08x tpl ", it, type, c, x, delta[acc_m[a]], w.cs, w.ce, sk);
+                for (int q = 0; q < w.J; ++q) fputc("ACGT"[w.t[q]], stderr);
+                fputc('\n', stderr);
+            }
+            if (orc_dbg_calib_ev && it == 0) {
+                wtpl_t w0 = w; uint32_t skc = skip_mask(&w0, orc_dbg_calib_ev);
+                int cc = c < w.J ? c : w.J - 1;
+                if ((skc >> cc) & 1u) {
+                    fprintf(stderr, "MISS type %d c %d x %d delta %.2f J %d tpl ", type, c, x, delta[acc_m[a]], w.J);
+                    for (int q = 0; q < w.J; ++q) fputc("ACGT"[w.t[q]], stderr);
+                    fprintf(stderr, " margins:");
+                    for (int q = 0; q < w.J; ++q) fprintf(stderr, " %d", orc_dbg_margin[q]);
+                    fputc('\n', stderr);
+                }
+            }
+            if (type == MT_INS) { ev = ev_insert(ev, c); memmove(pskip + c + 1, pskip + c, sizeof(float) * (JMAX - c)); pskip[c] = 0.0f; }
+            else if (type == MT_DEL) { ev = ev_delete(ev, c); memmove(pskip + c, pskip + c + 1, sizeof(float) * (JMAX - c)); }
+            tpl_apply(&w, type, c, x);
+            for (int q = c - SKIP_SPREAD; q <= c + SKIP_SPREAD; ++q) if (q >= 0 && q < 32) ev &= ~(1u << q);   /* re-open the neighbourhood */
+        }
     }
     /* A6: QVs from the last scoring round */
     int len = 0;
     for (int c = w.cs; c < w.ce; ++c) {
-        float s = 0.0f;
-        for (int slot = 0; slot < 8; ++slot) {
-            int m = slot * 32 + c;
-            if (mvalid[m]) { float d = delta[m]; if (d > 20.0f) d = 20.0f; s = s + orc_exp2f(d); }
+        float p;
+        if ((sk >> c) & 1u) p = pskip[c];                    /* skipped: error probability from the pile-up margin */
+        else {
+            float s = 0.0f;
+            for (int slot = 0; slot < 8; ++slot) {
+                int m = slot * 32 + c;
+                if (mvalid[m]) { float d = delta[m]; if (d > 20.0f) d = 20.0f; s = s + orc_exp2f(d); }
+            }
+            if (c == w.J - 1) for (int slot = 4; slot < 8; ++slot) {
+                int m = slot * 32 + w.J;
+                if (mvalid[m]) { float d = delta[m]; if (d > 20.0f) d = 20.0f; s = s + orc_exp2f(d); }
+            }
+            p = s / (1.0f + s);
         }
-        if (c == w.J - 1) for (int slot = 4; slot < 8; ++slot) {
-            int m = slot * 32 + w.J;
-            if (mvalid[m]) { float d = delta[m]; if (d > 20.0f) d = 20.0f; s = s + orc_exp2f(d); }
-        }
-        float p = s / (1.0f + s);
         if (p < 1e-10f) p = 1e-10f;
         float qv = -3.01029996f * orc_log2f(p);
         if (qv < 0.0f) qv = 0.0f;
@@ -644,6 +812,7 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
     *out_len = len; *out_nvalid = nvalid; *out_nonconv = nonconv;
     if (out_delta) memcpy(out_delta, delta, sizeof(delta));
     if (wfinal) *wfinal = w;
+    if (out_nscored) *out_nscored = nscored;
     free(gam); free(bet); free(base); free(valid);
     return iters;
 }
@@ -654,8 +823,19 @@ int orc_polish_window(const float *ME, const float *INS, const float *DL,
                       uint8_t *out_seq, float *out_perr, float *out_qv, int32_t *out_len,
                       int32_t *out_nvalid, int32_t *out_nonconv, float *out_delta /* [256] optional */)
 {
-    return polish_window_impl(ME, INS, DL, tpl, J0, cs, ce, lf, rf, nreads, obs, I, strand, out_seq, out_perr, out_qv,
-                              out_len, out_nvalid, out_nonconv, out_delta, NULL);
+    return polish_window_impl(ME, INS, DL, tpl, J0, cs, ce, lf, rf, nreads, obs, I, strand, 0u, NULL, NULL, NULL, 0.0f, out_seq, out_perr, out_qv,
+                              out_len, out_nvalid, out_nonconv, out_delta, NULL, NULL);
+}
+/* the same with the candidate filter: ev0 bit c = position c may be skipped, skip_p[c] its reported p_err */
+int orc_polish_window_ev(const float *ME, const float *INS, const float *DL,
+                      const uint8_t *tpl, int J0, int cs, int ce, int lf, int rf,
+                      int nreads, const uint8_t *const *obs, const int32_t *I, const uint8_t *strand,
+                      uint32_t ev0, const float *skip_p,
+                      uint8_t *out_seq, float *out_perr, float *out_qv, int32_t *out_len,
+                      int32_t *out_nvalid, int32_t *out_nonconv, float *out_delta /* [256] optional */)
+{
+    return polish_window_impl(ME, INS, DL, tpl, J0, cs, ce, lf, rf, nreads, obs, I, strand, ev0, skip_p, NULL, NULL, 0.0f, out_seq, out_perr, out_qv,
+                              out_len, out_nvalid, out_nonconv, out_delta, NULL, NULL);
 }
 
 /* ---------------- N4: HiFi kinetics (docs/faq/kinetics.md:8-18, tags docs/faq/bam-output.md:13-23) ------------
@@ -721,6 +901,34 @@ static inline uint8_t kin_mean_code(uint32_t sum, uint32_t cnt)
     return (uint8_t)orc_codec_v1_encode((int)((2u * sum + cnt) / (2u * cnt)));
 }
 
+/* banded unit-cost edit distance (accuracy tests: consensus vs the synthetic truth); band = max |i - j| explored */
+int orc_edit_distance(const uint8_t *a, int la, const uint8_t *b, int lb, int band)
+{
+    if (abs(la - lb) > band) return abs(la - lb) > band ? (la > lb ? la : lb) : 0;
+    int W = 2 * band + 1, INF = 1 << 29;
+    int *prev = (int *)malloc(sizeof(int) * W), *cur = (int *)malloc(sizeof(int) * W);
+    for (int k = 0; k < W; ++k) { int j = k - band; prev[k] = (j >= 0 && j <= lb) ? j : INF; }   /* row 0: j = i + k - band */
+    for (int i = 1; i <= la; ++i) {
+        for (int k = 0; k < W; ++k) {
+            int j = i + k - band, v = INF;
+            if (j >= 0 && j <= lb) {
+                if (j == 0) v = i;
+                else {
+                    int dg = prev[k] + (a[i - 1] != b[j - 1]);            /* (i-1, j-1) */
+                    int up = (k + 1 < W) ? prev[k + 1] + 1 : INF;          /* (i-1, j)   */
+                    int lf = (k > 0) ? cur[k - 1] + 1 : INF;               /* (i, j-1)   */
+                    v = dg < up ? dg : up; if (lf < v) v = lf;
+                }
+            }
+            cur[k] = v;
+        }
+        int *t = prev; prev = cur; cur = t;
+    }
+    int k = lb - la + band, r = (k >= 0 && k < W) ? prev[k] : INF;
+    free(prev); free(cur);
+    return r;
+}
+
 /* ---------------- first-principles helpers for tests/test_oracle_hmm.py ---------------------------------- */
 /* full refill likelihood of an explicit template: returns alpha(I,J) (scaled by 4^I), and beta(0,0) */
 void orc_window_likelihood(const float *ME, const float *INS, const float *DL, const uint8_t *t, int J, int lf,
@@ -760,6 +968,16 @@ double orc_bruteforce_likelihood(const float *ME, const float *INS, const float 
     return r;
 }
 
+/* error probability reported for a position the candidate filter skipped, from its pile-up margin g = clean - dirty:
+ * every agreeing pass multiplies the odds of each of the position's 8 mutations by well under 2^-3 (calibrated on
+ * the unfiltered path: tests/test_oracle_filter.py), so p = 8 * 2^(-3 g), at least the reporting floor.            */
+static inline float skip_perr(int g)
+{
+    if (g < 0) g = 0;
+    if (g > 12) g = 12;
+    return 8.0f * orc_exp2f(-3.0f * (float)g);
+}
+
 /* ---------------- whole-ZMW driver (steps 2,3,4,8,9,10) --------------------------------------------------- */
 typedef struct {
     int32_t status, seq_len, np, iters, n_windows;
@@ -796,6 +1014,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
     /* step 3 */
     int rev0 = flags[0] & 1;
     int32_t **rstart = (int32_t **)calloc(nreads, sizeof(int32_t *));
+    uint8_t **dirty = (uint8_t **)calloc(nreads, sizeof(uint8_t *));
     uint8_t *strand = (uint8_t *)malloc(nreads), *avalid = (uint8_t *)malloc(nreads);
     uint8_t *ob = (uint8_t *)malloc(maxL + 1);
     int np = 0;
@@ -804,8 +1023,9 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         strand[r] = (uint8_t)(((flags[r] & 1) != rev0) ? 1 : 0);
         orient(bases + base_off[r], NULL, L, strand[r], ob, NULL);
         rstart[r] = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
+        dirty[r] = (uint8_t *)malloc(Ld + 1);
         int32_t sc;
-        avalid[r] = (uint8_t)orc_align(ob, L, draft, Ld, rstart[r], &sc);
+        avalid[r] = (uint8_t)orc_align_ev(ob, L, draft, Ld, rstart[r], &sc, dirty[r]);
         np += avalid[r];
         if (avalid[r]) { if (strand[r]) out->rn += 1; else out->fn += 1; }
     }
@@ -815,16 +1035,19 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
     if (2 * np <= nreads) { out->status = ST_UNUSABLE; goto done; }
     {
         /* step 4 */
-        int wcap = Ld / WIN_CORE + 4;
+        int wcap = Ld / (WIN_CORE - 3) + 4;
         int32_t *wb = (int32_t *)malloc(sizeof(int32_t) * wcap);
         int nw = orc_windows(draft, Ld, wb, wcap);
         out->n_windows = nw;
         float ME[NCTX * NOBS], INS[NCTX * NOBS], DL[NCTX];
         orc_tables(model, snr, ME, INS, DL);
+        float MU[NCTX], VAR[NCTX];
+        orc_zparams(model, snr, MU, VAR);
         uint8_t *obuf = (uint8_t *)malloc((size_t)nreads * (IMAX + 1));
         const uint8_t **obs = (const uint8_t **)malloc(sizeof(uint8_t *) * nreads);
         int32_t *Iw = (int32_t *)malloc(sizeof(int32_t) * nreads);
         int64_t len = 0; double perr_sum = 0.0; int64_t nvalid_sum = 0; int nonconv_any = 0, overflow = 0;
+        int32_t nv_hist[65]; memset(nv_hist, 0, sizeof(nv_hist));
         for (int w = 0; w < nw; ++w) {
             int ws = wb[w] - WIN_OVH; if (ws < 0) ws = 0;
             int we = wb[w + 1] + WIN_OVH; if (we > Ld) we = Ld;
@@ -842,11 +1065,64 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                 uint8_t *oo = obuf + (size_t)r * (IMAX + 1);
                 for (int i = 0; i < n; ++i) oo[i] = (uint8_t)obs_of(bb[i], pp[i]);
             }
+            /* step 7, candidate filter (docs/how-does-ccs-work.md:80-83): pile-up of the step-3 alignments over the
+             * reads with a usable segment; position c may be skipped iff clean - dirty >= SKIP_MARGIN           */
+            uint32_t ev0 = 0; float skp[JMAX + 1]; int margin[JMAX + 1];
+            {
+                int nuse = 0;
+                for (int r = 0; r < nreads; ++r) if (Iw[r] >= 0) ++nuse;
+                for (int c = 0; c < J; ++c) {
+                    int nd = 0;
+                    for (int r = 0; r < nreads; ++r) if (Iw[r] >= 0) nd += dirty[r][ws + c];
+                    margin[c] = nuse - 2 * nd;
+                    skp[c] = skip_perr(margin[c]);
+                }
+                for (int c = 0; c < J; ++c) {
+                    int ok = !opts->disable_heuristics && margin[c] >= SKIP_MARGIN;
+                    for (int q = c - SKIP_SPREAD; ok && q <= c + SKIP_SPREAD; ++q) if (q >= 0 && q < J && margin[q] < 0) ok = 0;
+                    if (ok) ev0 |= 1u << c;
+                }
+            }
             uint8_t wseq[JMAX + 1]; float wperr[JMAX + 1], wqv[JMAX + 1]; int32_t wlen, wnv, wnc;
-            wtpl_t wf;
+            wtpl_t wf; int64_t nsc = 0;
+            orc_dbg_calib_ev = (orc_dbg.calib > 2) ? ev0 : 0u; memcpy(orc_dbg_margin, margin, sizeof(int) * J);
             int it = polish_window_impl(ME, INS, DL, draft + ws, J, cs, ce, lf, rf, nreads, obs, Iw, strand,
-                                        wseq, wperr, wqv, &wlen, &wnv, &wnc, NULL, &wf);
+                                        orc_dbg.calib ? 0u : ev0, skp, MU, VAR, opts->min_zscore, wseq, wperr, wqv, &wlen, &wnv, &wnc, NULL, &wf, &nsc);
             out->iters += it; nvalid_sum += wnv; nonconv_any |= wnc;
+            if (wnv >= 0 && wnv <= 64) nv_hist[wnv] += 1;
+            if (orc_dbg.stats == 2) {
+                fprintf(stderr, "WIN %d ws %d we %d cs %d ce %d it %d nv %d ev %08x draft ", w, ws, we, cs, ce, it, wnv, ev0);
+                for (int q = 0; q < J; ++q) fputc("ACGT"[draft[ws + q]], stderr);
+                fprintf(stderr, " core ");
+                for (int q = 0; q < wlen; ++q) fputc("ACGT"[wseq[q]], stderr);
+                fprintf(stderr, " margins");
+                for (int q = 0; q < J; ++q) fprintf(stderr, " %d", margin[q]);
+                fputc('\n', stderr);
+            }
+            if (orc_dbg.stats) {
+#pragma omp critical
+                {
+                    orc_dbg.n_scored += nsc; orc_dbg.n_windows += 1; orc_dbg.n_rounds += it;
+                    for (int c = cs; c < ce; ++c) { orc_dbg.n_pos += 1; if ((ev0 >> c) & 1u) orc_dbg.n_evok += 1; }
+                    if (orc_dbg.calib && it == 1 && wlen == ce - cs) {   /* unchanged window: true p_err of skippable positions by margin */
+                        wtpl_t w0; w0.J = J; w0.lf = lf; w0.rf = rf; memcpy(w0.t, draft + ws, J);
+                        uint32_t sk = skip_mask(&w0, 0xffffffffu);
+                        for (int c = cs; c < ce; ++c) if ((sk >> c) & 1u) {
+                            int g = margin[c]; if (g < 0) g = 0; if (g > 63) g = 63;
+                            orc_dbg.cal_cnt[g] += 1; orc_dbg.cal_sum[g] += wperr[c - cs];
+                            if (wperr[c - cs] > orc_dbg.cal_max[g]) orc_dbg.cal_max[g] = wperr[c - cs];
+                            if (orc_dbg.calib > 1 && g >= 6 && wperr[c - cs] > 1e-3f) {
+                                int nuse = 0; for (int r = 0; r < nreads; ++r) if (Iw[r] >= 0) ++nuse;
+                                fprintf(stderr, "CAL margin %d p %.3e c %d J %d nuse %d nvalid %d tpl ", g, wperr[c - cs], c, J, nuse, wnv);
+                                for (int q = 0; q < J; ++q) fputc("ACGT"[draft[ws + q]], stderr);
+                                fprintf(stderr, "  dirty:");
+                                for (int r = 0; r < nreads; ++r) if (Iw[r] >= 0) { fputc(' ', stderr); for (int q = 0; q < J; ++q) fputc(dirty[r][ws + q] ? 'x' : '.', stderr); }
+                                fputc('\n', stderr);
+                            }
+                        }
+                    }
+                }
+            }
             uint32_t ks[2][3][JMAX + 1];                          /* [strand][ipd, pw, count][forward column] */
             if (ipd) {
                 memset(ks, 0, sizeof(ks));
@@ -879,6 +1155,11 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         out->seq_len = (int32_t)len;
         out->rq = len > 0 ? (float)(1.0 - perr_sum / (double)len) : 0.0f;
         out->ec = nw > 0 ? (float)((double)nvalid_sum / (double)nw) : 0.0f;
+        {   /* np = mode over windows of the passes used for polishing (docs/faq/accuracy-vs-passes.md:18-24); ties: the smaller count */
+            int best = 0;
+            for (int v = 1; v <= 64; ++v) if (nv_hist[v] > nv_hist[best]) best = v;
+            out->np = best;
+        }
         if (len == 0) out->status = ST_EMPTY;
         else if (nonconv_any) out->status = ST_NONCONV;
         else if (out->rq < opts->min_rq) out->status = ST_LOWRQ;
@@ -887,8 +1168,8 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         free(wb); free(obuf); free(obs); free(Iw);
     }
 done:
-    for (int r = 0; r < nreads; ++r) free(rstart[r]);
-    free(rstart); free(strand); free(avalid); free(draft);
+    for (int r = 0; r < nreads; ++r) { free(rstart[r]); free(dirty[r]); }
+    free(rstart); free(dirty); free(strand); free(avalid); free(draft);
     return ret;
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/golden_v1.npz: inputs + expected outputs of the hot path.
+"""Generates tests/golden/golden_v2.npz: inputs + expected outputs of the hot path.
 
 The reference mount is documentation-only (no source, binary or test vectors: SURVEY.md §0/§8c), so these
 vectors come from this repository's own CPU restatement (oracle/ccs_oracle.c, "parity unpinned") at the
@@ -37,8 +37,8 @@ def main():
             out[f"{name}/out/{k}"] = getattr(r, k)
         out[f"{name}/draft0"] = O.poa_draft(b, 0, o.max_poa_cov)
     out["model_bytes"] = np.frombuffer(bytes(m), np.uint8)
-    np.savez_compressed(os.path.join(HERE, "golden_v1.npz"), **out)
-    print("wrote golden_v1.npz with", len(out), "arrays")
+    np.savez_compressed(os.path.join(HERE, "golden_v2.npz"), **out)
+    print("wrote golden_v2.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

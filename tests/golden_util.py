@@ -4,7 +4,7 @@ import numpy as np
 
 from ccs_amd import api
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v2.npz")
 CASES = ["p3_l300", "p5_l700", "p10_l2000", "mix"]
 
 

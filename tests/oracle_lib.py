@@ -84,7 +84,7 @@ def align(read_oriented, draft):
 
 def windows(draft):
     d = np.ascontiguousarray(draft, np.uint8)
-    cap = len(d) // 22 + 4
+    cap = len(d) // 19 + 4
     b = np.zeros(cap, np.int32)
     n = lib().orc_windows(_p(d, C.c_uint8), len(d), _p(b, C.c_int32), cap)
     return b[: n + 1].copy()

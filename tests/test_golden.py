@@ -1,4 +1,4 @@
-"""Committed golden vectors (tests/golden/golden_v1.npz, made by tests/golden/make_golden.py from the
+"""Committed golden vectors (tests/golden/golden_v2.npz, made by tests/golden/make_golden.py from the
 oracle): the oracle must keep reproducing them on CPU, the HIP path must reproduce them on the GPU."""
 import numpy as np
 import pytest
@@ -30,14 +30,14 @@ def test_gpu_reproduces_golden(built, case):
     h.close()
 
 
-# ---- HiFi kinetics (tests/golden/golden_kin_v1.npz, made by tests/golden/make_golden_kinetics.py) --------------------
+# ---- HiFi kinetics (tests/golden/golden_kin_v2.npz, made by tests/golden/make_golden_kinetics.py) --------------------
 KIN_CASES = ["p5_l700", "mix"]
 
 
 def _kin_case(case):
     import os
     batch, exp, _, _ = G.load(case)
-    g = np.load(os.path.join(os.path.dirname(G.GOLDEN), "golden_kin_v1.npz"))
+    g = np.load(os.path.join(os.path.dirname(G.GOLDEN), "golden_kin_v2.npz"))
     batch.ipd = np.ascontiguousarray(g[f"{case}/ipd"])
     return batch, exp, g[f"{case}/kin"], g[f"{case}/fn"], g[f"{case}/rn"]
 

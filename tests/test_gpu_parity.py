@@ -134,6 +134,18 @@ def test_baseline_config_shapes_bit_exact(handle, n, passes, length, seed):
     _compare(res, ref, batch)
 
 
+def test_headline_size_matches_oracle(handle):
+    """BASELINE configs[1] shape (10 passes x 10 kb) against the oracle itself, not only through properties:
+    64 ZMWs bit-exact (C2-size oracle parity inside -m gpu).  The oracle runs with OpenMP over ZMWs."""
+    import os
+    batch = api.synth(64, 10, 10000, seed=0xC2)
+    res = handle.consensus(batch)
+    ref = api.Results.allocate(batch)
+    O.consensus_batch(handle.model, handle.opts, batch, ref, nthreads=min(16, len(os.sched_getaffinity(0))))
+    _compare(res, ref, batch)
+    assert (res.status == 0).sum() >= 60
+
+
 def test_top_passes_and_poa_coverage_options(built):
     o = api.default_opts(); o.top_passes = 5; o.max_poa_cov = 3
     h = api.Handle(0, opts=o)

@@ -67,11 +67,29 @@ def test_windows_properties(built):
         b = O.windows(d)
         assert b[0] == 0 and b[-1] == L and (np.diff(b) > 0).all()
         core = np.diff(b)
-        assert core[:-1].min(initial=22) >= 22 and core[:-1].max(initial=22) <= 25 and core[-1] <= 28
+        assert core[:-1].min(initial=22) >= 19 and core[:-1].max(initial=22) <= 25 and core[-1] <= 28
         assert (core + 4 <= 31).all() or len(core) == 1
-        for x in b[1:-1]:                          # never break a homopolymer unless the 3-base shift is used up
-            if d[x] == d[x - 1]:
-                assert d[x - 1] == d[x - 2] == d[x - 3]
+
+        def bad(x):                                # SPEC: a break inside a tandem repeat of period 1..4
+            return any(x - p >= 0 and x + p <= L and np.array_equal(d[x - p:x], d[x:x + p]) for p in range(1, 5))
+        for k, x in enumerate(b[1:-1]):            # a bad break is only allowed when all seven candidates around cur+22 are bad
+            if bad(x):
+                cur = b[k]
+                assert x == cur + 22 and all(bad(cur + 22 + o) for o in (0, 1, -1, 2, -2, 3, -3))
+
+
+def test_windows_avoid_simple_repeats(built):
+    """docs/how-does-ccs-work.md:58-60: windows do not break homopolymers ... 4-mer repeats when a +-3 shift avoids it"""
+    rng = np.random.default_rng(5)
+    for unit in ("A", "TG", "CAG", "ACGT"):
+        d = rng.integers(0, 4, 200).astype(np.uint8)
+        rep = np.array(["ACGT".index(c) for c in unit * 3], np.uint8)[:5]      # a short tandem repeat across the target break
+        d[20:20 + len(rep)] = rep
+        d[19] = (rep[0] + 1) & 3 if unit != "A" else 1
+        b = O.windows(d)
+        x = int(b[1])
+        assert 19 <= x <= 25
+        assert not any(np.array_equal(d[x - p:x], d[x:x + p]) for p in range(1, 5))
 
 
 @pytest.mark.parametrize("passes,length,max_err", [(8, 600, 2), (12, 1500, 2)])
