@@ -59,6 +59,7 @@ def main():
                     "so kernels with different bottlenecks (POA: scalar issue, polish: VALU/LDS) overlap")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL; gloo for CPU-side tests)")
     ap.add_argument("--hifi-kinetics", action="store_true", help="also run the N4 kinetics kernel (not part of the headline metric)")
+    ap.add_argument("--disable-heuristics", action="store_true", help="polish every position (no candidate filter): A/B for the filter's cost")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -98,6 +99,7 @@ def main():
     parts = [batch.slice(i * args.zmws // nh, (i + 1) * args.zmws // nh) for i in range(nh)] if nh > 1 else [batch]
     opts = api.default_opts()
     opts.hifi_kinetics = 1 if args.hifi_kinetics else 0
+    opts.disable_heuristics = 1 if args.disable_heuristics else 0
     hs = [api.Handle(local_rank, opts=opts) for _ in range(nh)]
     h = hs[0]
     parts = [p.pinned() for p in parts]                      # page-locked staging, as the ccs driver uses

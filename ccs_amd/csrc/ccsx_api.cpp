@@ -165,11 +165,12 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     // ---- host-derived layout
     std::vector<int32_t> read_zmw(R), vcap(n), dcap(n);
     h->seq_off.assign(n + 1, 0); h->wb_off.assign(n + 1, 0); h->ent_off.assign(R + 1, 0);
-    int64_t maxL_max = 1, vcap_max = 1; int need_max = 2;
+    int64_t maxL_max = 1, vcap_max = 1; int need_max = 2, nr_max = 1;
     for (int z = 0; z < n; ++z) {
         int64_t maxL = 0;
         int nr = b->read_off[z + 1] - b->read_off[z];
         { const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > 64) ? 64 : h->opts.top_passes; if (nr > top) nr = top; }
+        nr_max = std::max(nr_max, nr);
         for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) {
             read_zmw[r] = z;
             const int64_t L = b->base_off[r + 1] - b->base_off[r];
@@ -286,6 +287,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     P.align_scratch = (int32_t *)h->d_align.p; P.align_slot_i32 = align_slot_i32; P.align_slots = align_slots;
     P.avalid = (uint8_t *)h->d_avalid.p; P.ascore = (int32_t *)h->d_ascore.p; P.ent = (int32_t *)h->d_ent.p; P.dmask = (uint32_t *)h->d_dmask.p;
     P.total_wslots = total_wslots;
+    if (ccsx_polish_lds(nr_max, &P.pw_obs_bytes, &P.pw_gb_floats)) { ccsx_set_error("ccsx_upload: cannot size the polish kernel's LDS"); return -2; }
     P.wseq = (uint8_t *)h->d_wseq.p; P.wqv = (float *)h->d_wqv.p; P.wsum = (float *)h->d_wsum.p; P.wmeta = (int4 *)h->d_wmeta.p;
     P.out_seq = (uint8_t *)h->d_out_seq.p; P.out_qual = (uint8_t *)h->d_out_qual.p; P.out_raw = (float *)h->d_out_raw.p;
     int32_t *oi = (int32_t *)h->d_out_i32.p;

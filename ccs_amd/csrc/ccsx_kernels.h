@@ -46,6 +46,7 @@ struct KParams {
     uint32_t *dmask;           // same indexing: pile-up dirty bits of the draft positions between two window-edge columns
     // ---- per-window polish outputs
     long long total_wslots;
+    int32_t pw_obs_bytes, pw_gb_floats;   // k_polish dynamic LDS: observation codes, gamma/beta floats
     uint8_t *wseq;             // [wslots][32]
     float *wqv;                // [wslots][32]
     float *wsum;               // [wslots] sum of p_err over the core
@@ -69,3 +70,4 @@ struct KParams {
 };
 
 void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev);
+int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats);

@@ -879,10 +879,17 @@ __global__ void k_post(KParams P)
 // Scoring: a pool of (64 compacted mutation lanes) x (pair of usable reads) tasks over the waves, serial over read rows
 // exactly as the SPEC orders the operations; per-read gains are summed in 2^-16 fixed point with LDS integer atomics, so
 // the sum does not depend on which wave scored which read.
-#define PW_THREADS 256
+#ifndef PW_THREADS
+#define PW_THREADS 256                // 4 waves.  Measured on the 10 x 10 kb workload (ms per 2048 ZMWs): 256 threads x 3 workgroups/CU 95,
+#endif                                //   512 x 2 (all ten reads in one LDS chunk) 101-103, 256 x 2 141, 320 x 2 208: resident waves per CU decide
+#ifndef PW_MINWAVES
+#define PW_MINWAVES 3
+#endif
 #define PW_WAVES (PW_THREADS / 64)
 #define PW_MAXREADS 64
-#define GB_FLOATS 8448               // 33 KB of LDS for gamma/beta of one chunk of reads (3 workgroups per CU with allocation-granularity slack)
+#ifndef PW_LDS_BYTES
+#define PW_LDS_BYTES 52992            // static + dynamic LDS of one workgroup: 3 workgroups per CU (160 KB) with allocation slack
+#endif
 #define MI_STRIDE 13
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
@@ -954,20 +961,22 @@ __device__ __forceinline__ int need_col(const int32_t *wb, int nw, int Ld, int k
     return k == 0 ? 0 : (k == 2 * nw - 1 ? Ld : wb[(k + 1) >> 1] + ((k & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
 }
 
-__global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
+__global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
 {
     __shared__ float2 sCTX[CCSX_NOBS * 32];                  // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0)
     __shared__ float sDL[16], sZP[32];                       // sZP: z-score MU[16], VAR[16]
     __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
     __shared__ float sDLJ[2][32];
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
-    __shared__ uint8_t sObs[PW_MAXREADS][68];                // 63 codes + look-ahead slack
+    // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta
+    uint8_t (*sObs)[68] = (uint8_t (*)[68])dyn_lds;
+    float *sGB = (float *)((uint8_t *)dyn_lds + P.pw_obs_bytes);
+    const int GB_FLOATS = P.pw_gb_floats;
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS], sVlist[PW_MAXREADS];
     __shared__ float sBase[PW_MAXREADS];
     __shared__ short2 sTask[PW_MAXREADS];                    // fill tasks: (read A, read B or -1)
-    __shared__ float sGB[GB_FLOATS];
     __shared__ int sDeltaI[256];                             // fixed-point sums of the per-read gains; converted in place to float
     float *sDelta = (float *)sDeltaI;                        // (each thread converts its own entry after the scoring barrier)
     __shared__ uint8_t sMvalid[256];
@@ -1127,11 +1136,12 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
             int v0;
             if (sl0 < 3) v0 = c0 < J;
             else if (sl0 == 3) v0 = c0 < J && !(c0 > 0 && t[c0 - 1] == t[c0]);
-            else v0 = c0 <= J && !(c0 > 0 && t[c0 - 1] == sl0 - 4);
+            else if (sl0 < 8) v0 = c0 <= J && !(c0 > 0 && t[c0 - 1] == sl0 - 4);
+            else v0 = 0;                                                      // threads 256.. own no mutation lane
             if (v0 && ((skmask >> (c0 < J ? c0 : J - 1)) & 1u)) v0 = 0;       // candidate filter (insertions after the last column follow J-1)
             const unsigned long long bal = __ballot(v0);
             if (lane == 0) sCnt[wave] = __popcll(bal);
-            sMvalid[tid] = (uint8_t)v0; sDeltaI[tid] = 0;
+            if (tid < 256) { sMvalid[tid] = (uint8_t)v0; sDeltaI[tid] = 0; }
             __syncthreads();
             int basew = 0;
             for (int q = 0; q < wave; ++q) basew += sCnt[q];
@@ -1329,9 +1339,9 @@ __global__ __launch_bounds__(PW_THREADS, 3) void k_polish(KParams P)
         ++iters;
         nvalid_last = nvalid;
         __syncthreads();
-        const float delta = (float)sDeltaI[tid] * (1.0f / DQ_SCALE);
-        sDelta[tid] = delta;                                 // same slot, same thread
-        const int fav = (sMvalid[tid] && delta > MUT_EPS) ? 1 : 0;
+        float delta = 0.0f;
+        if (tid < 256) { delta = (float)sDeltaI[tid] * (1.0f / DQ_SCALE); sDelta[tid] = delta; }   // same slot, same thread
+        const int fav = (tid < 256 && sMvalid[tid] && delta > MUT_EPS) ? 1 : 0;
         const int anyfav = __syncthreads_or(fav);
         if (!anyfav) break;
         if (it == CCSX_MAX_ITER - 1) { nonconv = 1; break; }
@@ -1694,6 +1704,21 @@ static void trace_sync(hipStream_t st, const char *what)
     fprintf(stderr, "[ccsx] %s done: %s\n", what, hipGetErrorString(e));
 }
 
+// dynamic LDS of k_polish: [reads][68] observation codes for the largest ZMW of the batch, the rest of the workgroup's
+// budget holds gamma/beta of one chunk of reads
+int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
+{
+    hipFuncAttributes fa;                                  // per call: the attribute is per device, handles live on several
+    if (hipFuncGetAttributes(&fa, (const void *)k_polish) != hipSuccess) return -1;
+    const int static_bytes = (int)fa.sharedSizeBytes;
+    if (hipFuncSetAttribute((const void *)k_polish, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES - static_bytes) != hipSuccess) return -1;
+    if (max_reads > PW_MAXREADS) max_reads = PW_MAXREADS;
+    if (max_reads < 1) max_reads = 1;
+    *obs_bytes = ((max_reads * 68) + 15) & ~15;
+    *gb_floats = (PW_LDS_BYTES - static_bytes - *obs_bytes) / 4;
+    return 0;
+}
+
 void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or NULL */)
 {
     if (ev) (void)hipEventRecord(ev[0], st);
@@ -1718,7 +1743,7 @@ void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or 
     trace_sync(st, "k_align");
     hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P);
     if (ev) (void)hipEventRecord(ev[3], st);
-    if (P.total_wslots > 0) hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), 0, st, P);
+    if (P.total_wslots > 0) hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), (size_t)P.pw_obs_bytes + (size_t)P.pw_gb_floats * 4, st, P);
     trace_sync(st, "k_polish");
     if (P.opts.hifi_kinetics && P.total_wslots > 0) {
         hipLaunchKernelGGL(k_kinetics, dim3((unsigned)P.total_wslots), dim3(256), 0, st, P);
