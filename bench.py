@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — ZMWs/s of the CCS per-ZMW consensus hot path on N MI355X (BASELINE.json metric).
 
-A "step" = one pass of the whole hot path (tables, POA draft, subread->draft alignment, windowing, Arrow
-polish + QVs, stitch) over one batch of synthetic ZMWs that is already resident in HBM.  Workload at N=1 is
-BASELINE.json configs[1]: 10 passes x 10 kb synthetic subreads (a --zmws sized slice of the 100k-ZMW job per
-step; every ZMW is independent so ZMWs/s does not depend on the job length).  ZMWs shard across ranks with
-no collective on the data path (weak scaling: per-GPU batch fixed).
+A "step" = one pass of the whole hot path (tables, POA draft, subread->draft alignment, windowing, candidate filter,
+Arrow polish + QVs, stitch) over one batch of synthetic ZMWs.  Workload at N=1 is BASELINE.json configs[1]: 10 passes x
+10 kb synthetic subreads, 8192 ZMWs per step; successive steps take successive DISTINCT batches (13 distinct batches =
+106 k ZMWs, the configs[1] job; a longer run cycles through them).  ZMWs shard across ranks with no collective on the data
+path (weak scaling: per-GPU batch fixed).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (HIP events on the library's own
-stream, via ccsx_get_timings); `cpu_baseline` times the CPU restatement (oracle, kind "port") on the host
-cores over a bounded sample of the same workload.
+Timed region: from the first submit to the last result of K steps through the library's asynchronous
+boundary (ccsx_submit / ccsx_wait): batches start in page-locked HOST memory, go H2D, through every kernel, and their
+results come back D2H into page-locked host memory; up to three batches are in flight, so the copies of batch k+1 / k-1
+run under the kernels of batch k.  `value` is that PCIe-inclusive rate.  `resident_zmws_per_s` is the same work counted
+over the kernels alone (HIP events on the compute stream): the rate with inputs already in HBM.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, its duration measured live with HIP events on the
+stream it is launched on (ccsx_ticket_timings); `cpu_baseline` times the CPU restatement (oracle, kind "port") on the host
+cores over a bounded sample of the same workload, and the reference `ccs` binary is probed for (command -v ccs).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -36,6 +43,25 @@ def effective_cores() -> int:
     return n
 
 
+def host_memory_budget() -> int:
+    """bytes of host memory this process may pin: MemAvailable capped by the cgroup limit, halved for safety"""
+    avail = 1 << 62
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        m = open("/sys/fs/cgroup/memory.max").read().strip()
+        if m != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+            avail = min(avail, int(m) - cur)
+    except Exception:
+        pass
+    return max(0, avail // 2)
+
+
 # BASELINE.json configs (SURVEY.md §8 sizes): (passes, template length, ZMWs per GPU per step in the default run)
 WORKLOADS = {"c1": (3, 1000, 65536), "c2": (10, 10000, 8192), "c4": (30, 20000, 1024), "c5": ((3, 50), (1000, 25000), 4096)}
 
@@ -48,15 +74,15 @@ def _span(v):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=13, help="timed steps (one batch each); the default 13 x 8192 ZMWs = the 100k-ZMW job of configs[1]")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="BASELINE.json config shape: c2 (default, the "
                     "one the metric is quoted on) 10 x 10 kb; c1 3 x 1 kb; c4 30 x 20 kb; c5 3-50 passes x 1-25 kb (log-uniform)")
     ap.add_argument("--zmws", type=int, default=0, help="ZMWs per GPU per step [workload default]")
     ap.add_argument("--passes", type=_span, default=None, help="passes per ZMW, N or LO-HI [workload default]")
     ap.add_argument("--length", type=_span, default=None, help="template length, N or LO-HI (log-uniform) [workload default]")
-    ap.add_argument("--handles", type=int, default=1, help="engine handles (HIP streams) per GPU; the batch is split between them "
-                    "so kernels with different bottlenecks (POA: scalar issue, polish: VALU/LDS) overlap")
+    ap.add_argument("--distinct", type=int, default=13, help="distinct synthetic batches the steps cycle through (bounded by host memory)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight (the engine has three batch slots)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL; gloo for CPU-side tests)")
     ap.add_argument("--hifi-kinetics", action="store_true", help="also run the N4 kinetics kernel (not part of the headline metric)")
     ap.add_argument("--disable-heuristics", action="store_true", help="polish every position (no candidate filter): A/B for the filter's cost")
@@ -67,6 +93,7 @@ def main():
     args.passes = wl[0] if args.passes is None else args.passes
     args.length = wl[1] if args.length is None else args.length
     args.zmws = wl[2] if args.zmws <= 0 else args.zmws
+    args.depth = max(1, min(3, args.depth))
 
     import numpy as np
     import torch
@@ -91,137 +118,154 @@ def main():
         graft.build()
     from ccs_amd import api
 
-    # ---- synthetic shard of this rank (deterministic; distinct ZMW ids per rank)
+    # ---- synthetic shards of this rank: distinct batches with distinct ZMW ids (deterministic), in page-locked memory
     t0 = time.time()
-    batch = api.synth(args.zmws, args.passes, args.length, seed=0xC0FFEE, first_zmw_id=rank * args.zmws)
+    first = api.synth(args.zmws, args.passes, args.length, seed=0xC0FFEE, first_zmw_id=rank * args.zmws)
+    batch_bytes = 4 * first.bases.nbytes                     # bases + pw + ipd page-locked, plus slack for the result buffers
+    nb = max(1, min(args.distinct, args.steps + args.warmup, host_memory_budget() // max(1, batch_bytes * world)))
+    alg_bytes = first.algorithmic_bytes()                   # 3*sum(len) + 48 + 2*L_out per ZMW
+    sample0 = first.slice(0, min(args.zmws, 4096))          # CPU baseline sample (pageable copy)
+    batches = [first.pinned()]
+    del first
+    for i in range(1, nb):
+        b = api.synth(args.zmws, args.passes, args.length, seed=0xC0FFEE, first_zmw_id=(i * world + rank) * args.zmws)
+        batches.append(b.pinned())
+        del b
     gen_s = time.time() - t0
-    nh = max(1, min(args.handles, args.zmws))
-    parts = [batch.slice(i * args.zmws // nh, (i + 1) * args.zmws // nh) for i in range(nh)] if nh > 1 else [batch]
     opts = api.default_opts()
     opts.hifi_kinetics = 1 if args.hifi_kinetics else 0
     opts.disable_heuristics = 1 if args.disable_heuristics else 0
-    hs = [api.Handle(local_rank, opts=opts) for _ in range(nh)]
-    h = hs[0]
-    parts = [p.pinned() for p in parts]                      # page-locked staging, as the ccs driver uses
-    t0 = time.time()
-    for hh, part in zip(hs, parts):
-        hh.upload(part)      # inputs resident in HBM before the timed region
-    for hh in hs:
-        hh.sync()
-    first_upload_s = time.time() - t0                        # includes every hipMalloc of the handle (POA scratch: tens of GB)
-    t0 = time.time()
-    for hh, part in zip(hs, parts):
-        hh.upload(part)      # steady state: device buffers are reused, this is layout + H2D only
-    for hh in hs:
-        hh.sync()
-    upload_s = time.time() - t0
+    h = api.Handle(local_rank, opts=opts)
+    kin = bool(args.hifi_kinetics)
+    # result buffers: one per batch in flight, page-locked, sized for the largest batch
+    def layout_cap(b):
+        cb = b.c_struct()
+        return int(api.lib().ccsx_result_layout(api.C.byref(cb), api._ptr(np.zeros(b.n_zmw + 1, np.int64), api.C.c_int64)))
+    big = max(batches, key=layout_cap)
+    results = [api.Results.allocate(big, kinetics=kin, pinned=True) for _ in range(args.depth)]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        for hh in hs:
-            hh.run()         # asynchronous launches on each handle's own stream
-        for hh in hs:
-            hh.sync()
+    def run_job(nsteps, collect):
+        """nsteps batches through the asynchronous boundary, `depth` in flight; returns (elapsed, per-ticket timings, stats)"""
+        tick = []
+        kt, ok, rqsum, rqn, checks = [], 0, 0.0, 0, 0
+        t_start = time.perf_counter()
+        for k in range(nsteps + args.depth):
+            if k >= args.depth:                              # retire the oldest batch before its slot / result buffer is reused
+                t_old = tick[k - args.depth]
+                r = h.wait(t_old)
+                n = batches[(k - args.depth) % nb].n_zmw
+                good = r.status[:n] == 0
+                ok += int(good.sum()); rqsum += float(r.rq[:n][good].sum()); rqn += int(good.sum())
+                checks += int(r.seq_len[:n].sum())
+                if collect:
+                    kt.append(h.ticket_timings(t_old))
+                h.release(t_old)
+            if k < nsteps:
+                b = batches[k % nb]
+                res = results[k % args.depth]
+                res_view = res if b.n_zmw == len(res.status) else None
+                if res_view is None:                         # ragged last batch cannot happen here (equal sizes); guard anyway
+                    raise RuntimeError("batches must have equal ZMW counts")
+                tick.append(h.submit(b, res))
+        return time.perf_counter() - t_start, kt, (ok, rqsum, rqn, checks)
 
-    for _ in range(args.warmup):
-        step()
+    t0 = time.time()
+    run_job(max(1, args.warmup), False)                      # untimed: every hipMalloc of the engine happens here
+    warm_s = time.time() - t0
     barrier()
-    t0 = time.perf_counter()
-    kt = []
-    for _ in range(args.steps):
-        step()
-        kt.append([hh.timings() for hh in hs])
+    elapsed, kt, (ok, rqsum, rqn, checks) = run_job(args.steps, True)
     barrier()
-    elapsed = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    t0 = time.time()
-    results = [hh.download() for hh in hs]
-    download_s = time.time() - t0
-    res = results[0]
-    ok = int(sum((r.status == 0).sum() for r in results))
-    rq_ok = np.concatenate([r.rq[r.status == 0] for r in results])
+
+    # un-overlapped copy times of one batch (context for the pipeline: what the copies would cost in the open)
+    t0 = time.time(); h.upload(batches[0]); h.sync(); upload_s = time.time() - t0
+    h.run(); h.sync()
+    res0 = h.download()                                      # also the GPU side of the CPU-baseline comparison
 
     if rank == 0:
         total_zmws = args.zmws * world * args.steps
         value = total_zmws / elapsed
-        # per-kernel launch durations (HIP events on each handle's stream), averaged over steps, summed over handles:
-        # with several handles the kernels of different handles overlap, so the sum can exceed the step time
-        stage_ms = {k: float(np.mean([sum(getattr(t, k) for t in step_t) for step_t in kt])) for k in
+        stage_ms = {k: float(np.mean([getattr(t, k) for t in kt])) for k in
                     ("setup_ms", "draft_ms", "align_ms", "polish_ms", "stitch_ms", "total_ms")}
         names = {"draft_ms": "k_poa", "align_ms": "k_align", "polish_ms": "k_polish", "stitch_ms": "k_stitch", "setup_ms": "k_setup"}
         dom = max(names, key=lambda k: stage_ms[k])
-        alg_bytes = batch.algorithmic_bytes()               # 3*sum(len) + 48 + 2*L_out per ZMW
-        # dominant kernel: algorithmic bytes of the whole step / summed launch duration of that kernel over the handles
+        # dominant kernel: algorithmic bytes of one batch / that kernel's average launch duration in the timed region
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-        # measured HBM traffic of that kernel (PMC 2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 passes,
-        # profiles/r01_traffic.json, per ZMW at the same 10 x 10 kb workload) scaled to the ZMWs of one launch
-        traffic = None
+        # HBM traffic and VALU issue of that kernel from this round's committed rocprofv3 PMC passes of the same workload
+        # (profiles/r02_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 with the calibrated FETCH_SIZE = bytes/2, per ZMW)
+        traffic, valu = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             kz = tj["kernels"][names[dom]]
-            if args.passes == 10 and args.length == 10000 and not args.hifi_kinetics:
-                traffic = int((2 * kz["fetch_size_kb_per_zmw"] + kz["write_size_kb_per_zmw"]) * 1024 * args.zmws)   # calibrated: FETCH_SIZE = bytes / 2
+            if args.passes == 10 and args.length == 10000 and not args.hifi_kinetics and not args.disable_heuristics:
+                traffic = int(kz["hbm_bytes_per_zmw"] * args.zmws)
+                valu = {k: kz[k] for k in ("valu_wave_instr_per_zmw", "valu_issue_frac_if_2cyc", "valu_issue_frac_if_4cyc", "lanes_active_frac") if k in kz}
+                valu["calibration"] = "profiles/r02_valu_peak.txt: v_add/mul_f32, v_add_u32 issue in 2 SIMD cycles per wave64, v_fma_f32, v_max_i32, DPP ops in 4"
         except Exception:
-            traffic = None
-        valu_busy = None
-        try:
-            valu_busy = tj["kernels"][names[dom]].get("valu_busy_frac")
-        except Exception:
-            pass
+            traffic, valu = None, None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 6), "traffic": traffic,
-                    # the interpretable ceiling of this integer/f32 stencil work is VALU issue, not HBM: measured occupancy of the
-                    # vector ALUs by that kernel (rocprofv3 SQ_THREAD_CYCLES_VALU, committed under profiles/)
-                    "valu_busy_frac": valu_busy,
-                    "avg_launch_ms": round(stage_ms[dom], 3), "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d)"}
+                    "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic else None,
+                    "avg_launch_ms": round(stage_ms[dom], 3), "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
+                    "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d); "
+                            "the kernel is bound by VALU issue and dependent-chain latency (DESIGN.md 4)"}
+        c2 = args.workload == "c2" and args.passes == 10 and args.length == 10000
         out = {
-            "metric": "ZMWs/sec (HiFi reads/sec), 10-pass x 10 kb synthetic" if args.workload == "c2" and args.passes == 10 and args.length == 10000
-                      else f"ZMWs/sec, {args.passes} passes x {args.length} bp synthetic", "value": round(value, 2), "unit": "ZMWs/s",
+            "metric": "ZMWs/sec (HiFi reads/sec), 10-pass x 10 kb synthetic" if c2 else f"ZMWs/sec, {args.passes} passes x {args.length} bp synthetic",
+            "value": round(value, 2), "unit": "ZMWs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.passes} passes x {args.length} bp synthetic subreads (BASELINE configs[{int(args.workload[1]) - 1}] shape), "
-                                   f"{args.zmws} ZMWs per GPU per step", "preset": args.workload, "zmws_per_gpu": args.zmws, "handles_per_gpu": nh, "passes": args.passes,
+                                   f"{args.zmws} ZMWs per GPU per step, {nb} distinct batches, host-pinned -> H2D -> kernels -> D2H, {args.depth} batches in flight",
+                       "preset": args.workload, "zmws_per_gpu": args.zmws, "distinct_batches": nb, "in_flight": args.depth, "passes": args.passes,
                        "template_len": args.length, "parallelism": f"zmw-shard x{world}", "model": "SYN-1",
-                       "hifi_kinetics": bool(args.hifi_kinetics)},
+                       "hifi_kinetics": kin, "candidate_filter": not args.disable_heuristics},
+            "timed_region": "first ccsx_submit to last ccsx_wait: pinned host -> H2D -> kernels -> D2H (PCIe-inclusive)",
+            "resident_zmws_per_s": round(args.zmws * world / (stage_ms["total_ms"] * 1e-3), 2),
             "roofline": roofline,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
-            "success_frac": ok / args.zmws, "mean_rq": float(rq_ok.mean()) if ok else None,
-            "host": {"synth_s": round(gen_s, 2), "first_upload_s": round(first_upload_s, 3), "upload_s": round(upload_s, 3), "download_s": round(download_s, 3),
-                     "pcie_inclusive_zmws_per_s": round(args.zmws / (elapsed / args.steps + upload_s + download_s), 2)},
+            "success_frac": ok / (args.zmws * args.steps), "mean_rq": rqsum / rqn if rqn else None, "consensus_bases": checks,
+            "host": {"synth_s": round(gen_s, 2), "warmup_s": round(warm_s, 2), "unoverlapped_upload_s": round(upload_s, 3),
+                     "copies_hidden_frac": round(min(1.0, stage_ms["total_ms"] * 1e-3 / (elapsed / args.steps)), 4)},
         }
+        # the reference tool, if the box has it (SURVEY.md §8c/d: expected absent; bioconda pbccs)
+        ccs_bin = shutil.which("ccs")
+        out["reference_ccs"] = {"found": bool(ccs_bin), "path": ccs_bin,
+                                "note": "command -v ccs on this box; not timed" if not ccs_bin else "present: see DESIGN.md for the concordance run"}
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             import oracle_lib
             cores = effective_cores()
-            probe = batch.slice(0, 1)
+            probe = sample0.slice(0, 1)
             pr = api.Results.allocate(probe)
             t1 = time.perf_counter()
             oracle_lib.consensus_batch(h.model, h.opts, probe, pr, nthreads=1)
             t1 = time.perf_counter() - t1
-            n_s = int(min(args.zmws, max(cores, round(args.cpu_seconds * cores / max(t1, 1e-3)))))
-            n_s = max(cores, (n_s // cores) * cores)    # whole rounds of one ZMW per thread
-            n_s = min(n_s, parts[0].n_zmw)              # compared against the results of handle 0
-            sample = batch.slice(0, n_s)
+            n_s = int(min(sample0.n_zmw, max(cores, round(args.cpu_seconds * cores / max(t1, 1e-3)))))
+            n_s = min(sample0.n_zmw, max(cores, (n_s // cores) * cores))    # whole rounds of one ZMW per thread
+            sample = sample0.slice(0, n_s)
             sr = api.Results.allocate(sample)
             t2 = time.perf_counter()
             oracle_lib.consensus_batch(h.model, h.opts, sample, sr, nthreads=cores)
             t2 = time.perf_counter() - t2
-            same = all(np.array_equal(sr.sequence(z), res.sequence(z)) for z in range(n_s))
+            same = all(np.array_equal(sr.sequence(z), res0.sequence(z)) for z in range(n_s))
+            qv_max = max((float(np.max(np.abs(sr.raw(z) - res0.raw(z)))) if len(sr.raw(z)) else 0.0) for z in range(n_s)) if same else None
             out["cpu_baseline"] = {"value": round(n_s / t2, 3), "unit": "ZMWs/s", "cores": cores, "kind": "port",
-                                   "sample": f"first {n_s} ZMWs of the same batch, oracle/ccs_oracle.c with OpenMP over ZMWs "
-                                             f"({t2:.1f} s wall; single-thread probe {t1:.2f} s/ZMW); reference ccs binary unavailable (docs-only mount)",
-                                   "gpu_matches_cpu_sequences": bool(same)}
+                                   "sample": f"first {n_s} ZMWs of batch 0, oracle/ccs_oracle.c with OpenMP over ZMWs "
+                                             f"({t2:.1f} s wall; single-thread probe {t1:.2f} s/ZMW); reference ccs binary "
+                                             f"{'found at ' + ccs_bin if ccs_bin else 'not on PATH (probed)'}",
+                                   "gpu_matches_cpu_sequences": bool(same), "max_abs_qv_diff": qv_max,
+                                   "context": "the port does ~0.2 core-s per ZMW; docs/img/runtime.png shows ~1 core-s for ccs 4.2 at 10 kb x 7 passes, so this "
+                                              "ratio is not a statement about ccs (PacBio's own GPU claim: 10x over 128 cores, docs/faq/revio.md:23-25)"}
             out["speedup_vs_cpu_all_cores"] = round(value / (n_s / t2), 2)
         print(json.dumps(out), flush=True)
-    for hh in hs:
-        hh.close()
+    h.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -41,7 +41,7 @@ class Opts(C.Structure):
     _fields_ = [
         ("max_poa_cov", C.c_int32), ("min_passes", C.c_int32), ("top_passes", C.c_int32),
         ("min_length", C.c_int32), ("max_length", C.c_int32), ("min_rq", C.c_float),
-        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("disable_heuristics", C.c_int32), ("min_zscore", C.c_float), ("reserved", C.c_int32 * 5),
+        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("disable_heuristics", C.c_int32), ("min_zscore", C.c_float), ("handles_per_device", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -84,6 +84,7 @@ EXPORTS = [
     "ccsx_create", "ccsx_destroy", "ccsx_result_layout", "ccsx_consensus_batch", "ccsx_upload", "ccsx_run",
     "ccsx_sync", "ccsx_download", "ccsx_get_timings", "ccsx_stage_draft", "ccsx_stage_align",
     "ccsx_stage_windows", "ccsx_synth_generate", "ccsx_synth_free", "ccsx_alloc_pinned", "ccsx_free_pinned",
+    "ccsx_submit", "ccsx_wait", "ccsx_poll", "ccsx_ticket_timings",
 ]
 
 _lib = None
@@ -106,6 +107,10 @@ def lib() -> C.CDLL:
         L.ccsx_download.argtypes = [C.c_void_p, C.POINTER(CResults)]
         L.ccsx_consensus_batch.argtypes = [C.c_void_p, C.POINTER(CBatch), C.POINTER(CResults)]
         L.ccsx_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+        L.ccsx_submit.argtypes = [C.c_void_p, C.POINTER(CBatch), C.POINTER(CResults), C.POINTER(C.c_int64)]
+        L.ccsx_wait.argtypes = [C.c_void_p, C.c_int64]
+        L.ccsx_poll.argtypes = [C.c_void_p, C.c_int64]
+        L.ccsx_ticket_timings.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Timings)]
         L.ccsx_stage_draft.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint8), C.c_int32, C.POINTER(C.c_int32)]
         L.ccsx_stage_align.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -272,15 +277,33 @@ class Results:
     kin: np.ndarray | None = None        # [4, capacity] planes fi, fp, ri, rp (CodecV1 codes); None without kinetics
 
     @staticmethod
-    def allocate(batch: Batch, kinetics: bool = False) -> "Results":
+    def allocate(batch: Batch, kinetics: bool = False, pinned: bool = False) -> "Results":
+        """pinned=True puts every array in page-locked memory (ccsx_alloc_pinned): asynchronous downloads (Handle.submit)
+        then run by DMA at PCIe rate."""
         n = batch.n_zmw
         cb = batch.c_struct()
         off = np.zeros(n + 1, np.int64)
         cap = lib().ccsx_result_layout(C.byref(cb), _ptr(off, C.c_int64))
-        return Results(off, np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(cap, np.uint8), np.zeros(cap, np.uint8),
-                       np.zeros(cap, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.float32),
-                       np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32),
-                       np.zeros((4, cap), np.uint8) if kinetics else None)
+        keep = []
+
+        def z(shape, dt):
+            if not pinned:
+                return np.zeros(shape, dt)
+            nb = max(1, int(np.prod(shape)) * np.dtype(dt).itemsize)
+            p = lib().ccsx_alloc_pinned(nb)
+            if not p:
+                raise RuntimeError("ccsx_alloc_pinned failed: " + lib().ccsx_last_error().decode())
+            keep.append(_Pinned(p))
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nb,))[: int(np.prod(shape)) * np.dtype(dt).itemsize]
+            a = a.view(dt).reshape(shape)
+            a[...] = 0
+            return a
+        r = Results(off, z(n, np.int32), z(n, np.int32), z(cap, np.uint8), z(cap, np.uint8),
+                    z(cap, np.float32), z(n, np.float32), z(n, np.int32), z(n, np.float32),
+                    z(n, np.int32), z(n, np.int32), z(n, np.int32), z(n, np.int32),
+                    z((4, cap), np.uint8) if kinetics else None)
+        r._pinned = keep
+        return r
 
     def c_struct(self) -> CResults:
         r = CResults()
@@ -364,6 +387,34 @@ class Handle:
     def timings(self) -> Timings:
         t = Timings()
         self._check(self._L.ccsx_get_timings(self._h, C.byref(t)), "ccsx_get_timings")
+        return t
+
+    # ---- asynchronous pipeline (ccsx_submit / ccsx_wait): up to three batches in flight, copies under compute
+    def submit(self, batch: Batch, res: "Results") -> int:
+        cb, cr = batch.c_struct(), res.c_struct()
+        t = C.c_int64()
+        self._check(self._L.ccsx_submit(self._h, C.byref(cb), C.byref(cr), C.byref(t)), "ccsx_submit")
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight[t.value] = (batch, res, cb, cr)      # the C structs and arrays must outlive the ticket
+        return t.value
+
+    def wait(self, ticket: int) -> "Results":
+        self._check(self._L.ccsx_wait(self._h, ticket), "ccsx_wait")
+        return self._inflight[ticket][1]
+
+    def release(self, ticket: int):
+        self._inflight.pop(ticket, None)
+
+    def poll(self, ticket: int) -> bool:
+        rc = self._L.ccsx_poll(self._h, ticket)
+        if rc < 0:
+            self._check(rc, "ccsx_poll")
+        return rc == 1
+
+    def ticket_timings(self, ticket: int) -> Timings:
+        t = Timings()
+        self._check(self._L.ccsx_ticket_timings(self._h, ticket, C.byref(t)), "ccsx_ticket_timings")
         return t
 
     def stage_draft(self, z: int) -> np.ndarray:

@@ -3,7 +3,10 @@
 #include "ccsx.h"
 #include "ccsx_internal.h"
 
+#include <atomic>
+#include <algorithm>
 #include <cmath>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -112,6 +115,50 @@ static int draw_pw(Rng &g, const double *pmf)
     return u < pmf[0] ? 1 : (u < pmf[0] + pmf[1] ? 2 : 3);
 }
 
+// one ZMW's arrays; the stream of ZMW id depends only on (seed, id), so ZMWs are generated independently (in parallel)
+struct SynthZmw {
+    float snr[4];
+    std::vector<uint8_t> bases, pw, ipd, flags, tpl;
+    std::vector<int64_t> read_end;      // exclusive end of every read within `bases`
+};
+
+static void synth_one(int id, int32_t passes_lo, int32_t passes_hi, int32_t len_lo, int32_t len_hi, uint64_t seed, SynthZmw &o)
+{
+    static const double PM[3] = {0.30, 0.30, 0.40}, PX[3] = {0.60, 0.25, 0.15};
+    static const double P_DEL = 0.04, P_SUB = 0.01, P_INS = 0.06;
+    Rng g(seed ^ 0xCC5ull ^ ((uint64_t)id * 0x9E3779B97F4A7C15ull));
+    const int P = passes_lo + g.below(passes_hi - passes_lo + 1);
+    int L = len_lo;
+    if (len_hi > len_lo) L = (int)std::floor(std::exp(std::log((double)len_lo) + g.uni() * (std::log((double)len_hi) - std::log((double)len_lo))) + 0.5);
+    static const float base_snr[4] = {9.0f, 16.0f, 8.0f, 13.0f};
+    for (int c = 0; c < 4; ++c) {
+        float s = base_snr[c] * (float)(1.0 + 0.1 * g.gauss());
+        o.snr[c] = s < 4.0f ? 4.0f : s;
+    }
+    std::vector<uint8_t> &t = o.tpl, tr(L);
+    t.resize(L);
+    for (int j = 0; j < L; ++j) t[j] = (uint8_t)g.below(4);
+    for (int j = 0; j < L; ++j) tr[j] = (uint8_t)(3 - t[L - 1 - j]);
+    o.bases.reserve((size_t)P * (L + L / 16)); o.pw.reserve(o.bases.capacity()); o.ipd.reserve(o.bases.capacity());
+    for (int k = 0; k < P; ++k) {
+        const int rev = k & 1;
+        const std::vector<uint8_t> &src = rev ? tr : t;
+        for (int j = 0; j < L; ++j) {
+            while (g.uni() < P_INS) {   // extra base before consuming src[j]: half cognate (branch), half not (stick)
+                uint8_t b = src[j];
+                if (g.uni() >= 0.5) b = (uint8_t)((b + 1 + g.below(3)) & 3);
+                o.bases.push_back(b); o.pw.push_back((uint8_t)draw_pw(g, PX)); o.ipd.push_back((uint8_t)(1 + g.below(60)));
+            }
+            if (g.uni() < P_DEL) continue;
+            uint8_t b = src[j];
+            if (g.uni() < P_SUB) b = (uint8_t)((b + 1 + g.below(3)) & 3);
+            o.bases.push_back(b); o.pw.push_back((uint8_t)draw_pw(g, PM)); o.ipd.push_back((uint8_t)(1 + g.below(60)));
+        }
+        o.flags.push_back((uint8_t)rev);
+        o.read_end.push_back((int64_t)o.bases.size());
+    }
+}
+
 int ccsx_synth_generate(int32_t n_zmw, int32_t first_zmw_id, int32_t passes_lo, int32_t passes_hi, int32_t len_lo,
                         int32_t len_hi, uint64_t seed, ccsx_synth **out)
 {
@@ -119,65 +166,46 @@ int ccsx_synth_generate(int32_t n_zmw, int32_t first_zmw_id, int32_t passes_lo, 
         ccsx_set_error("ccsx_synth_generate: bad arguments");
         return -1;
     }
-    static const double PM[3] = {0.30, 0.30, 0.40}, PX[3] = {0.60, 0.25, 0.15};
-    static const double P_DEL = 0.04, P_SUB = 0.01, P_INS = 0.06;
-    std::vector<int32_t> zmw_id(n_zmw), read_off(n_zmw + 1, 0);
-    std::vector<float> snr((size_t)n_zmw * 4);
-    std::vector<int64_t> base_off(1, 0), tpl_off(n_zmw + 1, 0);
-    std::vector<uint8_t> bases, pw, ipd, flags, tpl;
-    for (int z = 0; z < n_zmw; ++z) {
-        const int id = first_zmw_id + z;
-        zmw_id[z] = id;
-        Rng g(seed ^ 0xCC5ull ^ ((uint64_t)id * 0x9E3779B97F4A7C15ull));
-        const int P = passes_lo + g.below(passes_hi - passes_lo + 1);
-        int L = len_lo;
-        if (len_hi > len_lo) L = (int)std::floor(std::exp(std::log((double)len_lo) + g.uni() * (std::log((double)len_hi) - std::log((double)len_lo))) + 0.5);
-        static const float base_snr[4] = {9.0f, 16.0f, 8.0f, 13.0f};
-        for (int c = 0; c < 4; ++c) {
-            float s = base_snr[c] * (float)(1.0 + 0.1 * g.gauss());
-            snr[(size_t)z * 4 + c] = s < 4.0f ? 4.0f : s;
-        }
-        std::vector<uint8_t> t(L), tr(L);
-        for (int j = 0; j < L; ++j) t[j] = (uint8_t)g.below(4);
-        for (int j = 0; j < L; ++j) tr[j] = (uint8_t)(3 - t[L - 1 - j]);
-        tpl_off[z] = (int64_t)tpl.size();
-        tpl.insert(tpl.end(), t.begin(), t.end());
-        for (int k = 0; k < P; ++k) {
-            const int rev = k & 1;
-            const std::vector<uint8_t> &src = rev ? tr : t;
-            for (int j = 0; j < L; ++j) {
-                while (g.uni() < P_INS) {   // extra base before consuming src[j]: half cognate (branch), half not (stick)
-                    uint8_t b = src[j];
-                    if (g.uni() >= 0.5) b = (uint8_t)((b + 1 + g.below(3)) & 3);
-                    bases.push_back(b); pw.push_back((uint8_t)draw_pw(g, PX)); ipd.push_back((uint8_t)(1 + g.below(60)));
-                }
-                if (g.uni() < P_DEL) continue;
-                uint8_t b = src[j];
-                if (g.uni() < P_SUB) b = (uint8_t)((b + 1 + g.below(3)) & 3);
-                bases.push_back(b); pw.push_back((uint8_t)draw_pw(g, PM)); ipd.push_back((uint8_t)(1 + g.below(60)));
-            }
-            flags.push_back((uint8_t)rev);
-            base_off.push_back((int64_t)bases.size());
-        }
-        read_off[z + 1] = (int32_t)flags.size();
+    std::vector<SynthZmw> zs(n_zmw);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        if (const char *e = std::getenv("CCSX_SYNTH_THREADS")) nt = (unsigned)std::atoi(e);
+        nt = std::max(1u, std::min(nt, 32u));
+        if ((int64_t)n_zmw * passes_hi * len_hi < (int64_t)1 << 20) nt = 1;     // small batches: not worth the threads
+        std::atomic<int> next(0);
+        auto work = [&]() { for (int z; (z = next.fetch_add(1)) < n_zmw;) synth_one(first_zmw_id + z, passes_lo, passes_hi, len_lo, len_hi, seed, zs[z]); };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
     }
-    tpl_off[n_zmw] = (int64_t)tpl.size();
-
-    auto dup = [](const void *p, size_t n) { void *q = std::malloc(n ? n : 1); std::memcpy(q, p, n); return q; };
+    int64_t NB = 0, NT = 0; int64_t R = 0;
+    for (auto &z : zs) { NB += (int64_t)z.bases.size(); NT += (int64_t)z.tpl.size(); R += (int64_t)z.flags.size(); }
     ccsx_synth *s = (ccsx_synth *)std::calloc(1, sizeof(ccsx_synth));
-    s->batch.n_zmw = n_zmw;
-    s->batch.n_reads = (int32_t)flags.size();
-    s->batch.n_bases = (int64_t)bases.size();
-    s->batch.zmw_id = (const int32_t *)dup(zmw_id.data(), zmw_id.size() * 4);
-    s->batch.snr = (const float *)dup(snr.data(), snr.size() * 4);
-    s->batch.read_off = (const int32_t *)dup(read_off.data(), read_off.size() * 4);
-    s->batch.base_off = (const int64_t *)dup(base_off.data(), base_off.size() * 8);
-    s->batch.bases = (const uint8_t *)dup(bases.data(), bases.size());
-    s->batch.pw = (const uint8_t *)dup(pw.data(), pw.size());
-    s->batch.ipd = (const uint8_t *)dup(ipd.data(), ipd.size());
-    s->batch.flags = (const uint8_t *)dup(flags.data(), flags.size());
-    s->tpl_off = (int64_t *)dup(tpl_off.data(), tpl_off.size() * 8);
-    s->tpl = (uint8_t *)dup(tpl.data(), tpl.size());
+    auto alloc = [](size_t n) { return std::malloc(n ? n : 1); };
+    int32_t *zmw_id = (int32_t *)alloc((size_t)n_zmw * 4), *read_off = (int32_t *)alloc((size_t)(n_zmw + 1) * 4);
+    float *snr = (float *)alloc((size_t)n_zmw * 16);
+    int64_t *base_off = (int64_t *)alloc((size_t)(R + 1) * 8), *tpl_off = (int64_t *)alloc((size_t)(n_zmw + 1) * 8);
+    uint8_t *bases = (uint8_t *)alloc(NB), *pw = (uint8_t *)alloc(NB), *ipd = (uint8_t *)alloc(NB), *flags = (uint8_t *)alloc(R), *tpl = (uint8_t *)alloc(NT);
+    int64_t bo = 0, to = 0; int32_t ro = 0;
+    base_off[0] = 0; read_off[0] = 0;
+    for (int z = 0; z < n_zmw; ++z) {
+        SynthZmw &q = zs[z];
+        zmw_id[z] = first_zmw_id + z;
+        std::memcpy(snr + 4 * (size_t)z, q.snr, 16);
+        std::memcpy(bases + bo, q.bases.data(), q.bases.size()); std::memcpy(pw + bo, q.pw.data(), q.pw.size()); std::memcpy(ipd + bo, q.ipd.data(), q.ipd.size());
+        for (size_t k = 0; k < q.flags.size(); ++k) { flags[ro] = q.flags[k]; base_off[++ro] = bo + q.read_end[k]; }
+        read_off[z + 1] = ro;
+        tpl_off[z] = to;
+        std::memcpy(tpl + to, q.tpl.data(), q.tpl.size());
+        bo += (int64_t)q.bases.size(); to += (int64_t)q.tpl.size();
+        SynthZmw().bases.swap(q.bases); SynthZmw().pw.swap(q.pw); SynthZmw().ipd.swap(q.ipd);
+    }
+    tpl_off[n_zmw] = to;
+    s->batch.n_zmw = n_zmw; s->batch.n_reads = ro; s->batch.n_bases = bo;
+    s->batch.zmw_id = zmw_id; s->batch.snr = snr; s->batch.read_off = read_off; s->batch.base_off = base_off;
+    s->batch.bases = bases; s->batch.pw = pw; s->batch.ipd = ipd; s->batch.flags = flags;
+    s->tpl_off = tpl_off; s->tpl = tpl;
     *out = s;
     return 0;
 }

@@ -69,5 +69,5 @@ struct KParams {
     long long kin_plane;       // plane stride = seq_off[n]
 };
 
-void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev);
+const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev);   // NULL, or the name of the launch that failed
 int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats);

@@ -1719,13 +1719,17 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
     return 0;
 }
 
-void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or NULL */)
+// every launch status is captured: returns NULL, or the name of the first launch that failed (ccsx_api.cpp reports it)
+#define LAUNCH_CHECK(name) do { if (hipGetLastError() != hipSuccess && !failed) failed = name; } while (0)
+const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or NULL */)
 {
-    if (ev) (void)hipEventRecord(ev[0], st);
-    (void)hipMemsetAsync(P.ticket_poa, 0, 256, st);                // debug / phase-profile words (CCSX_DEBUG_CHECKS, CCSX_PROFILE_PHASES builds)
+    const char *failed = nullptr;
+    if (ev && hipEventRecord(ev[0], st) != hipSuccess) failed = "hipEventRecord";
+    if (hipMemsetAsync(P.ticket_poa, 0, 256, st) != hipSuccess && !failed) failed = "hipMemsetAsync";   // debug / phase-profile words (CCSX_DEBUG_CHECKS, CCSX_PROFILE_PHASES builds)
     {
         int n = P.n_zmw * CCSX_NCTX;
         hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, P);
+        LAUNCH_CHECK("k_setup");
     }
     trace_sync(st, "k_setup");
     if (ev) (void)hipEventRecord(ev[1], st);
@@ -1733,23 +1737,32 @@ void ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or 
     for (int z0 = 0; z0 < P.n_zmw; z0 += P.poa_slots) {
         const int nb = (P.n_zmw - z0) < P.poa_slots ? (P.n_zmw - z0) : P.poa_slots;
         hipLaunchKernelGGL(k_poa, dim3(nb), dim3(64), lds_read, st, P, z0);
+        LAUNCH_CHECK("k_poa");
     }
     trace_sync(st, "k_poa");
     if (ev) (void)hipEventRecord(ev[2], st);
     for (int rb = 0; rb < P.n_reads; rb += P.align_slots) {
         const int nb = (P.n_reads - rb) < P.align_slots ? (P.n_reads - rb) : P.align_slots;
         hipLaunchKernelGGL(k_align, dim3(nb), dim3(64), lds_read, st, P, rb);
+        LAUNCH_CHECK("k_align");
     }
     trace_sync(st, "k_align");
     hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P);
+    LAUNCH_CHECK("k_post");
     if (ev) (void)hipEventRecord(ev[3], st);
-    if (P.total_wslots > 0) hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), (size_t)P.pw_obs_bytes + (size_t)P.pw_gb_floats * 4, st, P);
+    if (P.total_wslots > 0) {
+        hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), (size_t)P.pw_obs_bytes + (size_t)P.pw_gb_floats * 4, st, P);
+        LAUNCH_CHECK("k_polish");
+    }
     trace_sync(st, "k_polish");
     if (P.opts.hifi_kinetics && P.total_wslots > 0) {
         hipLaunchKernelGGL(k_kinetics, dim3((unsigned)P.total_wslots), dim3(256), 0, st, P);
+        LAUNCH_CHECK("k_kinetics");
         trace_sync(st, "k_kinetics");
     }
     if (ev) (void)hipEventRecord(ev[4], st);
     hipLaunchKernelGGL(k_stitch, dim3(P.n_zmw), dim3(64), 0, st, P);
-    if (ev) (void)hipEventRecord(ev[5], st);
+    LAUNCH_CHECK("k_stitch");
+    if (ev && hipEventRecord(ev[5], st) != hipSuccess && !failed) failed = "hipEventRecord";
+    return failed;
 }

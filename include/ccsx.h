@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCSX_ABI_VERSION 2
+#define CCSX_ABI_VERSION 3
 
 /* ---- fixed constants of the algorithm specification ---- */
 #define CCSX_BAND          64   /* DP band rows of the POA / alignment kernels (one wave64)      */
@@ -82,7 +82,8 @@ typedef struct ccsx_opts {
     int32_t disable_heuristics; /* --disable-heuristics (docs/faq/low-complexity.md:15): no candidate filter, every position is polished */
     float   min_zscore;      /* a pass is dropped from a window when its z-score (log-likelihood vs the model's expectation for
                                 the window template) is below this; 0 = gate off                                   */
-    int32_t reserved[5];
+    int32_t handles_per_device; /* handles the caller runs on this GPU (0/1 = one): each takes 1/N of the free HBM for its POA scratch */
+    int32_t reserved[4];
 } ccsx_opts;
 
 /* ---- input batch: SoA + CSR ---- */
@@ -158,6 +159,16 @@ int64_t     ccsx_result_layout(const ccsx_batch *b, int64_t *seq_off);
 
 /* fused path, host buffers in / host buffers out (one synchronous call = upload + run + download) */
 int         ccsx_consensus_batch(ccsx_handle h, const ccsx_batch *b, ccsx_results *res);
+
+/* asynchronous pipeline (submit / wait tickets).  ccsx_submit enqueues upload -> kernels -> download of one
+ * batch on the handle's three streams (H2D, kernels, D2H) and returns; up to three batches are in flight, so the copies
+ * of batch k+1 / k-1 run under the kernels of batch k.  The batch arrays and the result buffers must stay valid (and
+ * should be page-locked: ccsx_alloc_pinned) until ccsx_wait returns for that ticket.  Tickets complete in order.      */
+typedef int64_t ccsx_ticket;
+int         ccsx_submit(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, ccsx_ticket *ticket);
+int         ccsx_wait(ccsx_handle h, ccsx_ticket ticket);              /* results of that batch are in `res`   */
+int         ccsx_poll(ccsx_handle h, ccsx_ticket ticket);              /* 1 done, 0 not yet, <0 error          */
+int         ccsx_ticket_timings(ccsx_handle h, ccsx_ticket ticket, ccsx_timings *t);
 
 /* split form used by the benchmark (inputs resident in HBM when the timed region starts)        */
 int         ccsx_upload(ccsx_handle h, const ccsx_batch *b);           /* H2D + workspace sizing */

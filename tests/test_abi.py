@@ -23,7 +23,7 @@ def test_header_and_exports_agree(built):
     L = C.CDLL(api.LIB_PATH)
     for name in decl:
         assert hasattr(L, name), f"{name} declared in include/ccsx.h but not exported by libccsx.so"
-    assert L.ccsx_abi_version() == 2
+    assert L.ccsx_abi_version() == 3
 
 
 def test_struct_layouts_match_header(built):

@@ -393,3 +393,48 @@ def test_pinned_batch_gives_identical_results(handle):
     assert np.array_equal(pb.bases, batch.bases) and np.array_equal(pb.pw, batch.pw) and np.array_equal(pb.ipd, batch.ipd)
     b = handle.consensus(pb)
     _compare(b, a, batch)
+
+
+def test_async_pipeline_matches_synchronous(built):
+    """ccsx_submit / ccsx_wait (three batches in flight, copies under compute) give the results of the synchronous call,
+    for batches of different shapes sharing the handle's slots and scratch"""
+    shapes = [(6, 5, 700), (3, 9, 1500), (8, 4, 300), (2, 12, 2500), (5, 6, 900), (4, 3, 400), (6, 8, 1100)]
+    batches = [api.synth(n, p, l, seed=60 + i) for i, (n, p, l) in enumerate(shapes)]
+    hs = api.Handle(0)
+    want = [hs.consensus(b) for b in batches]
+    hs.close()
+    h = api.Handle(0)
+    pinned = [b.pinned() for b in batches]
+    res = [api.Results.allocate(b, pinned=True) for b in batches]
+    tickets, depth = [], 3
+    for k in range(len(batches) + depth):
+        if k >= depth:
+            r = h.wait(tickets[k - depth])
+            w = want[k - depth]
+            assert np.array_equal(r.status, w.status) and np.array_equal(r.seq_len, w.seq_len) and np.array_equal(r.np_, w.np_)
+            assert np.array_equal(r.seq_off, w.seq_off)
+            for z in range(batches[k - depth].n_zmw):
+                assert np.array_equal(r.sequence(z), w.sequence(z)) and np.array_equal(r.raw(z), w.raw(z))
+            assert np.array_equal(r.rq, w.rq)
+            t = h.ticket_timings(tickets[k - depth])
+            assert t.total_ms > 0 and t.polish_workgroups == int(w.n_windows.sum())
+            h.release(tickets[k - depth])
+        if k < len(batches):
+            tickets.append(h.submit(pinned[k], res[k]))
+            assert h.poll(tickets[-1]) in (True, False)
+    # a recycled ticket is reported, not undefined behaviour
+    with pytest.raises(RuntimeError):
+        h.wait(tickets[0])
+    h.close()
+
+
+def test_async_submit_rejects_small_result_buffers(built):
+    h = api.Handle(0)
+    big, small = api.synth(4, 5, 800, seed=70), api.synth(2, 3, 200, seed=71)
+    res_small = api.Results.allocate(small)
+    with pytest.raises(RuntimeError):
+        h.submit(big, res_small)
+    # the handle stays usable
+    r = h.wait(h.submit(small, res_small))
+    assert (r.status >= 0).all()
+    h.close()
