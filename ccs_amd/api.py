@@ -85,6 +85,7 @@ EXPORTS = [
     "ccsx_sync", "ccsx_download", "ccsx_get_timings", "ccsx_stage_draft", "ccsx_stage_align",
     "ccsx_stage_windows", "ccsx_synth_generate", "ccsx_synth_free", "ccsx_alloc_pinned", "ccsx_free_pinned",
     "ccsx_submit", "ccsx_wait", "ccsx_poll", "ccsx_ticket_timings",
+    "ccsx_model_from_json", "ccsx_model_load", "ccsx_model_to_json", "ccsx_model_for_chemistry",
 ]
 
 _lib = None
@@ -122,6 +123,11 @@ def lib() -> C.CDLL:
         L.ccsx_alloc_pinned.argtypes = [C.c_size_t]
         L.ccsx_free_pinned.argtypes = [C.c_void_p]
         L.ccsx_model_default.argtypes = [C.POINTER(Model)]
+        L.ccsx_model_from_json.argtypes = [C.c_char_p, C.POINTER(Model)]
+        L.ccsx_model_load.argtypes = [C.c_char_p, C.POINTER(Model)]
+        L.ccsx_model_to_json.restype = C.c_int64
+        L.ccsx_model_to_json.argtypes = [C.POINTER(Model), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64]
+        L.ccsx_model_for_chemistry.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Model)]
         L.ccsx_opts_default.argtypes = [C.POINTER(Opts)]
         _lib = L
     return _lib
@@ -250,6 +256,44 @@ def synth(n_zmw: int, passes, length, seed: int = 1, first_zmw_id: int = 0) -> B
 def default_model() -> Model:
     m = Model()
     lib().ccsx_model_default(C.byref(m))
+    return m
+
+
+def set_model_name(m: Model, name: str) -> Model:
+    """name of a parameter set, zero padded (the blob is compared / hashed as bytes; ctypes assignment stops at the first NUL)"""
+    raw = name.encode()[:31].ljust(32, b"\0")
+    C.memmove(C.addressof(m), raw, 32)
+    return m
+
+
+def model_to_json(m: Model, chemistry=None) -> str:
+    """json text of a parameter set (ccsx_model_to_json); chemistry = (binding kit, sequencing kit, basecaller version) or None"""
+    L = lib()
+    tri = [c.encode() for c in chemistry] if chemistry else [None, None, None]
+    n = L.ccsx_model_to_json(C.byref(m), *tri, None, 0)
+    buf = C.create_string_buffer(n + 1)
+    L.ccsx_model_to_json(C.byref(m), *tri, buf, n + 1)
+    return buf.value.decode()
+
+
+def model_from_json(text: str) -> Model:
+    m = Model()
+    if lib().ccsx_model_from_json(text.encode(), C.byref(m)) != 0:
+        raise RuntimeError(lib().ccsx_last_error().decode())
+    return m
+
+
+def model_load(path: str) -> Model:
+    m = Model()
+    if lib().ccsx_model_load(path.encode(), C.byref(m)) != 0:
+        raise RuntimeError(lib().ccsx_last_error().decode())
+    return m
+
+
+def model_for_chemistry(binding_kit: str, sequencing_kit: str, basecaller_version: str) -> Model:
+    m = Model()
+    if lib().ccsx_model_for_chemistry(binding_kit.encode(), sequencing_kit.encode(), basecaller_version.encode(), C.byref(m)) != 0:
+        raise RuntimeError(lib().ccsx_last_error().decode())
     return m
 
 

@@ -236,8 +236,10 @@ public:
         if (!buf_.empty()) flush_block();
         drain(0);
         static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        std::fwrite(eof, 1, 28, f_);
-        std::fclose(f_); f_ = nullptr;
+        const bool ok = std::fwrite(eof, 1, 28, f_) == 28;
+        const bool closed = std::fclose(f_) == 0;
+        f_ = nullptr;
+        if (!ok || !closed) throw std::runtime_error("short write (final BGZF block / close)");
     }
 
 private:
@@ -287,17 +289,23 @@ inline bool read_header(BgzfReader &in, BamHeader &h)
 {
     uint8_t magic[4];
     if (!in.read(magic, 4) || std::memcmp(magic, "BAM\1", 4)) throw std::runtime_error("not a BAM file");
+    auto must = [&](void *dst, size_t n) { if (n && !in.read(dst, n)) throw std::runtime_error("truncated BAM header"); };
     uint8_t b4[4];
-    in.read(b4, 4);
-    h.text.resize(rd32(b4));
-    if (!h.text.empty()) in.read(&h.text[0], h.text.size());
-    in.read(b4, 4);
+    must(b4, 4);
+    const uint32_t l_text = rd32(b4);
+    if (l_text > (1u << 30)) throw std::runtime_error("malformed BAM header (text length)");
+    h.text.resize(l_text);
+    if (!h.text.empty()) must(&h.text[0], h.text.size());
+    must(b4, 4);
     const uint32_t nref = rd32(b4);
+    if (nref > (1u << 24)) throw std::runtime_error("malformed BAM header (reference count)");
     for (uint32_t i = 0; i < nref; ++i) {
-        in.read(b4, 4);
-        std::string nm(rd32(b4), '\0');
-        in.read(&nm[0], nm.size());
-        in.read(b4, 4);
+        must(b4, 4);
+        const uint32_t l_name = rd32(b4);
+        if (l_name > (1u << 16)) throw std::runtime_error("malformed BAM header (reference name)");
+        std::string nm(l_name, '\0');
+        if (l_name) must(&nm[0], nm.size());
+        must(b4, 4);
         h.refs.emplace_back(nm.c_str(), rd32(b4));
     }
     return true;
@@ -321,9 +329,14 @@ inline size_t tag_value_size(char t)
 }
 
 // decode one record body (the bytes after block_size)
+// Every length field of the record is checked against the record's own size before it is used (a lying l_seq, tag count or
+// an unterminated string must end in "malformed BAM record", not in an out-of-bounds read on a pool thread).
 inline void parse_subread(const uint8_t *p, uint32_t bs, Subread &r)
 {
+    auto bad = [] { throw std::runtime_error("malformed BAM record"); };
+    if (bs < 32) bad();
     const uint32_t l_name = p[8], n_cig = p[12] | (p[13] << 8), l_seq = rd32(p + 16);
+    if ((uint64_t)32 + l_name + (uint64_t)4 * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq > bs) bad();
     r = Subread();
     r.name.assign((const char *)p + 32, l_name ? l_name - 1 : 0);
     const uint8_t *seq = p + 32 + l_name + 4 * n_cig;
@@ -346,12 +359,14 @@ inline void parse_subread(const uint8_t *p, uint32_t bs, Subread &r)
                 default: return 0;
             }
         };
-        if (ty == 'Z' || ty == 'H') { while (t < end && *t) ++t; ++t; continue; }
+        if (ty == 'Z' || ty == 'H') { while (t < end && *t) ++t; if (t >= end) bad(); ++t; continue; }
         if (ty == 'B') {
+            if (t + 5 > end) bad();
             const char st = (char)t[0];
             const uint32_t n = rd32(t + 1);
             const uint8_t *q = t + 5;
             const size_t es = tag_value_size(st);
+            if (!es || (uint64_t)n * es > (uint64_t)(end - q)) bad();
             if (t0 == 's' && t1 == 'n' && st == 'f' && n == 4) { std::memcpy(r.snr, q, 16); r.has_snr = true; }
             else if ((t0 == 'p' && t1 == 'w') || (t0 == 'i' && t1 == 'p')) {
                 std::vector<uint8_t> &dst = (t0 == 'p') ? r.pw : r.ipd;
@@ -366,6 +381,7 @@ inline void parse_subread(const uint8_t *p, uint32_t bs, Subread &r)
         }
         const size_t vs = tag_value_size(ty);
         if (!vs) throw std::runtime_error("unknown BAM tag type");
+        if (t + vs > end) bad();
         if (t0 == 'z' && t1 == 'm') r.zm = (int32_t)rdint(ty, t);
         else if (t0 == 'c' && t1 == 'x') r.cx = (int32_t)rdint(ty, t);
         t += vs;
@@ -402,6 +418,7 @@ inline bool read_raw_chunk(BgzfReader &in, RawChunk &c)
         uint8_t b4[4];
         if (!in.read(b4, 4)) throw std::runtime_error("truncated BAM record");
         const uint32_t bs = rd32(b4);
+        if (bs > (1u << 28)) throw std::runtime_error("malformed BAM record (block size)");   // no subread record is 256 MB
         c.carry.emplace_back(bs);
         if (bs && !in.read(c.carry.back().data(), bs)) throw std::runtime_error("truncated BAM record");
         c.recs.emplace_back(c.carry.back().data(), bs);

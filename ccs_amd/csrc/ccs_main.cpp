@@ -4,7 +4,9 @@
 // Pipeline (the reference's docs/img/ccs-impl.png with the GPU consumers only):
 //   reader thread   BGZF inflate on the -j pool -> subread records -> ZMW grouping -> step-1 filters
 //                   (docs/how-does-ccs-work.md:19-32) -> SoA batches of --batch-size ZMWs
-//   GPU workers     one per device, each owns a ccsx_handle: ccsx_consensus_batch (draft + polish on the GPU)
+//   pack workers    SoA packing of a batch straight into page-locked staging (off the reader thread)
+//   GPU workers     one per device, each owns ONE ccsx_handle and keeps up to three batches in flight through
+//                   ccsx_submit / ccsx_wait: upload, kernels and download of consecutive batches overlap
 //   writer          restores input order, writes hifi BAM records with tags rq np ec sn zm RG
 //                   (docs/faq/bam-output.md:9-30), BGZF deflate on the pool, ccs_report.txt
 //                   (docs/faq/reports-aux-files.md:16-72)
@@ -41,7 +43,8 @@ struct Options {
     double min_snr = 2.5;
     int batch = 2048;
     int chunk_i = 1, chunk_n = 1;
-    int workers_per_gpu = 3;      // handles (streams) per device: packing/upload of one batch overlaps the kernels of another
+    int workers_per_gpu = 3;      // packing threads per device (one engine handle per device keeps three batches in flight)
+    std::string model_file;       // --model-file: Arrow parameter json (else: chemistry of the BAM header -> bundle dir / built-in)
     std::vector<int> gpus;
     ccsx_opts o;
     bool all_gpus = false;
@@ -67,6 +70,23 @@ struct ZmwIn {
     int32_t median_len = 0, n_full = 0;
 };
 
+// page-locked staging of one GPU worker (bases / pw / ipd of the batch in flight), grown geometrically and reused
+struct Arena {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    uint8_t *reserve(size_t bytes)
+    {
+        if (bytes > cap) {
+            ccsx_free_pinned(p);
+            cap = bytes + bytes / 4 + (1u << 20);
+            p = (uint8_t *)ccsx_alloc_pinned(cap);
+            if (!p) { cap = 0; throw std::runtime_error(std::string("pinned staging: ") + ccsx_last_error()); }
+        }
+        return p;
+    }
+    ~Arena() { ccsx_free_pinned(p); }
+};
+
 struct Batch {
     int64_t index = 0;
     std::vector<ZmwIn> zmws;      // including host-failed ones (they are only counted)
@@ -78,11 +98,15 @@ struct Batch {
     const uint8_t *bases = nullptr, *pw = nullptr, *ipd = nullptr;   // in the packing worker's pinned arena, valid during its engine call
     int64_t n_bases = 0;
     std::vector<int> slot;        // per zmws[]: index into the SoA or -1
-    // results
+    // results: views into the batch's page-locked output arena (asynchronous D2H), valid until the writer has emitted the batch
     std::vector<int64_t> seq_off;
-    std::vector<int32_t> status, seq_len, np, iters, n_windows, fn, rn;
-    std::vector<uint8_t> seq, qual, kin;   // kin: 4 planes (fi, fp, ri, rp) of seq.size() bytes each (--hifi-kinetics)
-    std::vector<float> rq, ec;
+    int32_t n = 0; int64_t cap = 0;
+    int32_t *status = nullptr, *seq_len = nullptr, *np = nullptr, *iters = nullptr, *n_windows = nullptr, *fn = nullptr, *rn = nullptr;
+    uint8_t *seq = nullptr, *qual = nullptr, *kin = nullptr;   // kin: 4 planes (fi, fp, ri, rp) of cap bytes each (--hifi-kinetics)
+    float *rq = nullptr, *ec = nullptr;
+    bool have_results = false;    // false: packing or the engine failed for this batch
+    std::unique_ptr<struct Arena> in_arena, out_arena;
+    ccsx_batch cb; ccsx_results cr; // the structs handed to ccsx_submit live as long as the ticket
 };
 
 template <class T> class Channel {
@@ -121,7 +145,11 @@ void usage()
                  "usage: ccs [options] IN.subreads.bam OUT.{bam,fastq.gz}\n"
                  "  -j, --num-threads N       host threads for BAM (de)compression [all usable: affinity / cgroup quota]\n"
                  "      --min-passes N        minimum full-length passes [3]\n"
-                 "      --top-passes N        use at most N passes, 0 = all [60]\n"
+                 "      --top-passes N        use at most the N passes closest to the median length [60]; the engine holds 64 passes\n"
+                 "                            per ZMW, so 0 (unlimited in the reference) and values above 64 mean 64 here\n"
+                 "      --model-file F        Arrow model parameters (json); default: chosen by the chemistry in the BAM header from\n"
+                 "                            $SMRT_CHEMISTRY_BUNDLE_DIR/arrow/*.json, then the built-in set\n"
+                 "      --disable-heuristics  polish every position (no candidate filter)\n"
                  "      --min-snr F           minimum SNR of a ZMW [2.5]\n"
                  "      --min-length N        minimum draft length [10]\n"
                  "      --max-length N        maximum draft length [50000]\n"
@@ -135,7 +163,7 @@ void usage()
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
                  "      --batch-size N        ZMWs per GPU batch [2048]\n"
                  "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"
-                 "      --workers-per-gpu N   engine handles per device, overlapping upload and compute [3]\n"
+                 "      --workers-per-gpu N   packing threads per device [3] (one engine handle per device, three batches in flight)\n"
                  "      --report-file F       ccs_report.txt path [<OUT prefix>.ccs_report.txt]\n"
                  "      --log-level L         ERROR|WARN|INFO [WARN]\n"
                  "  test helpers (not in the reference):\n"
@@ -171,9 +199,15 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--qv-binning") o.qv_binning = true;
         else if (a == "--hifi-kinetics") o.o.hifi_kinetics = 1;
         else if (a == "--suppress-reports") o.suppress_reports = true;
+        else if (a == "--model-file") o.model_file = need(a.c_str());
+        else if (a == "--disable-heuristics") o.o.disable_heuristics = 1;
         else if (a == "--metrics-json") o.metrics = need(a.c_str());
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
         else pos.push_back(a);
+    }
+    if (o.o.top_passes <= 0 || o.o.top_passes > 64) {
+        std::fprintf(stderr, "ccs: warning: --top-passes %d: this engine uses at most 64 passes per ZMW (the 64 closest to the median length)\n", o.o.top_passes);
+        o.o.top_passes = 64;
     }
     if (!o.write_synth.empty()) { if (pos.size() != 1) return false; o.out = pos[0]; return true; }
     if (o.dump) { if (pos.size() != 1) return false; o.in = pos[0]; return true; }
@@ -290,23 +324,33 @@ void finish_zmw(ZmwIn &z, const Options &o)
     // the engine handles subreads up to 65535 bases; longer inserts cannot pass --max-length (<= 50000) anyway
     for (auto &r : z.reads) if (r.bases.size() > 65535 || (double)r.bases.size() > 1.3 * (double)o.o.max_length + 1000.0) { z.host_status = HS_TOO_LONG; z.reads.clear(); return; }
     if ((int)z.reads.size() < o.o.min_passes) { z.host_status = HS_TOO_FEW; z.reads.clear(); return; }
+    // --top-passes: "at most the top 60 full-length passes after sorting by median length" (docs/faq/accuracy-vs-passes.md:49-52):
+    // the N passes whose length is closest to the median are kept, in their original order
+    const size_t top = (size_t)o.o.top_passes;
+    if (z.reads.size() > top) {
+        std::vector<size_t> idx(z.reads.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+        auto dist = [&](size_t i) { const double d = (double)z.reads[i].bases.size() - med; return d < 0 ? -d : d; };
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return dist(a) < dist(b); });
+        idx.resize(top);
+        std::sort(idx.begin(), idx.end());
+        std::vector<Subread> sel;
+        for (size_t i : idx) sel.push_back(std::move(z.reads[i]));
+        z.reads.swap(sel);
+    }
 }
 
-// page-locked staging of one GPU worker (bases / pw / ipd of the batch in flight), grown geometrically and reused
-struct Arena {
-    uint8_t *p = nullptr;
-    size_t cap = 0;
-    uint8_t *reserve(size_t bytes)
+struct ArenaPool {                          // free list of page-locked arenas: a batch holds its staging until its results are written
+    std::mutex m;
+    std::vector<std::unique_ptr<Arena>> free_;
+    std::unique_ptr<Arena> get()
     {
-        if (bytes > cap) {
-            ccsx_free_pinned(p);
-            cap = bytes + bytes / 4 + (1u << 20);
-            p = (uint8_t *)ccsx_alloc_pinned(cap);
-            if (!p) { cap = 0; throw std::runtime_error(std::string("pinned staging: ") + ccsx_last_error()); }
-        }
-        return p;
+        std::lock_guard<std::mutex> l(m);
+        if (free_.empty()) return std::unique_ptr<Arena>(new Arena());
+        auto a = std::move(free_.back()); free_.pop_back();
+        return a;
     }
-    ~Arena() { ccsx_free_pinned(p); }
+    void put(std::unique_ptr<Arena> a) { if (a) { std::lock_guard<std::mutex> l(m); free_.push_back(std::move(a)); } }
 };
 
 void pack(Batch &b, Arena &arena)
@@ -425,24 +469,52 @@ int main(int argc, char **argv)
         ThreadPool pool(nthreads);
         if (!opt.write_synth.empty()) return write_synthetic(opt, pool);
 
-        // ---- devices (not needed for --dump-zmws)
+        BgzfReader in(opt.in, pool);
+        BamHeader hdr; read_header(in, hdr);
+
+        // ---- model parameters: --model-file, else by the chemistry triple of the header (docs/faq/chemistry.md:27-56);
+        // "Abort if chemistry information is missing in BAM header" (docs/changelog.md:66)
+        ccsx_model model;
+        std::string chem_desc;
+        if (!opt.dump) {
+            auto ds_value = [&](const char *key) -> std::string {
+                const size_t rg = hdr.text.find("@RG");
+                const size_t k = rg == std::string::npos ? rg : hdr.text.find(std::string(key) + "=", rg);
+                if (k == std::string::npos) return "";
+                const size_t a = k + std::strlen(key) + 1, e = hdr.text.find_first_of(";\t\n", a);
+                return hdr.text.substr(a, e == std::string::npos ? std::string::npos : e - a);
+            };
+            const std::string bk = ds_value("BINDINGKIT"), sk = ds_value("SEQUENCINGKIT"), bc = ds_value("BASECALLERVERSION");
+            if (!opt.model_file.empty()) {
+                if (ccsx_model_load(opt.model_file.c_str(), &model)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); return 1; }
+                chem_desc = std::string(model.name) + " (" + opt.model_file + ")";
+            } else {
+                if (bk.empty() || sk.empty() || bc.empty()) {
+                    std::fprintf(stderr, "ccs: missing chemistry information in the BAM header (@RG DS: BINDINGKIT, SEQUENCINGKIT, BASECALLERVERSION)\n");
+                    return 1;
+                }
+                if (ccsx_model_for_chemistry(bk.c_str(), sk.c_str(), bc.c_str(), &model)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); return 1; }
+                chem_desc = std::string(model.name) + " for " + bk + "/" + sk + "/" + bc;
+            }
+            if (opt.log_level >= 2) std::fprintf(stderr, "ccs: consensus model %s\n", chem_desc.c_str());   // docs/changelog.md:101
+        }
+
+        // ---- devices (not needed for --dump-zmws): one engine handle per device
         std::vector<ccsx_handle> handles;
-        ccsx_model model; ccsx_model_default(&model);
         if (!opt.dump) {
             const int ndev = ccsx_device_count();
             if (ndev <= 0) { std::fprintf(stderr, "ccs: no gfx950 GPU available (this build has no CPU consensus path)\n"); return 1; }
             if (opt.all_gpus) for (int d = 0; d < ndev; ++d) opt.gpus.push_back(d);
             if (opt.gpus.empty()) opt.gpus.push_back(0);
-            for (int d : opt.gpus) for (int wk = 0; wk < opt.workers_per_gpu; ++wk) {
+            for (int d : opt.gpus) {
                 ccsx_handle h = nullptr;
                 if (ccsx_create(d, &model, &opt.o, &h)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); return 1; }
                 handles.push_back(h);
             }
         }
 
-        BgzfReader in(opt.in, pool);
-        BamHeader hdr; read_header(in, hdr);
-        Channel<std::shared_ptr<Batch>> to_gpu(2 * std::max<size_t>(1, handles.size())), to_writer(4 * std::max<size_t>(1, handles.size()));
+        Channel<std::shared_ptr<Batch>> to_pack(2 * std::max<size_t>(1, handles.size())), to_gpu(2 * std::max<size_t>(1, handles.size())),
+            to_writer(4 * std::max<size_t>(1, handles.size()));
         std::string movie;
         const auto t_start = std::chrono::steady_clock::now();
 
@@ -469,7 +541,7 @@ int main(int argc, char **argv)
                 }
                 else {
                     batch->zmws.push_back(std::move(zin));
-                    if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_gpu.push(batch); batch = std::make_shared<Batch>(); }
+                    if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_pack.push(batch); batch = std::make_shared<Batch>(); }
                 }
             };
             auto flush_zmw = [&] {
@@ -508,6 +580,7 @@ int main(int argc, char **argv)
                 auto t0 = std::chrono::steady_clock::now();
                 const bool more = read_raw_chunk(in, *raw);
                 rd_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                if (failed) break;                                  // an engine / writer failure ends the run: stop feeding it
                 if (more) pending.push_back(pool.submit([raw] { return decode_chunk(*raw); }));
                 while (!pending.empty() && (!more || pending.size() > (size_t)(2 * pool.size() + 4))) {
                     t0 = std::chrono::steady_clock::now();
@@ -520,9 +593,9 @@ int main(int argc, char **argv)
                 if (!more) break;
             }
             flush_zmw();
-            if (!opt.dump && !batch->zmws.empty()) { batch->index = nb++; to_gpu.push(batch); }
+            if (!opt.dump && !batch->zmws.empty()) { batch->index = nb++; to_pack.push(batch); }
             } catch (const std::exception &e) { fail(std::string("reading ") + opt.in + ": " + e.what()); }
-            to_gpu.close();
+            to_pack.close();
         });
         if (opt.dump) {
             reader.join();
@@ -530,42 +603,95 @@ int main(int argc, char **argv)
             return failed ? 1 : 0;
         }
 
-        // ---- GPU workers
-        std::vector<std::thread> workers;
+        // ---- pack workers: SoA packing off the reader thread, straight into page-locked staging; result views are carved from a
+        // second page-locked arena (the downloads are asynchronous DMA)
+        ArenaPool in_pool, out_pool;
         std::atomic<long long> us_pack{0}, us_engine{0}, us_wait{0};       // summed over workers (--log-level INFO)
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto us_since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
-        for (ccsx_handle h : handles) workers.emplace_back([&, h] {
+        const bool kin = opt.o.hifi_kinetics != 0;
+        std::vector<std::thread> packers;
+        std::atomic<int> packers_left{(int)(handles.size() * (size_t)opt.workers_per_gpu)};
+        for (size_t pk = 0; pk < handles.size() * (size_t)opt.workers_per_gpu; ++pk) packers.emplace_back([&] {
             std::shared_ptr<Batch> b;
-            Arena arena;
+            while (to_pack.pop(b)) {
+                auto t0 = now();
+                try {
+                    b->in_arena = in_pool.get();
+                    pack(*b, *b->in_arena);
+                    const int n = (int)b->zmw_id.size();
+                    b->n = n;
+                    if (n > 0) {
+                        b->cb = ccsx_batch{n, (int32_t)b->flags.size(), b->n_bases, b->zmw_id.data(), b->snr.data(), b->read_off.data(),
+                                           b->base_off.data(), b->bases, b->pw, b->ipd, b->flags.data()};
+                        b->seq_off.resize(n + 1);
+                        const int64_t cap = ccsx_result_layout(&b->cb, b->seq_off.data());
+                        b->cap = cap;
+                        b->out_arena = out_pool.get();
+                        const size_t n4 = ((size_t)n * 4 + 63) & ~(size_t)63, c1 = ((size_t)cap + 63) & ~(size_t)63;
+                        uint8_t *o = b->out_arena->reserve(9 * n4 + (kin ? 6 : 2) * c1);
+                        auto take = [&](size_t bytes) { uint8_t *r = o; o += bytes; return r; };
+                        b->status = (int32_t *)take(n4); b->seq_len = (int32_t *)take(n4); b->np = (int32_t *)take(n4); b->iters = (int32_t *)take(n4);
+                        b->n_windows = (int32_t *)take(n4); b->fn = (int32_t *)take(n4); b->rn = (int32_t *)take(n4);
+                        b->rq = (float *)take(n4); b->ec = (float *)take(n4);
+                        b->seq = take(c1); b->qual = take(c1);
+                        b->cr = ccsx_results{n, cap, b->seq_off.data(), b->status, b->seq_len, b->seq, b->qual, nullptr, b->rq, b->np, b->ec, b->iters, b->n_windows};
+                        b->cr.fn = b->fn; b->cr.rn = b->rn;
+                        if (kin) {
+                            b->kin = take(4 * c1);
+                            // planes are cap bytes apart in the library's result layout
+                            b->cr.fi = b->kin; b->cr.fp = b->kin + cap; b->cr.ri = b->kin + 2 * cap; b->cr.rp = b->kin + 3 * cap;
+                        }
+                    }
+                } catch (const std::exception &e) { fail(std::string("packing a batch: ") + e.what()); b->n = -1; }
+                us_pack += us_since(t0);
+                to_gpu.push(b);
+            }
+            if (--packers_left == 0) to_gpu.close();
+        });
+
+        // ---- GPU workers: one per device; up to three batches in flight through the asynchronous boundary
+        std::vector<std::thread> workers;
+        for (ccsx_handle h : handles) workers.emplace_back([&, h] {
+            std::deque<std::pair<ccsx_ticket, std::shared_ptr<Batch>>> inflight;
+            auto retire = [&] {
+                auto t0 = now();
+                auto fr = std::move(inflight.front()); inflight.pop_front();
+                std::shared_ptr<Batch> &b = fr.second;
+                if (ccsx_wait(h, fr.first)) fail(std::string("consensus engine: ") + ccsx_last_error());
+                else b->have_results = true;
+                in_pool.put(std::move(b->in_arena));                // inputs are on the device (and consumed): the staging is free again
+                b->bases = b->pw = b->ipd = nullptr;
+                us_engine += us_since(t0);
+                to_writer.push(b);
+            };
+            std::shared_ptr<Batch> b;
             for (;;) {
                 auto t0 = now();
                 if (!to_gpu.pop(b)) break;
-                us_wait += us_since(t0); t0 = now();
-                try { pack(*b, arena); }                        // SoA packing off the reader thread, straight into pinned memory
-                catch (const std::exception &e) { std::fprintf(stderr, "ccs: %s\n", e.what()); failed = 1; b->zmw_id.clear(); }
-                us_pack += us_since(t0); t0 = now();
-                const int n = (int)b->zmw_id.size();
-                if (n > 0) {
-                    ccsx_batch cb{n, (int32_t)b->flags.size(), b->n_bases, b->zmw_id.data(), b->snr.data(), b->read_off.data(),
-                                  b->base_off.data(), b->bases, b->pw, b->ipd, b->flags.data()};
-                    b->seq_off.resize(n + 1);
-                    const int64_t cap = ccsx_result_layout(&cb, b->seq_off.data());
-                    b->status.resize(n); b->seq_len.resize(n); b->np.resize(n); b->iters.resize(n); b->n_windows.resize(n);
-                    b->rq.resize(n); b->ec.resize(n); b->seq.resize(cap); b->qual.resize(cap);
-                    ccsx_results r{n, cap, b->seq_off.data(), b->status.data(), b->seq_len.data(), b->seq.data(), b->qual.data(), nullptr,
-                                   b->rq.data(), b->np.data(), b->ec.data(), b->iters.data(), b->n_windows.data()};
-                    if (opt.o.hifi_kinetics) {
-                        b->kin.resize((size_t)4 * cap); b->fn.resize(n); b->rn.resize(n);
-                        r.fi = b->kin.data(); r.fp = r.fi + cap; r.ri = r.fp + cap; r.rp = r.ri + cap;
-                        r.fn = b->fn.data(); r.rn = b->rn.data();
-                    }
-                    if (ccsx_consensus_batch(h, &cb, &r)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); failed = 1; }
-                    b->bases = b->pw = b->ipd = nullptr;        // the arena is reused for the next batch
+                us_wait += us_since(t0);
+                if (b->n <= 0 || failed) {                          // nothing for the GPU (all ZMWs failed on the host), or the run is ending
+                    if (b->n > 0 || b->n < 0) b->have_results = false;
+                    while (!inflight.empty()) retire();             // keep batch order towards the writer cheap: drain first
+                    in_pool.put(std::move(b->in_arena));
+                    to_writer.push(b);
+                    continue;
                 }
+                if (inflight.size() >= 3) retire();
+                t0 = now();
+                ccsx_ticket t = -1;
+                if (ccsx_submit(h, &b->cb, &b->cr, &t)) {
+                    // a failed batch must never reach the writer looking like SUCCESS records: it carries no results,
+                    // the run is marked failed and ends with exit code 1 and no output file
+                    fail(std::string("consensus engine: ") + ccsx_last_error());
+                    b->have_results = false;
+                    while (!inflight.empty()) retire();
+                    in_pool.put(std::move(b->in_arena));
+                    to_writer.push(b);
+                } else inflight.emplace_back(t, b);
                 us_engine += us_since(t0);
-                to_writer.push(b);
             }
+            while (!inflight.empty()) retire();
         });
 
         // ---- writer (restores batch order)
@@ -605,9 +731,9 @@ int main(int argc, char **argv)
                     const ZmwIn &z = bt.zmws[i];
                     int st = z.host_status;
                     const int s = bt.slot[i];
-                    if (st == HS_OK) st = bt.status.empty() ? CCSX_DRAFT_FAILURE : bt.status[s];
+                    if (st == HS_OK) st = bt.have_results ? bt.status[s] : -1;      // -1: EXCEPTION_THROWN / "Unknown error" (engine failure)
                     if (!opt.suppress_reports) {
-                        const bool have = (s >= 0 && !bt.status.empty());
+                        const bool have = (s >= 0 && bt.have_results);
                         const int32_t isz = (have && bt.seq_len[s] > 0) ? bt.seq_len[s] : z.median_len;
                         char line[512];
                         std::snprintf(line, sizeof(line), "%s    {\"effective_coverage\": %.2f, \"has_tandem_repeat\": false, \"insert_size\": %d, \"num_full_passes\": %d, "
@@ -629,11 +755,11 @@ int main(int argc, char **argv)
                         fq += "\n+\n";
                         for (int32_t q = 0; q < len; ++q) fq += (char)(33 + (bt.qual[o + q] > 93 ? 93 : bt.qual[o + q]));
                         fq += '\n';
-                        gzwrite(gzq, fq.data(), (unsigned)fq.size());
+                        if (gzwrite(gzq, fq.data(), (unsigned)fq.size()) != (int)fq.size()) throw std::runtime_error("short write (fastq.gz)");
                         rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.np_sum += bt.np[s];
                         continue;
                     }
-                    rb.begin(qname, bt.seq.data() + o, bt.qual.data() + o, (uint32_t)len);
+                    rb.begin(qname, bt.seq + o, bt.qual + o, (uint32_t)len);
                     rb.tagZ("RG", "ccsamd01");
                     rb.tagf("ec", bt.ec[s]);
                     rb.tagi("np", bt.np[s]);
@@ -641,8 +767,8 @@ int main(int argc, char **argv)
                     rb.tagBf("sn", z.snr, 4);
                     rb.tagi("zm", z.zm);
                     if (opt.o.hifi_kinetics) {                      // docs/faq/kinetics.md:8-18, tag table docs/faq/bam-output.md:13-23
-                        const size_t cap = bt.seq.size();
-                        const uint8_t *fi = bt.kin.data() + o, *fp = fi + cap, *ri = fp + cap, *rp = ri + cap;
+                        const size_t cap = (size_t)bt.cap;
+                        const uint8_t *fi = bt.kin + o, *fp = fi + cap, *ri = fp + cap, *rp = ri + cap;
                         const uint32_t nf = bt.fn[s] > 0 ? (uint32_t)len : 0, nr = bt.rn[s] > 0 ? (uint32_t)len : 0;   // a strand without passes: empty lists
                         if (z.strand_tag) {                         // single-strand record: its own strand is the forward pair
                             rb.tagBC("ip", fi, nf); rb.tagBC("pw", fp, nf);
@@ -660,14 +786,18 @@ int main(int argc, char **argv)
             };
             while (to_writer.pop(b)) {
                 hold[b->index] = b;
-                while (!hold.empty() && hold.begin()->first == next) { emit(*hold.begin()->second); hold.erase(hold.begin()); ++next; }
+                while (!hold.empty() && hold.begin()->first == next) {
+                    emit(*hold.begin()->second);
+                    out_pool.put(std::move(hold.begin()->second->out_arena));
+                    hold.erase(hold.begin()); ++next;
+                }
                 if (opt.log_level >= 2) {
                     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
                     std::fprintf(stderr, "%" PRId64 "/%.1f %" PRId64 "/%.1f\n", rep.input, rep.input / el * 60, rep.pass, rep.pass / el * 60);
                 }
             }
             for (auto &kv : hold) emit(*kv.second);
-            if (fastq) gzclose(gzq);
+            if (fastq) { if (gzclose(gzq) != Z_OK) throw std::runtime_error("short write (fastq.gz)"); }
             else {
                 if (!header_done) write_header(*outp, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:unknown\n");
                 outp->close();
@@ -681,6 +811,7 @@ int main(int argc, char **argv)
         });
 
         reader.join();
+        for (auto &w : packers) w.join();
         for (auto &w : workers) w.join();
         to_writer.close();
         writer.join();
@@ -691,12 +822,17 @@ int main(int argc, char **argv)
             std::fprintf(stderr, "ccs: reader thread: framing/inflate %.2f s, waiting for record decode %.2f s, grouping+filters+queue %.2f s\n",
                          rd_us[0] * 1e-6, rd_us[1] * 1e-6, rd_us[2] * 1e-6);
         if (opt.log_level >= 2)
-            std::fprintf(stderr, "ccs: GPU workers (sum over %zu): waiting for input %.2f s, packing %.2f s, upload+kernels+download %.2f s\n", handles.size(),
+            std::fprintf(stderr, "ccs: GPU workers (sum over %zu): waiting for input %.2f s, packing (pack threads) %.2f s, submit + wait %.2f s\n", handles.size(),
                          us_wait.load() * 1e-6, us_pack.load() * 1e-6, us_engine.load() * 1e-6);
         if (opt.log_level >= 1)
             std::fprintf(stderr, "ccs: %" PRId64 " ZMWs in, %" PRId64 " HiFi reads out, %.2f s (%.1f ZMWs/s, %d host threads, %zu GPU worker%s)\n", rep.input, rep.pass, el,
                          rep.input / el, nthreads, handles.size(), handles.size() == 1 ? "" : "s");
-        if (failed && !err_msg.empty()) std::fprintf(stderr, "ccs: %s\n", err_msg.c_str());
+        if (failed) {
+            if (!err_msg.empty()) std::fprintf(stderr, "ccs: %s\n", err_msg.c_str());
+            // no plausible-looking partial output after a failed run
+            std::remove(opt.out.c_str());
+            std::fprintf(stderr, "ccs: run failed, %s removed\n", opt.out.c_str());
+        }
         return failed ? 1 : 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "ccs: %s\n", e.what());

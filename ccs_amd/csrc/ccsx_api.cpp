@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -453,6 +454,8 @@ static int enqueue_download(Slot &S, ccsx_results *res, hipStream_t s)
 int ccsx_submit(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, ccsx_ticket *ticket)
 {
     if (!h || !b || !res || !ticket) { ccsx_set_error("ccsx_submit: null argument"); return -1; }
+    if (const char *e = std::getenv("CCSX_TEST_FAIL_SUBMIT"))        // fault injection for the driver's error-path test
+        if (std::atoll(e) == (long long)h->next_ticket) { ++h->next_ticket; ccsx_set_error("injected failure (CCSX_TEST_FAIL_SUBMIT)"); return -2; }
     HIPTRY(hipSetDevice(h->device));
     Slot &S = h->slot[h->next_ticket % CCSX_SLOTS];
     if (S.inflight) {                                    // the slot's previous batch was never waited for: finish it first

@@ -975,6 +975,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS], sVlist[PW_MAXREADS];
+    __shared__ uint8_t sZdrop[PW_MAXREADS];                  // z-score gate: decided on the draft window (round 0), then kept
     __shared__ float sBase[PW_MAXREADS];
     __shared__ short2 sTask[PW_MAXREADS];                    // fill tasks: (read A, read B or -1)
     __shared__ int sDeltaI[256];                             // fixed-point sums of the per-read gains; converted in place to float
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 if (n < 0 || n > CCSX_IMAX) n = -1;
                 na = st ? L - b : a;
             }
-            sI[tid] = n; sStrand[tid] = (uint8_t)st;
+            sI[tid] = n; sStrand[tid] = (uint8_t)st; sZdrop[tid] = 0;
             sGoff[tid] = (int)(bo0 - bo_r0) + na;            // segment start relative to the ZMW's first base (sGoff is re-planned later)
             // interval k covers draft positions col(k-1) .. col(k)-1: bit (p - col(k-1))
             sDirty[tid] = av ? (m1 | (m2 << (c1 - ws)) | (m3 << (c2 - ws))) : 0u;
@@ -1249,10 +1250,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                         la = det_log2f(aIJ); const float lb = det_log2f(b00);
                         float df = la - lb; if (df < 0.0f) df = -df;
                         v = !(df > AB_TOL);
-                        if (v && P.opts.min_zscore != 0.0f) {               // A7 z-score gate (x4 per emitted base = 2 bits per read base)
+                        if (sZdrop[myr]) v = 0;
+                        else if (v && it == 0 && P.opts.min_zscore != 0.0f) {   // A7 z-score gate, round 0 only (x4 per emitted base = 2 bits per read base)
                             const float zd = (la - (float)(2 * I)) - sZS[2 * sd];
                             const float zm = P.opts.min_zscore;
-                            if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) v = 0;
+                            if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) { v = 0; sZdrop[myr] = 1; }
                         }
                     }
                     sValid[myr] = (uint8_t)v; sBase[myr] = la;

@@ -145,6 +145,19 @@ int         ccsx_device_count(void);
 void        ccsx_model_default(ccsx_model *m);          /* synthetic parameter set "SYN-1"      */
 void        ccsx_opts_default(ccsx_opts *o);
 
+/* model parameter files and chemistry lookup (docs/faq/chemistry.md:27-56, docs/changelog.md:66,101).  The json schema is
+ * this library's own ("ConsensusModelVersion": "ccsx-1"): the ccsx_model blob plus the (BindingKit, SequencingKit,
+ * BasecallerVersion) triples it supports; floats round-trip exactly.                                                      */
+int         ccsx_model_from_json(const char *json_text, ccsx_model *m);
+int         ccsx_model_load(const char *path, ccsx_model *m);
+/* writes at most cap-1 bytes + NUL, returns the bytes needed (call with buf = NULL to size); the triple may be NULL      */
+int64_t     ccsx_model_to_json(const ccsx_model *m, const char *binding_kit, const char *sequencing_kit,
+                               const char *basecaller_version, char *buf, int64_t cap);
+/* $SMRT_CHEMISTRY_BUNDLE_DIR/arrow/ (every .json there; injected models take precedence), then the built-in set.  <0 with
+ * "Unsupported chemistries found: (...)" when no model supports the triple (basecaller versions match on major.minor)    */
+int         ccsx_model_for_chemistry(const char *binding_kit, const char *sequencing_kit, const char *basecaller_version,
+                                     ccsx_model *m);
+
 /* lifecycle: binds to GPU `device_ordinal`, creates a stream, copies the model */
 int         ccsx_create(int device_ordinal, const ccsx_model *model, const ccsx_opts *opts, ccsx_handle *out);
 int         ccsx_destroy(ccsx_handle h);

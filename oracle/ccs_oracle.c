@@ -684,6 +684,7 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
     float *bet = (float *)malloc(sizeof(float) * (size_t)nreads * (IMAX + 2) * GS);
     float *base = (float *)malloc(sizeof(float) * nreads);
     uint8_t *valid = (uint8_t *)malloc(nreads);
+    uint8_t *zdrop = (uint8_t *)calloc(nreads > 0 ? nreads : 1, 1);   /* z-score gate: decided on the draft window (round 0), then kept */
     float delta[256]; uint8_t mvalid[256];
     float pskip[JMAX + 2];                                   /* travels with the bases like ev */
     for (int c = 0; c <= JMAX; ++c) pskip[c] = (skip_p && c < J0) ? skip_p[c] : 0.0f;
@@ -704,14 +705,16 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
             if (!(a > TINY_P) || !(b > TINY_P)) continue;
             float la = orc_log2f(a), lb = orc_log2f(b);
             if (fabsf(la - lb) > AB_TOL) continue;
-            if (MU && zmin != 0.0f) {                        /* z-score gate; the x4 per emitted base is 2 bits per read base */
+            if (zdrop[r]) continue;
+            if (it == 0 && MU && zmin != 0.0f) {             /* z-score gate (round 0 only: a changing read set between rounds can make
+                                                                the polish oscillate); the x4 per emitted base is 2 bits per read base */
                 int kk[JMAX + 1]; tpl_ctx(strand[r] ? tr : w.t, w.J, strand[r] ? lfr : w.lf, kk);
                 float M = 0.0f, V = 0.0f;
                 for (int j = 0; j < w.J; ++j) { M = M + MU[kk[j]]; V = V + VAR[kk[j]]; }
                 float d = (la - (float)(2 * I[r])) - M;
                 if (orc_dbg.stats == 3) { float z = d / sqrtf(V); int bin = (int)floorf(z * 2.0f) + 32; if (bin < 0) bin = 0; if (bin > 63) bin = 63;
                     _Pragma("omp atomic") orc_dbg.cal_cnt[bin] += 1; }
-                if (d < 0.0f && d * d > (zmin * zmin) * V) continue;
+                if (d < 0.0f && d * d > (zmin * zmin) * V) { zdrop[r] = 1; continue; }
             }
             base[r] = la; valid[r] = 1; ++nvalid;
         }
@@ -813,7 +816,7 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
     if (out_delta) memcpy(out_delta, delta, sizeof(delta));
     if (wfinal) *wfinal = w;
     if (out_nscored) *out_nscored = nscored;
-    free(gam); free(bet); free(base); free(valid);
+    free(gam); free(bet); free(base); free(valid); free(zdrop);
     return iters;
 }
 

@@ -90,3 +90,19 @@ def write_bam(path, text: str, records: list, block: int = 0xff00, extra_first: 
                 f.write(_bgzf_block(b"", extra_first))
         if eof:
             f.write(BGZF_EOF)
+
+
+def read_bam_raw_records(path):
+    """(header text, [raw record bytes incl. block_size]) — to rewrite a BAM with another header"""
+    data = gzip.open(path, "rb").read()
+    l_text, = struct.unpack_from("<i", data, 4)
+    text = data[8:8 + l_text].decode()
+    p = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, p); p += 4
+    for _ in range(n_ref):
+        l, = struct.unpack_from("<i", data, p); p += 4 + l + 4
+    recs = []
+    while p < len(data):
+        bs, = struct.unpack_from("<i", data, p)
+        recs.append(data[p:p + 4 + bs]); p += 4 + bs
+    return text, recs
