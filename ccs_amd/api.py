@@ -22,7 +22,7 @@ BAND, MAXPRED, WIN_CORE, WIN_OVERHANG, JMAX, IMAX, MAX_ITER, NCTX, NOBS = 64, 8,
 
 STATUS_NAMES = {
     0: "SUCCESS", 1: "TOO_FEW_PASSES", 2: "DRAFT_FAILURE", 3: "TOO_MANY_UNUSABLE", 4: "NON_CONVERGENT",
-    5: "TOO_SHORT", 6: "TOO_LONG", 7: "LOW_RQ", 8: "EMPTY_WINDOW",
+    5: "TOO_SHORT", 6: "TOO_LONG", 7: "LOW_RQ", 8: "EMPTY_WINDOW", 9: "CAPACITY",
 }
 
 

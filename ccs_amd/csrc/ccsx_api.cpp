@@ -334,7 +334,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
 
     // ---- resident POA graphs / alignment slots: as many as fit this handle's share of the free memory, never more than
     // the work.  The scratch is shared by the handle's batch slots; it only grows, and growing waits for the compute stream.
-    S.poa_slot_bytes = (((size_t)vcap_max + 64) * 392 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
+    S.poa_slot_bytes = (((size_t)vcap_max + 64) * 393 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
     S.align_slot_i32 = (size_t)need_max * 128 + need_max + 64;   // (origin, dirty bits) per cell and edge + band starts
     int poa_slots, align_slots;
     {

@@ -226,7 +226,7 @@ __device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { 
 struct PoaSlot {
     int4 *vrec, *kinfo;
     int32_t *predx, *M, *rank, *order0, *order1, *bestK, *bpK, *pathv;
-    uint8_t *mvK;
+    uint8_t *mvK, *needK;
 };
 
 __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
@@ -244,6 +244,7 @@ __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
     s.order1 = (int32_t *)p;  p += vc * 4;
     s.bestK = (int32_t *)p;   p += vc * 4;      // also the run-count / shift array while threading a read
     s.bpK = (int32_t *)p;     p += vc * 4;
+    s.needK = p;              p += vc;          // by topological position: 1 = some in-edge reaches this column from more than 3 positions ahead
     s.pathv = (int32_t *)p;
     return s;
 }
@@ -315,8 +316,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 }
             } else {
             PHASE(8);
-            // ---- DP over the graph in topological order
             const int n0 = n;
+            // ---- which score columns will be read back?  Columns k-1..k-3 stay in registers, so only the source of an in-edge that
+            // spans more than 3 positions has to be stored (a few per cent of the vertices): the other 256-byte columns were the
+            // bulk of this kernel's HBM writes.  One pass over the graph marks them by topological position.
+            for (int q = lane; q < n0; q += LANES) g.needK[q] = 0;
+            __threadfence_block();
+            for (int kb = 0; kb < n0; kb += LANES) {
+                const int kk = kb + lane;
+                if (kk < n0) {
+                    const int v = order[kk];
+                    const int4 rec = g.vrec[v];
+                    const int np = (rec.x >> 8) & 255;
+                    for (int q = 0; q < np; ++q) {
+                        const int pu = g.rank[poa_pred(g, rec, v, q)];
+                        if (kk - pu > 3) g.needK[pu] = 1;
+                    }
+                }
+            }
+            __threadfence_block();
+            // ---- DP over the graph in topological order
             int Mprev = NEGV, lo_prev = 0, cm_prev = NEGV, br_prev = 0;
             int M2 = NEGV, M3 = NEGV, lo2 = 0, lo3 = 0;             // columns k-2, k-3: most branch in-edges end there
             int rbK = 4;                                            // read base of row lo + lane - 1 of the current band position
@@ -328,7 +347,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 const int kkL = kb + lane;
                 const int vL = kkL < n0 ? order[kkL] : 0;
                 int4 rL = make_int4(0, 0, 0, 0);
-                if (kkL < n0) rL = g.vrec[vL];
+                int needL = 0;
+                if (kkL < n0) { rL = g.vrec[vL]; needL = g.needK[kkL]; }
                 // topological positions of in-edges 0..2 of the block's columns (ranks are fixed during a DP pass): gathered
                 // once per block, so a branch column needs no dependent rank[] load on its critical path
                 int pLx = -1, pLy = -1, pLz = -1;
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 int4 myInfo = make_int4(0, NEGV, 0, -1);                   // (lo, colmax, bestrow, pp) of column kb + lane
                 // consume the block loads here, so the compiler waits for them once per block and not at the top of
                 // every column (a vmcnt(0) there would also drain each column's streaming stores)
-                asm volatile("" :: "v"(vL), "v"(rL.x), "v"(rL.y), "v"(rL.z), "v"(rL.w), "v"(pLx), "v"(pLy), "v"(pLz));
+                asm volatile("" :: "v"(vL), "v"(rL.x), "v"(rL.y), "v"(rL.z), "v"(rL.w), "v"(pLx), "v"(pLy), "v"(pLz), "v"(needL));
                 int32_t *Mrow = g.M + (size_t)kb * 64 + lane;
                 uint8_t *mvrow = g.mvK + (size_t)kb * 64 + lane;
                 for (int j = 0; j < nblk; ++j, Mrow += 64, mvrow += 64) {
@@ -443,7 +463,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const int cm = wave_reduce_max_i32(best);
                     const unsigned long long bal = __ballot(best == cm);
                     const int br = lo + (__ffsll((long long)bal) - 1);
-                    *Mrow = best;
+                    if (rl(needL, j)) *Mrow = best;                            // wave-uniform: only columns a far in-edge will read
                     *mvrow = (uint8_t)bm;
                     if (lane == j) myInfo = make_int4(lo, cm, br, pp);
                     const int oe = I - lo;
@@ -919,16 +939,18 @@ __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_
 struct ScoreChain {                  // running state of one (lane, read) mutation evaluation
     float ap, bp, acc, b, bq;
     float2 pA, pB;
+    const float *g, *be;             // gamma(i, c) and beta(i+1, q) of the row about to be processed: both advance by S per row
 };
 
-// one row of the extend+link recursion
-__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, const float2 *sCTX, const float *gam, const float *bet,
-                                           int S, int i, int o, bool last)
+// one row of the extend+link recursion.  tA / tB = the lane's columns of sCTX (context kA / kB), o256 = the row's
+// observation code as a byte offset (obs * 256 = one sCTX row of 32 float2)
+__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, const char *tA, const char *tB, int S, int o256, bool last)
 {
-    const float gmm = gam[i * S];
+    const float gmm = *s.g;
     float2 nA = make_float2(0.f, 0.f), nB = make_float2(0.f, 0.f);
-    if (!last) { nA = sCTX[o * 32 + L.kA]; nB = sCTX[o * 32 + L.kB]; }
-    const float bqn = bet[(i + 1) * S];
+    if (!last) { nA = *(const float2 *)(tA + o256); nB = *(const float2 *)(tB + o256); }
+    const float bqn = *s.be;
+    s.g += S; s.be += S;
     const float insA = s.pA.y, meA = s.pA.x, insB = s.pB.y;
     const float a = gmm + s.ap * insA;
     float b;
@@ -968,8 +990,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
     __shared__ float sDLJ[2][32];
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
-    // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta
-    uint8_t (*sObs)[68] = (uint8_t (*)[68])dyn_lds;
+    // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
+    // A code is stored as obs * 256 = the byte offset of its row in sCTX, so the scoring loop adds it to a per-lane base.
+    uint16_t (*sObs)[68] = (uint16_t (*)[68])dyn_lds;
     float *sGB = (float *)((uint8_t *)dyn_lds + P.pw_obs_bytes);
     const int GB_FLOATS = P.pw_gb_floats;
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
@@ -1068,7 +1091,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             const int r = rb + PW_WAVES * q + wave;
             if (r < nreads) {
                 const int n = sI[r];
-                sObs[r][lane] = (lane < n) ? (uint8_t)obs_of(bq[q], pq[q]) : (uint8_t)0;   // rows beyond the segment read as obs 0
+                sObs[r][lane] = (lane < n) ? (uint16_t)(obs_of(bq[q], pq[q]) << 8) : (uint16_t)0;   // rows beyond the segment read as obs 0
                 if (lane < 4) sObs[r][64 + lane] = 0;
             }
         }
@@ -1100,13 +1123,22 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
         __syncthreads();
         const int lfr = (rf < 4) ? 3 - rf : 4;
-        for (int e = tid; e < 2 * 32 * CCSX_NOBS; e += PW_THREADS) {
-            const int sd = e / (32 * CCSX_NOBS), rem = e - sd * (32 * CCSX_NOBS), j = rem / CCSX_NOBS, o = rem - j * CCSX_NOBS;
-            if (j < J) {
-                const int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
-                const int k = ctx_of(prev, sT[sd][j]);
-                sMI[sd][j * MI_STRIDE + o] = sCTX[o * 32 + k];
-                if (o == 0) sDLJ[sd][j] = sDL[k];
+        // per-column copies of the tables for the fill.  Two extra entries make the sweep branch-free: slot 12 of every column is
+        // (0, 0) (the "no base" code of row 0 / row I: the SPEC's "no diagonal / no stay there" becomes an exact +0 product), and
+        // column J is all zeros with DL = 1 (no stay in the final column; beta's start value passes through 1 * beta).
+        for (int e = tid; e < 2 * 32 * MI_STRIDE; e += PW_THREADS) {
+            const int sd = e / (32 * MI_STRIDE), rem = e - sd * (32 * MI_STRIDE), j = rem / MI_STRIDE, o = rem - j * MI_STRIDE;
+            if (j <= J) {
+                float2 ent = make_float2(0.0f, 0.0f);
+                float dlv = 1.0f;
+                if (j < J) {
+                    const int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
+                    const int k = ctx_of(prev, sT[sd][j]);
+                    if (o < CCSX_NOBS) ent = sCTX[o * 32 + k];
+                    dlv = sDL[k];
+                }
+                sMI[sd][j * MI_STRIDE + o] = ent;
+                if (o == 0) sDLJ[sd][j] = dlv;
             }
         }
         // z-score expectation of the window template on each strand, summed in column order (SPEC)
@@ -1190,54 +1222,54 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const float2 *MI = sMI[sd];
                 const float *DLJ = sDLJ[sd];
                 const bool rowok = row <= I;
-                const int op = (row >= 1 && rowok) ? sObs[myr][row - 1] : 0;            // o_{i-1}
-                const int oc = (row < I) ? sObs[myr][row] : 0;                           // o_i
+                const int op = (row >= 1 && rowok) ? (sObs[myr][row - 1] >> 8) : 12;           // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                const int oc = (row < I) ? (sObs[myr][row] >> 8) : 12;                          // o_i;     12 = no base: row I emits nothing more
                 // activity windows: alpha computes column j = t - row for t in [row, row+J]; beta computes column
-                // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step.
+                // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step; two steps per
+                // loop iteration, so the second step's addresses are immediates and no state has to be copied between registers.
                 const int tA0 = rowok ? row : (1 << 20), tB0 = rowok ? I - row : (1 << 20);
                 const float one0 = (row == 0) ? 1.0f : 0.0f, oneI = (row == I) ? 1.0f : 0.0f;
                 const float2 *pA = MI + op - row * MI_STRIDE;
                 const float *dA = DLJ - row;
                 float *gA = sGB + sGoff[myr] + row * S - row;
-                const float2 *pB = MI + oc + (J + I - row) * MI_STRIDE;
-                const float *dB = DLJ + (J + I - row);
-                float *bB = sGB + sBoff[myr] + row * S + (J + I - row);
-                float acur = 0.0f, updiag = 0.0f, mePrev = 0.0f, dlPrev = 0.0f;
-                float bcur = 0.0f, dndiag = 0.0f;
-                for (int t = 0; t <= Tmax; ++t, pA += MI_STRIDE, ++dA, ++gA, pB -= MI_STRIDE, --dB, --bB) {
-                    float up = wave_shr1_f32(acur, 0.0f);
-                    if (row == 0) up = 0.0f;
-                    float dn = wave_shl1_f32(bcur, 0.0f);
-                    if (row >= I) dn = 0.0f;
-                    const unsigned ja = (unsigned)(t - tA0);                 // = column j when active
-                    if (ja <= (unsigned)J) {
-                        const float m = updiag * mePrev, dl = acur * dlPrev;
-                        float gmm = m + dl;
-                        if (ja == 0) gmm = one0;
-                        float st = 0.0f;
-                        if (ja < (unsigned)J) {
-                            const float2 pr = *pA;
-                            st = up * pr.y;                                  // row 0: up == 0 -> +0, same bits as the SPEC's "no stay"
-                            mePrev = pr.x; dlPrev = *dA;
-                        }
-                        *gA = gmm;
-                        acur = gmm + st;
-                    }
-                    updiag = up;
-                    const unsigned jbk = (unsigned)(t - tB0);                // = J - jb when active
-                    if (jbk <= (unsigned)J) {
-                        float bv = oneI;
-                        if (jbk != 0) {
-                            const float2 pr = *pB;
-                            const float t1 = pr.x * dndiag, t2 = pr.y * dn;  // last row: dn == dndiag == 0 -> +0
-                            const float t3 = *dB * bcur;
-                            bv = (t1 + t2) + t3;
-                        }
-                        *bB = bv;
-                        bcur = bv;
-                    }
-                    dndiag = dn;
+                const float2 *pB = MI + oc + (J + I - row - 1) * MI_STRIDE;               // the SECOND step of an iteration; the first is one column up
+                const float *dB = DLJ + (J + I - row - 1);
+                float *bB = sGB + sBoff[myr] + row * S + (J + I - row - 1);
+                // start values chosen so that the general recurrence yields the boundary cells: gamma(i,0) = 0*x + one0*1,
+                // beta(i,J) = (0 + 0) + 1*oneI (column J of the tables is zero with DL = 1)
+                float acur = one0, updiag = 0.0f, mePrev = 0.0f, dlPrev = 1.0f;
+                float bcur = oneI, dndiag = 0.0f;
+                const unsigned uJ = (unsigned)J;
+#define CCSX_FILL_STEP(T, AOFF, BOFF)                                                                                      \
+                {                                                                                                          \
+                    const float up = wave_shr1_f32_z(acur);          /* all rows of the read shift together (full exec) */     \
+                    const float dn = wave_shl1_f32_z(bcur);                                                                    \
+                    if ((unsigned)((T) - tA0) <= uJ) {               /* alpha, column j = T - row */                          \
+                        const float2 pr = pA[(AOFF) * MI_STRIDE];                                                            \
+                        const float dlc = dA[(AOFF)];                                                                        \
+                        const float m = updiag * mePrev, dl = acur * dlPrev;                                                  \
+                        const float gmm = m + dl;                                                                            \
+                        const float st = up * pr.y;                  /* row 0 and column J read zero entries: +0 */           \
+                        gA[(AOFF)] = gmm;                                                                                    \
+                        acur = gmm + st;                                                                                     \
+                        mePrev = pr.x; dlPrev = dlc;                                                                         \
+                    }                                                                                                        \
+                    updiag = up;                                                                                             \
+                    if ((unsigned)((T) - tB0) <= uJ) {               /* beta, column jb = J - (T - (I - row)) */              \
+                        const float2 pr = pB[(BOFF) * MI_STRIDE];                                                            \
+                        const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                                       \
+                        const float t3 = dB[(BOFF)] * bcur;                                                                  \
+                        const float bv = (t1 + t2) + t3;                                                                     \
+                        bB[(BOFF)] = bv;                                                                                     \
+                        bcur = bv;                                                                                           \
+                    }                                                                                                        \
+                    dndiag = dn;                                                                                             \
                 }
+                for (int t = 0; t <= Tmax; t += 2, pA += 2 * MI_STRIDE, dA += 2, gA += 2, pB -= 2 * MI_STRIDE, dB -= 2, bB -= 2) {
+                    CCSX_FILL_STEP(t, 0, 1)
+                    CCSX_FILL_STEP(t + 1, 1, 0)                      // an odd extra step past Tmax is inactive in every lane
+                }
+#undef CCSX_FILL_STEP
                 // zero row I+1 of beta, validity
                 if (row < S && (paired || lane < 32) ) sGB[sBoff[myr] + (I + 1) * S + row] = 0.0f;
                 if (!paired && lane >= 32 && lane < S) sGB[sBoff[myr] + (I + 1) * S + lane] = 0.0f;   // S can reach 33
@@ -1300,28 +1332,31 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     const int Ia = sI[ra], Ib = two ? sI[rb] : -1;
                     const LaneMut La = sStrand[ra] ? LR : LF;
                     const LaneMut Lb = (two && sStrand[rb]) ? LR : LF;
-                    const float *gamA = sGB + sGoff[ra] + La.c, *betA = sGB + sBoff[ra] + La.q;
-                    const float *gamB = sGB + sGoff[rb] + Lb.c, *betB = sGB + sBoff[rb] + Lb.q;
-                    const uint8_t *obA = sObs[ra], *obB = sObs[rb];
+                    const uint16_t *obA = sObs[ra], *obB = sObs[rb];
+                    const char *tAa = (const char *)(sCTX + La.kA), *tBa = (const char *)(sCTX + La.kB);
+                    const char *tAb = (const char *)(sCTX + Lb.kA), *tBb = (const char *)(sCTX + Lb.kB);
                     ScoreChain ca, cb;
-                    ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f); ca.bq = betA[0];
-                    cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f); cb.bq = betB[0];
+                    ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
+                    cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f);
+                    ca.g = sGB + sGoff[ra] + La.c; ca.be = sGB + sBoff[ra] + La.q; ca.bq = *ca.be; ca.be += S;
+                    cb.g = sGB + sGoff[rb] + Lb.c; cb.be = sGB + sBoff[rb] + Lb.q; cb.bq = *cb.be; cb.be += S;
                     const int Imin = two ? (Ia < Ib ? Ia : Ib) : -1;
                     int i = 0;
                     int oa = obA[0], ob = obB[0];                               // obs codes are fetched one row ahead
+#pragma unroll 2
                     for (; i < Imin; ++i) {                                    // both chains, neither at its last row
                         const int oan = obA[i + 1], obn = obB[i + 1];
-                        score_step(ca, La, sCTX, gamA, betA, S, i, oa, false);
-                        score_step(cb, Lb, sCTX, gamB, betB, S, i, ob, false);
+                        score_step(ca, La, tAa, tBa, S, oa, false);
+                        score_step(cb, Lb, tAb, tBb, S, ob, false);
                         oa = oan; ob = obn;
                     }
                     {
                         int o = oa;
-                        for (int ia = i; ia <= Ia; ++ia) { const int on = obA[ia + 1]; score_step(ca, La, sCTX, gamA, betA, S, ia, o, ia == Ia); o = on; }
+                        for (int ia = i; ia <= Ia; ++ia) { const int on = obA[ia + 1]; score_step(ca, La, tAa, tBa, S, o, ia == Ia); o = on; }
                     }
                     if (two) {
                         int o = ob;
-                        for (int ib = i; ib <= Ib; ++ib) { const int on = obB[ib + 1]; score_step(cb, Lb, sCTX, gamB, betB, S, ib, o, ib == Ib); o = on; }
+                        for (int ib = i; ib <= Ib; ++ib) { const int on = obB[ib + 1]; score_step(cb, Lb, tAb, tBb, S, o, ib == Ib); o = on; }
                     }
                     int dq;
                     {
@@ -1682,12 +1717,15 @@ __global__ __launch_bounds__(64) void k_stitch(KParams P)
     }
     if (lane == 0) {
         if (stat == CCSX_SUCCESS) P.np[z] = npmode;
-        int64_t len = run; if (len > cap) len = cap;
+        int64_t len = run;
+        const bool overflow = len > cap;                    // never a silently truncated HiFi read
+        if (overflow) len = cap;
         float rq = 0.0f, ec = 0.0f;
         if (stat == CCSX_SUCCESS) {
-            rq = len > 0 ? (float)(1.0 - sSum / (double)len) : 0.0f;
+            rq = len > 0 ? (float)(1.0 - sSum / (double)run) : 0.0f;
             ec = nw > 0 ? (float)((double)nvs / (double)nw) : 0.0f;
-            if (len == 0) stat = CCSX_EMPTY_WINDOW;
+            if (overflow) { stat = CCSX_CAPACITY; len = 0; }
+            else if (len == 0) stat = CCSX_EMPTY_WINDOW;
             else if (ncv) stat = CCSX_NON_CONVERGENT;
             else if (rq < P.opts.min_rq) stat = CCSX_LOW_RQ;
         } else len = 0;
@@ -1716,7 +1754,7 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
     if (hipFuncSetAttribute((const void *)k_polish, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES - static_bytes) != hipSuccess) return -1;
     if (max_reads > PW_MAXREADS) max_reads = PW_MAXREADS;
     if (max_reads < 1) max_reads = 1;
-    *obs_bytes = ((max_reads * 68) + 15) & ~15;
+    *obs_bytes = ((max_reads * 68 * 2) + 15) & ~15;
     *gb_floats = (PW_LDS_BYTES - static_bytes - *obs_bytes) / 4;
     return 0;
 }

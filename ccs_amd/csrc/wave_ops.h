@@ -17,6 +17,10 @@ __device__ __forceinline__ int wave_shl1_i32(int x, int fill) { return __builtin
 __device__ __forceinline__ float wave_shr1_f32(float x, float fill) { return __int_as_float(wave_shr1_i32(__float_as_int(x), __float_as_int(fill))); }
 __device__ __forceinline__ float wave_shl1_f32(float x, float fill) { return __int_as_float(wave_shl1_i32(__float_as_int(x), __float_as_int(fill))); }
 
+// the same shifts with a zero fill: bound_ctrl:1 makes the hardware supply the 0, no register has to be pre-loaded with it
+__device__ __forceinline__ float wave_shr1_f32_z(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), DPP_WAVE_SHR1, 0xf, 0xf, true)); }
+__device__ __forceinline__ float wave_shl1_f32_z(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), DPP_WAVE_SHL1, 0xf, 0xf, true)); }
+
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 // inclusive prefix maximum over the 64 lanes.  `old` = INT_MIN (the identity of max) lets the DPP combiner

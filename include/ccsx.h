@@ -52,7 +52,8 @@ enum ccsx_status {
     CCSX_TOO_SHORT             = 5,
     CCSX_TOO_LONG              = 6,
     CCSX_LOW_RQ                = 7,  /* predicted accuracy below opts.min_rq                          */
-    CCSX_EMPTY_WINDOW          = 8   /* EMPTY_WINDOW_DURING_POLISHING                                 */
+    CCSX_EMPTY_WINDOW          = 8,  /* EMPTY_WINDOW_DURING_POLISHING                                 */
+    CCSX_CAPACITY              = 9   /* the polished consensus outgrew its buffer (1.25 x longest subread + 64): reported, never truncated */
 };
 
 /* ---- Arrow model parameter blob (interface of docs/faq/chemistry.md:27-56 the "arrow" json files) ----

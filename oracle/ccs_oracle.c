@@ -988,7 +988,7 @@ typedef struct {
     int32_t fn, rn;             /* passes used on the strand of SEQ / on the other strand (fn + rn = np) */
 } orc_zmw_out;
 
-enum { ST_SUCCESS = 0, ST_TOO_FEW = 1, ST_DRAFT_FAIL = 2, ST_UNUSABLE = 3, ST_NONCONV = 4, ST_SHORT = 5, ST_LONG = 6, ST_LOWRQ = 7, ST_EMPTY = 8 };
+enum { ST_SUCCESS = 0, ST_TOO_FEW = 1, ST_DRAFT_FAIL = 2, ST_UNUSABLE = 3, ST_NONCONV = 4, ST_SHORT = 5, ST_LONG = 6, ST_LOWRQ = 7, ST_EMPTY = 8, ST_CAPACITY = 9 };
 
 int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const float *snr, int nreads_in,
                       const int64_t *base_off /* [nreads+1], relative to bases */, const uint8_t *bases, const uint8_t *pw,
@@ -1154,16 +1154,17 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
             }
             perr_sum += (double)wsum;
         }
-        if (overflow) len = cap;
-        out->seq_len = (int32_t)len;
         out->rq = len > 0 ? (float)(1.0 - perr_sum / (double)len) : 0.0f;
+        if (overflow) len = 0;                                   /* never a silently truncated read: status CAPACITY */
+        out->seq_len = (int32_t)len;
         out->ec = nw > 0 ? (float)((double)nvalid_sum / (double)nw) : 0.0f;
         {   /* np = mode over windows of the passes used for polishing (docs/faq/accuracy-vs-passes.md:18-24); ties: the smaller count */
             int best = 0;
             for (int v = 1; v <= 64; ++v) if (nv_hist[v] > nv_hist[best]) best = v;
             out->np = best;
         }
-        if (len == 0) out->status = ST_EMPTY;
+        if (overflow) out->status = ST_CAPACITY;
+        else if (len == 0) out->status = ST_EMPTY;
         else if (nonconv_any) out->status = ST_NONCONV;
         else if (out->rq < opts->min_rq) out->status = ST_LOWRQ;
         else out->status = ST_SUCCESS;

@@ -438,3 +438,23 @@ def test_async_submit_rejects_small_result_buffers(built):
     r = h.wait(h.submit(small, res_small))
     assert (r.status >= 0).all()
     h.close()
+
+
+def test_bench_two_ranks_on_one_device(built, tmp_path):
+    """the N>1 code path of bench.py (one process per rank, barrier + max-over-ranks timing, ZMW shards
+    with distinct ids, no data-path collective) executes the HIP kernels before an 8-GPU node ever sees it: two ranks share
+    GPU 0 through the CCSX_BENCH_DEVICE hook, the timing collectives run over gloo."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CCSX_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--zmws", "48", "--length", "2000", "--backend", "gloo",
+           "--distinct", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
+    assert out["value"] > 0 and out["success_frac"] > 0.9
+    assert abs(out["value"] - 2 * 48 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3      # whole-job aggregate over both ranks

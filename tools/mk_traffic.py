@@ -1,25 +1,41 @@
 #!/usr/bin/env python3
-"""Per-kernel HBM traffic (FETCH_SIZE + WRITE_SIZE, raw KB) and VALU occupancy from the PMC passes of tools/prof_round.sh."""
+"""Per-kernel HBM traffic (FETCH_SIZE + WRITE_SIZE, raw KB) and VALU issue from the PMC passes of tools/prof_round.sh.
+Counters are summed over every dispatch of a kernel in the run; one bench run = (warmup + steps + 1) passes over the batch,
+taken from the number of k_polish dispatches (one per pass)."""
 import glob, json, os, sqlite3, sys
 root, n = sys.argv[1], int(sys.argv[2])
-val = {}
+val, cnt = {}, {}
 for db in glob.glob(os.path.join(root, "pmc_*", "pmc_results.db")):
     c = sqlite3.connect(db)
-    for kn, cn, v in c.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
+    for kn, cn, v, k in c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"):
         val.setdefault(kn.split("(")[0], {})[cn] = v
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ_THREAD_CYCLES_VALU (separate passes), python bench.py "
-                 f"--zmws {n} --steps 1 --warmup 0, tools/prof_round.sh",
+        cnt.setdefault(kn.split("(")[0], {})[cn] = k
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ_* (separate passes), python bench.py "
+                 f"--zmws {n} --steps 1 --warmup 1 --distinct 1, tools/prof_round.sh",
        "note": "hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on this gfx950 stack FETCH_SIZE reports exactly half of the bytes of a "
                "coalesced streaming read at 1, 4 and 16 bytes per lane and WRITE_SIZE is exact (profiles/r01_counter_calibration.txt, "
                "tools/calib; MI355X_MICROARCH.md HBM section)",
        "zmws": n, "workload": "10 passes x 10 kb", "kernels": {},
-       "valu_busy_note": "SQ_THREAD_CYCLES_VALU/64 quad-cycles x4 / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs)"}
+       "valu_note": "valu_issue_frac_if_{2,4}cyc = SQ_INSTS_VALU x {2,4} SIMD cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the bounds of the "
+                    "VALU pipe occupancy (profiles/r02_valu_peak.txt: v_add/mul_f32 and v_add_u32 issue in 2 cycles per wave64, v_fma_f32, "
+                    "v_max_i32, DPP ops in 4); lanes_active_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)"}
 for k, d in sorted(val.items()):
+    runs = max(1, cnt.get("k_polish", {}).get(next(iter(d)), 1))
     e = {}
-    if "FETCH_SIZE" in d: e["fetch_size_kb_per_zmw"] = d["FETCH_SIZE"] / n
-    if "WRITE_SIZE" in d: e["write_size_kb_per_zmw"] = d["WRITE_SIZE"] / n
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d: e["hbm_bytes_per_zmw"] = int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024 / n)
-    if "SQ_THREAD_CYCLES_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
-        e["valu_busy_frac"] = round(d["SQ_THREAD_CYCLES_VALU"] / 64 * 4 / (d["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
+    per = lambda name: d[name] / (runs * n)
+    if "FETCH_SIZE" in d: e["fetch_size_kb_per_zmw"] = per("FETCH_SIZE")
+    if "WRITE_SIZE" in d: e["write_size_kb_per_zmw"] = per("WRITE_SIZE")
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d: e["hbm_bytes_per_zmw"] = int((2 * per("FETCH_SIZE") + per("WRITE_SIZE")) * 1024)
+    if "SQ_INSTS_VALU" in d:
+        e["valu_wave_instr_per_zmw"] = int(per("SQ_INSTS_VALU"))
+        if d.get("GRBM_GUI_ACTIVE"):
+            simd_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 1024
+            e["valu_issue_frac_if_2cyc"] = round(d["SQ_INSTS_VALU"] * 2 / simd_cycles, 3)
+            e["valu_issue_frac_if_4cyc"] = round(d["SQ_INSTS_VALU"] * 4 / simd_cycles, 3)
+        if d.get("SQ_THREAD_CYCLES_VALU"):
+            e["lanes_active_frac"] = round(d["SQ_THREAD_CYCLES_VALU"] / (64 * d["SQ_INSTS_VALU"]), 3)
+    if d.get("GRBM_GUI_ACTIVE"): e["gpu_active_ms_per_pass"] = round(d["GRBM_GUI_ACTIVE"] / 8 / 2.4e6 / runs, 3)
+    if "SQ_WAIT_ANY" in d and d.get("SQ_WAVE_CYCLES"): e["wave_wait_frac"] = round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 3)
+    if "SQ_LDS_BANK_CONFLICT" in d and d.get("SQ_LDS_IDX_ACTIVE"): e["lds_bank_conflict_frac"] = round(d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"], 3)
     out["kernels"][k] = e
 print(json.dumps(out, indent=1))
