@@ -936,19 +936,23 @@ __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_
     return L;
 }
 
+// 32-bit LDS pointers (address space 3): they survive being made opaque to the optimiser as LDS pointers (ds_read, not flat)
+typedef const float __attribute__((address_space(3))) *lds_cf;
+typedef const char __attribute__((address_space(3))) *lds_cc;
+
 struct ScoreChain {                  // running state of one (lane, read) mutation evaluation
     float ap, bp, acc, b, bq;
     float2 pA, pB;
-    const float *g, *be;             // gamma(i, c) and beta(i+1, q) of the row about to be processed: both advance by S per row
+    lds_cf g, be;                    // gamma(i, c) and beta(i+1, q) of the row about to be processed: both advance by S per row
 };
 
 // one row of the extend+link recursion.  tA / tB = the lane's columns of sCTX (context kA / kB), o256 = the row's
 // observation code as a byte offset (obs * 256 = one sCTX row of 32 float2)
-__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, const char *tA, const char *tB, int S, int o256, bool last)
+__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_cc tA, lds_cc tB, int S, int o256, bool last)
 {
     const float gmm = *s.g;
     float2 nA = make_float2(0.f, 0.f), nB = make_float2(0.f, 0.f);
-    if (!last) { nA = *(const float2 *)(tA + o256); nB = *(const float2 *)(tB + o256); }
+    if (!last) { const lds_cf pa = (lds_cf)(tA + o256), pb = (lds_cf)(tB + o256); nA = make_float2(pa[0], pa[1]); nB = make_float2(pb[0], pb[1]); }   // one 8-byte LDS load each
     const float bqn = *s.be;
     s.g += S; s.be += S;
     const float insA = s.pA.y, meA = s.pA.x, insB = s.pB.y;
@@ -1011,7 +1015,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __shared__ int sCnt[PW_WAVES];
     __shared__ short sList[256];                             // compacted valid mutation lanes
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);      // wave-uniform values are made scalar explicitly (rfl):
+    // loop counters, read indices and observation codes then live in SGPRs and cost no vector instructions
     PHASE_T0();
     // ---- locate (zmw, window).  The prologue is a chain of dependent global loads; every level issues all of its
     // loads before the first use (clamped indices instead of branches), so the chain is 4 round trips deep
@@ -1118,7 +1123,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     int nvalid_last = 0;
     for (int it = 0; it < CCSX_MAX_ITER; ++it) {
         __syncthreads();
-        const int J = sCtl[0];
+        const int J = rfl(sCtl[0]);
         const int S = (J + 1) | 1;                           // odd row stride >= J+1
         if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
         __syncthreads();
@@ -1183,7 +1188,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         }
         int nvm = 0;
 #pragma unroll
-        for (int q = 0; q < PW_WAVES; ++q) nvm += sCnt[q];
+        for (int q = 0; q < PW_WAVES; ++q) nvm += rfl(sCnt[q]);
         const int nblk = (nvm + 63) >> 6;
         PHASE(1);
         int nvalid = 0;
@@ -1207,16 +1212,16 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 sCtl[5] = r; sCtl[6] = nt;
             }
             __syncthreads();
-            const int rend = sCtl[5], ntask = sCtl[6];
+            const int rend = rfl(sCtl[5]), ntask = rfl(sCtl[6]);
             PHASE(2);
             // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals
             for (int tk = wave; tk < ntask; tk += PW_WAVES) {
                 const short2 task = sTask[tk];
-                const bool paired = task.y >= 0;
+                const bool paired = rfl((int)task.y) >= 0;
                 const int myr = paired ? (half ? task.y : task.x) : task.x;
                 const int row = paired ? hrow : lane;
                 const int I = sI[myr];
-                const int Ia = sI[task.x], Ib = paired ? sI[task.y] : -1;
+                const int Ia = rfl(sI[task.x]), Ib = paired ? rfl(sI[task.y]) : -1;
                 const int Tmax = (Ia > Ib ? Ia : Ib) + J;
                 const int sd = sStrand[myr];
                 const float2 *MI = sMI[sd];
@@ -1303,7 +1308,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             // ---- A3/A4: task pool.  Task id = block * npairs + pair; a block is 64 compacted mutation lanes, a pair two usable
             // reads (two independent chains per lane).  Gains are added to sDeltaI in fixed point (order independent).
             {
-                const int nv = sCtl[8], npairs = (nv + 1) >> 1, ntk = nblk * npairs;
+                const int nv = rfl(sCtl[8]), npairs = (nv + 1) >> 1, ntk = nblk * npairs;
                 nvalid += nv;
                 int curblk = -1;
                 LaneMut LF, LR;
@@ -1326,38 +1331,35 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                             LR = lane_mut(type, (type == 2) ? J - cpos : J - 1 - cpos, 3 - x, sT[1], J, lfr, sDL);
                         } else { LF = lane_mut(0, 0, 0, sT[0], J, lf, sDL); LR = LF; }
                     }
-                    const int ra = sVlist[2 * pr];
+                    const int ra = rfl((int)sVlist[2 * pr]);
                     const bool two = 2 * pr + 1 < nv;
-                    const int rb = two ? sVlist[2 * pr + 1] : ra;
-                    const int Ia = sI[ra], Ib = two ? sI[rb] : -1;
-                    const LaneMut La = sStrand[ra] ? LR : LF;
-                    const LaneMut Lb = (two && sStrand[rb]) ? LR : LF;
-                    const uint16_t *obA = sObs[ra], *obB = sObs[rb];
-                    const char *tAa = (const char *)(sCTX + La.kA), *tBa = (const char *)(sCTX + La.kB);
-                    const char *tAb = (const char *)(sCTX + Lb.kA), *tBb = (const char *)(sCTX + Lb.kB);
+                    const int rb = two ? rfl((int)sVlist[2 * pr + 1]) : ra;
+                    const int Ia = rfl(sI[ra]), Ib = two ? rfl(sI[rb]) : -1;
+                    const LaneMut La = rfl((int)sStrand[ra]) ? LR : LF;
+                    const LaneMut Lb = (two && rfl((int)sStrand[rb])) ? LR : LF;
+                    // the observation codes of both reads go to registers with ONE load each (lane k holds codes 2k, 2k+1); the row loop
+                    // then takes the (wave-uniform) code of a row with v_readlane into an SGPR: no LDS access, no address arithmetic
+                    const uint32_t obAv = ((const uint32_t *)sObs[ra])[lane < 34 ? lane : 33];
+                    const uint32_t obBv = ((const uint32_t *)sObs[rb])[lane < 34 ? lane : 33];
+                    auto obs_at = [](uint32_t v, int i) { return (int)(((uint32_t)__builtin_amdgcn_readlane((int)v, i >> 1) >> ((i & 1) << 4)) & 0xffffu); };
+                    lds_cc tAa = (lds_cc)(sCTX + La.kA), tBa = (lds_cc)(sCTX + La.kB);
+                    lds_cc tAb = (lds_cc)(sCTX + Lb.kA), tBb = (lds_cc)(sCTX + Lb.kB);
                     ScoreChain ca, cb;
                     ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
                     cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f);
-                    ca.g = sGB + sGoff[ra] + La.c; ca.be = sGB + sBoff[ra] + La.q; ca.bq = *ca.be; ca.be += S;
-                    cb.g = sGB + sGoff[rb] + Lb.c; cb.be = sGB + sBoff[rb] + Lb.q; cb.bq = *cb.be; cb.be += S;
+                    ca.g = (lds_cf)(sGB + sGoff[ra] + La.c); ca.be = (lds_cf)(sGB + sBoff[ra] + La.q); ca.bq = *ca.be; ca.be += S;
+                    cb.g = (lds_cf)(sGB + sGoff[rb] + Lb.c); cb.be = (lds_cf)(sGB + sBoff[rb] + Lb.q); cb.bq = *cb.be; cb.be += S;
+                    // opaque to the optimiser from here: the four running pointers hold complete LDS addresses (otherwise the
+                    // dynamic-LDS base is re-added at every use)
+                    asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(cb.g), "+v"(cb.be), "+v"(tAa), "+v"(tBa), "+v"(tAb), "+v"(tBb));
                     const int Imin = two ? (Ia < Ib ? Ia : Ib) : -1;
                     int i = 0;
-                    int oa = obA[0], ob = obB[0];                               // obs codes are fetched one row ahead
-#pragma unroll 2
                     for (; i < Imin; ++i) {                                    // both chains, neither at its last row
-                        const int oan = obA[i + 1], obn = obB[i + 1];
-                        score_step(ca, La, tAa, tBa, S, oa, false);
-                        score_step(cb, Lb, tAb, tBb, S, ob, false);
-                        oa = oan; ob = obn;
+                        score_step(ca, La, tAa, tBa, S, obs_at(obAv, i), false);
+                        score_step(cb, Lb, tAb, tBb, S, obs_at(obBv, i), false);
                     }
-                    {
-                        int o = oa;
-                        for (int ia = i; ia <= Ia; ++ia) { const int on = obA[ia + 1]; score_step(ca, La, tAa, tBa, S, o, ia == Ia); o = on; }
-                    }
-                    if (two) {
-                        int o = ob;
-                        for (int ib = i; ib <= Ib; ++ib) { const int on = obB[ib + 1]; score_step(cb, Lb, tAb, tBb, S, o, ib == Ib); o = on; }
-                    }
+                    for (int ia = i; ia <= Ia; ++ia) score_step(ca, La, tAa, tBa, S, obs_at(obAv, ia), ia == Ia);
+                    if (two) for (int ib = i; ib <= Ib; ++ib) score_step(cb, Lb, tAb, tBb, S, obs_at(obBv, ib), ib == Ib);
                     int dq;
                     {
                         const float res = La.fin ? ca.b : ca.acc;
