@@ -1118,6 +1118,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     }
     const int half = lane >> 5, hrow = lane & 31;          // fill: which read of the pair, row within it
     PHASE(0);
+#ifdef CCSX_EXIT_AFTER_PROLOGUE                             // experiment: what the prologue alone costs in kernel time
+    __syncthreads();
+    if (tid == 0) P.wsum[(size_t)(P.wb_off[z] - z) + w] = (float)sI[0] + (float)sObs[0][0] + sPskip[0] + sCTX[5].x;
+    return;
+#endif
     int iters = 0, nonconv = 0;
     unsigned skmask = 0;                                     // positions skipped in the current round (wave-uniform)
     int nvalid_last = 0;
