@@ -458,3 +458,27 @@ def test_bench_two_ranks_on_one_device(built, tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
     assert out["value"] > 0 and out["success_frac"] > 0.9
     assert abs(out["value"] - 2 * 48 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3      # whole-job aggregate over both ranks
+
+
+def test_inserted_blocks_fuzz_matches_oracle(handle):
+    """passes carrying 40-200 base blocks of foreign sequence (beyond what the 64-row band can follow) must end
+    in the same deliberate outcome on the GPU as in the oracle — same statuses, np, sequences, QVs — never a crash or a hang"""
+    rng = np.random.default_rng(12)
+    base = api.synth(12, (4, 12), (600, 2500), seed=91)
+    bases, pw, ipd, off = [], [], [], [0]
+    for r in range(int(base.read_off[-1])):
+        a, b = int(base.base_off[r]), int(base.base_off[r + 1])
+        bb, pp, ii = base.bases[a:b], base.pw[a:b], base.ipd[a:b]
+        if rng.random() < 0.35:
+            at, size = int(rng.integers(0, len(bb) + 1)), int(rng.integers(40, 201))
+            blk = rng.integers(0, 4, size, dtype=np.uint8)
+            bb = np.concatenate([bb[:at], blk, bb[at:]]); pp = np.concatenate([pp[:at], np.full(size, 2, np.uint8), pp[at:]])
+            ii = np.concatenate([ii[:at], np.full(size, 5, np.uint8), ii[at:]])
+        bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
+    batch = api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                      np.concatenate(ipd), base.flags, base.tpl_off, base.tpl)
+    res = handle.consensus(batch)
+    ref = _oracle(handle, batch)
+    _compare(res, ref, batch)
+    assert set(int(s) for s in res.status) <= {0, 2, 3, 4, 7}           # SUCCESS, DRAFT_FAILURE, TOO_MANY_UNUSABLE, NON_CONVERGENT, LOW_RQ
+    assert (res.status == 0).sum() >= 4

@@ -142,3 +142,47 @@ def test_np_is_the_mode_over_windows(built):
     res = _run(batch)
     assert res.np_[1] == 9 and res.ec[1] < 9.0               # a few windows lost the pass: the mode is still 9, the mean is not
     assert res.np_[0] == 9 and res.np_[2] == 9
+
+
+def test_large_inserted_blocks_end_in_a_deliberate_outcome(built):
+    """VERDICT r01 item 9 (band robustness): passes with a 40-200 base block of foreign sequence inserted (spurious sequencing
+    activity, docs/how-does-ccs-work.md:74-78) are not trimmed by this SPEC: the band loses them and they fail their alignment
+    gate — the pass is dropped, the ZMW still succeeds from the remaining passes, and the consensus is not damaged.  A ZMW in
+    which most passes carry such a block ends TOO_MANY_UNUSABLE (never a crash, never a wrong-length read)."""
+    rng = np.random.default_rng(11)
+    base = api.synth(6, 8, 1500, seed=90)
+
+    def with_blocks(batch, zmw, reads, size):
+        """rebuild the batch with a random block inserted into the given passes of one ZMW"""
+        bases, pw, ipd, off = [], [], [], [0]
+        for r in range(int(batch.read_off[-1])):
+            a, b = int(batch.base_off[r]), int(batch.base_off[r + 1])
+            bb, pp, ii = batch.bases[a:b], batch.pw[a:b], batch.ipd[a:b]
+            z = int(np.searchsorted(batch.read_off, r, side="right") - 1)
+            if z == zmw and (r - int(batch.read_off[z])) in reads:
+                at = len(bb) // 2
+                blk = rng.integers(0, 4, size, dtype=np.uint8)
+                bb = np.concatenate([bb[:at], blk, bb[at:]]); pp = np.concatenate([pp[:at], np.full(size, 2, np.uint8), pp[at:]])
+                ii = np.concatenate([ii[:at], np.full(size, 5, np.uint8), ii[at:]])
+            bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
+        return api.Batch(batch.zmw_id, batch.snr, batch.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                         np.concatenate(ipd), batch.flags, batch.tpl_off, batch.tpl)
+
+    clean = _run(base)
+    for size in (40, 90, 200):
+        b1 = with_blocks(base, 2, {1, 4}, size)                  # two of eight passes: dropped, consensus intact
+        r1 = _run(b1)
+        assert r1.status[2] == 0 and 6 <= r1.np_[2] <= 8 and r1.ec[2] < 8.0      # dropped from the windows it cannot serve (or entirely)
+        if size > 64:
+            assert r1.np_[2] == 6                                                 # beyond the band: the two passes fail their alignment gate
+        # losing two of eight passes costs that ZMW a few errors (8 -> 6 passes): this is why the reference TRIMS such insertions
+        # instead of dropping the pass (documented omission, DESIGN.md §2) — but nothing worse may happen
+        assert _edit_errors(b1, r1) <= _edit_errors(base, clean) + 10
+        for z in (0, 1, 3, 4, 5):                                # the other ZMWs are untouched
+            assert np.array_equal(r1.sequence(z), clean.sequence(z))
+        b2 = with_blocks(base, 3, {1, 2, 3, 5, 6}, size)         # five of eight passes: more than half unusable
+        r2 = _run(b2)
+        if size > 64:
+            assert r2.status[3] == 3 and r2.seq_len[3] == 0       # TOO_MANY_UNUSABLE
+        else:
+            assert r2.status[3] in (0, 3, 7)

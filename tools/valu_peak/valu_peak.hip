@@ -13,9 +13,9 @@
 #define ITERS 2048
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-enum { OP_FMA, OP_ADD, OP_MUL, OP_MAXI, OP_ADDU, OP_CNDMASK, OP_MAXI_DPP, OP_MOV_DPP, OP_PKFMA, OP_READLANE, NOPS };
+enum { OP_FMA, OP_ADD, OP_MUL, OP_MAXI, OP_ADDU, OP_CNDMASK, OP_MAXI_DPP, OP_MOV_DPP, OP_PKFMA, OP_READLANE, OP_LSHLADD, OP_MOV, OP_CMP, OP_DSREAD, OP_CNDMASK_S, OP_CMP_CND, OP_MED3, OP_MINMAX, NOPS };
 static const char *opname[NOPS] = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_max_i32", "v_add_u32", "v_cndmask_b32", "v_max_i32_dpp row_shr:1",
-                                   "v_mov_b32_dpp wave_shr:1", "v_pk_fma_f32", "v_readlane_b32 (to SGPR)"};
+                                   "v_mov_b32_dpp wave_shr:1", "v_pk_fma_f32", "v_readlane_b32 (to SGPR)", "v_lshl_add_u32", "v_mov_b32", "v_cmp_gt_u32 (to vcc)", "ds_read_b32 (bank-conflict free)", "v_cndmask_b32_e64 (SGPR-pair mask)", "v_cmp_gt_u32 + v_cndmask_b32 (pair)", "v_med3_i32", "v_min_i32 + v_max_i32 (pair)"};
 
 template <int OP> __global__ void k(unsigned long long *cyc, float *sink, float seed)
 {
@@ -25,6 +25,11 @@ template <int OP> __global__ void k(unsigned long long *cyc, float *sink, float 
     for (int i = 0; i < 8; ++i) { a[i] = seed + i + threadIdx.x; b[i] = (int)threadIdx.x * 7 + i; p[i] = make_float2(a[i], a[i] + 1.f); }
     const float c = seed * 0.5f;
     int sacc = 0;
+    __shared__ int lds[256];
+    lds[threadIdx.x & 255] = (int)threadIdx.x;
+    const int ldsaddr = (int)(threadIdx.x & 63) * 4;
+    const unsigned long long smask = __ballot((int)(threadIdx.x & 1));
+    asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b[0]), "v"(b[1]) : "vcc");       // vcc defined for the v_cndmask test
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITERS; ++it) {
@@ -36,17 +41,26 @@ template <int OP> __global__ void k(unsigned long long *cyc, float *sink, float 
     else if (OP == OP_MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));                                   \
     else if (OP == OP_MAXI) asm volatile("v_max_i32 %0, %0, %1" : "+v"(b[i]) : "v"(b[(i + 1) & 7]));                       \
     else if (OP == OP_ADDU) asm volatile("v_add_u32 %0, %0, %1" : "+v"(b[i]) : "v"(b[(i + 1) & 7]));                       \
-    else if (OP == OP_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(b[i]) : "v"(b[(i + 1) & 7]) : );        \
+    else if (OP == OP_CNDMASK) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(b[i]) : "v"(b[(i + 1) & 7]) : );    \
     else if (OP == OP_MAXI_DPP) asm volatile("v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(b[i])); \
     else if (OP == OP_MOV_DPP) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); \
     else if (OP == OP_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));                \
-    else if (OP == OP_READLANE) { int s_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s_) : "v"(b[i])); sacc += s_; }
+    else if (OP == OP_READLANE) { int s_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s_) : "v"(b[i])); sacc += s_; }        \
+    else if (OP == OP_LSHLADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(b[i]) : "v"(b[(i + 1) & 7]));              \
+    else if (OP == OP_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(b[i]) : "v"(b[(i + 1) & 7]));                               \
+    else if (OP == OP_CMP) asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b[i]), "v"(b[(i + 1) & 7]) : "vcc");               \
+    else if (OP == OP_DSREAD) asm volatile("ds_read_b32 %0, %1" : "=v"(b[i]) : "v"(ldsaddr));                                \
+    else if (OP == OP_CNDMASK_S) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "s"(smask)); \
+    else if (OP == OP_CMP_CND) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(b[i]) : "v"(b[(i + 1) & 7]) : "vcc"); \
+    else if (OP == OP_MED3) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7]));   \
+    else if (OP == OP_MINMAX) asm volatile("v_min_i32 %0, %0, %1\n\tv_max_i32 %0, %0, %2" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7]));
             REP8(ONE)
 #undef ONE
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
-    float s = 0.f; int q = sacc;
+    if (OP == OP_DSREAD) asm volatile("s_waitcnt lgkmcnt(0)");
+    float s = 0.f; int q = sacc + lds[0];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s += a[i] + p[i].x + p[i].y; q += b[i]; }
     if (s == 12345.678f || q == 0x7fffffff) sink[0] = s + q;     // keep everything live
@@ -95,6 +109,14 @@ int main()
         run<OP_MOV_DPP>(w, p.multiProcessorCount, clk);
         run<OP_PKFMA>(w, p.multiProcessorCount, clk);
         run<OP_READLANE>(w, p.multiProcessorCount, clk);
+        run<OP_LSHLADD>(w, p.multiProcessorCount, clk);
+        run<OP_MOV>(w, p.multiProcessorCount, clk);
+        run<OP_CMP>(w, p.multiProcessorCount, clk);
+        run<OP_DSREAD>(w, p.multiProcessorCount, clk);
+        run<OP_CNDMASK_S>(w, p.multiProcessorCount, clk);
+        run<OP_CMP_CND>(w, p.multiProcessorCount, clk);
+        run<OP_MED3>(w, p.multiProcessorCount, clk);
+        run<OP_MINMAX>(w, p.multiProcessorCount, clk);
     }
     return 0;
 }
