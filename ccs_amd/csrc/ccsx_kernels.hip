@@ -1310,16 +1310,21 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             }
             __syncthreads();
             PHASE(3);
-            // ---- A3/A4: task pool.  Task id = block * npairs + pair; a block is 64 compacted mutation lanes, a pair two usable
-            // reads (two independent chains per lane).  Gains are added to sDeltaI in fixed point (order independent).
+            // ---- A3/A4: work pool.  A unit = (block of 64 compacted mutation lanes) x (one usable read), numbered block-major; every
+            // wave takes an equal contiguous share and walks it two reads at a time (two independent chains per lane) while the
+            // block stays the same — 2 blocks x 5 reads are 3+3+2+2 units, not 2+2+1+1 pair tasks.  Gains are added to sDeltaI in
+            // fixed point (order independent).
             {
-                const int nv = rfl(sCtl[8]), npairs = (nv + 1) >> 1, ntk = nblk * npairs;
+                const int nv = rfl(sCtl[8]), nunits = nblk * nv;
                 nvalid += nv;
                 int curblk = -1;
                 LaneMut LF, LR;
                 int myM = 0; bool mval = false;
-                for (int tk = wave; tk < ntk; tk += PW_WAVES) {
-                    const int blk = tk / npairs, pr = tk - blk * npairs;
+                const int u_end = ((wave + 1) * nunits) / PW_WAVES;
+                for (int u = (wave * nunits) / PW_WAVES; u < u_end;) {
+                    const int blk = u / nv, k0 = u - blk * nv;
+                    const bool two = (u + 1 < u_end) && (k0 + 1 < nv);       // the next unit is mine and in the same block
+                    u += two ? 2 : 1;
                     if (blk != curblk) {
                         curblk = blk;
                         const int li = blk * 64 + lane;
@@ -1336,9 +1341,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                             LR = lane_mut(type, (type == 2) ? J - cpos : J - 1 - cpos, 3 - x, sT[1], J, lfr, sDL);
                         } else { LF = lane_mut(0, 0, 0, sT[0], J, lf, sDL); LR = LF; }
                     }
-                    const int ra = rfl((int)sVlist[2 * pr]);
-                    const bool two = 2 * pr + 1 < nv;
-                    const int rb = two ? rfl((int)sVlist[2 * pr + 1]) : ra;
+                    const int ra = rfl((int)sVlist[k0]);
+                    const int rb = two ? rfl((int)sVlist[k0 + 1]) : ra;
                     const int Ia = rfl(sI[ra]), Ib = two ? rfl(sI[rb]) : -1;
                     const LaneMut La = rfl((int)sStrand[ra]) ? LR : LF;
                     const LaneMut Lb = (two && rfl((int)sStrand[rb])) ? LR : LF;
