@@ -318,7 +318,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
 #define RES(buf, bytes) do { if ((buf).reserve(bytes)) return -2; } while (0)
     RES(S.d_tabME, (size_t)n * 192 * 4); RES(S.d_tabINS, (size_t)n * 192 * 4); RES(S.d_tabDL, (size_t)n * 16 * 4); RES(S.d_tabZ, (size_t)n * 32 * 4);
     RES(S.d_draft, (size_t)cap_total);
-    RES(S.d_zmw_i32, (size_t)n * 4 * 6);
+    RES(S.d_zmw_i32, (size_t)n * 4 * 6);   // draft_len, nwin, zstat, nreads_used, np, zref
     RES(S.d_wbounds, (size_t)S.wb_off[n] * 4);
     RES(S.d_ticket, 256);
     RES(S.d_avalid, (size_t)(R > 0 ? R : 1)); RES(S.d_ascore, (size_t)(R > 0 ? R : 1) * 4);
@@ -375,7 +375,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.tabME = (float *)S.d_tabME.p; P.tabINS = (float *)S.d_tabINS.p; P.tabDL = (float *)S.d_tabDL.p; P.tabZ = (float *)S.d_tabZ.p;
     P.draft = (uint8_t *)S.d_draft.p;
     int32_t *zi = (int32_t *)S.d_zmw_i32.p;
-    P.draft_len = zi; P.nwin = zi + n; P.zstat = zi + 2 * (size_t)n; P.nreads_used = zi + 3 * (size_t)n; P.np = zi + 4 * (size_t)n;
+    P.draft_len = zi; P.nwin = zi + n; P.zstat = zi + 2 * (size_t)n; P.nreads_used = zi + 3 * (size_t)n; P.np = zi + 4 * (size_t)n; P.zref = zi + 5 * (size_t)n;
     P.wbounds = (int32_t *)S.d_wbounds.p;
     P.ticket_poa = (int32_t *)S.d_ticket.p; P.ticket_align = P.ticket_poa + 1; P.debug = P.ticket_poa + 4; P.phase = (unsigned long long *)(P.ticket_poa + 16);
     P.poa_scratch = (uint8_t *)h->d_poa.p; P.poa_slot_bytes = S.poa_slot_bytes; P.poa_slots = poa_slots;

@@ -271,7 +271,9 @@ __device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to
 extern __shared__ uint32_t dyn_lds[];
 #define TB_BLOCK 32                   // positions cached per traceback block (LDS per wave bounds the POA occupancy)
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa(KParams P, int z0)
+#define ZREF_RETRY 256                  // k_post: this ZMW's first draft failed or most passes do not map to it
+#define ZREF_DONE 512                   // the fallback draft has been made
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa(KParams P, int z0, int pass)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sMv[TB_BLOCK * 64];   // move rows of the traceback's current block
     const int lane = threadIdx.x;
@@ -287,17 +289,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int top = (P.opts.top_passes <= 0 || P.opts.top_passes > PW_MAXREADS_SPEC) ? PW_MAXREADS_SPEC : P.opts.top_passes;
             if (nreads > top) nreads = top;
         }
-        if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; }
+        // SPEC "fallback draft" (docs/faq/accuracy-vs-passes.md:41-46: a cascade from fast to robust draft generators): pass 1
+        // (only for ZMWs k_post marked) takes the pass whose length is closest to the median as backbone and threads twice as
+        // many passes, starting at the backbone and wrapping around
+        int bb = 0;
+        if (pass == 1) {
+            if (rfl(P.zref[z]) != ZREF_RETRY) return;
+            const int len = lane < nreads ? (int)(P.base_off[r0 + lane + 1] - P.base_off[r0 + lane]) : 0x7fffffff;
+            int rank = 0;                                   // position of my length in the sorted order (ties by index)
+            for (int q = 0; q < nreads; ++q) { const int lq = __shfl(len, q); rank += (lq < len || (lq == len && q < lane)) ? 1 : 0; }
+            const int med = rfl(__shfl(len, __ffsll((long long)__ballot(lane < nreads && rank == nreads / 2)) - 1));
+            int dist = len - med; dist = dist < 0 ? -dist : dist;
+            const int key = lane < nreads ? ((dist > 0xffffff ? 0xffffff : dist) << 6) | lane : 0x7fffffff;
+            bb = rfl(wave_min_i32(key)) & 63;
+        }
+        if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_DONE : 0); }
         const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
         if (!enough && lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES;
         if (enough) {
-        const int npoa = nreads < P.opts.max_poa_cov ? nreads : P.opts.max_poa_cov;
+        const int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
+        const int npoa = nreads < cov ? nreads : cov;
         const int vcap = rfl(P.vcap[z]);
-        const int rev0 = rfl(P.flags[r0] & 1);
+        const int rev0 = rfl(P.flags[r0 + bb] & 1);
         int n = 0, nadded = 0, ok = 1;
         int32_t *order = g.order0, *order_nx = g.order1;
         for (int rr = 0; rr < npoa && ok; ++rr) {
-            const int r = r0 + rr;
+            const int r = r0 + (bb + rr < nreads ? bb + rr : bb + rr - nreads);
             const uint8_t *rb = P.bases + P.base_off[r];
             const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
             const int rev = rfl(((P.flags[r] & 1) != rev0) ? 1 : 0);
@@ -738,7 +755,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // in registers.  Instead of storing moves and tracing back every cell, each cell carries the row at which
 // its best path ENTERED the most recent window-edge column ("origin"); at every window-edge column the
 // propagated origins are saved (64 x int32), and the entry rows are recovered by hopping edge to edge.
-__global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
+__global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
 {
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
@@ -747,13 +764,15 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
     const int r = rfl(P.read_perm[rbase + blockIdx.x]); // longest reads first
     const int z = rfl(P.read_zmw[r]);
     const int r0 = rfl(P.read_off[z]);
+    const int zr = rfl(P.zref[z]);
+    if (pass == 1 && !(zr & ZREF_DONE)) return;        // second pass: only the ZMWs whose draft was redone
     if (lane == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
     if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z]) return;
     const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
     const uint8_t *d = P.draft + P.seq_off[z];
     const int32_t *wb = P.wbounds + P.wb_off[z];
     const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
-    const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0] & 1)) ? 1 : 0);
+    const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0 + (zr & 63)] & 1)) ? 1 : 0);
     load_read_packed(sread, P.bases + P.base_off[r], I, rev, lane);
     __syncthreads();
     const int nneed = 2 * nw;                           // needed columns: 0, b1-2, b1+2, ..., Ld
@@ -871,19 +890,29 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase)
 }
 
 // per-ZMW: count usable reads, raise TOO_MANY_UNUSABLE (docs/faq/accuracy-vs-passes.md:37-39)
-__global__ void k_post(KParams P)
+__global__ void k_post(KParams P, int pass)
 {
     int z = blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= P.n_zmw) return;
-    if (P.zstat[z] != CCSX_SUCCESS) { P.np[z] = 0; P.out_fn[z] = 0; P.out_rn[z] = 0; return; }
+    const int zr = P.zref[z];
+    if (pass == 1 && !(zr & ZREF_DONE)) return;
+    if (P.zstat[z] != CCSX_SUCCESS) {
+        P.np[z] = 0; P.out_fn[z] = 0; P.out_rn[z] = 0;
+        if (pass == 0 && P.zstat[z] == CCSX_DRAFT_FAILURE && !P.opts.no_fallback_draft) P.zref[z] = ZREF_RETRY;
+        return;
+    }
     int r0 = P.read_off[z], nr = P.nreads_used[z], np = 0, rn = 0;
+    const int f0 = P.flags[r0 + (zr & 63)];
     for (int r = 0; r < nr; ++r) {
         const int v = P.avalid[r0 + r];
         np += v;
-        if (v && ((P.flags[r0 + r] ^ P.flags[r0]) & 1)) ++rn;
+        if (v && ((P.flags[r0 + r] ^ f0) & 1)) ++rn;
     }
     P.np[z] = np; P.out_fn[z] = np - rn; P.out_rn[z] = rn;
-    if (2 * np <= nr) { P.zstat[z] = CCSX_TOO_MANY_UNUSABLE; P.nwin[z] = 0; }
+    if (2 * np <= nr) {
+        if (pass == 0 && !P.opts.no_fallback_draft) P.zref[z] = ZREF_RETRY;      // try the fallback draft before giving up
+        else { P.zstat[z] = CCSX_TOO_MANY_UNUSABLE; P.nwin[z] = 0; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1032,7 +1061,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     const uint8_t *draft = P.draft + so;
     const int wb0 = wb[w], wb1 = wb[w + 1];
     const int64_t bo_r0 = P.base_off[r0];
-    const int fl0 = P.flags[r0] & 1;
+    const int fl0 = P.flags[r0 + (P.zref[z] & 63)] & 1;    // orientation of the draft = that of its backbone pass
     int ws = wb0 - CCSX_WIN_OVERHANG; if (ws < 0) ws = 0;
     int we = wb1 + CCSX_WIN_OVERHANG; if (we > Ld) we = Ld;
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
@@ -1581,7 +1610,7 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
     if (tid < nreads) {                                      // one lane per read: segment of the read inside this window
         const int rr = r0 + tid;
         int n = -1, off = 0;
-        const int st = ((P.flags[rr] ^ P.flags[r0]) & 1) ? 1 : 0;
+        const int st = ((P.flags[rr] ^ P.flags[r0 + (P.zref[z] & 63)]) & 1) ? 1 : 0;
         if (P.avalid[rr]) {
             const int32_t *ent = P.ent + P.ent_off[rr];
             const int a = ent[idx_ws], b = ent[idx_we];
@@ -1785,21 +1814,25 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* 
     trace_sync(st, "k_setup");
     if (ev) (void)hipEventRecord(ev[1], st);
     const size_t lds_read = (((size_t)P.maxL_max + 15) / 16) * 4 + 64;
-    for (int z0 = 0; z0 < P.n_zmw; z0 += P.poa_slots) {
-        const int nb = (P.n_zmw - z0) < P.poa_slots ? (P.n_zmw - z0) : P.poa_slots;
-        hipLaunchKernelGGL(k_poa, dim3(nb), dim3(64), lds_read, st, P, z0);
-        LAUNCH_CHECK("k_poa");
+    // pass 0 = the draft; pass 1 = the fallback draft of the ZMWs k_post marked (their waves run, all others leave at once:
+    // the second round of launches costs microseconds unless something failed)
+    for (int pass = 0; pass < (P.opts.no_fallback_draft ? 1 : 2); ++pass) {
+        for (int z0 = 0; z0 < P.n_zmw; z0 += P.poa_slots) {
+            const int nb = (P.n_zmw - z0) < P.poa_slots ? (P.n_zmw - z0) : P.poa_slots;
+            hipLaunchKernelGGL(k_poa, dim3(nb), dim3(64), lds_read, st, P, z0, pass);
+            LAUNCH_CHECK("k_poa");
+        }
+        trace_sync(st, "k_poa");
+        if (ev && pass == 0) (void)hipEventRecord(ev[2], st);
+        for (int rb = 0; rb < P.n_reads; rb += P.align_slots) {
+            const int nb = (P.n_reads - rb) < P.align_slots ? (P.n_reads - rb) : P.align_slots;
+            hipLaunchKernelGGL(k_align, dim3(nb), dim3(64), lds_read, st, P, rb, pass);
+            LAUNCH_CHECK("k_align");
+        }
+        trace_sync(st, "k_align");
+        hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P, pass);
+        LAUNCH_CHECK("k_post");
     }
-    trace_sync(st, "k_poa");
-    if (ev) (void)hipEventRecord(ev[2], st);
-    for (int rb = 0; rb < P.n_reads; rb += P.align_slots) {
-        const int nb = (P.n_reads - rb) < P.align_slots ? (P.n_reads - rb) : P.align_slots;
-        hipLaunchKernelGGL(k_align, dim3(nb), dim3(64), lds_read, st, P, rb);
-        LAUNCH_CHECK("k_align");
-    }
-    trace_sync(st, "k_align");
-    hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P);
-    LAUNCH_CHECK("k_post");
     if (ev) (void)hipEventRecord(ev[3], st);
     if (P.total_wslots > 0) {
         hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), (size_t)P.pw_obs_bytes + (size_t)P.pw_gb_floats * 4, st, P);

@@ -84,7 +84,8 @@ typedef struct ccsx_opts {
     float   min_zscore;      /* a pass is dropped from a window when its z-score (log-likelihood vs the model's expectation for
                                 the window template) is below this; 0 = gate off                                   */
     int32_t handles_per_device; /* handles the caller runs on this GPU (0/1 = one): each takes 1/N of the free HBM for its POA scratch */
-    int32_t reserved[4];
+    int32_t no_fallback_draft;  /* 1: a failed / unmappable first draft is final (default 0: one fallback draft, SPEC "fallback draft") */
+    int32_t reserved[3];
 } ccsx_opts;
 
 /* ---- input batch: SoA + CSR ---- */

@@ -78,7 +78,9 @@ typedef struct orc_opts {
     int32_t hifi_kinetics;
     int32_t disable_heuristics;     /* --disable-heuristics: no candidate filter (every position is polished) */
     float   min_zscore;             /* a pass is dropped from a window when its z-score is below this (0 = gate off) */
-    int32_t reserved[5];
+    int32_t handles_per_device;     /* (engine only) */
+    int32_t no_fallback_draft;      /* 1: a failed / unmappable first draft is final */
+    int32_t reserved[3];
 } orc_opts;
 
 /* ---------------- deterministic log2 / exp2 (DESIGN.md §SPEC "det math") -------------------------------- */
@@ -423,18 +425,20 @@ static void orient(const uint8_t *b, const uint8_t *pw, int L, int rev, uint8_t 
 
 /* step 2: draft from the first min(nreads, max_poa_cov) reads.  Orientation = that of read 0.
  * returns draft length, 0 = failure                                                                          */
-int orc_poa_draft(int nreads, const int64_t *base_off, const uint8_t *bases, const uint8_t *flags, int max_poa_cov,
-                  int vcap, uint8_t *draft, int draft_cap)
+/* backbone = pass bb; passes bb, bb+1, ... (wrapping) are threaded, max_poa_cov of them; orientation = that of pass bb */
+int orc_poa_draft_bb(int nreads, const int64_t *base_off, const uint8_t *bases, const uint8_t *flags, int max_poa_cov,
+                     int vcap, uint8_t *draft, int draft_cap, int bb)
 {
     int npoa = nreads < max_poa_cov ? nreads : max_poa_cov;
     if (npoa <= 0) return 0;
     int maxL = 0;
-    for (int r = 0; r < npoa; ++r) { int L = (int)(base_off[r + 1] - base_off[r]); if (L > maxL) maxL = L; }
+    for (int r = 0; r < nreads; ++r) { int L = (int)(base_off[r + 1] - base_off[r]); if (L > maxL) maxL = L; }
     poa_t *g = poa_new(vcap);
     uint8_t *ob = (uint8_t *)malloc(maxL + 1);
     int32_t *pathv = (int32_t *)malloc(sizeof(int32_t) * (maxL + 1));
-    int rev0 = flags[0] & 1, ok = 1;
-    for (int r = 0; r < npoa && ok; ++r) {
+    int rev0 = flags[bb] & 1, ok = 1;
+    for (int rr = 0; rr < npoa && ok; ++rr) {
+        int r = bb + rr < nreads ? bb + rr : bb + rr - nreads;
         int L = (int)(base_off[r + 1] - base_off[r]);
         orient(bases + base_off[r], NULL, L, (flags[r] & 1) != rev0, ob, NULL);
         if (poa_add_read(g, ob, L, pathv) < 0) ok = 0;
@@ -443,6 +447,11 @@ int orc_poa_draft(int nreads, const int64_t *base_off, const uint8_t *bases, con
     if (len < 0) len = 0;
     free(ob); free(pathv); poa_free(g);
     return len;
+}
+int orc_poa_draft(int nreads, const int64_t *base_off, const uint8_t *bases, const uint8_t *flags, int max_poa_cov,
+                  int vcap, uint8_t *draft, int draft_cap)
+{
+    return orc_poa_draft_bb(nreads, base_off, bases, flags, max_poa_cov, vcap, draft, draft_cap, 0);
 }
 
 /* step 3: read (draft orientation) vs draft, global, adaptive band.  rstart[0..Ld]; returns 1 if valid.
@@ -1008,34 +1017,60 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
     int dcap = maxL + maxL / 4 + 64;
     uint8_t *draft = (uint8_t *)malloc(dcap);
     int vcap = (5 * maxL) / 2 + 256;
-    int Ld = orc_poa_draft(nreads, base_off, bases, flags, opts->max_poa_cov, vcap, draft, dcap);
-    if (draft_len_out) *draft_len_out = Ld;
-    if (draft_out && Ld > 0) memcpy(draft_out, draft, Ld);
-    if (Ld <= 0) { out->status = ST_DRAFT_FAIL; free(draft); return 0; }
-    if (Ld < opts->min_length) { out->status = ST_SHORT; free(draft); return 0; }
-    if (Ld > opts->max_length) { out->status = ST_LONG; free(draft); return 0; }
-    /* step 3 */
-    int rev0 = flags[0] & 1;
+    /* SPEC "fallback draft" (docs/faq/accuracy-vs-passes.md:41-46, a cascade from fast to robust draft generators): when the first
+     * draft fails or at most half of the passes map to it, ONE more draft is made with the pass whose length is closest to the
+     * median as backbone (ties: the first) and twice as many passes threaded, starting at the backbone and wrapping around.
+     * Draft, alignments and the consensus then have the orientation of that backbone pass.                                      */
+    int bb = 0, attempt = 0, Ld, rev0, np;
     int32_t **rstart = (int32_t **)calloc(nreads, sizeof(int32_t *));
     uint8_t **dirty = (uint8_t **)calloc(nreads, sizeof(uint8_t *));
     uint8_t *strand = (uint8_t *)malloc(nreads), *avalid = (uint8_t *)malloc(nreads);
-    uint8_t *ob = (uint8_t *)malloc(maxL + 1);
-    int np = 0;
-    for (int r = 0; r < nreads; ++r) {
-        int L = (int)(base_off[r + 1] - base_off[r]);
-        strand[r] = (uint8_t)(((flags[r] & 1) != rev0) ? 1 : 0);
-        orient(bases + base_off[r], NULL, L, strand[r], ob, NULL);
-        rstart[r] = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
-        dirty[r] = (uint8_t *)malloc(Ld + 1);
-        int32_t sc;
-        avalid[r] = (uint8_t)orc_align_ev(ob, L, draft, Ld, rstart[r], &sc, dirty[r]);
-        np += avalid[r];
-        if (avalid[r]) { if (strand[r]) out->rn += 1; else out->fn += 1; }
-    }
-    free(ob);
-    out->np = np;
     int ret = 0;
-    if (2 * np <= nreads) { out->status = ST_UNUSABLE; goto done; }
+    for (;;) {
+        Ld = orc_poa_draft_bb(nreads, base_off, bases, flags, attempt ? 2 * opts->max_poa_cov : opts->max_poa_cov, vcap, draft, dcap, bb);
+        if (draft_len_out) *draft_len_out = Ld;
+        if (draft_out && Ld > 0) memcpy(draft_out, draft, Ld);
+        int want_retry = 0;
+        np = 0; out->np = 0; out->fn = out->rn = 0;
+        if (Ld <= 0) { out->status = ST_DRAFT_FAIL; want_retry = 1; }
+        else if (Ld < opts->min_length) { out->status = ST_SHORT; goto done; }
+        else if (Ld > opts->max_length) { out->status = ST_LONG; goto done; }
+        else {
+            /* step 3 */
+            rev0 = flags[bb] & 1;
+            uint8_t *ob = (uint8_t *)malloc(maxL + 1);
+            for (int r = 0; r < nreads; ++r) {
+                int L = (int)(base_off[r + 1] - base_off[r]);
+                strand[r] = (uint8_t)(((flags[r] & 1) != rev0) ? 1 : 0);
+                orient(bases + base_off[r], NULL, L, strand[r], ob, NULL);
+                free(rstart[r]); free(dirty[r]);
+                rstart[r] = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
+                dirty[r] = (uint8_t *)malloc(Ld + 1);
+                int32_t sc;
+                avalid[r] = (uint8_t)orc_align_ev(ob, L, draft, Ld, rstart[r], &sc, dirty[r]);
+                np += avalid[r];
+                if (avalid[r]) { if (strand[r]) out->rn += 1; else out->fn += 1; }
+            }
+            free(ob);
+            out->np = np;
+            if (2 * np <= nreads) { out->status = ST_UNUSABLE; want_retry = 1; }
+        }
+        if (!want_retry) break;
+        if (attempt || opts->no_fallback_draft) { if (out->status == ST_DRAFT_FAIL) { out->np = 0; out->fn = out->rn = 0; } goto done; }
+        {   /* backbone of the fallback draft */
+            int med = 0, best = -1;
+            for (int r = 0; r < nreads; ++r) {
+                int len = (int)(base_off[r + 1] - base_off[r]), rank = 0;
+                for (int q = 0; q < nreads; ++q) { int lq = (int)(base_off[q + 1] - base_off[q]); rank += (lq < len || (lq == len && q < r)) ? 1 : 0; }
+                if (rank == nreads / 2) med = len;
+            }
+            for (int r = 0; r < nreads; ++r) {
+                int d = (int)(base_off[r + 1] - base_off[r]) - med; if (d < 0) d = -d;
+                if (best < 0 || d < best) { best = d; bb = r; }
+            }
+        }
+        attempt = 1;
+    }
     {
         /* step 4 */
         int wcap = Ld / (WIN_CORE - 3) + 4;
