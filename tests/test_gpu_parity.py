@@ -508,6 +508,6 @@ def test_fallback_draft_matches_oracle(built):
         if nofb:
             lost = set(np.nonzero(res.status == 3)[0].tolist())
         else:
-            ok = set(np.nonzero(res.status == 0)[0].tolist())
+            ok = set(np.nonzero((res.status == 0) | (res.status == 7))[0].tolist())
         h.close()
-    assert len(lost) >= 2 and lost <= ok                      # what fails without the fallback succeeds with it
+    assert len(lost) >= 2 and lost <= ok                      # what is lost without the fallback gets a consensus with it (HiFi or LOW_RQ)
