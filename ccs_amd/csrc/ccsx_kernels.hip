@@ -806,17 +806,18 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
             // fetch a new base (4 = no base: rows 0 and > I)
             int x, y, ox, oy;
             unsigned kx, ky;
-            if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; ox = wave_shr1_i32(Oprev, 0); oy = Oprev; kx = (unsigned)wave_shr1_i32((int)Kprev, 0); ky = Kprev; }
+            // (origins and dirty bits shift with a hardware zero fill: bound_ctrl, no register pre-loaded with the fill value)
+            if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; ox = wave_shr1_i32_z(Oprev); oy = Oprev; kx = (unsigned)wave_shr1_i32_z((int)Kprev); ky = Kprev; }
             else {
                 const int top = lo + 62;                                // read index of lane 63's base
                 const int nb = top < I ? read_base_packed(sread, top < 0 ? 0 : top) : 4;
                 if (sh == 1) {
-                    x = Mprev; y = wave_shl1_i32(Mprev, NEGV); ox = Oprev; oy = wave_shl1_i32(Oprev, 0);
-                    kx = Kprev; ky = (unsigned)wave_shl1_i32((int)Kprev, 0);
+                    x = Mprev; y = wave_shl1_i32(Mprev, NEGV); ox = Oprev; oy = wave_shl1_i32_z(Oprev);
+                    kx = Kprev; ky = (unsigned)wave_shl1_i32_z((int)Kprev);
                     rbv = wave_shl1_i32(rbv, nb);
                 } else {
-                    x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); ox = wave_shl1_i32(Oprev, 0); oy = wave_shl1_i32(ox, 0);
-                    kx = (unsigned)wave_shl1_i32((int)Kprev, 0); ky = (unsigned)wave_shl1_i32((int)kx, 0);
+                    x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); ox = wave_shl1_i32_z(Oprev); oy = wave_shl1_i32_z(ox);
+                    kx = (unsigned)wave_shl1_i32_z((int)Kprev); ky = (unsigned)wave_shl1_i32_z((int)kx);
                     const int nb1 = top - 1 < I ? read_base_packed(sread, top - 1 < 0 ? 0 : top - 1) : 4;
                     rbv = wave_shl1_i32(wave_shl1_i32(rbv, nb1), nb);
                 }

@@ -21,6 +21,9 @@ __device__ __forceinline__ float wave_shl1_f32(float x, float fill) { return __i
 __device__ __forceinline__ float wave_shr1_f32_z(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), DPP_WAVE_SHR1, 0xf, 0xf, true)); }
 __device__ __forceinline__ float wave_shl1_f32_z(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), DPP_WAVE_SHL1, 0xf, 0xf, true)); }
 
+__device__ __forceinline__ int wave_shr1_i32_z(int x) { return __builtin_amdgcn_mov_dpp(x, DPP_WAVE_SHR1, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_shl1_i32_z(int x) { return __builtin_amdgcn_mov_dpp(x, DPP_WAVE_SHL1, 0xf, 0xf, true); }
+
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 // inclusive prefix maximum over the 64 lanes.  `old` = INT_MIN (the identity of max) lets the DPP combiner
