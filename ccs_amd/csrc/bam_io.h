@@ -5,8 +5,11 @@
 // docs/faq/parallelize.md:17).  Records are unaligned (FLAG 4) PacBio subreads with the tags this path needs:
 // zm:i hole number, sn:B,f SNR (A,C,G,T), pw:B,C|S pulse widths, ip:B,C|S, cx:i local context
 // (docs/faq/bam-output.md:9-30, docs/faq/missing-adapters.md:11-12).  htslib/pbbam are not in the image;
-// zlib is.
+// zlib is — and so is the runtime library of libdeflate (no headers): when libdeflate.so.0 can be dlopen-ed its whole-buffer
+// DEFLATE routines replace zlib's streaming ones for the 64 KiB BGZF blocks (the host side of `ccs` is inflate-bound:
+// DESIGN.md §7); CCS_NO_LIBDEFLATE=1 forces zlib.
 #pragma once
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -17,6 +20,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -75,19 +79,58 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------- BGZF
+// libdeflate's public C API ([RECALL] libdeflate.h, stable since 1.0), bound at run time from libdeflate.so.0
+struct LibDeflate {
+    void *(*alloc_decompressor)(void) = nullptr;
+    int (*deflate_decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;   // 0 = success
+    void (*free_decompressor)(void *) = nullptr;
+    void *(*alloc_compressor)(int) = nullptr;
+    size_t (*deflate_compress)(void *, const void *, size_t, void *, size_t) = nullptr;            // 0 = does not fit
+    void (*free_compressor)(void *) = nullptr;
+    bool ok = false;
+    static const LibDeflate &get()
+    {
+        static const LibDeflate L = [] {
+            LibDeflate l;
+            const char *no = std::getenv("CCS_NO_LIBDEFLATE");
+            if (no && *no && *no != '0') return l;
+            void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return l;
+            l.alloc_decompressor = (void *(*)(void))dlsym(h, "libdeflate_alloc_decompressor");
+            l.deflate_decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+            l.free_decompressor = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+            l.alloc_compressor = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+            l.deflate_compress = (size_t (*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+            l.free_compressor = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+            l.ok = l.alloc_decompressor && l.deflate_decompress && l.free_decompressor && l.alloc_compressor && l.deflate_compress && l.free_compressor;
+            return l;
+        }();
+        return L;
+    }
+};
+
 inline std::vector<uint8_t> deflate_block(const uint8_t *data, size_t n, int level)
 {
     std::vector<uint8_t> out(18 + compressBound((uLong)n) + 8);
     static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
     std::memcpy(out.data(), hdr, 16);
+    size_t clen = 0;
+    const LibDeflate &ld = LibDeflate::get();
+    if (ld.ok) {
+        thread_local struct Comp { void *c = nullptr; int level = -1; ~Comp() { if (c) LibDeflate::get().free_compressor(c); } } tc;
+        if (!tc.c || tc.level != level) { if (tc.c) ld.free_compressor(tc.c); tc.c = ld.alloc_compressor(level); tc.level = level; }
+        if (tc.c) clen = ld.deflate_compress(tc.c, data, n, out.data() + 18, out.size() - 18 - 8);
+    }
+    if (clen == 0) {                                            // zlib (no libdeflate, or it declined)
     z_stream zs; std::memset(&zs, 0, sizeof(zs));
     if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
     zs.next_in = const_cast<Bytef *>(data); zs.avail_in = (uInt)n;
     zs.next_out = out.data() + 18; zs.avail_out = (uInt)(out.size() - 18 - 8);
     const int rc = deflate(&zs, Z_FINISH);
-    const size_t clen = zs.total_out;
+    clen = zs.total_out;
     deflateEnd(&zs);
     if (rc != Z_STREAM_END) throw std::runtime_error("deflate failed");
+    }
     const size_t total = 18 + clen + 8;
     if (total > 65536) throw std::runtime_error("BGZF block too large");
     out[16] = (uint8_t)((total - 1) & 0xff); out[17] = (uint8_t)((total - 1) >> 8);
@@ -173,6 +216,25 @@ private:
             pending_.push_back(pool_.submit([map, blks, raw]() -> Slab {
                 Slab out = std::make_shared<std::vector<uint8_t>>(raw);
                 size_t at = 0;
+                const LibDeflate &ld = LibDeflate::get();
+                if (ld.ok) {                                    // whole-buffer inflate of every block of the slab
+                    thread_local struct Dec { void *d = nullptr; ~Dec() { if (d) LibDeflate::get().free_decompressor(d); } } td;
+                    if (!td.d) td.d = ld.alloc_decompressor();
+                    if (!td.d) throw std::runtime_error("libdeflate_alloc_decompressor failed");
+                    for (const Blk &b : blks) {
+                        const uint8_t *h = map + b.off;
+                        const size_t xlen = h[10] | (h[11] << 8), off = 12 + xlen;
+                        const uint8_t *t = h + b.size - 4;
+                        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+                        if (isize == 0) continue;
+                        if (at + isize > out->size()) throw std::runtime_error("BGZF block sizes are inconsistent");
+                        size_t got = 0;
+                        if (ld.deflate_decompress(td.d, h + off, b.size - off - 8, out->data() + at, isize, &got) != 0 || got != isize)
+                            throw std::runtime_error("BGZF block does not inflate");
+                        at += isize;
+                    }
+                    return out;
+                }
                 z_stream zs; std::memset(&zs, 0, sizeof(zs));
                 if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
                 for (const Blk &b : blks) {
