@@ -921,8 +921,8 @@ __global__ void k_post(KParams P, int pass)
 //
 // v3.  LDS holds: sCTX[obs][ctx] = (ME, INS) as float2 — 16 contexts = 16 distinct 8-byte slots, so a wave's
 // ds_read_b64 with a uniform obs row is bank-conflict free by construction; per-column copies sMI[strand][j][obs]
-// (row stride 13) for the fill; gamma/beta of one chunk of reads (sGB, ODD row stride: the fill's lane = row stores and
-// the scoring's lane = column loads are both conflict free).  Fill: two reads per wave (lanes 0-31 / 32-63, lane = read
+// (row stride 13) for the fill; gamma/beta of one chunk of reads (sGB, even row stride: the fill's lane = row stores step by
+// S - 1 words from lane to lane, the scoring's lane = column loads by 1: both conflict free).  Fill: two reads per wave (lanes 0-31 / 32-63, lane = read
 // row) when both have <= 31 bases, alpha and beta swept in the same anti-diagonal loop (two independent dependency
 // chains), neighbours via DPP wave shifts.  Candidate filter (docs/how-does-ccs-work.md:80-83): the step-3 alignments'
 // dirty bits give a per-position pile-up margin; unambiguous non-homopolymer positions enumerate no mutations.
@@ -982,7 +982,12 @@ __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_
 {
     const float gmm = *s.g;
     float2 nA = make_float2(0.f, 0.f), nB = make_float2(0.f, 0.f);
-    if (!last) { const lds_cf pa = (lds_cf)(tA + o256), pb = (lds_cf)(tB + o256); nA = make_float2(pa[0], pa[1]); nB = make_float2(pb[0], pb[1]); }   // one 8-byte LDS load each
+    if (!last) {                                             // one ds_read_b64 each (a 64-bit typed load; two floats would become ds_read2_b32)
+        typedef const unsigned long long __attribute__((address_space(3))) *lds_cu64;
+        const unsigned long long va = *(lds_cu64)(tA + o256), vb = *(lds_cu64)(tB + o256);
+        nA = make_float2(__uint_as_float((unsigned)va), __uint_as_float((unsigned)(va >> 32)));
+        nB = make_float2(__uint_as_float((unsigned)vb), __uint_as_float((unsigned)(vb >> 32)));
+    }
     const float bqn = *s.be;
     s.g += S; s.be += S;
     const float insA = s.pA.y, meA = s.pA.x, insB = s.pB.y;
@@ -1159,7 +1164,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     for (int it = 0; it < CCSX_MAX_ITER; ++it) {
         __syncthreads();
         const int J = rfl(sCtl[0]);
-        const int S = (J + 1) | 1;                           // odd row stride >= J+1
+        const int S = (J + 2) & ~1;                          // EVEN row stride >= J+1: in the fill lane = row writes column t - row, so the
+                                                             // lane-to-lane address stride is S - 1, which must be odd to be bank-conflict free
         if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
         __syncthreads();
         const int lfr = (rf < 4) ? 3 - rf : 4;
@@ -1345,7 +1351,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             // block stays the same — 2 blocks x 5 reads are 3+3+2+2 units, not 2+2+1+1 pair tasks.  Gains are added to sDeltaI in
             // fixed point (order independent).
             {
+#ifdef CCSX_EXP_SKIP_ROUND2_SCORE
+                const int nv = rfl(sCtl[8]), nunits = (it == 0) ? nblk * nv : 0;   // experiment: upper bound of what neighbourhood-only rescoring could save
+#else
                 const int nv = rfl(sCtl[8]), nunits = nblk * nv;
+#endif
                 nvalid += nv;
                 int curblk = -1;
                 LaneMut LF, LR;
