@@ -1217,7 +1217,13 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             else if (sl0 == 3) v0 = c0 < J && !(c0 > 0 && t[c0 - 1] == t[c0]);
             else if (sl0 < 8) v0 = c0 <= J && !(c0 > 0 && t[c0 - 1] == sl0 - 4);
             else v0 = 0;                                                      // threads 256.. own no mutation lane
-            if (v0 && ((skmask >> (c0 < J ? c0 : J - 1)) & 1u)) v0 = 0;       // candidate filter (insertions after the last column follow J-1)
+            {                                                                 // candidate filter (insertions after the last column follow J-1)
+                const int cc = c0 < J ? c0 : J - 1;
+                if (v0 && ((skmask >> cc) & 1u)) v0 = 0;
+                // a quiet position inside a homopolymer keeps only the mutations that change the run's LENGTH: deletion of the
+                // run's first base, insertion of the run's base before it (the enumeration admits both at run starts only)
+                else if (v0 && (((unsigned)sCtl[7] >> cc) & 1u) && !(c0 < J && (sl0 == 3 || (sl0 >= 4 && sl0 - 4 == t[c0])))) v0 = 0;
+            }
             const unsigned long long bal = __ballot(v0);
             if (lane == 0) sCnt[wave] = __popcll(bal);
             if (tid < 256) { sMvalid[tid] = (uint8_t)v0; sDeltaI[tid] = 0; }
@@ -1256,7 +1262,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             const int rend = rfl(sCtl[5]), ntask = rfl(sCtl[6]);
             PHASE(2);
             // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals
+#ifdef CCSX_EXP_NO_FILL
+            for (int tk = wave; tk < 0; tk += PW_WAVES) {
+#else
             for (int tk = wave; tk < ntask; tk += PW_WAVES) {
+#endif
                 const short2 task = sTask[tk];
                 const bool paired = rfl((int)task.y) >= 0;
                 const int myr = paired ? (half ? task.y : task.x) : task.x;
@@ -1353,6 +1363,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             {
 #ifdef CCSX_EXP_SKIP_ROUND2_SCORE
                 const int nv = rfl(sCtl[8]), nunits = (it == 0) ? nblk * nv : 0;   // experiment: upper bound of what neighbourhood-only rescoring could save
+#elif defined(CCSX_EXP_NO_SCORE)
+                const int nv = rfl(sCtl[8]), nunits = 0;
 #else
                 const int nv = rfl(sCtl[8]), nunits = nblk * nv;
 #endif
@@ -1502,7 +1514,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         float p;
         if ((skmask >> c) & 1u) p = sPskip[c];              // skipped by the candidate filter: error probability from the pile-up margin
         else {
-            float s = 0.0f;
+            float s = (((unsigned)sCtl[7] >> c) & 1u) ? sPskip[c] : 0.0f;   // quiet homopolymer position: its untested mutations
             for (int sl = 0; sl < 8; ++sl) {
                 int m = sl * 32 + c;
                 if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }

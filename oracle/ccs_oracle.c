@@ -733,6 +733,9 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
             if (mvalid[m]) {                                 /* candidate filter: insertions after the last column follow J-1 */
                 int cc = (c < w.J) ? c : w.J - 1;
                 if ((sk >> cc) & 1u) mvalid[m] = 0;
+                /* a quiet position inside a homopolymer keeps only the mutations that change the run's LENGTH (deletion of the
+                 * run's first base, insertion of the run's base before it: mut_decode admits them at run starts only)          */
+                else if (((ev >> cc) & 1u) && !(c < w.J && (type == MT_DEL || (type == MT_INS && x == w.t[c])))) mvalid[m] = 0;
             }
             if (!mvalid[m]) continue;
             int32_t dsum = 0;
@@ -751,6 +754,8 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
             delta[m] = (float)dsum * (1.0f / DQ_SCALE);
         }
         ++iters;
+        if (orc_dbg.stats == 4) { int nm = 0; for (int m = 0; m < 256; ++m) nm += mvalid[m]; if (nm > 255) nm = 255;
+            _Pragma("omp atomic") orc_dbg.cal_cnt[nm >> 2] += 1; }
         /* A5: greedy selection of favourable, well-separated mutations */
         int acc_m[32], nacc = 0, Jn = w.J, nfav = 0;
         uint8_t cand[256];
@@ -804,7 +809,7 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
         float p;
         if ((sk >> c) & 1u) p = pskip[c];                    /* skipped: error probability from the pile-up margin */
         else {
-            float s = 0.0f;
+            float s = ((ev >> c) & 1u) ? pskip[c] : 0.0f;   /* quiet homopolymer position: the untested mutations */
             for (int slot = 0; slot < 8; ++slot) {
                 int m = slot * 32 + c;
                 if (mvalid[m]) { float d = delta[m]; if (d > 20.0f) d = 20.0f; s = s + orc_exp2f(d); }
