@@ -54,6 +54,7 @@
 #define TINY_P 1e-30f
 #define SKIP_MARGIN 6
 #define SKIP_SPREAD 3
+#define SCORE_BAND 5                  // SPEC: half width (read rows) of the mutation scoring band around the window diagonal
 #define DQ_SCALE 65536.0f
 #define DQ_CLAMP 100.0f
 
@@ -970,26 +971,27 @@ __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_
 typedef const float __attribute__((address_space(3))) *lds_cf;
 typedef const char __attribute__((address_space(3))) *lds_cc;
 
+typedef const uint16_t __attribute__((address_space(3))) *lds_cu16;
 struct ScoreChain {                  // running state of one (lane, read) mutation evaluation
     float ap, bp, acc, b, bq;
     float2 pA, pB;
     lds_cf g, be;                    // gamma(i, c) and beta(i+1, q) of the row about to be processed: both advance by S per row
+    lds_cu16 op;                     // observation code of that row (as the byte offset of its sCTX row)
 };
 
-// one row of the extend+link recursion.  tA / tB = the lane's columns of sCTX (context kA / kB), o256 = the row's
-// observation code as a byte offset (obs * 256 = one sCTX row of 32 float2)
-__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_cc tA, lds_cc tB, int S, int o256, bool last)
+// one row of the extend+link recursion.  tA / tB = the lane's columns of sCTX (context kA / kB).  Every lane walks
+// its own rows (the SPEC's band around the window diagonal starts at a per-lane row), so the row's observation code comes from LDS;
+// row I of a read carries code 12 = the all-zero row of sCTX ("no base left": the SPEC's i < I cases become exact +0 products).
+__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_cc tA, lds_cc tB, int S)
 {
+    typedef const unsigned long long __attribute__((address_space(3))) *lds_cu64;
     const float gmm = *s.g;
-    float2 nA = make_float2(0.f, 0.f), nB = make_float2(0.f, 0.f);
-    if (!last) {                                             // one ds_read_b64 each (a 64-bit typed load; two floats would become ds_read2_b32)
-        typedef const unsigned long long __attribute__((address_space(3))) *lds_cu64;
-        const unsigned long long va = *(lds_cu64)(tA + o256), vb = *(lds_cu64)(tB + o256);
-        nA = make_float2(__uint_as_float((unsigned)va), __uint_as_float((unsigned)(va >> 32)));
-        nB = make_float2(__uint_as_float((unsigned)vb), __uint_as_float((unsigned)(vb >> 32)));
-    }
+    const int o256 = (int)*s.op;
+    const unsigned long long va = *(lds_cu64)(tA + o256), vb = *(lds_cu64)(tB + o256);   // one ds_read_b64 each
+    const float2 nA = make_float2(__uint_as_float((unsigned)va), __uint_as_float((unsigned)(va >> 32)));
+    const float2 nB = make_float2(__uint_as_float((unsigned)vb), __uint_as_float((unsigned)(vb >> 32)));
     const float bqn = *s.be;
-    s.g += S; s.be += S;
+    s.g += S; s.be += S; s.op += 1;
     const float insA = s.pA.y, meA = s.pA.x, insB = s.pB.y;
     const float a = gmm + s.ap * insA;
     float b;
@@ -998,6 +1000,20 @@ __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_
     const float term = (nB.x * bqn) + (L.dlL * s.bq);
     s.acc = s.acc + b * term;
     s.ap = a; s.bp = b; s.b = b; s.pA = nA; s.pB = nB; s.bq = bqn;
+}
+
+// first row of a lane's scoring band: floor((2 c I + J) / (2 J)) - Wr, clamped so that nrows rows fit into 0..I (SPEC "banded link");
+// the quotient through a float reciprocal with an exact remainder correction (all values < 2^12)
+__device__ __forceinline__ int band_row0(int c, int I, int J2, float invJ2, int J, int Wr, int nrows)
+{
+    const int num = __mul24(2 * c, I) + J;
+    int q = (int)((float)num * invJ2);
+    const int r = num - __mul24(q, J2);
+    q += (r >= J2 ? 1 : 0) - (r < 0 ? 1 : 0);
+    int i0 = q - Wr;
+    i0 = i0 < 0 ? 0 : i0;
+    const int hi = I + 1 - nrows;
+    return i0 > hi ? hi : i0;
 }
 
 // fixed-point image of one read's log2-likelihood gain (SPEC "integer sum over reads")
@@ -1024,7 +1040,7 @@ __device__ __forceinline__ int need_col(const int32_t *wb, int nw, int Ld, int k
 
 __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
 {
-    __shared__ float2 sCTX[CCSX_NOBS * 32];                  // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0)
+    __shared__ float2 sCTX[(CCSX_NOBS + 1) * 32];            // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0); row 12 = zeros ("no base")
     __shared__ float sDL[16], sZP[32];                       // sZP: z-score MU[16], VAR[16]
     __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
     __shared__ float sDLJ[2][32];
@@ -1096,6 +1112,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         const unsigned m3 = (idx_ws + 3 <= idx_we) ? P.dmask[eo + idx_ws + 3] : 0u;
         sCTX[e0] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
         if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[e1] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
+        if (tid < 32) sCTX[CCSX_NOBS * 32 + tid] = make_float2(0.0f, 0.0f);
         if (tid < 16) sDL[tid] = dl;
         if (tid < 32) sZP[tid] = zp;
         if (tid < we - ws) sT[0][tid] = dr;
@@ -1131,7 +1148,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             const int r = rb + PW_WAVES * q + wave;
             if (r < nreads) {
                 const int n = sI[r];
-                sObs[r][lane] = (lane < n) ? (uint16_t)(obs_of(bq[q], pq[q]) << 8) : (uint16_t)0;   // rows beyond the segment read as obs 0
+                sObs[r][lane] = (lane < n) ? (uint16_t)(obs_of(bq[q], pq[q]) << 8) : (uint16_t)(lane == n ? CCSX_NOBS << 8 : 0);   // row n: "no base"
                 if (lane < 4) sObs[r][64 + lane] = 0;
             }
         }
@@ -1164,6 +1181,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     for (int it = 0; it < CCSX_MAX_ITER; ++it) {
         __syncthreads();
         const int J = rfl(sCtl[0]);
+        const float invJ2 = 1.0f / (float)(2 * J);           // band_row0's reciprocal
         const int S = (J + 2) & ~1;                          // EVEN row stride >= J+1: in the fill lane = row writes column t - row, so the
                                                              // lane-to-lane address stride is S - 1, which must be odd to be bank-conflict free
         if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
@@ -1398,29 +1416,32 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     const int Ia = rfl(sI[ra]), Ib = two ? rfl(sI[rb]) : -1;
                     const LaneMut La = rfl((int)sStrand[ra]) ? LR : LF;
                     const LaneMut Lb = (two && rfl((int)sStrand[rb])) ? LR : LF;
-                    // the observation codes of both reads go to registers with ONE load each (lane k holds codes 2k, 2k+1); the row loop
-                    // then takes the (wave-uniform) code of a row with v_readlane into an SGPR: no LDS access, no address arithmetic
-                    const uint32_t obAv = ((const uint32_t *)sObs[ra])[lane < 34 ? lane : 33];
-                    const uint32_t obBv = ((const uint32_t *)sObs[rb])[lane < 34 ? lane : 33];
-                    auto obs_at = [](uint32_t v, int i) { return (int)(((uint32_t)__builtin_amdgcn_readlane((int)v, i >> 1) >> ((i & 1) << 4)) & 0xffffu); };
+                    // SPEC "banded link": every lane scores the rows around its column's point on the window diagonal only
+                    const int dA = Ia > J ? Ia - J : J - Ia, WrA = SCORE_BAND + (dA > 2 ? dA - 2 : 0);
+                    const int nrA = (Ia < 2 * WrA ? Ia : 2 * WrA) + 1;
+                    const int dB = Ib > J ? Ib - J : J - Ib, WrB = SCORE_BAND + (dB > 2 ? dB - 2 : 0);
+                    const int nrB = two ? (Ib < 2 * WrB ? Ib : 2 * WrB) + 1 : 0;
+                    const int i0a = band_row0(La.c, Ia, 2 * J, invJ2, J, WrA, nrA);
+                    const int i0b = two ? band_row0(Lb.c, Ib, 2 * J, invJ2, J, WrB, nrB) : 0;
                     lds_cc tAa = (lds_cc)(sCTX + La.kA), tBa = (lds_cc)(sCTX + La.kB);
                     lds_cc tAb = (lds_cc)(sCTX + Lb.kA), tBb = (lds_cc)(sCTX + Lb.kB);
                     ScoreChain ca, cb;
                     ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
                     cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f);
-                    ca.g = (lds_cf)(sGB + sGoff[ra] + La.c); ca.be = (lds_cf)(sGB + sBoff[ra] + La.q); ca.bq = *ca.be; ca.be += S;
-                    cb.g = (lds_cf)(sGB + sGoff[rb] + Lb.c); cb.be = (lds_cf)(sGB + sBoff[rb] + Lb.q); cb.bq = *cb.be; cb.be += S;
-                    // opaque to the optimiser from here: the four running pointers hold complete LDS addresses (otherwise the
+                    ca.g = (lds_cf)(sGB + sGoff[ra] + i0a * S + La.c); ca.be = (lds_cf)(sGB + sBoff[ra] + i0a * S + La.q); ca.bq = *ca.be; ca.be += S;
+                    cb.g = (lds_cf)(sGB + sGoff[rb] + i0b * S + Lb.c); cb.be = (lds_cf)(sGB + sBoff[rb] + i0b * S + Lb.q); cb.bq = *cb.be; cb.be += S;
+                    ca.op = (lds_cu16)(&sObs[ra][0] + i0a); cb.op = (lds_cu16)(&sObs[rb][0] + i0b);
+                    // opaque to the optimiser from here: the running pointers hold complete LDS addresses (otherwise the
                     // dynamic-LDS base is re-added at every use)
-                    asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(cb.g), "+v"(cb.be), "+v"(tAa), "+v"(tBa), "+v"(tAb), "+v"(tBb));
-                    const int Imin = two ? (Ia < Ib ? Ia : Ib) : -1;
+                    asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(cb.g), "+v"(cb.be), "+v"(tAa), "+v"(tBa), "+v"(tAb), "+v"(tBb), "+v"(ca.op), "+v"(cb.op));
+                    const int nmin = nrA < nrB ? nrA : nrB;
                     int i = 0;
-                    for (; i < Imin; ++i) {                                    // both chains, neither at its last row
-                        score_step(ca, La, tAa, tBa, S, obs_at(obAv, i), false);
-                        score_step(cb, Lb, tAb, tBb, S, obs_at(obBv, i), false);
+                    for (; i < nmin; ++i) {                                    // both chains
+                        score_step(ca, La, tAa, tBa, S);
+                        score_step(cb, Lb, tAb, tBb, S);
                     }
-                    for (int ia = i; ia <= Ia; ++ia) score_step(ca, La, tAa, tBa, S, obs_at(obAv, ia), ia == Ia);
-                    if (two) for (int ib = i; ib <= Ib; ++ib) score_step(cb, Lb, tAb, tBb, S, obs_at(obBv, ib), ib == Ib);
+                    for (int ia = i; ia < nrA; ++ia) score_step(ca, La, tAa, tBa, S);
+                    for (int ib = i; ib < nrB; ++ib) score_step(cb, Lb, tAb, tBb, S);
                     int dq;
                     {
                         const float res = La.fin ? ca.b : ca.acc;

@@ -51,6 +51,7 @@
 #define SC_DEL      (-4)
 #define NEG       (-(1 << 28))
 #define MUT_EPS   0.01f     /* favourable iff summed log2-likelihood gain > MUT_EPS                 */
+#define SCORE_BAND 5        /* half width (read rows) of the mutation scoring band around the window diagonal */
 #define MUT_SEP   5         /* accepted mutations of one round are >= MUT_SEP columns apart          */
 #define MULTI_ROUNDS 2      /* rounds >= MULTI_ROUNDS apply only the single best mutation (cycle guard) */
 #define JMIN_DEL  4         /* deletions are not applied when the window would shrink to <= JMIN_DEL */
@@ -599,7 +600,16 @@ static float score_mut(const float *ME, const float *INS, const float *DL, const
     else if (type == MT_INS) { kA = ctx_of(P, x); fin = (c == J);     if (!fin) kB = ctx_of(x, t[c]);     q = c + 1; }
     else                     { fin = (c + 1 == J); if (!fin) kA = ctx_of(P, t[c + 1]); kB = kA; q = c + 2; }
     float ap = 0.0f, bp = 0.0f, acc = 0.0f, res = 0.0f;
-    for (int i = 0; i <= I; ++i) {
+    /* SPEC "banded link": the extension runs over the read rows around the straight line from (0,0) to (I,J) only (a
+     * build-defined approximation of "marginalizing over all possible alignments", docs/how-does-ccs-work.md:94-96: the
+     * probability mass off the band is below float resolution for every read the alpha/beta check accepts): half width SCORE_BAND, widened by
+     * the part of the length difference a single indel could move the path off that line; rows outside contribute 0.   */
+    int dIJ = I > J ? I - J : J - I;
+    int Wr = SCORE_BAND + (dIJ > 2 ? dIJ - 2 : 0);
+    int nrows = (I < 2 * Wr ? I : 2 * Wr) + 1;
+    int rc = (J > 0) ? (2 * c * I + J) / (2 * J) : 0;
+    int i0 = rc - Wr; if (i0 < 0) i0 = 0; if (i0 > I + 1 - nrows) i0 = I + 1 - nrows;
+    for (int i = i0; i < i0 + nrows; ++i) {
         float insA = 0.0f, meA = 0.0f, insB = 0.0f;
         if (i > 0) {
             if (!(type == MT_DEL && fin)) insA = INS[kA * NOBS + o[i - 1]];
