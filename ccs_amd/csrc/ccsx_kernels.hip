@@ -950,14 +950,18 @@ struct LaneMut {                     // per-lane constants of one mutation on on
 
 __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_t *t, int J, int lf, const float *sDL)
 {
+    // branch-free: both template neighbours are loaded unconditionally (clamped indices; sT has 32 entries), then selected
     LaneMut L;
-    int Pb = (c > 0) ? t[c - 1] : lf;
-    int pA = Pb, xA = x, nB = 0, q, fin;
-    if (type == 0)      { fin = (c + 1 == J); if (!fin) nB = t[c + 1]; q = c + 2; }
-    else if (type == 2) { fin = (c == J);     if (!fin) nB = t[c];     q = c + 1; }
-    else                { fin = (c + 1 == J); xA = fin ? 0 : t[c + 1]; q = c + 2; }
+    const int tm1 = t[c > 0 ? c - 1 : 0];
+    const int nidx = (type == 2) ? c : c + 1;
+    const int tn = t[nidx < 31 ? nidx : 31];
+    const int fin = (type == 2) ? (c == J) : (c + 1 == J);
+    const int nx = fin ? 0 : tn;                             // the template base after the mutated column (0 when there is none)
+    int pA = (c > 0) ? tm1 : lf;
+    const int xA = (type == 1) ? nx : x;
     if (pA > 3) pA = (xA + 2) & 3;
-    const int kA = pA * 4 + xA, kB = (type == 1) ? kA : xA * 4 + nB;
+    const int kA = pA * 4 + xA, kB = (type == 1) ? kA : xA * 4 + nx;
+    const int q = (type == 2) ? c + 1 : c + 2;
     L.c = c; L.q = q > J ? J : q; L.isdel = (type == 1); L.fin = fin;
     L.dlA = sDL[kA]; L.dlL = sDL[kB];
     // the SPEC's "no stay move" cases (a deletion whose extension is the final column: INS[kA] unused; any extension
@@ -1257,6 +1261,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         const int nblk = (nvm + 63) >> 6;
         PHASE(1);
         int nvalid = 0;
+        int curblk = -1;                                     // the block whose lane constants this wave holds (they survive the chunks of a round)
+        LaneMut LF, LR;
+        int myM = 0; bool mval = false;
         // ---- chunks of reads whose gamma/beta fit the LDS budget
         int rbeg = 0;
         while (rbeg < nreads) {
@@ -1387,9 +1394,13 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const int nv = rfl(sCtl[8]), nunits = nblk * nv;
 #endif
                 nvalid += nv;
-                int curblk = -1;
-                LaneMut LF, LR;
-                int myM = 0; bool mval = false;
+                // per-read scalars of the chunk's usable reads, one read per lane: a unit takes them with v_readlane (no chain of
+                // dependent LDS loads at the start of every unit)
+                int vR, vI, vSt, vG, vB; float vBase;
+                {
+                    vR = (int)sVlist[lane < nv ? lane : 0];
+                    vI = sI[vR]; vSt = (int)sStrand[vR]; vG = sGoff[vR]; vB = sBoff[vR]; vBase = sBase[vR];
+                }
                 const int u_end = ((wave + 1) * nunits) / PW_WAVES;
                 for (int u = (wave * nunits) / PW_WAVES; u < u_end;) {
                     const int blk = u / nv, k0 = u - blk * nv;
@@ -1411,11 +1422,12 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                             LR = lane_mut(type, (type == 2) ? J - cpos : J - 1 - cpos, 3 - x, sT[1], J, lfr, sDL);
                         } else { LF = lane_mut(0, 0, 0, sT[0], J, lf, sDL); LR = LF; }
                     }
-                    const int ra = rfl((int)sVlist[k0]);
-                    const int rb = two ? rfl((int)sVlist[k0 + 1]) : ra;
-                    const int Ia = rfl(sI[ra]), Ib = two ? rfl(sI[rb]) : -1;
-                    const LaneMut La = rfl((int)sStrand[ra]) ? LR : LF;
-                    const LaneMut Lb = (two && rfl((int)sStrand[rb])) ? LR : LF;
+                    const int k1 = two ? k0 + 1 : k0;
+                    const int ra = rl(vR, k0), rb = rl(vR, k1);
+                    const int Ia = rl(vI, k0), Ib = two ? rl(vI, k1) : -1;
+                    const LaneMut La = rl(vSt, k0) ? LR : LF;
+                    const LaneMut Lb = (two && rl(vSt, k1)) ? LR : LF;
+                    const int gA_ = rl(vG, k0), bA_ = rl(vB, k0), gB_ = rl(vG, k1), bB_ = rl(vB, k1);
                     // SPEC "banded link": every lane scores the rows around its column's point on the window diagonal only
                     const int dA = Ia > J ? Ia - J : J - Ia, WrA = SCORE_BAND + (dA > 2 ? dA - 2 : 0);
                     const int nrA = (Ia < 2 * WrA ? Ia : 2 * WrA) + 1;
@@ -1428,8 +1440,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     ScoreChain ca, cb;
                     ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
                     cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f);
-                    ca.g = (lds_cf)(sGB + sGoff[ra] + i0a * S + La.c); ca.be = (lds_cf)(sGB + sBoff[ra] + i0a * S + La.q); ca.bq = *ca.be; ca.be += S;
-                    cb.g = (lds_cf)(sGB + sGoff[rb] + i0b * S + Lb.c); cb.be = (lds_cf)(sGB + sBoff[rb] + i0b * S + Lb.q); cb.bq = *cb.be; cb.be += S;
+                    ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, S) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, S) + La.q); ca.bq = *ca.be; ca.be += S;
+                    cb.g = (lds_cf)(sGB + gB_ + __mul24(i0b, S) + Lb.c); cb.be = (lds_cf)(sGB + bB_ + __mul24(i0b, S) + Lb.q); cb.bq = *cb.be; cb.be += S;
                     ca.op = (lds_cu16)(&sObs[ra][0] + i0a); cb.op = (lds_cu16)(&sObs[rb][0] + i0b);
                     // opaque to the optimiser from here: the running pointers hold complete LDS addresses (otherwise the
                     // dynamic-LDS base is re-added at every use)
@@ -1445,11 +1457,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     int dq;
                     {
                         const float res = La.fin ? ca.b : ca.acc;
-                        dq = dq_fix(det_log2f(res) - sBase[ra]);
+                        dq = dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k0)));
                     }
                     if (two) {
                         const float res = Lb.fin ? cb.b : cb.acc;
-                        dq += dq_fix(det_log2f(res) - sBase[rb]);
+                        dq += dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k1)));
                     }
                     if (mval) atomicAdd(&sDeltaI[myM], dq);
                 }
