@@ -129,6 +129,14 @@ __device__ __forceinline__ float wave_max_f32(float v)
 }
 __device__ __forceinline__ int bcast_i32(int v, int lane) { return __shfl(v, lane); }
 
+// scalar min / max of wave-uniform values (the compiler otherwise moves such chains to the VALU for v_min3 and reads them back)
+__device__ __forceinline__ int smin(int a, int b) { int r; asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int smax(int a, int b) { int r; asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+// band placement of a column from scalars (k_align, k_poa's chain step): same arithmetic as band_lo
+__device__ __forceinline__ int band_lo_s(int lo_u, int bestrow_u, int hi /* max(I - 63, 0) */)
+{
+    return smax(smin(smin(smax(bestrow_u + 1 - CCSX_BAND / 2, lo_u), lo_u + 2), hi), 0);
+}
 __device__ __forceinline__ int band_lo(int lo_u, int bestrow_u, int I)
 {
     int lo = bestrow_u + 1 - CCSX_BAND / 2;
@@ -390,10 +398,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const int vb = meta & 255, np = (meta >> 8) & 255;
                     int lo, best = NEGV, bm = 0, pp, i, rbv;
                     if (np == 1 && q0 == k - 1) {                          // chain step: registers only, no branches
-                        int t = br_prev + 1 - CCSX_BAND / 2;
-                        t = t > lo_prev ? t : lo_prev;
-                        t = t < lo_prev + 2 ? t : lo_prev + 2;
-                        lo = rfl(t < hiI ? t : hiI);
+                        lo = smin(smin(smax(br_prev + 1 - CCSX_BAND / 2, lo_prev), lo_prev + 2), hiI);   // wave-uniform: scalar unit
                         const int sh = lo - lo_prev;                       // 0..2: the band follows the best row of the previous column
                         // rows of the previous column by wave shifts (no LDS crossbar on the chain); the read base of row i-1
                         // travels with the band, only the top lane(s) fetch a new one.  Invalid cells carry NEGV, lose every
@@ -792,6 +797,7 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
     int ecol = 0;                                       // last window-edge column
     int lo = 0, br = 0;
     int rbv = (lane >= 1 && lane <= I) ? read_base_packed(sread, lane - 1) : 4;   // base of row lo + lane (minus one), band at lo = 0
+    const int hiI = I - (CCSX_BAND - 1) > 0 ? I - (CCSX_BAND - 1) : 0;
     for (int jb = 0; jb < Ld; jb += LANES) {            // draft bases: one coalesced load per 64 columns
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
         asm volatile("" :: "v"(dL));                     // wait for the block load here, not inside the column loop
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
         for (int jj = 0; jj < nblk; ++jj) {
             const int j = jb + jj + 1;
             const int plo = lo;
-            lo = rfl(band_lo(plo, br, I));
+            lo = band_lo_s(plo, br, hiI);                // wave-uniform operands: scalar unit
             const int sh = lo - plo;                    // 0..2
             const int i = lo + lane;
             const int vb = rl(dL, jj);
