@@ -221,6 +221,20 @@ __device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t 
     }
 }
 __device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { return (int)((sread[i >> 4] >> (2 * (i & 15))) & 3u); }
+// the band's next read base, wave-uniform index: 64 packed words (1024 bases) of the read sit in one VGPR, lane = word, loaded
+// at a point from which the band cannot advance past the window before the next load (<= 2 rows per column); a column takes
+// its word with v_readlane into an SGPR (scalar shift / mask): no LDS access and no vector arithmetic in the column
+struct BaseCursor { uint32_t vw; int w0; };
+__device__ __forceinline__ void cursor_load(BaseCursor &c, const uint32_t *sread, int nwords, int t0, int lane)
+{
+    c.w0 = (t0 < 0 ? 0 : t0) >> 4;
+    const int wi = c.w0 + lane;
+    c.vw = sread[wi < nwords ? wi : (nwords > 0 ? nwords - 1 : 0)];
+}
+__device__ __forceinline__ int base_at(const BaseCursor &c, int t)
+{
+    return (int)(((uint32_t)__builtin_amdgcn_readlane((int)c.vw, ((t >> 4) - c.w0) & 63) >> (2 * (t & 15))) & 3u);
+}
 
 // ------------------------------------------------------------------------------------------------
 // D2/D3: sparse POA.  One wave per resident graph ("slot"); the kernel is launched per chunk of poa_slots ZMWs, longest first.
@@ -408,12 +422,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         else {
                             const int top = lo + 62;
                             int tc = top >= I ? I - 1 : top; tc = tc < 0 ? 0 : tc;   // clamped: the value only matters for valid rows
-                            const int nb = read_base_packed(sread, tc);
-                            if (sh == 1) { x = Mprev; y = wave_shl1_i32(Mprev, NEGV); rbK = wave_shl1_i32(rbK, nb); }
+                            if (sh == 1) { const int nb = read_base_packed(sread, tc); x = Mprev; y = wave_shl1_i32(Mprev, NEGV); rbK = wave_shl1_i32(rbK, nb); }
                             else {
                                 x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV);
                                 int tc1 = top - 1 >= I ? I - 1 : top - 1; tc1 = tc1 < 0 ? 0 : tc1;
                                 const int nb1 = read_base_packed(sread, tc1);
+                                const int nb = read_base_packed(sread, tc);
                                 rbK = wave_shl1_i32(wave_shl1_i32(rbK, nb1), nb);
                             }
                         }
@@ -798,14 +812,17 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
     int lo = 0, br = 0;
     int rbv = (lane >= 1 && lane <= I) ? read_base_packed(sread, lane - 1) : 4;   // base of row lo + lane (minus one), band at lo = 0
     const int hiI = I - (CCSX_BAND - 1) > 0 ? I - (CCSX_BAND - 1) : 0;
+    BaseCursor bcur; bcur.w0 = 0; bcur.vw = 0u;
+    const int nwords = (I + 15) >> 4;
     for (int jb = 0; jb < Ld; jb += LANES) {            // draft bases: one coalesced load per 64 columns
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
-        asm volatile("" :: "v"(dL));                     // wait for the block load here, not inside the column loop
+        cursor_load(bcur, sread, nwords, lo + 61, lane);  // the next 64 columns fetch their band-top bases from this window
+        asm volatile("" :: "v"(dL), "v"(bcur.vw));       // wait for the block loads here, not inside the column loop
         const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
         for (int jj = 0; jj < nblk; ++jj) {
             const int j = jb + jj + 1;
             const int plo = lo;
-            lo = band_lo_s(plo, br, hiI);                // wave-uniform operands: scalar unit
+            lo = rfl(band_lo_s(plo, br, hiI));           // scalar unit; the readfirstlane tells the compiler the result is wave-uniform
             const int sh = lo - plo;                    // 0..2
             const int i = lo + lane;
             const int vb = rl(dL, jj);
@@ -817,15 +834,16 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
             if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; ox = wave_shr1_i32_z(Oprev); oy = Oprev; kx = (unsigned)wave_shr1_i32_z((int)Kprev); ky = Kprev; }
             else {
                 const int top = lo + 62;                                // read index of lane 63's base
-                const int nb = top < I ? read_base_packed(sread, top < 0 ? 0 : top) : 4;
                 if (sh == 1) {
+                    const int nb = top < I ? base_at(bcur, top) : 4;
                     x = Mprev; y = wave_shl1_i32(Mprev, NEGV); ox = Oprev; oy = wave_shl1_i32_z(Oprev);
                     kx = Kprev; ky = (unsigned)wave_shl1_i32_z((int)Kprev);
                     rbv = wave_shl1_i32(rbv, nb);
                 } else {
                     x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV); ox = wave_shl1_i32_z(Oprev); oy = wave_shl1_i32_z(ox);
                     kx = (unsigned)wave_shl1_i32_z((int)Kprev); ky = (unsigned)wave_shl1_i32_z((int)kx);
-                    const int nb1 = top - 1 < I ? read_base_packed(sread, top - 1 < 0 ? 0 : top - 1) : 4;
+                    const int nb1 = top - 1 < I ? base_at(bcur, top - 1) : 4;
+                    const int nb = top < I ? base_at(bcur, top) : 4;
                     rbv = wave_shl1_i32(wave_shl1_i32(rbv, nb1), nb);
                 }
             }
