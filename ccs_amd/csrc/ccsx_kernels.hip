@@ -1233,16 +1233,20 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 if (o == 0) sDLJ[sd][j] = dlv;
             }
         }
-        // z-score expectation of the window template on each strand, summed in column order (SPEC)
-        if (lane == 0 && wave < 2) {
+        // z-score expectation of the window template on each strand, summed in column order (SPEC); the gate is decided in round 0
+        // only.  Lane j fetches column j's terms, the ordered sum takes them with v_readlane (no chain of dependent LDS loads).
+        if (it == 0 && wave < 2 && P.opts.min_zscore != 0.0f) {
             const uint8_t *t = sT[wave];
+            const int j = lane < J ? lane : 0;
+            const int prev = j > 0 ? t[j - 1] : (wave ? lfr : lf);
+            const int k = ctx_of(prev, t[j]);
+            const float mu = sZP[k], va = sZP[16 + k];
             float M = 0.0f, V = 0.0f;
-            for (int j = 0; j < J; ++j) {
-                const int prev = j > 0 ? t[j - 1] : (wave ? lfr : lf);
-                const int k = ctx_of(prev, t[j]);
-                M = M + sZP[k]; V = V + sZP[16 + k];
+            for (int q = 0; q < J; ++q) {
+                M = M + __int_as_float(rl(__float_as_int(mu), q));
+                V = V + __int_as_float(rl(__float_as_int(va), q));
             }
-            sZS[2 * wave] = M; sZS[2 * wave + 1] = V;
+            if (lane == 0) { sZS[2 * wave] = M; sZS[2 * wave + 1] = V; }
         }
         // positions skipped this round: evidence bit set and not inside a homopolymer of the CURRENT template
         {
@@ -1292,20 +1296,32 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         int rbeg = 0;
         while (rbeg < nreads) {
             __syncthreads();
-            if (tid == 0) {
-                int off = 0, r = rbeg, nt = 0, pend = -1;
-                for (; r < nreads; ++r) {
-                    const int n = sI[r];
-                    if (n < 0) { sGoff[r] = -1; sValid[r] = 0; continue; }
-                    const int need = (2 * n + 3) * S;
-                    if (off + need > GB_FLOATS) break;
-                    sGoff[r] = off; sBoff[r] = off + (n + 1) * S; off += need;
-                    if (n > 31) sTask[nt++] = make_short2((short)r, (short)-1);           // long segment: a wave of its own
-                    else if (pend < 0) pend = r;
-                    else { sTask[nt++] = make_short2((short)pend, (short)r); pend = -1; }
+            if (wave == 0) {                                                 // lane = read: the greedy plan by prefix sum and ballots
+                const int r = lane;
+                const int n = (r >= rbeg && r < nreads) ? sI[r] : -1;
+                const bool cand = n >= 0;
+                const int need = cand ? (2 * n + 3) * S : 0;
+                const int incl = wave_scan_add_i32(need);
+                const unsigned long long over = __ballot(cand && incl > GB_FLOATS);
+                const int rend_ = over ? (int)__ffsll((long long)over) - 1 : nreads;   // the first read that does not fit any more
+                if (r >= rbeg && r < rend_) {
+                    if (!cand) { sGoff[r] = -1; sValid[r] = 0; }
+                    else { const int off = incl - need; sGoff[r] = off; sBoff[r] = off + (n + 1) * S; }
                 }
-                if (pend >= 0) sTask[nt++] = make_short2((short)pend, (short)-1);
-                sCtl[5] = r; sCtl[6] = nt;
+                const bool inchunk = cand && r < rend_;
+                const bool lng = inchunk && n > 31, sht = inchunk && n <= 31;  // long segment: a wave of its own; short ones pair up in order
+                const unsigned long long bl = __ballot(lng), bs = __ballot(sht);
+                const unsigned long long lower = (1ull << lane) - 1ull;
+                const int nl = __popcll(bl), ns = __popcll(bs);
+                if (lng) sTask[__popcll(bl & lower)] = make_short2((short)r, (short)-1);
+                if (sht) {
+                    const int rank = __popcll(bs & lower);
+                    if (!(rank & 1)) {
+                        const unsigned long long hi = bs & ~(lower | (1ull << lane));
+                        sTask[nl + (rank >> 1)] = make_short2((short)r, (short)(hi ? (int)__ffsll((long long)hi) - 1 : -1));
+                    }
+                }
+                if (lane == 0) { sCtl[5] = rend_; sCtl[6] = nl + ((ns + 1) >> 1); }
             }
             __syncthreads();
             const int rend = rfl(sCtl[5]), ntask = rfl(sCtl[6]);
@@ -1398,10 +1414,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 }
             }
             __syncthreads();
-            if (tid == 0) {                                                  // usable reads of the chunk, in read order
-                int nv = 0;
-                for (int r = rbeg; r < rend; ++r) if (sValid[r]) sVlist[nv++] = (uint8_t)r;
-                sCtl[8] = nv;
+            if (wave == 0) {                                                 // usable reads of the chunk, in read order
+                const bool v = lane >= rbeg && lane < rend && sValid[lane];
+                const unsigned long long bv = __ballot(v);
+                if (v) sVlist[__popcll(bv & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                if (lane == 0) sCtl[8] = __popcll(bv);
             }
             __syncthreads();
             PHASE(3);
@@ -1565,7 +1582,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     // ---- A6: QVs of the core positions from the last scoring round
     const int J = sCtl[0], cs = sCtl[1], ce = sCtl[2];
     const size_t wi = (size_t)(P.wb_off[z] - z) + w;
-    float *sPerr = sGB;                                     // reuse
+    float pl = 0.0f;                                        // this position's error probability
     if (tid < ce - cs) {
         const int c = cs + tid;
         float p;
@@ -1588,15 +1605,16 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         if (qv > 93.0f) qv = 93.0f;
         P.wseq[wi * 32 + tid] = sT[0][c];
         P.wqv[wi * 32 + tid] = qv;
-        sPerr[tid] = p;
+        pl = p;
     }
-    __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {                                         // the core positions (<= 32) all sit in wave 0: ordered sum by v_readlane
         float wsum = 0.0f;
-        for (int k = 0; k < ce - cs; ++k) wsum = wsum + sPerr[k];
+        for (int k = 0; k < ce - cs; ++k) wsum = wsum + __int_as_float(rl(__float_as_int(pl), k));
+      if (tid == 0) {
         P.wsum[wi] = wsum;
         P.wmeta[wi] = make_int4(ce - cs, nvalid_last, nonconv, iters);
         if (P.wtmeta) P.wtmeta[wi] = make_short2((short)J, (short)cs);
+      }
     }
     if (P.wtpl && tid < J) P.wtpl[wi * 32 + tid] = sT[0][tid];
     PHASE(6);
