@@ -1185,7 +1185,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     if (wave == 0) {
         const int J0 = we - ws;
         int nuse = 0, nd = 0;
-        for (int r = 0; r < nreads; ++r) if (sI[r] >= 0) { ++nuse; nd += (int)((sDirty[r] >> (lane & 31)) & 1u); }
+        const int vIr = lane < nreads ? sI[lane] : -1;                      // lane = read: one load each, then v_readlane per read
+        const unsigned vDr = lane < nreads ? sDirty[lane] : 0u;
+        for (int r = 0; r < nreads; ++r) if (rl(vIr, r) >= 0) { ++nuse; nd += (int)(((unsigned)rl((int)vDr, r) >> (lane & 31)) & 1u); }
         const int margin = nuse - 2 * nd;
         const bool inw = lane < J0;
         const unsigned neg = (unsigned)__ballot(inw && margin < 0);
