@@ -1205,6 +1205,18 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     if (tid == 0) P.wsum[(size_t)(P.wb_off[z] - z) + w] = (float)sI[0] + (float)sObs[0][0] + sPskip[0] + sCTX[5].x;
     return;
 #endif
+#ifdef CCSX_EXP_REPEAT                                      // experiment: the compute of a window CCSX_EXP_REPEAT times after ONE prologue
+    __syncthreads();                                        // (T(R=2) - T(R=1) = a window's compute without the memory latency at its head)
+    const int xr_t = sT[0][tid & 31], xr_c0 = sCtl[0], xr_c1 = sCtl[1], xr_c2 = sCtl[2], xr_c7 = sCtl[7];
+    const float xr_p = sPskip[tid < 36 ? tid : 0];
+    for (int xrep = 0; xrep < CCSX_EXP_REPEAT; ++xrep) {
+    __syncthreads();
+    if (tid < 32) sT[0][tid] = (uint8_t)xr_t;
+    if (tid < 36) sPskip[tid] = xr_p;
+    if (tid < PW_MAXREADS) sZdrop[tid] = 0;
+    if (tid == 0) { sCtl[0] = xr_c0; sCtl[1] = xr_c1; sCtl[2] = xr_c2; sCtl[7] = xr_c7; }
+    __syncthreads();
+#endif
     int iters = 0, nonconv = 0;
     unsigned skmask = 0;                                     // positions skipped in the current round (wave-uniform)
     int nvalid_last = 0;
@@ -1619,6 +1631,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
       }
     }
     if (P.wtpl && tid < J) P.wtpl[wi * 32 + tid] = sT[0][tid];
+#ifdef CCSX_EXP_REPEAT
+    }
+#endif
     PHASE(6);
 }
 

@@ -1,7 +1,7 @@
 # attribute k_polish's VALU instructions to its parts: counting runs with parts of the kernel compiled out (results are garbage)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for v in "" _pro _nofill _noscore; do
+for v in "" _nofill _noscore; do
   rm -rf /tmp/cv; CCSX_LIB=$R/ccs_amd/libccsx$v.so timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -d /tmp/cv -o pmc -- python $R/tools/phase_run.py > /dev/null 2>&1
   python - <<PY
 import sqlite3,glob
