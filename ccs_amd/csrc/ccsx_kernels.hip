@@ -863,16 +863,19 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
                 org = i;                                // reset: this column is the new edge
                 kd = 0u; insbits = 0x80000001u; ecol = j;
             }
-            // insertion chain with origin: (1) prefix max of d = c + 4*lane; (2) the winner of lane l is the highest
-            // lane k <= l that attains its own running maximum ("record holder": ties keep the higher lane, as the
-            // SPEC's serial chain does); a second prefix max over (k << 16 | origin_k) of the record holders finds it.
+            // insertion chain with origin: the winner of lane l is the highest lane k <= l that attains the prefix maximum of
+            // d = c + 4*lane (ties keep the higher lane, as the SPEC's serial chain does).  ONE max-scan finds value and lane
+            // together: the key is (d << 6) | lane, with d clamped at -2^24 so that it fits (cells of valid paths are above
+            // -2^19; anything below -2^22 is an invalid cell and is reset to NEGV at the end of the column).
             const int d0 = best + 4 * lane;
-            const int dd = wave_scan_max_i32(d0);
-            const int key = wave_scan_max_i32(d0 == dd ? ((lane << 16) | org) : -1);
-            const int xi = dd - 4 * lane;
-            const unsigned ksrc = (unsigned)__shfl((int)kd, (key >> 16) & 63);   // dirty bits of the cell the insertion run starts from
-            if (xi > best) { best = xi; org = key & 0xffff; kd = ksrc | insbits; }
-            if (i > I || best < NEGV / 2) best = NEGV;
+            const int dc = d0 > -(1 << 24) ? d0 : -(1 << 24);
+            const int key = wave_scan_max_i32((dc << 6) | lane);
+            const int xi = (key >> 6) - 4 * lane;
+            const int ksl = key & 63;
+            const int osrc = __shfl(org, ksl);                                   // origin / dirty bits of the cell the insertion run starts from
+            const unsigned ksrc = (unsigned)__shfl((int)kd, ksl);
+            if (xi > best) { best = xi; org = osrc; kd = ksrc | insbits; }
+            if (i > I || best < -(1 << 22)) best = NEGV;
             const int cm = wave_reduce_max_i32(best);
             const unsigned long long bal = __ballot(best == cm);
             br = lo + (__ffsll((long long)bal) - 1);
