@@ -41,7 +41,7 @@ class Opts(C.Structure):
     _fields_ = [
         ("max_poa_cov", C.c_int32), ("min_passes", C.c_int32), ("top_passes", C.c_int32),
         ("min_length", C.c_int32), ("max_length", C.c_int32), ("min_rq", C.c_float),
-        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("disable_heuristics", C.c_int32), ("min_zscore", C.c_float), ("handles_per_device", C.c_int32), ("no_fallback_draft", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("disable_heuristics", C.c_int32), ("min_zscore", C.c_float), ("handles_per_device", C.c_int32), ("no_fallback_draft", C.c_int32), ("max_insertion_size", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -150,6 +150,7 @@ void usage()
                  "      --model-file F        Arrow model parameters (json); default: chosen by the chemistry in the BAM header from\n"
                  "                            $SMRT_CHEMISTRY_BUNDLE_DIR/arrow/*.json, then the built-in set\n"
                  "      --disable-heuristics  polish every position (no candidate filter)\n"
+                 "      --max-insertion-size N  trim subread insertions longer than N bases relative to the draft [30]; 0 = never\n"
                  "      --min-snr F           minimum SNR of a ZMW [2.5]\n"
                  "      --min-length N        minimum draft length [10]\n"
                  "      --max-length N        maximum draft length [50000]\n"
@@ -187,6 +188,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--max-length") o.o.max_length = std::atoi(need(a.c_str()).c_str());
         else if (a == "--min-rq") o.o.min_rq = (float)std::atof(need(a.c_str()).c_str());
         else if (a == "--maxPoaCoverage") o.o.max_poa_cov = std::atoi(need(a.c_str()).c_str());
+        else if (a == "--max-insertion-size") { const int v = std::atoi(need(a.c_str()).c_str()); o.o.max_insertion_size = v > 0 ? v : -1; }
         else if (a == "--batch-size") o.batch = std::atoi(need(a.c_str()).c_str());
         else if (a == "--report-file") o.report = need(a.c_str());
         else if (a == "--workers-per-gpu") o.workers_per_gpu = std::max(1, std::atoi(need(a.c_str()).c_str()));

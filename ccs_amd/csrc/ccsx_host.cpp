@@ -67,6 +67,7 @@ void ccsx_opts_default(ccsx_opts *o)
     o->min_rq = 0.99f;       // docs/how-does-ccs-work.md:111, docs/faq/reads-bam.md:38
     o->poa_slots = 0;
     o->min_zscore = -3.4f;   // [RECALL] unanimity's MinZScore; DESIGN.md §2 "z-score gate"
+    o->max_insertion_size = 30;   // docs/how-does-ccs-work.md:74-78
 }
 
 int64_t ccsx_result_layout(const ccsx_batch *b, int64_t *seq_off)

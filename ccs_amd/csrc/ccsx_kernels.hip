@@ -1122,6 +1122,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     const int lf = ws > 0 ? lfv : 4, rf = we < Ld ? rfv : 4;
     // the (at most three) alignment intervals this window spans: start columns relative to ws and lengths
     const int c1 = need_col(wb, nw, Ld, idx_ws + 1), c2 = (idx_ws + 2 <= idx_we) ? need_col(wb, nw, Ld, idx_ws + 2) : we;
+    int trimflag = 0;
+    const int maxins = P.opts.max_insertion_size == 0 ? 30 : P.opts.max_insertion_size;
     {
         // level 2: everything that needs only z / r0 / the window bounds
         const int e0 = tid, e1 = tid + PW_THREADS < CCSX_NOBS * 32 ? tid + PW_THREADS : tid;
@@ -1154,16 +1156,19 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             int n = -1, na = 0;
             if (av) {
                 n = b - a;
-                if (n < 0 || n > CCSX_IMAX) n = -1;
+                // SPEC "trim large insertions": a segment more than max_insertion_size bases longer than the window is cut down
+                // to the window's length below (sBoff keeps the full length until the chunk plan re-uses it)
+                if (n >= 0 && maxins > 0 && n > (we - ws) + maxins) { trimflag = 1; sBoff[tid] = n; n = we - ws; }
+                else { sBoff[tid] = 0; if (n < 0 || n > CCSX_IMAX) n = -1; }
                 na = st ? L - b : a;
-            }
+            } else sBoff[tid] = 0;
             sI[tid] = n; sStrand[tid] = (uint8_t)st; sZdrop[tid] = 0;
             sGoff[tid] = (int)(bo0 - bo_r0) + na;            // segment start relative to the ZMW's first base (sGoff is re-planned later)
             // interval k covers draft positions col(k-1) .. col(k)-1: bit (p - col(k-1))
             sDirty[tid] = av ? (m1 | (m2 << (c1 - ws)) | (m3 << (c2 - ws))) : 0u;
         }
     }
-    __syncthreads();
+    const int anytrim = __syncthreads_or(trimflag);
     // level 4: the read segments (native orientation), four reads per wave in flight
     for (int rb = 0; rb < nreads; rb += 4 * PW_WAVES) {
         uint8_t bq[4], pq[4];
@@ -1182,6 +1187,26 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 sObs[r][lane] = (lane < n) ? (uint16_t)(obs_of(bq[q], pq[q]) << 8) : (uint16_t)(lane == n ? CCSX_NOBS << 8 : 0);   // row n: "no base"
                 if (lane < 4) sObs[r][64 + lane] = 0;
             }
+        }
+    }
+    if (anytrim) {
+        // rare: cut over-long segments down to J bases = their first s and last J - s bases, s = the split with the most diagonal
+        // matches of prefix and suffix against the window in read orientation (ties: the smallest s).  The main loop above has
+        // already stored the first J codes; the same wave owns the read here.
+        const int J0 = we - ws;
+        for (int r = wave; r < nreads; r += PW_WAVES) {
+            const int nfull = rfl(sBoff[r]);
+            if (nfull == 0) continue;
+            const int st = rfl((int)sStrand[r]);
+            const int64_t p0 = bo_r0 + sGoff[r];
+            const bool in = lane < J0;
+            const int bp = in ? P.bases[p0 + lane] : 0;
+            const int bs = in ? P.bases[p0 + nfull - J0 + lane] : 0, ps = in ? P.pw[p0 + nfull - J0 + lane] : 0;
+            const int T = in ? (st ? 3 - (int)sT[0][J0 - 1 - lane] : (int)sT[0][lane]) : 9;
+            const unsigned long long mp = __ballot(in && (bp & 3) == T), ms = __ballot(in && (bs & 3) == T);
+            const int tot = (lane <= J0) ? __popcll(mp & ((1ull << lane) - 1ull)) + __popcll(ms >> lane) : -1;
+            const int sb = 63 - (rfl(wave_max_i32((tot << 6) | (63 - lane))) & 63);
+            if (in && lane >= sb) sObs[r][lane] = (uint16_t)(obs_of(bs, ps) << 8);
         }
     }
     // ---- step 7, candidate filter: pile-up margin of every window position over the reads with a usable segment

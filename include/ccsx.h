@@ -85,7 +85,10 @@ typedef struct ccsx_opts {
                                 the window template) is below this; 0 = gate off                                   */
     int32_t handles_per_device; /* handles the caller runs on this GPU (0/1 = one): each takes 1/N of the free HBM for its POA scratch */
     int32_t no_fallback_draft;  /* 1: a failed / unmappable first draft is final (default 0: one fallback draft, SPEC "fallback draft") */
-    int32_t reserved[3];
+    int32_t max_insertion_size; /* SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78, --max-insertion-size): a subread segment more
+                                 * than this many bases longer than its window is cut down to the window's length before polishing;
+                                 * 0 = the default 30, < 0 = never trim (such a segment then leaves the window when it exceeds 63 bases) */
+    int32_t reserved[2];
 } ccsx_opts;
 
 /* ---- input batch: SoA + CSR ---- */

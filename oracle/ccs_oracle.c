@@ -81,7 +81,8 @@ typedef struct orc_opts {
     float   min_zscore;             /* a pass is dropped from a window when its z-score is below this (0 = gate off) */
     int32_t handles_per_device;     /* (engine only) */
     int32_t no_fallback_draft;      /* 1: a failed / unmappable first draft is final */
-    int32_t reserved[3];
+    int32_t max_insertion_size;     /* trim segments longer than window + this (0 = 30, < 0 = off) */
+    int32_t reserved[2];
 } orc_opts;
 
 /* ---------------- deterministic log2 / exp2 (DESIGN.md §SPEC "det math") -------------------------------- */
@@ -1098,7 +1099,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         orc_zparams(model, snr, MU, VAR);
         uint8_t *obuf = (uint8_t *)malloc((size_t)nreads * (IMAX + 1));
         const uint8_t **obs = (const uint8_t **)malloc(sizeof(uint8_t *) * nreads);
-        int32_t *Iw = (int32_t *)malloc(sizeof(int32_t) * nreads);
+        int32_t *Iw = (int32_t *)malloc(sizeof(int32_t) * nreads), *Ikin = (int32_t *)malloc(sizeof(int32_t) * nreads);
         int64_t len = 0; double perr_sum = 0.0; int64_t nvalid_sum = 0; int nonconv_any = 0, overflow = 0;
         int32_t nv_hist[65]; memset(nv_hist, 0, sizeof(nv_hist));
         for (int w = 0; w < nw; ++w) {
@@ -1106,16 +1107,36 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
             int we = wb[w + 1] + WIN_OVH; if (we > Ld) we = Ld;
             int J = we - ws, cs = wb[w] - ws, ce = wb[w + 1] - ws;
             int lf = ws > 0 ? draft[ws - 1] : 4, rf = we < Ld ? draft[we] : 4;
+            const int maxins = opts->max_insertion_size == 0 ? 30 : opts->max_insertion_size;
             for (int r = 0; r < nreads; ++r) {
-                Iw[r] = -1; obs[r] = obuf + (size_t)r * (IMAX + 1);
+                Iw[r] = -1; Ikin[r] = -1; obs[r] = obuf + (size_t)r * (IMAX + 1);
                 if (!avalid[r]) continue;
                 int a = rstart[r][ws], b = rstart[r][we], L = (int)(base_off[r + 1] - base_off[r]);
                 int n = b - a;
-                if (n < 0 || n > IMAX) continue;
-                Iw[r] = n;
+                if (n < 0) continue;
+                if (n <= IMAX) Ikin[r] = n;                  /* the kinetics always see the untrimmed segment */
                 int na = strand[r] ? L - b : a;              /* native start of the segment */
                 const uint8_t *bb = bases + base_off[r] + na, *pp = pw + base_off[r] + na;
                 uint8_t *oo = obuf + (size_t)r * (IMAX + 1);
+                if (maxins > 0 && n > J + maxins) {
+                    /* SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78): the segment is cut down to the window's
+                     * length: its first s and last J - s bases, s = the split with the most diagonal matches of prefix and
+                     * suffix against the window (read orientation; ties: the smallest s)                                    */
+                    uint8_t T[JMAX + 1];
+                    for (int j = 0; j < J; ++j) T[j] = strand[r] ? (uint8_t)(3 - draft[ws + J - 1 - j]) : draft[ws + j];
+                    int best = -1, sb = 0;
+                    for (int s = 0; s <= J; ++s) {
+                        int m = 0;
+                        for (int i = 0; i < s; ++i) m += ((bb[i] & 3) == T[i]);
+                        for (int j = s; j < J; ++j) m += ((bb[n - J + j] & 3) == T[j]);
+                        if (m > best) { best = m; sb = s; }
+                    }
+                    for (int i = 0; i < J; ++i) { int src = i < sb ? i : n - J + i; oo[i] = (uint8_t)obs_of(bb[src], pp[src]); }
+                    Iw[r] = J;
+                    continue;
+                }
+                if (n > IMAX) continue;
+                Iw[r] = n;
                 for (int i = 0; i < n; ++i) oo[i] = (uint8_t)obs_of(bb[i], pp[i]);
             }
             /* step 7, candidate filter (docs/how-does-ccs-work.md:80-83): pile-up of the step-3 alignments over the
@@ -1181,12 +1202,12 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                 memset(ks, 0, sizeof(ks));
                 uint8_t tr[JMAX + 1]; int lfr; revcomp_tpl(&wf, tr, &lfr);
                 for (int r = 0; r < nreads; ++r) {
-                    if (Iw[r] < 0) continue;
+                    if (Ikin[r] < 0) continue;
                     int a = rstart[r][ws], b = rstart[r][we], L = (int)(base_off[r + 1] - base_off[r]);
                     int na = strand[r] ? L - b : a;
                     int64_t p0 = base_off[r] + na;
                     (void)a;
-                    orc_kinetics_read(strand[r] ? tr : wf.t, wf.J, bases + p0, ipd + p0, pw + p0, Iw[r], strand[r],
+                    orc_kinetics_read(strand[r] ? tr : wf.t, wf.J, bases + p0, ipd + p0, pw + p0, Ikin[r], strand[r],
                                       ks[strand[r]][0], ks[strand[r]][1], ks[strand[r]][2]);
                 }
             }
@@ -1219,7 +1240,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         else if (out->rq < opts->min_rq) out->status = ST_LOWRQ;
         else out->status = ST_SUCCESS;
         ret = 1;
-        free(wb); free(obuf); free(obs); free(Iw);
+        free(wb); free(obuf); free(obs); free(Iw); free(Ikin);
     }
 done:
     for (int r = 0; r < nreads; ++r) { free(rstart[r]); free(dirty[r]); }

@@ -510,4 +510,67 @@ def test_fallback_draft_matches_oracle(built):
         else:
             ok = set(np.nonzero((res.status == 0) | (res.status == 7))[0].tolist())
         h.close()
+    assert len(lost) >= 2 and lost <= ok                      # what is lost without the fallback gets a consensus with it (HiFi or LOW_RQ)@pytest.mark.gpu
+@pytest.mark.parametrize("maxins,kin", [(10, 0), (6, 1), (-1, 0)])
+def test_large_insertion_trimming_matches_oracle(built, maxins, kin):
+    """SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78, opts.max_insertion_size): passes with 8-30 base blocks of
+    foreign sequence, trimmed in their window at thresholds 10 / 6 (with kinetics: those always see the untrimmed segment) and never:
+    the GPU must reproduce the oracle bit for bit, and trimming must keep more passes per window than not trimming"""
+    rng = np.random.default_rng(14)
+    base = api.synth(10, (6, 12), (700, 2200), seed=93)
+    bases, pw, ipd, off = [], [], [], [0]
+    for r in range(int(base.read_off[-1])):
+        a, b = int(base.base_off[r]), int(base.base_off[r + 1])
+        bb, pp, ii = base.bases[a:b], base.pw[a:b], base.ipd[a:b]
+        for _ in range(int(rng.integers(0, 3))):
+            at, size = int(rng.integers(0, len(bb) + 1)), int(rng.integers(8, 31))
+            blk = rng.integers(0, 4, size, dtype=np.uint8)
+            bb = np.concatenate([bb[:at], blk, bb[at:]]); pp = np.concatenate([pp[:at], np.full(size, 2, np.uint8), pp[at:]])
+            ii = np.concatenate([ii[:at], np.full(size, 5, np.uint8), ii[at:]])
+        bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
+    batch = api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                      np.concatenate(ipd), base.flags, base.tpl_off, base.tpl)
+    o = api.default_opts(); o.max_insertion_size = maxins; o.hifi_kinetics = kin
+    h = api.Handle(0, opts=o)
+    res = h.consensus(batch)
+    ref = api.Results.allocate(batch)
+    O.consensus_batch(h.model, o, batch, ref)
+    h.close()
+    _compare(res, ref, batch)
+    if maxins > 0 and not kin:
+        o2 = api.default_opts(); o2.max_insertion_size = -1
+        h2 = api.Handle(0, opts=o2)
+        off_ = h2.consensus(batch)
+        h2.close()
+        ok = (res.status == 0) & (off_.status == 0)
+        assert ok.sum() >= 5 and res.ec[ok].sum() > off_.ec[ok].sum()
+
+
+@pytest.mark.gpu
+def test_fallback_draft_matches_oracle(built):
+    """the second draft attempt (median-length backbone, twice the passes, orientation of the new backbone) on the GPU: ZMWs whose
+    pass 0 is junk, next to ZMWs that need no fallback, with and without opts.no_fallback_draft, and with kinetics"""
+    rng = np.random.default_rng(21)
+    batch = api.synth(12, (5, 9), (500, 1600), seed=97)
+    for z in (1, 3, 4, 6, 7, 9, 10):
+        r = int(batch.read_off[z])
+        a, b = int(batch.base_off[r]), int(batch.base_off[r + 1])
+        batch.bases[a:b] = rng.integers(0, 4, b - a, dtype=np.uint8)
+    seen_rescue = False
+    for nofb, kin in ((0, 0), (1, 0), (0, 1)):
+        o = api.default_opts(); o.no_fallback_draft = nofb; o.hifi_kinetics = kin
+        h = api.Handle(0, opts=o)
+        res = h.consensus(batch)
+        ref = api.Results.allocate(batch, kinetics=bool(kin))
+        O.consensus_batch(h.model, o, batch, ref, nthreads=4)
+        _compare(res, ref, batch)
+        assert np.array_equal(res.fn, ref.fn) and np.array_equal(res.rn, ref.rn)
+        if kin:
+            for z in range(batch.n_zmw):
+                assert np.array_equal(res.kinetics(z), ref.kinetics(z))
+        if nofb:
+            lost = set(np.nonzero(res.status == 3)[0].tolist())
+        else:
+            ok = set(np.nonzero((res.status == 0) | (res.status == 7))[0].tolist())
+        h.close()
     assert len(lost) >= 2 and lost <= ok                      # what is lost without the fallback gets a consensus with it (HiFi or LOW_RQ)

@@ -146,8 +146,9 @@ def test_np_is_the_mode_over_windows(built):
 
 def test_large_inserted_blocks_end_in_a_deliberate_outcome(built):
     """VERDICT r01 item 9 (band robustness): passes with a 40-200 base block of foreign sequence inserted (spurious sequencing
-    activity, docs/how-does-ccs-work.md:74-78) are not trimmed by this SPEC: the band loses them and they fail their alignment
-    gate — the pass is dropped, the ZMW still succeeds from the remaining passes, and the consensus is not damaged.  A ZMW in
+    activity, docs/how-does-ccs-work.md:74-78) are beyond what the 64-row alignment band can carry (trimming, the test below,
+    works on what the alignment delivers): the band loses them and they fail their alignment gate — the pass is dropped, the ZMW
+    still succeeds from the remaining passes, and the consensus is not damaged.  A ZMW in
     which most passes carry such a block ends TOO_MANY_UNUSABLE (never a crash, never a wrong-length read)."""
     rng = np.random.default_rng(11)
     base = api.synth(6, 8, 1500, seed=90)
@@ -175,8 +176,7 @@ def test_large_inserted_blocks_end_in_a_deliberate_outcome(built):
         assert r1.status[2] == 0 and 6 <= r1.np_[2] <= 8 and r1.ec[2] < 8.0      # dropped from the windows it cannot serve (or entirely)
         if size > 64:
             assert r1.np_[2] == 6                                                 # beyond the band: the two passes fail their alignment gate
-        # losing two of eight passes costs that ZMW a few errors (8 -> 6 passes): this is why the reference TRIMS such insertions
-        # instead of dropping the pass (documented omission) — but nothing worse may happen
+        # losing two of eight passes costs that ZMW a few errors (8 -> 6 passes) — but nothing worse may happen
         assert _edit_errors(b1, r1) <= _edit_errors(base, clean) + 10
         for z in (0, 1, 3, 4, 5):                                # the other ZMWs are untouched
             assert np.array_equal(r1.sequence(z), clean.sequence(z))
@@ -187,6 +187,38 @@ def test_large_inserted_blocks_end_in_a_deliberate_outcome(built):
             assert _run(b2, no_fallback_draft=1).status[3] == 3
         else:
             assert r2.status[3] in (0, 3, 7)
+
+
+def test_large_insertions_are_trimmed_in_their_window(built):
+    """SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78): a segment more than max_insertion_size bases longer than its
+    window is cut down to the window's length (the split with the most diagonal matches), so the pass keeps serving that window;
+    without trimming it is lost there to the alpha/beta or z-score gate.  The 64-row alignment band carries insertions of up to
+    about 30 bases, so the default threshold of 30 rarely fires; a smaller one shows the mechanism."""
+    rng = np.random.default_rng(5)
+    base = api.synth(4, 8, 1500, seed=90)
+    bases, pw, ipd, off = [], [], [], [0]
+    for r in range(int(base.read_off[-1])):
+        a, b = int(base.base_off[r]), int(base.base_off[r + 1])
+        bb, pp, ii = base.bases[a:b], base.pw[a:b], base.ipd[a:b]
+        z = int(np.searchsorted(base.read_off, r, side="right") - 1)
+        if z == 2 and (r - int(base.read_off[z])) in (1, 4):
+            at = len(bb) // 2
+            blk = rng.integers(0, 4, 18, dtype=np.uint8)
+            bb = np.concatenate([bb[:at], blk, bb[at:]]); pp = np.concatenate([pp[:at], np.full(18, 2, np.uint8), pp[at:]])
+            ii = np.concatenate([ii[:at], np.full(18, 5, np.uint8), ii[at:]])
+        bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
+    batch = api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                      np.concatenate(ipd), base.flags, base.tpl_off, base.tpl)
+    clean = _run(base)
+    never, trimmed = _run(batch, max_insertion_size=-1), _run(batch, max_insertion_size=10)
+    assert never.status[2] == 0 and trimmed.status[2] == 0
+    assert never.ec[2] < trimmed.ec[2] <= 8.0                    # windows keep the passes whose blocks are cut out (a block that
+                                                                 # straddles two windows may stay under the threshold in both)
+    assert np.array_equal(trimmed.sequence(2), clean.sequence(2))
+    for z in (0, 1, 3):                                          # nothing else changes, and the default threshold leaves this batch alone
+        assert np.array_equal(trimmed.sequence(z), clean.sequence(z))
+    dflt = _run(batch)
+    assert np.array_equal(dflt.sequence(2), never.sequence(2)) and dflt.ec[2] == never.ec[2]
 
 
 def _junk_first_pass(batch, zmws):
