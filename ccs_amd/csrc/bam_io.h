@@ -185,6 +185,19 @@ public:
     Slab current() { while (!cur_ || pos_ == cur_->size()) if (!next_slab()) return Slab(); return cur_; }
     size_t pos() const { return pos_; }
     void advance(size_t n) { pos_ += n; }
+    // continue at a BGZF virtual offset (compressed block start << 16 | offset in the inflated block), e.g. from a .pbi
+    void seek(uint64_t voff)
+    {
+        for (auto &f : pending_) { try { f.get(); } catch (...) {} }
+        pending_.clear(); cur_.reset(); pos_ = 0;
+        foff_ = (size_t)(voff >> 16);
+        if (foff_ > size_) throw std::runtime_error("virtual offset beyond the end of the file");
+        const size_t skip = (size_t)(voff & 0xffff);
+        if (skip) {
+            if (!next_slab() || skip > cur_->size()) throw std::runtime_error("virtual offset does not point into a BGZF block");
+            pos_ = skip;
+        }
+    }
 
 private:
     struct Blk { size_t off, size; };
@@ -282,6 +295,14 @@ public:
         if (!f_) throw std::runtime_error("cannot create " + path);
     }
     ~BgzfWriter() { try { close(); } catch (...) {} }
+    // position of the next byte as (block number << 16 | offset in that block); virtual_offset() resolves it after close()
+    uint64_t mark() const { return ((uint64_t)nblocks_ << 16) | (uint64_t)buf_.size(); }
+    uint64_t virtual_offset(uint64_t mark) const
+    {
+        const size_t blk = (size_t)(mark >> 16);
+        if (blk >= block_off_.size()) throw std::runtime_error("BGZF mark beyond the written blocks");
+        return (block_off_[blk] << 16) | (mark & 0xffff);
+    }
     void write(const void *src, size_t n)
     {
         const uint8_t *s = (const uint8_t *)src;
@@ -297,6 +318,7 @@ public:
         if (!f_) return;
         if (!buf_.empty()) flush_block();
         drain(0);
+        block_off_.push_back(written_);      // a mark taken at the very end resolves to the EOF block
         static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const bool ok = std::fwrite(eof, 1, 28, f_) == 28;
         const bool closed = std::fclose(f_) == 0;
@@ -310,6 +332,7 @@ private:
     {
         auto sp = std::make_shared<std::vector<uint8_t>>(std::move(buf_));
         buf_.clear(); buf_.reserve(kBlock);
+        ++nblocks_;
         const int lvl = level_;
         pending_.push_back(pool_.submit([sp, lvl] { return deflate_block(sp->data(), sp->size(), lvl); }));
         drain(128);
@@ -318,6 +341,8 @@ private:
     {
         while (pending_.size() > keep) {
             const std::vector<uint8_t> c = pending_.front().get(); pending_.pop_front();
+            block_off_.push_back(written_);
+            written_ += c.size();
             if (std::fwrite(c.data(), 1, c.size(), f_) != c.size()) throw std::runtime_error("short write");
         }
     }
@@ -326,7 +351,54 @@ private:
     FILE *f_ = nullptr;
     std::vector<uint8_t> buf_;
     std::deque<std::future<std::vector<uint8_t>>> pending_;
+    size_t nblocks_ = 0;                     // blocks handed to the pool so far
+    uint64_t written_ = 0;                   // compressed bytes written
+    std::vector<uint64_t> block_off_;        // file offset of every written block
 };
+
+// ---------------------------------------------------------------------------------------------- PacBio BAM index (.pbi)
+// "the .pbi file enables random access by ZMW" (docs/faq/parallelize.md:9-13).  The format specification is not part of the
+// reference mount; this is the layout of pbbam 3.x as recalled ([RECALL], unverified against pbindex): a BGZF stream with
+// magic "PBI\1", u32 version, u16 section flags (0 = basic only), u32 n_reads, 18 reserved bytes, then the basic section
+// column by column: rgId i32[n], qStart i32[n], qEnd i32[n], holeNumber i32[n], readQual f32[n], ctxtFlag u8[n],
+// fileOffset i64[n] (BGZF virtual offsets of the records).  Extra sections (mapped / reference / barcode) are ignored.
+struct PbiIndex {
+    std::vector<int32_t> rg_id, q_start, q_end, hole;
+    std::vector<float> read_qual;
+    std::vector<uint8_t> ctxt;
+    std::vector<int64_t> file_offset;
+    size_t size() const { return hole.size(); }
+};
+
+inline bool read_pbi(const std::string &path, ThreadPool &pool, PbiIndex &x)
+{
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0) return false;
+    BgzfReader in(path, pool);
+    uint8_t h[32];
+    if (!in.read(h, 32) || std::memcmp(h, "PBI\1", 4) != 0) throw std::runtime_error(path + ": not a PacBio BAM index");
+    const uint32_t n = h[10] | (h[11] << 8) | (h[12] << 16) | ((uint32_t)h[13] << 24);
+    auto col = [&](void *dst, size_t bytes) { if (bytes && !in.read(dst, bytes)) throw std::runtime_error(path + ": truncated PacBio BAM index"); };
+    x.rg_id.resize(n); x.q_start.resize(n); x.q_end.resize(n); x.hole.resize(n); x.read_qual.resize(n); x.ctxt.resize(n); x.file_offset.resize(n);
+    col(x.rg_id.data(), 4 * (size_t)n); col(x.q_start.data(), 4 * (size_t)n); col(x.q_end.data(), 4 * (size_t)n); col(x.hole.data(), 4 * (size_t)n);
+    col(x.read_qual.data(), 4 * (size_t)n); col(x.ctxt.data(), (size_t)n); col(x.file_offset.data(), 8 * (size_t)n);
+    return true;
+}
+
+inline void write_pbi(const std::string &path, ThreadPool &pool, const PbiIndex &x)
+{
+    BgzfWriter out(path, pool);
+    const uint32_t n = (uint32_t)x.size();
+    uint8_t h[32]; std::memset(h, 0, sizeof(h));
+    std::memcpy(h, "PBI\1", 4);
+    h[4] = 1; h[5] = 0; h[6] = 3; h[7] = 0;                  // version 3.0.1 as 0x00030001
+    h[10] = (uint8_t)n; h[11] = (uint8_t)(n >> 8); h[12] = (uint8_t)(n >> 16); h[13] = (uint8_t)(n >> 24);
+    out.write(h, 32);
+    out.write(x.rg_id.data(), 4 * (size_t)n); out.write(x.q_start.data(), 4 * (size_t)n); out.write(x.q_end.data(), 4 * (size_t)n);
+    out.write(x.hole.data(), 4 * (size_t)n); out.write(x.read_qual.data(), 4 * (size_t)n); out.write(x.ctxt.data(), (size_t)n);
+    out.write(x.file_offset.data(), 8 * (size_t)n);
+    out.close();
+}
 
 // ---------------------------------------------------------------------------------------------- BAM records
 struct Subread {

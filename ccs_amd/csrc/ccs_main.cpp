@@ -266,6 +266,7 @@ int write_synthetic(const Options &o, ThreadPool &pool)
                       "BINDINGKIT=101-789-500;SEQUENCINGKIT=101-826-100;BASECALLERVERSION=5.0.0;FRAMERATEHZ=100.000000\tPU:" + movie + "\tPM:SEQUELII\n");
     const ccsx_batch &b = s->batch;
     RecordBuilder rb;
+    PbiIndex pbi; std::vector<uint64_t> marks;
     for (int z = 0; z < b.n_zmw; ++z) {
         int64_t q = 0;
         for (int r = b.read_off[z]; r < b.read_off[z + 1]; ++r) {
@@ -280,11 +281,16 @@ int write_synthetic(const Options &o, ThreadPool &pool)
             rb.tagBC("ip", b.ipd + a, (uint32_t)len);
             rb.tagBC("pw", b.pw + a, (uint32_t)len);
             rb.tagC("cx", (uint8_t)(3 | ((b.flags[r] & 1) ? 32 : 16)));      // ADAPTER_BEFORE|AFTER + FORWARD/REVERSE_PASS
+            marks.push_back(out.mark());
+            pbi.rg_id.push_back(0); pbi.q_start.push_back((int32_t)q); pbi.q_end.push_back((int32_t)(q + len)); pbi.hole.push_back(b.zmw_id[z]);
+            pbi.read_qual.push_back(0.8f); pbi.ctxt.push_back(3);
             rb.finish(out);
             q += len + 45;
         }
     }
     out.close();
+    for (uint64_t m : marks) pbi.file_offset.push_back((int64_t)out.virtual_offset(m));
+    write_pbi(o.out + ".pbi", pool, pbi);
     ccsx_synth_free(s);
     return 0;
 }
@@ -528,6 +534,29 @@ int main(int argc, char **argv)
         std::string err_msg;
         auto fail = [&](const std::string &m) { std::lock_guard<std::mutex> l(err_m); if (!failed.exchange(1)) err_msg = m; };
 
+        // ---- IN.bam.pbi: random access for --chunk, and the number of ZMWs ahead for the progress line
+        bool have_pbi = false, chunk_done = false;
+        int64_t chunk_zmws = 0, total_zmws = -1;
+        {
+            PbiIndex pbi;
+            bool ok = false;
+            try { ok = read_pbi(opt.in + ".pbi", pool, pbi); }
+            catch (const std::exception &e) { std::fprintf(stderr, "ccs: warning: ignoring %s.pbi: %s\n", opt.in.c_str(), e.what()); }
+            if (ok && pbi.size() > 0) {
+                std::vector<size_t> first;                        // first record of every ZMW (consecutive records of one hole number)
+                for (size_t i = 0; i < pbi.size(); ++i) if (i == 0 || pbi.hole[i] != pbi.hole[i - 1]) first.push_back(i);
+                const int64_t Z = (int64_t)first.size();
+                total_zmws = Z;
+                if (opt.chunk_n > 1) {
+                    const int64_t lo = (opt.chunk_i - 1) * Z / opt.chunk_n, hi = (int64_t)opt.chunk_i * Z / opt.chunk_n;
+                    have_pbi = true; chunk_zmws = hi - lo; total_zmws = chunk_zmws;
+                    if (chunk_zmws == 0) chunk_done = true;
+                    else in.seek((uint64_t)pbi.file_offset[first[(size_t)lo]]);
+                    if (opt.log_level >= 2) std::fprintf(stderr, "ccs: chunk %d/%d = ZMWs %" PRId64 "..%" PRId64 " of %" PRId64 " (%s.pbi)\n", opt.chunk_i, opt.chunk_n, lo, hi, Z, opt.in.c_str());
+                }
+            }
+        }
+
         // ---- reader
         long long rd_us[3] = {0, 0, 0};                  // framing (BGZF inflate wait), waiting for record decode, grouping + filters + queue
         std::thread reader([&] {
@@ -550,8 +579,11 @@ int main(int argc, char **argv)
             };
             auto flush_zmw = [&] {
                 if (!have) return;
-                const bool mine = ((nz % opt.chunk_n) == (opt.chunk_i - 1));     // --chunk i/N (round-robin over ZMWs; needs no .pbi)
+                // --chunk i/N: with IN.bam.pbi a contiguous range of ZMWs (the reader has seeked to its first record and stops after
+                // its last ZMW: docs/faq/parallelize.md:9-13); without an index round-robin over the ZMWs of the whole file
+                const bool mine = have_pbi ? (nz < chunk_zmws) : ((nz % opt.chunk_n) == (opt.chunk_i - 1));
                 cur.order = nz++;
+                if (have_pbi && nz >= chunk_zmws) chunk_done = true;
                 if (mine) {
                     // strand of every pass: cx REVERSE_PASS (32) / FORWARD_PASS (16) when present, else consecutive subreads alternate
                     for (size_t k = 0; k < cur.reads.size(); ++k) {
@@ -582,7 +614,7 @@ int main(int argc, char **argv)
             for (;;) {
                 auto raw = std::make_shared<RawChunk>();
                 auto t0 = std::chrono::steady_clock::now();
-                const bool more = read_raw_chunk(in, *raw);
+                const bool more = !chunk_done && read_raw_chunk(in, *raw);
                 rd_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
                 if (failed) break;                                  // an engine / writer failure ends the run: stop feeding it
                 if (more) pending.push_back(pool.submit([raw] { return decode_chunk(*raw); }));
@@ -596,7 +628,7 @@ int main(int argc, char **argv)
                 }
                 if (!more) break;
             }
-            flush_zmw();
+            if (!chunk_done) flush_zmw();                          // (a finished chunk ends inside the next chunk's first ZMW)
             if (!opt.dump && !batch->zmws.empty()) { batch->index = nb++; to_pack.push(batch); }
             } catch (const std::exception &e) { fail(std::string("reading ") + opt.in + ": " + e.what()); }
             to_pack.close();
@@ -712,6 +744,7 @@ int main(int argc, char **argv)
             std::map<int64_t, std::shared_ptr<Batch>> hold;
             int64_t next = 0;
             RecordBuilder rb;
+            PbiIndex pbi; std::vector<uint64_t> marks;             // OUT.bam.pbi: one entry per HiFi record
             std::vector<uint8_t> kin_rev;
             std::shared_ptr<Batch> b;
             std::string metrics = "{\n  \"zmws\": [\n";
@@ -784,6 +817,9 @@ int main(int argc, char **argv)
                             rb.tagBC("rp", kin_rev.data(), nr); rb.tagi("rn", bt.rn[s]);
                         }
                     }
+                    marks.push_back(outp->mark());
+                    pbi.rg_id.push_back(0); pbi.q_start.push_back(0); pbi.q_end.push_back(len); pbi.hole.push_back(z.zm);
+                    pbi.read_qual.push_back(bt.rq[s]); pbi.ctxt.push_back(0);
                     rb.finish(*outp);
                     rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.np_sum += bt.np[s];
                 }
@@ -797,6 +833,10 @@ int main(int argc, char **argv)
                 }
                 if (opt.log_level >= 2) {
                     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                    if (total_zmws > 0 && rep.input > 0)               // with an index the number of ZMWs ahead is known: ETA (reports-aux-files.md:183-192)
+                        std::fprintf(stderr, "%" PRId64 "/%.1f %" PRId64 "/%.1f ETA %.0f s\n", rep.input, rep.input / el * 60, rep.pass, rep.pass / el * 60,
+                                     el * (double)(total_zmws - rep.input) / (double)rep.input);
+                    else
                     std::fprintf(stderr, "%" PRId64 "/%.1f %" PRId64 "/%.1f\n", rep.input, rep.input / el * 60, rep.pass, rep.pass / el * 60);
                 }
             }
@@ -805,6 +845,8 @@ int main(int argc, char **argv)
             else {
                 if (!header_done) write_header(*outp, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:ccsamd01\tPL:PACBIO\tDS:READTYPE=CCS\tPU:unknown\n");
                 outp->close();
+                for (uint64_t m : marks) pbi.file_offset.push_back((int64_t)outp->virtual_offset(m));
+                write_pbi(opt.out + ".pbi", pool, pbi);
             }
             if (gzm) { metrics += "\n  ]\n}\n"; flush_metrics(true); gzclose(gzm); }
             } catch (const std::exception &e) {
@@ -835,6 +877,7 @@ int main(int argc, char **argv)
             if (!err_msg.empty()) std::fprintf(stderr, "ccs: %s\n", err_msg.c_str());
             // no plausible-looking partial output after a failed run
             std::remove(opt.out.c_str());
+            std::remove((opt.out + ".pbi").c_str());
             std::fprintf(stderr, "ccs: run failed, %s removed\n", opt.out.c_str());
         }
         return failed ? 1 : 0;

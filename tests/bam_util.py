@@ -106,3 +106,51 @@ def read_bam_raw_records(path):
         bs, = struct.unpack_from("<i", data, p)
         recs.append(data[p:p + 4 + bs]); p += 4 + bs
     return text, recs
+
+
+# ---- PacBio BAM index (.pbi) and BGZF virtual offsets -----------------------------------------------------------------
+def read_pbi(path):
+    """columns of a .pbi (layout as ccs_amd/csrc/bam_io.h documents it): dict of numpy arrays"""
+    data = gzip.open(path, "rb").read()
+    assert data[:4] == b"PBI\x01"
+    version, flags, n = struct.unpack_from("<IHI", data, 4)
+    p = 32
+    out = {"version": version, "flags": flags, "n": n}
+    for key, dt in (("rg_id", np.int32), ("q_start", np.int32), ("q_end", np.int32), ("hole", np.int32), ("read_qual", np.float32),
+                    ("ctxt", np.uint8), ("file_offset", np.int64)):
+        out[key] = np.frombuffer(data, dt, n, p).copy(); p += n * np.dtype(dt).itemsize
+    assert p == len(data)
+    return out
+
+
+def record_virtual_offsets(path):
+    """BGZF virtual offset (block start << 16 | offset in the inflated block) of every BAM record, by walking the blocks"""
+    import zlib
+    raw = open(path, "rb").read()
+    blocks, p, upos = [], 0, 0                      # (uncompressed start, compressed start, inflated size)
+    chunks = []
+    while p < len(raw):
+        assert raw[p:p + 2] == b"\x1f\x8b"
+        xlen, = struct.unpack_from("<H", raw, p + 10)
+        q, bsize = p + 12, None
+        while q < p + 12 + xlen:
+            si, sl = raw[q:q + 2], struct.unpack_from("<H", raw, q + 2)[0]
+            if si == b"BC": bsize = struct.unpack_from("<H", raw, q + 4)[0] + 1
+            q += 4 + sl
+        payload = zlib.decompress(raw[p + 12 + xlen:p + bsize - 8], -15)
+        blocks.append((upos, p, len(payload))); chunks.append(payload)
+        upos += len(payload); p += bsize
+    data = b"".join(chunks)
+    l_text, = struct.unpack_from("<i", data, 4)
+    u = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, u); u += 4
+    for _ in range(n_ref):
+        l, = struct.unpack_from("<i", data, u); u += 4 + l + 4
+    starts = np.array([b[0] for b in blocks]); sizes = np.array([b[2] for b in blocks])
+    offs = []
+    while u < len(data):
+        k = int(np.searchsorted(starts, u, side="right") - 1)
+        while sizes[k] == 0 or u >= starts[k] + sizes[k]: k += 1          # (empty blocks)
+        offs.append((blocks[k][1] << 16) | (u - blocks[k][0]))
+        bs, = struct.unpack_from("<i", data, u); u += 4 + bs
+    return np.array(offs, np.int64)

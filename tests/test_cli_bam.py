@@ -426,3 +426,55 @@ def test_cli_engine_failure_leaves_no_output(built, tmp_path):
     # and without the fault the same command succeeds
     r = subprocess.run([CCS, str(bam), str(out), "--batch-size", "4"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and len(bam_util.read_bam(out)[1]) > 8
+
+
+def test_pbi_index_and_chunking_by_random_access(built, tmp_path):
+    """docs/faq/parallelize.md:9-13 (--chunk uses the .pbi): the synthetic subreads.bam comes with IN.bam.pbi (one entry per
+    subread: hole number, BGZF virtual offset); with it --chunk i/N seeks to a contiguous range of ZMWs, without it the chunks are
+    round-robin over the whole file; either way the chunks partition the ZMWs and every ZMW's content is unchanged (--dump-zmws
+    hashes bases / pw / ip, no GPU)"""
+    bam = tmp_path / "s.subreads.bam"
+    _run("--write-synthetic", "157,5,1500,9", bam)                 # ~2 MB: dozens of BGZF blocks, records straddle them
+    x = bam_util.read_pbi(str(bam) + ".pbi")
+    text, recs = bam_util.read_bam(bam)
+    assert x["n"] == len(recs) == 157 * 5 and x["flags"] == 0
+    assert np.array_equal(x["hole"], [r["tags"]["zm"] for r in recs])
+    assert np.array_equal(x["q_start"], [r["tags"]["qs"] for r in recs]) and np.array_equal(x["q_end"], [r["tags"]["qe"] for r in recs])
+    assert np.array_equal(x["file_offset"], bam_util.record_virtual_offsets(bam))
+    assert len(set((x["file_offset"] >> 16).tolist())) > 20 and ((x["file_offset"] & 0xffff) != 0).any()
+    full = _run("--dump-zmws", bam).stdout.splitlines()
+    assert len(full) == 157
+    for n in (2, 5):
+        parts = [_run("--dump-zmws", "--chunk", f"{i}/{n}", bam).stdout.splitlines() for i in range(1, n + 1)]
+        assert sum(parts, []) == full                               # contiguous ranges, in file order
+        assert all(abs(len(q) - 157 / n) < 1 for q in parts)
+    assert _run("--dump-zmws", "--chunk", "1/400", bam).stdout == ""   # more chunks than ZMWs: some are empty
+    os.rename(str(bam) + ".pbi", str(bam) + ".pbi.off")
+    parts = [_run("--dump-zmws", "--chunk", f"{i}/3", bam).stdout.splitlines() for i in (1, 2, 3)]
+    assert sorted(sum(parts, [])) == sorted(full) and parts[1][0] == full[1]      # round-robin without the index
+    open(str(bam) + ".pbi", "wb").write(b"garbage")                 # a broken index is reported and ignored
+    p = _run("--dump-zmws", "--chunk", "2/3", bam)
+    assert p.stdout.splitlines() == parts[1] and "ignoring" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_chunks_and_output_index(built, tmp_path):
+    """HiFi reads of the pbi-addressed chunks = the HiFi reads of the whole file; OUT.bam.pbi indexes the output (hole number,
+    rq, length, virtual offsets that point at the records)"""
+    bam, out = tmp_path / "s.subreads.bam", tmp_path / "o.bam"
+    _run("--write-synthetic", "40,6,900,4", bam)
+    _run(bam, out, "--batch-size", 16)
+    _, full = bam_util.read_bam(out)
+    x = bam_util.read_pbi(str(out) + ".pbi")
+    assert x["n"] == len(full) > 30
+    assert np.array_equal(x["hole"], [r["tags"]["zm"] for r in full]) and np.array_equal(x["q_end"], [len(r["seq"]) for r in full])
+    assert np.array_equal(x["read_qual"], np.array([r["tags"]["rq"] for r in full], np.float32))
+    assert np.array_equal(x["file_offset"], bam_util.record_virtual_offsets(out))
+    got = []
+    for i in (1, 2, 3):
+        o = tmp_path / f"c{i}.bam"
+        _run(bam, o, "--chunk", f"{i}/3", "--batch-size", 16)
+        got += bam_util.read_bam(o)[1]
+    assert [r["name"] for r in got] == [r["name"] for r in full]
+    for a, b in zip(got, full):
+        assert np.array_equal(a["seq"], b["seq"]) and np.array_equal(a["qual"], b["qual"]) and a["tags"]["rq"] == b["tags"]["rq"]
