@@ -335,7 +335,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     // ---- resident POA graphs / alignment slots: as many as fit this handle's share of the free memory, never more than
     // the work.  The scratch is shared by the handle's batch slots; it only grows, and growing waits for the compute stream.
     S.poa_slot_bytes = (((size_t)vcap_max + 64) * 393 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
-    S.align_slot_i32 = (size_t)need_max * 128 + need_max + 64;   // (origin, dirty bits) per cell and edge + band starts
+    S.align_slot_i32 = (size_t)need_max * 128 + 4 * (size_t)need_max + 64;   // (origin, dirty bits) per cell and edge + band starts + best cell (score, row, entry row) per edge
     int poa_slots, align_slots;
     {
         std::lock_guard<std::mutex> lk(g_scratch_mutex);
@@ -347,7 +347,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         poa_slots = h->opts.poa_slots > 0 ? h->opts.poa_slots : 8192;
         poa_slots = std::min(poa_slots, n);
         poa_slots = (int)std::min<size_t>((size_t)poa_slots, std::max<size_t>(1, (budget * 3 / 4) / S.poa_slot_bytes));
-        align_slots = std::min(16384, std::max(R, 1));
+        align_slots = std::min(16384, std::max(R, 2));            // (the split alignment uses two slots per pass)
         align_slots = (int)std::min<size_t>((size_t)align_slots, std::max<size_t>(1, (budget / 8) / (S.align_slot_i32 * 4)));
         const size_t need_align = (size_t)align_slots * S.align_slot_i32 * 4;
         if ((size_t)poa_slots * S.poa_slot_bytes > h->d_poa.cap || need_align > h->d_align.cap) {

@@ -206,7 +206,9 @@ __global__ void k_setup(KParams P)
 
 // ------------------------------------------------------------------------------------------------
 // packed 2-bit oriented read in LDS (one wave owns it)
-__device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t *bases, int L, int rev, int lane)
+// mode bit 0: walk the bytes backwards, bit 1: complement.  0 = as stored, 3 = reverse complement (rev), 1 / 2 = those two read
+// from their last base to their first (the reversed half of the split alignment)
+__device__ __forceinline__ void load_read_packed_mode(uint32_t *sread, const uint8_t *bases, int L, int mode, int lane)
 {
     int nw = (L + 15) >> 4;
     for (int w = lane; w < nw; w += LANES) {
@@ -215,10 +217,14 @@ __device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t 
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             int i = i0 + k;
-            if (i < L) { uint32_t b = rev ? (uint32_t)(3 - bases[L - 1 - i]) : (uint32_t)bases[i]; v |= (b & 3u) << (2 * k); }
+            if (i < L) { uint32_t b = (uint32_t)bases[(mode & 1) ? L - 1 - i : i]; if (mode & 2) b = 3u - b; v |= (b & 3u) << (2 * k); }
         }
         sread[w] = v;
     }
+}
+__device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t *bases, int L, int rev, int lane)
+{
+    load_read_packed_mode(sread, bases, L, rev ? 3 : 0, lane);
 }
 __device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { return (int)((sread[i >> 4] >> (2 * (i & 15))) & 3u); }
 // the band's next read base, wave-uniform index: 64 packed words (1024 bases) of the read sit in one VGPR, lane = word, loaded
@@ -775,31 +781,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // in registers.  Instead of storing moves and tracing back every cell, each cell carries the row at which
 // its best path ENTERED the most recent window-edge column ("origin"); at every window-edge column the
 // propagated origins are saved (64 x int32), and the entry rows are recovered by hopping edge to edge.
-__global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
+// window-edge column of needed-column index k (k_align's list: 0, b1-2, b1+2, b2-2, ..., Ld)
+__device__ __forceinline__ int need_col(const int32_t *wb, int nw, int Ld, int k)
 {
-    const int lane = threadIdx.x;
-    uint32_t *sread = dyn_lds;
-    int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] then lo_need[need]
-    if (rbase + (int)blockIdx.x >= P.n_reads) return;   // launched in chunks of align_slots reads: slot = block
-    const int r = rfl(P.read_perm[rbase + blockIdx.x]); // longest reads first
-    const int z = rfl(P.read_zmw[r]);
-    const int r0 = rfl(P.read_off[z]);
-    const int zr = rfl(P.zref[z]);
-    if (pass == 1 && !(zr & ZREF_DONE)) return;        // second pass: only the ZMWs whose draft was redone
-    if (lane == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
-    if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z]) return;
-    const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
-    const uint8_t *d = P.draft + P.seq_off[z];
-    const int32_t *wb = P.wbounds + P.wb_off[z];
-    const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
-    const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0 + (zr & 63)] & 1)) ? 1 : 0);
-    load_read_packed(sread, P.bases + P.base_off[r], I, rev, lane);
-    __syncthreads();
+    return k == 0 ? 0 : (k == 2 * nw - 1 ? Ld : wb[(k + 1) >> 1] + ((k & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
+}
+struct AlignEnd { int M, O, lo; unsigned K; };
+// the column loop of step 3 over one oriented read in LDS (REV: the draft is walked backwards, the window-edge columns are
+// mirrored: the suffix-against-suffix half of the split alignment).  Saves (origin, dirty) of every cell, the band start and the
+// best cell (score, row, entry row) at every window-edge column.
+template <int REV>
+__device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t *sread, int I, const uint8_t *d, int Ld, const int32_t *wb, int nw,
+                                               int32_t *Osave, int lane)
+{
     const int nneed = 2 * nw;                           // needed columns: 0, b1-2, b1+2, ..., Ld
     int32_t *lo_need = Osave + (size_t)P.need_max * 128;
+    int32_t *cm_need = lo_need + P.need_max + 64, *br_need = cm_need + P.need_max, *eb_need = br_need + P.need_max;   // best cell of every window-edge column (split alignment)
     int2 *OMsave = (int2 *)Osave;                      // per window-edge column and cell: (origin row at the previous edge, dirty bits)
     int kk = 1;                                         // next needed column index
-    int next_need = (nw == 1) ? Ld : rfl(wb[1]) - CCSX_WIN_OVERHANG;
+    auto need_at = [&](int k) { return REV ? Ld - need_col(wb, nw, Ld, nneed - 1 - k) : need_col(wb, nw, Ld, k); };
+    int next_need = rfl(need_at(1));
     // column 0 = START
     int Mprev = (lane <= I) ? lane * SC_INS : NEGV;
     int Oprev = 0;                                      // entry row at column 0 is 0 for every cell
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
     BaseCursor bcur; bcur.w0 = 0; bcur.vw = 0u;
     const int nwords = (I + 15) >> 4;
     for (int jb = 0; jb < Ld; jb += LANES) {            // draft bases: one coalesced load per 64 columns
-        const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
+        const int dL = (jb + lane < Ld) ? d[REV ? Ld - 1 - (jb + lane) : jb + lane] : 0;
         cursor_load(bcur, sread, nwords, lo + 61, lane);  // the next 64 columns fetch their band-top bases from this window
         asm volatile("" :: "v"(dL), "v"(bcur.vw));       // wait for the block loads here, not inside the column loop
         const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
@@ -881,11 +882,42 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
             br = lo + (__ffsll((long long)bal) - 1);
             Mprev = best; Oprev = org; Kprev = kd;
             if (need) {
+                const int ebest = rl(org, br - lo);          // row at which the best cell's path entered this column
+                if (lane == 0) { cm_need[kk] = cm; br_need[kk] = br; eb_need[kk] = ebest; }
                 ++kk;
-                next_need = (kk >= nneed) ? -1 : ((kk == nneed - 1) ? Ld : rfl(wb[(kk + 1) >> 1]) + ((kk & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
+                next_need = (kk >= nneed) ? -1 : rfl(need_at(kk));
             }
         }
     }
+    AlignEnd out; out.M = Mprev; out.O = Oprev; out.K = Kprev; out.lo = lo;
+    return out;
+}
+
+__global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
+{
+    const int lane = threadIdx.x;
+    uint32_t *sread = dyn_lds;
+    int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] then lo_need[need]
+    if (rbase + (int)blockIdx.x >= P.n_reads) return;   // launched in chunks of align_slots reads: slot = block
+    const int r = rfl(P.read_perm[rbase + blockIdx.x]); // longest reads first
+    const int z = rfl(P.read_zmw[r]);
+    const int r0 = rfl(P.read_off[z]);
+    const int zr = rfl(P.zref[z]);
+    if (pass == 1 && !(zr & ZREF_DONE)) return;        // second pass: only the ZMWs whose draft was redone
+    if (lane == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
+    if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z]) return;
+    const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
+    const uint8_t *d = P.draft + P.seq_off[z];
+    const int32_t *wb = P.wbounds + P.wb_off[z];
+    const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
+    const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0 + (zr & 63)] & 1)) ? 1 : 0);
+    load_read_packed(sread, P.bases + P.base_off[r], I, rev, lane);
+    __syncthreads();
+    const AlignEnd ae = align_pass<0>(P, sread, I, d, Ld, wb, nw, Osave, lane);
+    const int lo = ae.lo, Mprev = ae.M, Oprev = ae.O; const unsigned Kprev = ae.K;
+    const int nneed = 2 * nw;
+    int32_t *lo_need = Osave + (size_t)P.need_max * 128;
+    int2 *OMsave = (int2 *)Osave;
     const int oe = I - lo;
     int sc = NEGV, eLast = 0;
     unsigned kLast = 0u;
@@ -915,6 +947,81 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
             }
             ent[0] = 0; dm[0] = 0u;
         }
+    }
+}
+
+// SPEC "split alignment": a pass that failed step 3 and is more than RESCUE_MIN_EXCESS bases longer than the draft is tried as
+// prefix + ONE large insertion + suffix ("spurious sequencing activity", docs/how-does-ccs-work.md:74-78; the 64-row band cannot
+// follow an insertion run of more than ~31 rows).  The forward pass and the pass over the reversed read and draft each leave the
+// best cell of every window-edge column; the split is the interior edge column with the largest sum of the two scores whose rows do
+// not overlap.  Entry rows left of it come from the forward origins, right of it from the mirrored reverse origins; every position
+// counts as dirty.  One wave per read over a grid-stride loop (rare reads: most iterations end at the first test); two scratch slots.
+#define RESCUE_MIN_EXCESS 24
+__global__ __launch_bounds__(64) void k_rescue(KParams P, int pass)
+{
+    const int lane = threadIdx.x;
+    uint32_t *sread = dyn_lds;
+    int32_t *OsF = P.align_scratch + (size_t)(2 * blockIdx.x) * P.align_slot_i32, *OsR = OsF + P.align_slot_i32;
+    for (int rbase = blockIdx.x * LANES; rbase < P.n_reads; rbase += gridDim.x * LANES) {
+      // 64 passes per look: nearly all of them aligned
+      unsigned long long todo = __ballot(rbase + lane < P.n_reads && !P.avalid[P.read_perm[rbase + lane < P.n_reads ? rbase + lane : 0]]);
+      while (todo) {
+        const int rp = rbase + (int)__ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int r = rfl(P.read_perm[rp]);
+        const int z = rfl(P.read_zmw[r]);
+        const int r0 = rfl(P.read_off[z]);
+        const int zr = rfl(P.zref[z]);
+        if (pass == 1 && !(zr & ZREF_DONE)) continue;
+        if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z] || P.avalid[r]) continue;
+        const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
+        const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
+        const int nneed = 2 * nw;
+        if (I - Ld <= RESCUE_MIN_EXCESS || nneed < 3) continue;
+        const uint8_t *d = P.draft + P.seq_off[z];
+        const int32_t *wb = P.wbounds + P.wb_off[z];
+        const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0 + (zr & 63)] & 1)) ? 1 : 0);
+        __syncthreads();
+        load_read_packed_mode(sread, P.bases + P.base_off[r], I, rev ? 3 : 0, lane);
+        __syncthreads();
+        (void)align_pass<0>(P, sread, I, d, Ld, wb, nw, OsF, lane);
+        __syncthreads();
+        load_read_packed_mode(sread, P.bases + P.base_off[r], I, rev ? 2 : 1, lane);     // the oriented read, last base first
+        __syncthreads();
+        (void)align_pass<1>(P, sread, I, d, Ld, wb, nw, OsR, lane);
+        __threadfence_block();
+        const int32_t *loF = OsF + (size_t)P.need_max * 128, *cmF = loF + P.need_max + 64, *brF = cmF + P.need_max, *ebF = brF + P.need_max;
+        const int32_t *loR = OsR + (size_t)P.need_max * 128, *cmR = loR + P.need_max + 64, *brR = cmR + P.need_max, *ebR = brR + P.need_max;
+        // the split: interior edge column k (mirror index nneed-1-k) with the largest score sum, rows not overlapping; ties: smallest k
+        int best = NEGV, bk = 1 << 30;
+        for (int k = 1 + lane; k + 1 < nneed; k += LANES) {
+            const int cf = cmF[k], cr = cmR[nneed - 1 - k];
+            if (cf > NEGV / 2 && cr > NEGV / 2 && brF[k] + brR[nneed - 1 - k] <= I) { const int tot = cf + cr; if (tot > best) { best = tot; bk = k; } }
+        }
+        const int wbest = rfl(wave_max_i32(best));
+        const int ks = rfl(wave_min_i32(best == wbest ? bk : (1 << 30)));
+        if (wbest <= NEGV / 2 || wbest < Ld) continue;            // no valid split
+        if (lane == 0) {
+            int32_t *ent = P.ent + P.ent_off[r];
+            uint32_t *dm = P.dmask + P.ent_off[r];
+            const int2 *OMF = (const int2 *)OsF, *OMR = (const int2 *)OsR;
+            int e = ebF[ks];
+            ent[ks] = e;
+            for (int k2 = ks; k2 >= 2; --k2) { e = OMF[(size_t)k2 * 64 + (e - loF[k2])].x; ent[k2 - 1] = e; }
+            ent[0] = 0;
+            const int ksr = nneed - 1 - ks;                         // the same column in the mirrored list
+            // reverse entries of the mirrored columns below ksr are the forward entries of the columns above ks: I - entry
+            int er = ebR[ksr];
+            for (int kq = ksr; kq >= 1; --kq) {
+                er = (kq >= 2) ? OMR[(size_t)kq * 64 + (er - loR[kq])].x : 0;
+                ent[nneed - kq] = I - er;
+            }
+            ent[nneed - 1] = I;
+            dm[0] = 0u;
+            for (int k2 = 1; k2 < nneed; ++k2) dm[k2] = 0x7fffffffu;
+            P.avalid[r] = 1; P.ascore[r] = wbest;
+        }
+      }
     }
 }
 
@@ -1063,11 +1170,6 @@ __device__ __forceinline__ float skip_perr(int g)
     return 8.0f * det_exp2f(-3.0f * (float)g);
 }
 
-// window-edge column of needed-column index k (k_align's list: 0, b1-2, b1+2, b2-2, ..., Ld)
-__device__ __forceinline__ int need_col(const int32_t *wb, int nw, int Ld, int k)
-{
-    return k == 0 ? 0 : (k == 2 * nw - 1 ? Ld : wb[(k + 1) >> 1] + ((k & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG));
-}
 
 __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
 {
@@ -1973,6 +2075,11 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* 
             LAUNCH_CHECK("k_align");
         }
         trace_sync(st, "k_align");
+        {
+            const int g = P.align_slots / 2 < 1 ? 1 : (P.align_slots / 2 > 2048 ? 2048 : P.align_slots / 2);
+            hipLaunchKernelGGL(k_rescue, dim3(g), dim3(64), lds_read, st, P, pass);
+            LAUNCH_CHECK("k_rescue");
+        }
         hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P, pass);
         LAUNCH_CHECK("k_post");
     }

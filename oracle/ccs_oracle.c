@@ -51,6 +51,7 @@
 #define SC_DEL      (-4)
 #define NEG       (-(1 << 28))
 #define MUT_EPS   0.01f     /* favourable iff summed log2-likelihood gain > MUT_EPS                 */
+#define RESCUE_MIN_EXCESS 24 /* a failed pass is tried as prefix + insertion + suffix iff it is this much longer than the draft */
 #define SCORE_BAND 5        /* half width (read rows) of the mutation scoring band around the window diagonal */
 #define MUT_SEP   5         /* accepted mutations of one round are >= MUT_SEP columns apart          */
 #define MULTI_ROUNDS 2      /* rounds >= MULTI_ROUNDS apply only the single best mutation (cycle guard) */
@@ -504,6 +505,73 @@ int orc_align_ev(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rst
 int orc_align(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out)
 {
     return orc_align_ev(r, I, d, Ld, rstart, score_out, NULL);
+}
+
+/* SPEC "split alignment" (the rescue of a pass that carries an insertion the 64-row band cannot follow: "spurious sequencing
+ * activity", docs/how-does-ccs-work.md:74-78).  The same banded recurrence runs forward (read prefix against draft prefix) and on
+ * the reversed read and draft (suffix against suffix); the pass is split at the interior window-edge column s that maximises
+ * colmax_F(s) + colmax_R(Ld - s) with bestrow_F(s) + bestrow_R(Ld - s) <= I (ties: the smallest s); the read rows in between are
+ * the insertion.  Valid iff that sum reaches Ld.  Entry rows of the window-edge columns <= s come from the forward path that
+ * ends in (s, bestrow_F(s)), those > s from the reverse path: rstart[c] = I - rstartR[Ld - c].  Every draft position counts as
+ * dirty for such a pass (the candidate filter gets no evidence from it).  need[0] = 0 < ... < need[nneed-1] = Ld.            */
+static void dp_all_columns(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *lo, uint8_t *mv, int32_t *cmc, int32_t *brc)
+{
+    int32_t A[BAND], B[BAND], *prevM = A, *curM = B;
+    start_column(I, prevM);
+    lo[0] = 0; cmc[0] = 0; brc[0] = 0;
+    int32_t cm = 0, br = 0; int plo = 0;
+    for (int j = 1; j <= Ld; ++j) {
+        int l0 = band_lo(plo, br, I);
+        int32_t plos[1] = { plo }; const int32_t *pMs[1] = { prevM };
+        dp_column(d[j - 1], r, I, l0, 1, plos, pMs, curM, mv + (size_t)j * BAND, &cm, &br);
+        lo[j] = l0; plo = l0; cmc[j] = cm; brc[j] = br;
+        int32_t *t = prevM; prevM = curM; curM = t;
+    }
+}
+static void trace_entries(const uint8_t *mv, const int32_t *lo, int j, int i, int32_t *rstart)
+{
+    while (j > 0) {
+        int t = mv[(size_t)j * BAND + (i - lo[j])] & 3;
+        if (t == MV_INS) { --i; continue; }
+        rstart[j] = i;
+        if (t == MV_DIAG) --i;
+        --j;
+    }
+    rstart[0] = 0;
+}
+int orc_align_rescue(const uint8_t *r, int I, const uint8_t *d, int Ld, const int32_t *need, int nneed,
+                     int32_t *rstart, int32_t *score_out, uint8_t *dirty)
+{
+    int valid = 0;
+    uint8_t *rr = (uint8_t *)malloc(I + 1), *dr = (uint8_t *)malloc(Ld + 1);
+    for (int i = 0; i < I; ++i) rr[i] = r[I - 1 - i];
+    for (int j = 0; j < Ld; ++j) dr[j] = d[Ld - 1 - j];
+    int32_t *loF = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1) * 6), *cmF = loF + (Ld + 1), *brF = cmF + (Ld + 1);
+    int32_t *loR = brF + (Ld + 1), *cmR = loR + (Ld + 1), *brR = cmR + (Ld + 1);
+    uint8_t *mvF = (uint8_t *)malloc((size_t)(Ld + 1) * BAND * 2), *mvR = mvF + (size_t)(Ld + 1) * BAND;
+    int32_t *rsR = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
+    dp_all_columns(r, I, d, Ld, loF, mvF, cmF, brF);
+    dp_all_columns(rr, I, dr, Ld, loR, mvR, cmR, brR);
+    int32_t best = NEG; int ks = -1;
+    for (int k = 1; k + 1 < nneed; ++k) {
+        int s = need[k];
+        if (cmF[s] < NEG / 2 || cmR[Ld - s] < NEG / 2 || brF[s] + brR[Ld - s] > I) continue;
+        int32_t tot = cmF[s] + cmR[Ld - s];
+        if (tot > best) { best = tot; ks = k; }
+    }
+    if (score_out) *score_out = best;
+    if (ks >= 0 && best >= Ld) {
+        valid = 1;
+        int s = need[ks];
+        for (int j = 0; j <= Ld; ++j) rstart[j] = -1;
+        trace_entries(mvF, loF, s, brF[s], rstart);
+        for (int j = 0; j <= Ld - s; ++j) rsR[j] = -1;
+        trace_entries(mvR, loR, Ld - s, brR[Ld - s], rsR);
+        for (int c = s + 1; c <= Ld; ++c) rstart[c] = I - rsR[Ld - c];
+        if (dirty) memset(dirty, 1, Ld);
+    }
+    free(rr); free(dr); free(loF); free(mvF); free(rsR);
+    return valid;
 }
 
 /* step 4: window core boundaries b[0]=0 < ... < b[n]=Ld ; returns n (docs/how-does-ccs-work.md:57-61).
@@ -1055,6 +1123,15 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
             /* step 3 */
             rev0 = flags[bb] & 1;
             uint8_t *ob = (uint8_t *)malloc(maxL + 1);
+            /* window-edge columns (step 4 depends on the draft only): the split alignment may split a pass at one of them */
+            int wcap0 = Ld / (WIN_CORE - 3) + 4, nneed = 0;
+            int32_t *wb0 = (int32_t *)malloc(sizeof(int32_t) * wcap0), *need = (int32_t *)malloc(sizeof(int32_t) * 2 * wcap0);
+            {
+                int nw0 = orc_windows(draft, Ld, wb0, wcap0);
+                need[nneed++] = 0;
+                for (int w = 1; w < nw0; ++w) { need[nneed++] = wb0[w] - WIN_OVH; need[nneed++] = wb0[w] + WIN_OVH; }
+                need[nneed++] = Ld;
+            }
             for (int r = 0; r < nreads; ++r) {
                 int L = (int)(base_off[r + 1] - base_off[r]);
                 strand[r] = (uint8_t)(((flags[r] & 1) != rev0) ? 1 : 0);
@@ -1064,10 +1141,13 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                 dirty[r] = (uint8_t *)malloc(Ld + 1);
                 int32_t sc;
                 avalid[r] = (uint8_t)orc_align_ev(ob, L, draft, Ld, rstart[r], &sc, dirty[r]);
+                /* a pass much longer than the draft that failed: look for ONE large insertion (SPEC "split alignment") */
+                if (!avalid[r] && L - Ld > RESCUE_MIN_EXCESS && nneed >= 3)
+                    avalid[r] = (uint8_t)orc_align_rescue(ob, L, draft, Ld, need, nneed, rstart[r], &sc, dirty[r]);
                 np += avalid[r];
                 if (avalid[r]) { if (strand[r]) out->rn += 1; else out->fn += 1; }
             }
-            free(ob);
+            free(ob); free(wb0); free(need);
             out->np = np;
             if (2 * np <= nreads) { out->status = ST_UNUSABLE; want_retry = 1; }
         }

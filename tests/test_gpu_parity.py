@@ -511,6 +511,38 @@ def test_fallback_draft_matches_oracle(built):
             ok = set(np.nonzero((res.status == 0) | (res.status == 7))[0].tolist())
         h.close()
     assert len(lost) >= 2 and lost <= ok                      # what is lost without the fallback gets a consensus with it (HiFi or LOW_RQ)@pytest.mark.gpu
+def test_split_alignment_keeps_passes_with_large_blocks(handle):
+    """SPEC "split alignment" on the GPU (k_rescue): passes with a 60 / 150 / 400 base foreign block fail the banded alignment, are
+    split into prefix + insertion + suffix, keep serving every window (the block is trimmed in its window) — np counts them, the
+    consensus equals the one without blocks, and everything matches the oracle bit for bit"""
+    rng = np.random.default_rng(17)
+    base = api.synth(5, 8, 2500, seed=95)
+    bases, pw, ipd, off = [], [], [], [0]
+    sizes = {(1, 2): 60, (1, 5): 150, (3, 0): 400, (3, 7): 60}
+    for r in range(int(base.read_off[-1])):
+        a, b = int(base.base_off[r]), int(base.base_off[r + 1])
+        bb, pp, ii = base.bases[a:b], base.pw[a:b], base.ipd[a:b]
+        z = int(np.searchsorted(base.read_off, r, side="right") - 1)
+        size = sizes.get((z, r - int(base.read_off[z])))
+        if size:
+            at = int(rng.integers(300, len(bb) - 300))
+            blk = rng.integers(0, 4, size, dtype=np.uint8)
+            bb = np.concatenate([bb[:at], blk, bb[at:]]); pp = np.concatenate([pp[:at], np.full(size, 2, np.uint8), pp[at:]])
+            ii = np.concatenate([ii[:at], np.full(size, 5, np.uint8), ii[at:]])
+        bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
+    batch = api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                      np.concatenate(ipd), base.flags, base.tpl_off, base.tpl)
+    res = handle.consensus(batch)
+    _compare(res, _oracle(handle, batch), batch)
+    clean = handle.consensus(base)
+    assert (res.status == 0).all() and (res.np_ == 8).all()           # no pass is lost (pass 0 of ZMW 3 is even the POA backbone)
+    for z in (0, 2, 4):
+        assert np.array_equal(res.sequence(z), clean.sequence(z))
+    for z in (1, 3):
+        assert abs(int(res.seq_len[z]) - int(clean.seq_len[z])) <= 2 and res.ec[z] > 7.5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("maxins,kin", [(10, 0), (6, 1), (-1, 0)])
 def test_large_insertion_trimming_matches_oracle(built, maxins, kin):
     """SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78, opts.max_insertion_size): passes with 8-30 base blocks of

@@ -144,12 +144,12 @@ def test_np_is_the_mode_over_windows(built):
     assert res.np_[0] == 9 and res.np_[2] == 9
 
 
-def test_large_inserted_blocks_end_in_a_deliberate_outcome(built):
-    """VERDICT r01 item 9 (band robustness): passes with a 40-200 base block of foreign sequence inserted (spurious sequencing
-    activity, docs/how-does-ccs-work.md:74-78) are beyond what the 64-row alignment band can carry (trimming, the test below,
-    works on what the alignment delivers): the band loses them and they fail their alignment gate — the pass is dropped, the ZMW
-    still succeeds from the remaining passes, and the consensus is not damaged.  A ZMW in
-    which most passes carry such a block ends TOO_MANY_UNUSABLE (never a crash, never a wrong-length read)."""
+def test_large_inserted_blocks_are_split_out_and_trimmed(built):
+    """VERDICT r01 item 9 (band robustness) + "trim large insertions" (docs/how-does-ccs-work.md:74-78): passes with a 40-200 base
+    block of foreign sequence (spurious sequencing activity) are beyond what the 64-row band can follow; SPEC "split alignment"
+    aligns prefix and suffix separately, the block ends up in one window's segment and is trimmed there — the pass is kept, the
+    consensus is what the clean passes give.  When most passes carry a block the draft itself absorbs it: never a crash, never a
+    HiFi read with a foreign block in it."""
     rng = np.random.default_rng(11)
     base = api.synth(6, 8, 1500, seed=90)
 
@@ -171,29 +171,29 @@ def test_large_inserted_blocks_end_in_a_deliberate_outcome(built):
 
     clean = _run(base)
     for size in (40, 90, 200):
-        b1 = with_blocks(base, 2, {1, 4}, size)                  # two of eight passes: dropped, consensus intact
+        b1 = with_blocks(base, 2, {1, 4}, size)                  # two of eight passes carry a block
         r1 = _run(b1)
-        assert r1.status[2] == 0 and 6 <= r1.np_[2] <= 8 and r1.ec[2] < 8.0      # dropped from the windows it cannot serve (or entirely)
-        if size > 64:
-            assert r1.np_[2] == 6                                                 # beyond the band: the two passes fail their alignment gate
-        # losing two of eight passes costs that ZMW a few errors (8 -> 6 passes) — but nothing worse may happen
-        assert _edit_errors(b1, r1) <= _edit_errors(base, clean) + 10
+        assert r1.status[2] == 0 and r1.np_[2] == 8 and r1.ec[2] > 7.5           # both passes are kept (split + trimmed)
+        assert _edit_errors(b1, r1) <= _edit_errors(base, clean) + 2              # and the consensus does not suffer
+        assert len(r1.sequence(2)) == len(clean.sequence(2))
+        never = _run(b1, max_insertion_size=-1)                  # split but not trimmed: the block's window loses the two passes
+        assert never.status[2] == 0 and never.np_[2] == 8 and never.ec[2] <= r1.ec[2]
         for z in (0, 1, 3, 4, 5):                                # the other ZMWs are untouched
             assert np.array_equal(r1.sequence(z), clean.sequence(z))
-        b2 = with_blocks(base, 3, {1, 2, 3, 5, 6}, size)         # five of eight passes: more than half unusable
+        b2 = with_blocks(base, 3, {1, 2, 3, 5, 6}, size)         # five of eight passes, each with its OWN random block at the same place
         r2 = _run(b2)
-        if size > 64:                                             # TOO_MANY_UNUSABLE, or LOW_RQ when the fallback draft (all passes in the
-            assert r2.status[3] in (3, 7)                         # POA) absorbs the majority's blocks: never a HiFi read
-            assert _run(b2, no_fallback_draft=1).status[3] == 3
-        else:
-            assert r2.status[3] in (0, 3, 7)
+        assert r2.status[3] in (0, 3, 7)                         # SUCCESS, TOO_MANY_UNUSABLE or LOW_RQ
+        if r2.status[3] == 0 and size > 64:                      # blocks the POA band cannot thread never reach the draft: a clean read
+            assert abs(len(r2.sequence(3)) - len(clean.sequence(3))) <= 3
+        # (a 40-base block IS threaded into the POA graph; with three of the five draft passes carrying one, part of it is the
+        #  majority path and stays in the consensus with low QVs — the majority of the passes does have extra sequence there)
 
 
 def test_large_insertions_are_trimmed_in_their_window(built):
     """SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78): a segment more than max_insertion_size bases longer than its
     window is cut down to the window's length (the split with the most diagonal matches), so the pass keeps serving that window;
-    without trimming it is lost there to the alpha/beta or z-score gate.  The 64-row alignment band carries insertions of up to
-    about 30 bases, so the default threshold of 30 rarely fires; a smaller one shows the mechanism."""
+    without trimming it is lost there to the alpha/beta or z-score gate.  (Blocks the 64-row alignment band cannot follow come
+    through the split alignment: the test above.)"""
     rng = np.random.default_rng(5)
     base = api.synth(4, 8, 1500, seed=90)
     bases, pw, ipd, off = [], [], [], [0]
