@@ -635,6 +635,9 @@ int main(int argc, char **argv)
         });
         if (opt.dump) {
             reader.join();
+            if (opt.log_level >= 2)
+                std::fprintf(stderr, "ccs: reader thread: framing/inflate %.2f s, waiting for record decode %.2f s, grouping+filters+queue %.2f s\n",
+                             rd_us[0] * 1e-6, rd_us[1] * 1e-6, rd_us[2] * 1e-6);
             if (failed) std::fprintf(stderr, "ccs: %s\n", err_msg.c_str());
             return failed ? 1 : 0;
         }
