@@ -1,0 +1,67 @@
+"""Fuzz of the robustness paths on the GPU box: HIP path vs CPU restatement (bit-exact or fail) on batches whose passes are
+corrupted the way real subreads are — foreign blocks of 8..600 bases (one or several per pass, anywhere incl. the first / last
+bases), missing stretches, junk passes, truncated passes — under random option sets (max_insertion_size, fallback draft,
+candidate filter, kinetics).  Exercises k_rescue (split alignment), the large-insertion trim, the fallback draft and every gate.
+
+python tools/corruption_fuzz.py [n_batches] [seed0]"""
+import sys, os, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+from ccs_amd import api
+import oracle_lib as O
+
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+bad = 0
+for k in range(nb):
+    rng = np.random.default_rng(seed0 + k)
+    n = int(rng.integers(8, 40))
+    lmax = int(rng.choice([300, 1500, 4000, 12000]))
+    base = api.synth(n, (int(rng.integers(1, 6)), int(rng.integers(6, 24))), (max(40, lmax // 4), lmax), seed=seed0 + 31 * k)
+    base.ipd = rng.integers(0, 256, len(base.bases)).astype(np.uint8)
+    bases, pw, ipd, off = [], [], [], [0]
+    ncorr = 0
+    for r in range(int(base.read_off[-1])):
+        a, b = int(base.base_off[r]), int(base.base_off[r + 1])
+        bb, pp, ii = base.bases[a:b].copy(), base.pw[a:b].copy(), base.ipd[a:b].copy()
+        u = rng.random()
+        if u < 0.30:                                        # 1..3 foreign blocks
+            for _ in range(int(rng.integers(1, 4))):
+                size = int(rng.choice([8, 20, 33, 45, 70, 150, 600]))
+                at = int(rng.integers(0, len(bb) + 1))
+                blk = rng.integers(0, 4, size, dtype=np.uint8)
+                bb = np.concatenate([bb[:at], blk, bb[at:]]); pp = np.concatenate([pp[:at], rng.integers(1, 4, size).astype(np.uint8), pp[at:]])
+                ii = np.concatenate([ii[:at], rng.integers(0, 256, size).astype(np.uint8), ii[at:]])
+            ncorr += 1
+        elif u < 0.38 and len(bb) > 80:                     # a missing stretch
+            at, size = int(rng.integers(0, len(bb) - 40)), int(rng.integers(10, 200))
+            bb = np.concatenate([bb[:at], bb[at + size:]]); pp = np.concatenate([pp[:at], pp[at + size:]]); ii = np.concatenate([ii[:at], ii[at + size:]])
+            ncorr += 1
+        elif u < 0.43:                                      # junk
+            bb = rng.integers(0, 4, len(bb), dtype=np.uint8); ncorr += 1
+        elif u < 0.47 and len(bb) > 60:                     # truncated
+            cut = int(rng.integers(20, len(bb)))
+            bb, pp, ii = bb[:cut], pp[:cut], ii[:cut]; ncorr += 1
+        bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
+    batch = api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                      np.concatenate(ipd), base.flags, base.tpl_off, base.tpl)
+    o = api.default_opts()
+    o.max_insertion_size = int(rng.choice([0, 30, 10, 5, -1])); o.no_fallback_draft = int(rng.random() < 0.25)
+    o.disable_heuristics = int(rng.random() < 0.2); o.hifi_kinetics = int(rng.random() < 0.4); o.max_poa_cov = int(rng.choice([3, 5, 7]))
+    o.min_rq = float(rng.choice([0.99, 0.9, 0.0]))
+    h = api.Handle(0, opts=o)
+    t0 = time.time(); res = h.consensus(batch); tg = time.time() - t0
+    ref = api.Results.allocate(batch, kinetics=bool(o.hifi_kinetics))
+    t0 = time.time(); O.consensus_batch(h.model, o, batch, ref, nthreads=16); tc = time.time() - t0
+    ok = all(np.array_equal(getattr(res, f), getattr(ref, f)) for f in ("status", "seq_len", "np_", "iters", "fn", "rn", "rq", "ec"))
+    for z in range(n):
+        if not ok: break
+        ok = np.array_equal(res.sequence(z), ref.sequence(z)) and np.array_equal(res.quals(z), ref.quals(z)) and np.array_equal(res.raw(z), ref.raw(z))
+        if ok and o.hifi_kinetics: ok = np.array_equal(res.kinetics(z), ref.kinetics(z))
+    st = np.bincount(res.status, minlength=10)
+    print(f"batch {k} n {n} lmax {lmax} corrupted passes {ncorr}/{int(base.read_off[-1])} maxins {o.max_insertion_size} nofb {o.no_fallback_draft} "
+          f"noheur {o.disable_heuristics} kin {o.hifi_kinetics} cov {o.max_poa_cov}: {'OK ' if ok else 'MISMATCH'} status {st.tolist()} gpu {tg:.2f}s cpu {tc:.1f}s", flush=True)
+    bad += 0 if ok else 1
+    h.close()
+print("FAILED" if bad else "ALL BIT-EXACT")
+sys.exit(1 if bad else 0)
