@@ -994,9 +994,10 @@ __global__ __launch_bounds__(64) void k_rescue(KParams P, int pass)
         const int32_t *loR = OsR + (size_t)P.need_max * 128, *cmR = loR + P.need_max + 64, *brR = cmR + P.need_max, *ebR = brR + P.need_max;
         // the split: interior edge column k (mirror index nneed-1-k) with the largest score sum, rows not overlapping; ties: smallest k
         int best = NEGV, bk = 1 << 30;
-        for (int k = 1 + lane; k + 1 < nneed; k += LANES) {
-            const int cf = cmF[k], cr = cmR[nneed - 1 - k];
-            if (cf > NEGV / 2 && cr > NEGV / 2 && brF[k] + brR[nneed - 1 - k] <= I) { const int tot = cf + cr; if (tot > best) { best = tot; bk = k; } }
+        for (int k = lane; k < nneed; k += LANES) {              // k = 0 / nneed-1: an empty half (score 0, no rows): a block at the very start / end
+            const int kr = nneed - 1 - k;
+            const int cf = k ? cmF[k] : 0, cr = kr ? cmR[kr] : 0, a = k ? brF[k] : 0, b = kr ? brR[kr] : 0;
+            if (cf > NEGV / 2 && cr > NEGV / 2 && a + b <= I) { const int tot = cf + cr; if (tot > best) { best = tot; bk = k; } }
         }
         const int wbest = rfl(wave_max_i32(best));
         const int ks = rfl(wave_min_i32(best == wbest ? bk : (1 << 30)));
@@ -1005,18 +1006,17 @@ __global__ __launch_bounds__(64) void k_rescue(KParams P, int pass)
             int32_t *ent = P.ent + P.ent_off[r];
             uint32_t *dm = P.dmask + P.ent_off[r];
             const int2 *OMF = (const int2 *)OsF, *OMR = (const int2 *)OsR;
-            int e = ebF[ks];
+            int e = ks ? ebF[ks] : 0;
             ent[ks] = e;
             for (int k2 = ks; k2 >= 2; --k2) { e = OMF[(size_t)k2 * 64 + (e - loF[k2])].x; ent[k2 - 1] = e; }
             ent[0] = 0;
             const int ksr = nneed - 1 - ks;                         // the same column in the mirrored list
             // reverse entries of the mirrored columns below ksr are the forward entries of the columns above ks: I - entry
-            int er = ebR[ksr];
+            int er = ksr ? ebR[ksr] : 0;
             for (int kq = ksr; kq >= 1; --kq) {
                 er = (kq >= 2) ? OMR[(size_t)kq * 64 + (er - loR[kq])].x : 0;
                 ent[nneed - kq] = I - er;
             }
-            ent[nneed - 1] = I;
             dm[0] = 0u;
             for (int k2 = 1; k2 < nneed; ++k2) dm[k2] = 0x7fffffffu;
             P.avalid[r] = 1; P.ascore[r] = wbest;

@@ -510,7 +510,8 @@ int orc_align(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart
 /* SPEC "split alignment" (the rescue of a pass that carries an insertion the 64-row band cannot follow: "spurious sequencing
  * activity", docs/how-does-ccs-work.md:74-78).  The same banded recurrence runs forward (read prefix against draft prefix) and on
  * the reversed read and draft (suffix against suffix); the pass is split at the interior window-edge column s that maximises
- * colmax_F(s) + colmax_R(Ld - s) with bestrow_F(s) + bestrow_R(Ld - s) <= I (ties: the smallest s); the read rows in between are
+ * colmax_F(s) + colmax_R(Ld - s) with bestrow_F(s) + bestrow_R(Ld - s) <= I (ties: the smallest s; s = 0 and s = Ld, where one
+ * half is empty with score 0, stand for a block before the first / after the last aligned base); the read rows in between are
  * the insertion.  Valid iff that sum reaches Ld.  Entry rows of the window-edge columns <= s come from the forward path that
  * ends in (s, bestrow_F(s)), those > s from the reverse path: rstart[c] = I - rstartR[Ld - c].  Every draft position counts as
  * dirty for such a pass (the candidate filter gets no evidence from it).  need[0] = 0 < ... < need[nneed-1] = Ld.            */
@@ -553,7 +554,7 @@ int orc_align_rescue(const uint8_t *r, int I, const uint8_t *d, int Ld, const in
     dp_all_columns(r, I, d, Ld, loF, mvF, cmF, brF);
     dp_all_columns(rr, I, dr, Ld, loR, mvR, cmR, brR);
     int32_t best = NEG; int ks = -1;
-    for (int k = 1; k + 1 < nneed; ++k) {
+    for (int k = 0; k < nneed; ++k) {                       /* k = 0 / nneed-1: the whole pass is suffix / prefix (a block at its very start / end) */
         int s = need[k];
         if (cmF[s] < NEG / 2 || cmR[Ld - s] < NEG / 2 || brF[s] + brR[Ld - s] > I) continue;
         int32_t tot = cmF[s] + cmR[Ld - s];

@@ -189,6 +189,31 @@ def test_large_inserted_blocks_are_split_out_and_trimmed(built):
         #  majority path and stays in the consensus with low QVs — the majority of the passes does have extra sequence there)
 
 
+def test_blocks_at_the_ends_of_a_pass_are_split_off(built):
+    """SPEC "split alignment", s = 0 / s = Ld: a pass that starts or ends with foreign sequence (a block before its first / after its
+    last aligned base) is kept as all-suffix / all-prefix; the window at that end sees the extra bases and trims them"""
+    rng = np.random.default_rng(8)
+    base = api.synth(3, 8, 1500, seed=90)
+    bases, pw, ipd, off = [], [], [], [0]
+    for r in range(int(base.read_off[-1])):
+        a, b = int(base.base_off[r]), int(base.base_off[r + 1])
+        bb, pp, ii = base.bases[a:b], base.pw[a:b], base.ipd[a:b]
+        z, k = int(np.searchsorted(base.read_off, r, side="right") - 1), r - int(base.read_off[int(np.searchsorted(base.read_off, r, side="right") - 1)])
+        if z == 1 and k in (2, 5, 6):
+            blk = rng.integers(0, 4, 120, dtype=np.uint8); f2, f5 = np.full(120, 2, np.uint8), np.full(120, 5, np.uint8)
+            if k == 2: bb, pp, ii = np.concatenate([blk, bb]), np.concatenate([f2, pp]), np.concatenate([f5, ii])          # leading
+            elif k == 5: bb, pp, ii = np.concatenate([bb, blk]), np.concatenate([pp, f2]), np.concatenate([ii, f5])        # trailing
+            else: bb, pp, ii = np.concatenate([bb[:7], blk, bb[7:]]), np.concatenate([pp[:7], f2, pp[7:]]), np.concatenate([ii[:7], f5, ii[7:]])   # inside the first interval
+        bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
+    batch = api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                      np.concatenate(ipd), base.flags, base.tpl_off, base.tpl)
+    clean, res = _run(base), _run(batch)
+    assert res.status[1] == 0 and res.np_[1] == 8 and res.ec[1] > 7.5
+    assert np.array_equal(res.sequence(1), clean.sequence(1))
+    for z in (0, 2):
+        assert np.array_equal(res.sequence(z), clean.sequence(z))
+
+
 def test_large_insertions_are_trimmed_in_their_window(built):
     """SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78): a segment more than max_insertion_size bases longer than its
     window is cut down to the window's length (the split with the most diagonal matches), so the pass keeps serving that window;
