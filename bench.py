@@ -142,7 +142,8 @@ def main():
         cb = b.c_struct()
         return int(api.lib().ccsx_result_layout(api.C.byref(cb), api._ptr(np.zeros(b.n_zmw + 1, np.int64), api.C.c_int64)))
     big = max(batches, key=layout_cap)
-    results = [api.Results.allocate(big, kinetics=kin, pinned=True) for _ in range(args.depth)]
+    # the optional float QVs (raw_qv) are not requested in the pipelined job: the HiFi record needs seq + qual + rq/ec/np/status
+    results = [api.Results.allocate(big, kinetics=kin, pinned=True, raw=False) for _ in range(args.depth)]
 
     def barrier():
         if dist is not None:
@@ -227,7 +228,7 @@ def main():
                        "preset": args.workload, "zmws_per_gpu": args.zmws, "distinct_batches": nb, "in_flight": args.depth, "passes": args.passes,
                        "template_len": args.length, "parallelism": f"zmw-shard x{world}", "model": "SYN-1",
                        "hifi_kinetics": kin, "candidate_filter": not args.disable_heuristics},
-            "timed_region": "first ccsx_submit to last ccsx_wait: pinned host -> H2D -> kernels -> D2H (PCIe-inclusive)",
+            "timed_region": "first ccsx_submit to last ccsx_wait: pinned host -> H2D -> kernels -> D2H (PCIe-inclusive); downloaded per ZMW: status, sequence, phred QVs, rq, ec, np, fn/rn, iterations (the optional float QVs are not requested)",
             "resident_zmws_per_s": round(args.zmws * world / (stage_ms["total_ms"] * 1e-3), 2),
             "roofline": roofline,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},

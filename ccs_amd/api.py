@@ -321,7 +321,7 @@ class Results:
     kin: np.ndarray | None = None        # [4, capacity] planes fi, fp, ri, rp (CodecV1 codes); None without kinetics
 
     @staticmethod
-    def allocate(batch: Batch, kinetics: bool = False, pinned: bool = False) -> "Results":
+    def allocate(batch: Batch, kinetics: bool = False, pinned: bool = False, raw: bool = True) -> "Results":
         """pinned=True puts every array in page-locked memory (ccsx_alloc_pinned): asynchronous downloads (Handle.submit)
         then run by DMA at PCIe rate."""
         n = batch.n_zmw
@@ -343,7 +343,7 @@ class Results:
             a[...] = 0
             return a
         r = Results(off, z(n, np.int32), z(n, np.int32), z(cap, np.uint8), z(cap, np.uint8),
-                    z(cap, np.float32), z(n, np.float32), z(n, np.int32), z(n, np.float32),
+                    z(cap, np.float32) if raw else None, z(n, np.float32), z(n, np.int32), z(n, np.float32),
                     z(n, np.int32), z(n, np.int32), z(n, np.int32), z(n, np.int32),
                     z((4, cap), np.uint8) if kinetics else None)
         r._pinned = keep
@@ -358,7 +358,7 @@ class Results:
         r.seq_len = _ptr(self.seq_len, C.c_int32)
         r.seq = _ptr(self.seq, C.c_uint8)
         r.qual = _ptr(self.qual, C.c_uint8)
-        r.raw_qv = _ptr(self.raw_qv, C.c_float)
+        r.raw_qv = _ptr(self.raw_qv, C.c_float) if self.raw_qv is not None else None   # optional output: NULL = not downloaded
         r.rq = _ptr(self.rq, C.c_float)
         r.np = _ptr(self.np_, C.c_int32)
         r.ec = _ptr(self.ec, C.c_float)
