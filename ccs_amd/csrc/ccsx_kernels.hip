@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     const int GB_FLOATS = P.pw_gb_floats;
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
-    __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS], sVlist[PW_MAXREADS];
+    __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
     __shared__ uint8_t sZdrop[PW_MAXREADS];                  // z-score gate: decided on the draft window (round 0), then kept
     __shared__ float sBase[PW_MAXREADS];
     __shared__ short2 sTask[PW_MAXREADS];                    // fill tasks: (read A, read B or -1)
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     float *sDelta = (float *)sDeltaI;                        // (each thread converts its own entry after the scoring barrier)
     __shared__ uint8_t sMvalid[256];
     __shared__ int sAcc[32];
-    __shared__ int sCtl[12];                                 // 0:J 1:cs 2:ce 3:nacc 5:chunk_end 6:ntasks 7:ev bits 8:usable valid reads of the chunk
+    __shared__ int sCtl[12];                                 // 0:J 1:cs 2:ce 3:nacc 7:ev bits
     __shared__ float sZS[4];                                 // z-score sums: M fwd, V fwd, M rev, V rev
     __shared__ float sPskip[36];                             // error probability of a position if it is skipped (travels with the base)
     __shared__ int sCnt[PW_WAVES];
@@ -1440,7 +1440,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         int rbeg = 0;
         while (rbeg < nreads) {
             __syncthreads();
-            if (wave == 0) {                                                 // lane = read: the greedy plan by prefix sum and ballots
+            int rend, ntask;
+            {   // lane = read: the greedy plan by prefix sum and ballots.  EVERY wave computes it (identical values, benign identical
+                // LDS writes): a wave then reads only what it wrote itself, so no barrier is needed before the fill
                 const int r = lane;
                 const int n = (r >= rbeg && r < nreads) ? sI[r] : -1;
                 const bool cand = n >= 0;
@@ -1465,10 +1467,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                         sTask[nl + (rank >> 1)] = make_short2((short)r, (short)(hi ? (int)__ffsll((long long)hi) - 1 : -1));
                     }
                 }
-                if (lane == 0) { sCtl[5] = rend_; sCtl[6] = nl + ((ns + 1) >> 1); }
+                rend = rfl(rend_); ntask = rfl(nl + ((ns + 1) >> 1));
             }
-            __syncthreads();
-            const int rend = rfl(sCtl[5]), ntask = rfl(sCtl[6]);
             PHASE(2);
             // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals
 #ifdef CCSX_EXP_NO_FILL
@@ -1558,13 +1558,16 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 }
             }
             __syncthreads();
-            if (wave == 0) {                                                 // usable reads of the chunk, in read order
+            // usable reads of the chunk, in read order: every wave builds the list in a register (lane k = the k-th usable read) with one
+            // ds_permute (valid lane r sends r to lane rank(r), the others fill the remaining lanes): no LDS list, no second barrier
+            int vRlist, nv_chunk;
+            {
                 const bool v = lane >= rbeg && lane < rend && sValid[lane];
-                const unsigned long long bv = __ballot(v);
-                if (v) sVlist[__popcll(bv & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-                if (lane == 0) sCtl[8] = __popcll(bv);
+                const unsigned long long bv = __ballot(v), lower = (1ull << lane) - 1ull;
+                nv_chunk = rfl(__popcll(bv));
+                const int dest = v ? __popcll(bv & lower) : nv_chunk + __popcll(~bv & lower);
+                vRlist = __builtin_amdgcn_ds_permute(dest << 2, lane);
             }
-            __syncthreads();
             PHASE(3);
             // ---- A3/A4: work pool.  A unit = (block of 64 compacted mutation lanes) x (one usable read), numbered block-major; every
             // wave takes an equal contiguous share and walks it two reads at a time (two independent chains per lane) while the
@@ -1572,18 +1575,18 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             // fixed point (order independent).
             {
 #ifdef CCSX_EXP_SKIP_ROUND2_SCORE
-                const int nv = rfl(sCtl[8]), nunits = (it == 0) ? nblk * nv : 0;   // experiment: upper bound of what neighbourhood-only rescoring could save
+                const int nv = nv_chunk, nunits = (it == 0) ? nblk * nv : 0;   // experiment: upper bound of what neighbourhood-only rescoring could save
 #elif defined(CCSX_EXP_NO_SCORE)
-                const int nv = rfl(sCtl[8]), nunits = 0;
+                const int nv = nv_chunk, nunits = 0;
 #else
-                const int nv = rfl(sCtl[8]), nunits = nblk * nv;
+                const int nv = nv_chunk, nunits = nblk * nv;
 #endif
                 nvalid += nv;
                 // per-read scalars of the chunk's usable reads, one read per lane: a unit takes them with v_readlane (no chain of
                 // dependent LDS loads at the start of every unit)
                 int vR, vI, vSt, vG, vB; float vBase;
                 {
-                    vR = (int)sVlist[lane < nv ? lane : 0];
+                    vR = lane < nv ? vRlist : rl(vRlist, 0);
                     vI = sI[vR]; vSt = (int)sStrand[vR]; vG = sGoff[vR]; vB = sBoff[vR]; vBase = sBase[vR];
                 }
                 const int u_end = ((wave + 1) * nunits) / PW_WAVES;
