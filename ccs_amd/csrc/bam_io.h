@@ -378,6 +378,7 @@ inline bool read_pbi(const std::string &path, ThreadPool &pool, PbiIndex &x)
     uint8_t h[32];
     if (!in.read(h, 32) || std::memcmp(h, "PBI\1", 4) != 0) throw std::runtime_error(path + ": not a PacBio BAM index");
     const uint32_t n = h[10] | (h[11] << 8) | (h[12] << 16) | ((uint32_t)h[13] << 24);
+    if ((uint64_t)n * 29 > (uint64_t)st.st_size * 1100 + 64) throw std::runtime_error(path + ": record count does not fit the file size");   // (deflate expands < 1100x)
     auto col = [&](void *dst, size_t bytes) { if (bytes && !in.read(dst, bytes)) throw std::runtime_error(path + ": truncated PacBio BAM index"); };
     x.rg_id.resize(n); x.q_start.resize(n); x.q_end.resize(n); x.hole.resize(n); x.read_qual.resize(n); x.ctxt.resize(n); x.file_offset.resize(n);
     col(x.rg_id.data(), 4 * (size_t)n); col(x.q_start.data(), 4 * (size_t)n); col(x.q_end.data(), 4 * (size_t)n); col(x.hole.data(), 4 * (size_t)n);

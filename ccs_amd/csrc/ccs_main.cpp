@@ -537,6 +537,7 @@ int main(int argc, char **argv)
         // ---- IN.bam.pbi: random access for --chunk, and the number of ZMWs ahead for the progress line
         bool have_pbi = false, chunk_done = false;
         int64_t chunk_zmws = 0, total_zmws = -1;
+        int pbi_first_hole = -1;                              // the ZMW the index promises at the seek target (a stale index is an error)
         {
             PbiIndex pbi;
             bool ok = false;
@@ -551,7 +552,7 @@ int main(int argc, char **argv)
                     const int64_t lo = (opt.chunk_i - 1) * Z / opt.chunk_n, hi = (int64_t)opt.chunk_i * Z / opt.chunk_n;
                     have_pbi = true; chunk_zmws = hi - lo; total_zmws = chunk_zmws;
                     if (chunk_zmws == 0) chunk_done = true;
-                    else in.seek((uint64_t)pbi.file_offset[first[(size_t)lo]]);
+                    else { in.seek((uint64_t)pbi.file_offset[first[(size_t)lo]]); pbi_first_hole = pbi.hole[first[(size_t)lo]]; }
                     if (opt.log_level >= 2) std::fprintf(stderr, "ccs: chunk %d/%d = ZMWs %" PRId64 "..%" PRId64 " of %" PRId64 " (%s.pbi)\n", opt.chunk_i, opt.chunk_n, lo, hi, Z, opt.in.c_str());
                 }
             }
@@ -605,6 +606,10 @@ int main(int argc, char **argv)
             std::deque<std::future<std::vector<Subread>>> pending;
             auto consume = [&](std::vector<Subread> recs) {
                 for (Subread &rec : recs) {
+                    if (pbi_first_hole >= 0) {                       // first record after the seek
+                        if (rec.zm != pbi_first_hole) throw std::runtime_error(opt.in + ".pbi does not match the BAM (stale index?): delete it or re-index");
+                        pbi_first_hole = -1;
+                    }
                     if (movie.empty()) movie = movie_of(rec.name);
                     if (!have || rec.zm != cur.zm) { flush_zmw(); cur.zm = rec.zm; have = true; }
                     if (rec.has_snr) std::memcpy(cur.snr, rec.snr, 16);

@@ -452,6 +452,10 @@ def test_pbi_index_and_chunking_by_random_access(built, tmp_path):
     os.rename(str(bam) + ".pbi", str(bam) + ".pbi.off")
     parts = [_run("--dump-zmws", "--chunk", f"{i}/3", bam).stdout.splitlines() for i in (1, 2, 3)]
     assert sorted(sum(parts, [])) == sorted(full) and parts[1][0] == full[1]      # round-robin without the index
+    _run("--write-synthetic", "157,5,1500,10", tmp_path / "other.bam")   # an index of a DIFFERENT file: refused, not silently wrong
+    os.replace(str(tmp_path / "other.bam") + ".pbi", str(bam) + ".pbi")
+    p = _run("--dump-zmws", "--chunk", "2/3", bam, check=False)
+    assert p.returncode != 0 and ("does not match" in p.stderr or "BGZF" in p.stderr)   # (its offsets point into the middle of blocks)
     open(str(bam) + ".pbi", "wb").write(b"garbage")                 # a broken index is reported and ignored
     p = _run("--dump-zmws", "--chunk", "2/3", bam)
     assert p.stdout.splitlines() == parts[1] and "ignoring" in p.stderr
