@@ -85,7 +85,7 @@ struct Slot {
     // inputs
     DevBuf d_snr, d_read_off, d_base_off, d_bases, d_pw, d_ipd, d_flags;
     // layout
-    DevBuf d_read_zmw, d_vcap, d_dcap, d_seq_off, d_wb_off, d_ent_off, d_wslot, d_zperm, d_rperm;
+    DevBuf d_read_zmw, d_vcap, d_dcap, d_seq_off, d_wb_off, d_ent_off, d_wslot, d_zperm, d_rperm, d_quads, d_retry;
     // state
     DevBuf d_tabME, d_tabINS, d_tabDL, d_tabZ, d_dmask, d_draft, d_zmw_i32 /* 6 x n int32 */, d_wbounds, d_ticket;
     DevBuf d_avalid, d_ascore, d_ent;
@@ -93,7 +93,7 @@ struct Slot {
     DevBuf d_out_seq, d_out_qual, d_out_raw, d_out_i32 /* 6 x n */, d_out_f32 /* 2 x n */;
     DevBuf d_wtpl, d_wtmeta, d_wkin, d_out_kin;   // HiFi kinetics only
     // host copies of the layout (page-locked: sources of the asynchronous uploads)
-    PinVec<int32_t> read_zmw, vcap, dcap, wslot, zperm, rperm, wb_off, read_off;
+    PinVec<int32_t> read_zmw, vcap, dcap, wslot, zperm, rperm, wb_off, read_off, quads, qperm;
     PinVec<int64_t> seq_off, ent_off, base_off;
     KParams P;
     hipEvent_t ev[6] = {}, ev_up = nullptr, ev_done = nullptr;
@@ -106,11 +106,11 @@ struct Slot {
     void release()
     {
         DevBuf *bufs[] = {&d_snr, &d_read_off, &d_base_off, &d_bases, &d_pw, &d_ipd, &d_flags, &d_read_zmw, &d_vcap, &d_dcap, &d_seq_off,
-                          &d_wb_off, &d_ent_off, &d_wslot, &d_zperm, &d_rperm, &d_tabME, &d_tabINS, &d_tabDL, &d_tabZ, &d_dmask, &d_draft,
+                          &d_wb_off, &d_ent_off, &d_wslot, &d_zperm, &d_rperm, &d_quads, &d_retry, &d_tabME, &d_tabINS, &d_tabDL, &d_tabZ, &d_dmask, &d_draft,
                           &d_zmw_i32, &d_wbounds, &d_ticket, &d_avalid, &d_ascore, &d_ent, &d_wseq, &d_wqv, &d_wsum, &d_wmeta, &d_out_seq,
                           &d_out_qual, &d_out_raw, &d_out_i32, &d_out_f32, &d_wtpl, &d_wtmeta, &d_wkin, &d_out_kin};
         for (auto *b : bufs) b->release();
-        read_zmw.release(); vcap.release(); dcap.release(); wslot.release(); zperm.release(); rperm.release(); wb_off.release();
+        read_zmw.release(); vcap.release(); dcap.release(); wslot.release(); zperm.release(); rperm.release(); quads.release(); qperm.release(); wb_off.release();
         read_off.release(); seq_off.release(); ent_off.release(); base_off.release();
         for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_up) { (void)hipEventDestroy(ev_up); ev_up = nullptr; }
@@ -251,7 +251,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     if (S.read_zmw.resize(R > 0 ? R : 1) || S.vcap.resize(n) || S.dcap.resize(n) || S.seq_off.assign(n + 1, 0) || S.wb_off.assign(n + 1, 0) ||
         S.ent_off.assign(R + 1, 0) || S.read_off.resize(n + 1) || S.base_off.resize(R + 1) || S.zperm.resize(n) || S.rperm.resize(R > 0 ? R : 1))
         return -2;
-    int64_t maxL_max = 1, vcap_max = 1; int need_max = 2, nr_max = 1;
+    int64_t maxL_max = 1, vcap_max = 1; int need_max = 2, nr_max = 1, n_quads = 0;
     for (int z = 0; z < n; ++z) {
         int64_t maxL = 0;
         int nr = b->read_off[z + 1] - b->read_off[z];
@@ -286,6 +286,25 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         };
         order_by(S.zperm, (size_t)n, [&](size_t z) { return (int64_t)S.dcap[z]; });
         if (R > 0) order_by(S.rperm, (size_t)R, [&](size_t r) { return b->base_off[r + 1] - b->base_off[r]; });
+        // k_align16's work items: up to four consecutive passes of one ZMW (of the passes the engine uses), longest first
+        std::vector<int32_t> qpack; std::vector<int64_t> qlen;
+        const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > 64) ? 64 : h->opts.top_passes;
+        for (int z = 0; z < n; ++z) {
+            const int r0 = b->read_off[z], nr = std::min(b->read_off[z + 1] - r0, top);
+            for (int g = 0; g < nr; g += 4) {
+                const int c = std::min(4, nr - g);
+                int64_t ml = 0;
+                for (int q = 0; q < c; ++q) ml = std::max<int64_t>(ml, b->base_off[r0 + g + q + 1] - b->base_off[r0 + g + q]);
+                qpack.push_back(((r0 + g) << 2) | (c - 1)); qlen.push_back(ml);
+            }
+        }
+        n_quads = (int)qpack.size();
+        if (S.quads.resize(n_quads > 0 ? n_quads : 1)) return -2;
+        if (n_quads > 0) {
+            if (S.qperm.resize(n_quads)) return -2;
+            order_by(S.qperm, (size_t)n_quads, [&](size_t q) { return qlen[q]; });
+            for (int q = 0; q < n_quads; ++q) S.quads[q] = qpack[S.qperm[q]];
+        }
     }
     const int64_t total_wslots = (int64_t)S.wb_off[n] - n;
     if (S.wslot.resize(total_wslots > 0 ? total_wslots : 1)) return -2;
@@ -312,6 +331,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     UP(S.d_wslot, S.wslot.p, S.wslot.size() * 4);
     UP(S.d_zperm, S.zperm.p, S.zperm.size() * 4);
     UP(S.d_rperm, S.rperm.p, S.rperm.size() * 4);
+    UP(S.d_quads, S.quads.p, S.quads.size() * 4);
 #undef UP
 
     const int64_t cap_total = S.seq_off[n];
@@ -322,6 +342,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     RES(S.d_wbounds, (size_t)S.wb_off[n] * 4);
     RES(S.d_ticket, 256);
     RES(S.d_avalid, (size_t)(R > 0 ? R : 1)); RES(S.d_ascore, (size_t)(R > 0 ? R : 1) * 4);
+    RES(S.d_retry, ((size_t)(R > 0 ? R : 1) + 16) * 4);
     RES(S.d_ent, (size_t)(S.ent_off[R] + 1) * 4); RES(S.d_dmask, (size_t)(S.ent_off[R] + 1) * 4);
     RES(S.d_wseq, (size_t)(total_wslots + 1) * 32); RES(S.d_wqv, (size_t)(total_wslots + 1) * 32 * 4);
     RES(S.d_wsum, (size_t)(total_wslots + 1) * 4); RES(S.d_wmeta, (size_t)(total_wslots + 1) * 16);
@@ -372,6 +393,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.read_zmw = (const int32_t *)S.d_read_zmw.p; P.vcap = (const int32_t *)S.d_vcap.p; P.dcap = (const int32_t *)S.d_dcap.p;
     P.seq_off = (const int64_t *)S.d_seq_off.p; P.wb_off = (const int32_t *)S.d_wb_off.p; P.ent_off = (const int64_t *)S.d_ent_off.p; P.wslot_zmw = (const int32_t *)S.d_wslot.p;
     P.zmw_perm = (const int32_t *)S.d_zperm.p; P.read_perm = (const int32_t *)S.d_rperm.p;
+    P.quads = (const int32_t *)S.d_quads.p; P.n_quads = n_quads; P.align_retry = (int32_t *)S.d_retry.p;
     P.tabME = (float *)S.d_tabME.p; P.tabINS = (float *)S.d_tabINS.p; P.tabDL = (float *)S.d_tabDL.p; P.tabZ = (float *)S.d_tabZ.p;
     P.draft = (uint8_t *)S.d_draft.p;
     int32_t *zi = (int32_t *)S.d_zmw_i32.p;

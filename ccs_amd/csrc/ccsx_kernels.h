@@ -62,6 +62,9 @@ struct KParams {
     // ---- launch order (cost-sorted, longest first: the one-wave-per-ZMW / per-read kernels finish together)
     const int32_t *zmw_perm;   // [n_zmw]
     const int32_t *read_perm;  // [n_reads]
+    const int32_t *quads;      // [n_quads] (first pass << 2 | passes - 1): up to four consecutive passes of one ZMW, longest first
+    int32_t n_quads;
+    int32_t *align_retry;      // [16 + n_reads]: [0] = count, [16..] = passes for the 64-row retry (appended by k_align16)
     // ---- HiFi kinetics (NULL unless opts.hifi_kinetics); kept at the end so the hot kernels' kernarg offsets do not move
     const uint8_t *ipd;
     uint8_t *wtpl;             // [wslots][32] converged window template incl. overhangs

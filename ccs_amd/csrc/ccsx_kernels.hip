@@ -893,19 +893,167 @@ __device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t 
     return out;
 }
 
-__global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
+// ------------------------------------------------------------------------------------------------
+// step 3, first attempt of the alignment cascade (SPEC "alignment cascade"): FOUR passes of one ZMW per wave, each in a 16-row band
+// that lives in one 16-lane DPP row — row shifts, the insertion-chain scan and the column maximum are native row operations
+// (row_shr / row_shl with the hardware's fill, 4-step scans), the band position is a per-lane value that is uniform inside a row.
+// The band follows the best row, so this finds the path of the 64-row band unless an indel run of more than ~8 rows occurs
+// (bit-identical consensus on the test sets); a pass that is not valid here goes on a list for the 64-row retry (k_align), and
+// from there to the split alignment.  Same cell recurrence, origin / dirty tracking and edge saves as align_pass.
+#define AB16 16
+__global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
+{
+    const int lane = threadIdx.x, h = lane >> 4, l = lane & 15, rowb = lane & 48;
+    uint32_t *sread = dyn_lds;
+    int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] (origin, dirty), then lo_need[need][4]
+    if (qbase + (int)blockIdx.x >= P.n_quads) return;
+    const int qd = rfl(P.quads[qbase + blockIdx.x]);    // (first pass << 2) | (passes - 1): up to four consecutive passes of one ZMW
+    const int rfirst = qd >> 2, nq = (qd & 3) + 1;
+    const int z = rfl(P.read_zmw[rfirst]);
+    const int r0 = rfl(P.read_off[z]);
+    const int zr = rfl(P.zref[z]);
+    if (pass == 1 && !(zr & ZREF_DONE)) return;        // second pass: only the ZMWs whose draft was redone
+    const bool live = h < nq;
+    const int r = rfirst + (live ? h : 0);
+    if (live && l == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
+    if (P.zstat[z] != CCSX_SUCCESS) return;
+    const int nused = rfl(P.nreads_used[z]);
+    if (rfirst - r0 >= nused) return;
+    const bool use = live && (r - r0 < nused);
+    const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
+    const uint8_t *d = P.draft + P.seq_off[z];
+    const int32_t *wb = P.wbounds + P.wb_off[z];
+    const int wstride = ((P.maxL_max + 15) >> 4) + 1;   // LDS words per pass
+    const int fl0 = rfl(P.flags[r0 + (zr & 63)] & 1);
+    for (int hh = 0; hh < nq; ++hh) {
+        const int rr = rfirst + hh;
+        const int Ih = rfl((int)(P.base_off[rr + 1] - P.base_off[rr]));
+        load_read_packed(sread + hh * wstride, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), lane);
+    }
+    __syncthreads();
+    const int I = use ? (int)(P.base_off[r + 1] - P.base_off[r]) : 0;
+    const uint32_t *myread = sread + h * wstride;
+    const int nneed = 2 * nw;
+    int2 *OMsave = (int2 *)Osave;
+    int32_t *lo_need = Osave + (size_t)P.need_max * 128;        // [need][4]
+    int kk = 1;
+    int next_need = rfl(need_col(wb, nw, Ld, 1));
+    int Mprev = (l <= I) ? l * SC_INS : NEGV;
+    int Oprev = 0;
+    unsigned Kprev = (l >= 1) ? 1u : 0u;
+    int ecol = 0;
+    int lo = 0, br = 0;                                  // per lane, uniform inside a row
+    const int hiI = I - (AB16 - 1) > 0 ? I - (AB16 - 1) : 0;
+    for (int jb = 0; jb < Ld; jb += LANES) {
+        const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
+        asm volatile("" :: "v"(dL));
+        const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
+        for (int jj = 0; jj < nblk; ++jj) {
+            const int j = jb + jj + 1;
+            const int plo = lo;
+            {   // band_lo with 16 rows, per row
+                int t = br + 1 - AB16 / 2;
+                t = t > plo ? t : plo;
+                t = t < plo + 2 ? t : plo + 2;
+                t = t < hiI ? t : hiI;
+                lo = t > 0 ? t : 0;
+            }
+            const int sh = lo - plo;                    // 0..2, per row
+            const int i = lo + l;
+            const int vb = rl(dL, jj);
+            const int rbv = (i >= 1 && i <= I) ? read_base_packed(myread, i - 1) : 4;
+            // rows of the previous column in the new band position: the three possible shifts, selected per row
+            const int mR = row_shr1_i32(Mprev, NEGV), m1 = row_shl1_i32(Mprev, NEGV), m2 = row_shl2_i32(Mprev, NEGV);
+            const int oR = row_shr1_i32_z(Oprev), o1 = row_shl1_i32_z(Oprev), o2 = row_shl2_i32_z(Oprev);
+            const int kR = row_shr1_i32_z((int)Kprev), k1 = row_shl1_i32_z((int)Kprev), k2 = row_shl2_i32_z((int)Kprev);
+            const bool s0 = sh == 0, s1 = sh == 1;
+            const int x = s0 ? mR : (s1 ? Mprev : m1), y = s0 ? Mprev : (s1 ? m1 : m2);
+            const int ox = s0 ? oR : (s1 ? Oprev : o1), oy = s0 ? Oprev : (s1 ? o1 : o2);
+            const unsigned kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1)), ky = (unsigned)(s0 ? (int)Kprev : (s1 ? k1 : k2));
+            const unsigned bitj = 1u << (j - ecol - 1);
+            const bool match = (vb == rbv);
+            int best = x + (match ? SC_MATCH : SC_MISMATCH), org = ox;
+            unsigned kd = match ? kx : (kx | bitj);
+            { const int c = y + SC_DEL; if (c > best) { best = c; org = oy; kd = ky | bitj; } }
+            const bool need = (j == next_need);
+            unsigned insbits = bitj | (bitj << 1);
+            if (need) {
+                OMsave[(size_t)kk * 64 + lane] = make_int2(org, (int)kd);
+                if (l == 0) lo_need[kk * 4 + h] = lo;
+                org = i;
+                kd = 0u; insbits = 0x80000001u; ecol = j;
+            }
+            // insertion chain inside the row: one packed max-scan (value << 6 | lane), origin / dirty bits of the winner by bpermute
+            const int d0 = best + 4 * lane;
+            const int dc = d0 > -(1 << 24) ? d0 : -(1 << 24);
+            const int key = row_scan_max_i32((dc << 6) | lane);
+            const int xi = (key >> 6) - 4 * lane;
+            const int ksl = key & 63;
+            const int osrc = __shfl(org, ksl);
+            const unsigned ksrc = (unsigned)__shfl((int)kd, ksl);
+            if (xi > best) { best = xi; org = osrc; kd = ksrc | insbits; }
+            if (i > I || best < -(1 << 22)) best = NEGV;
+            // column maximum of the row and its lowest row
+            const int cm = __shfl(row_scan_max_i32(best), lane | 15);
+            const unsigned long long bal = __ballot(best == cm);
+            const unsigned m16 = (unsigned)(bal >> rowb) & 0xffffu;
+            br = lo + (__ffs((int)m16) - 1);
+            Mprev = best; Oprev = org; Kprev = kd;
+            if (need) {
+                ++kk;
+                next_need = (kk >= nneed) ? -1 : rfl(need_col(wb, nw, Ld, kk));
+            }
+        }
+    }
+    const int oe = I - lo;
+    const bool inr = oe >= 0 && oe < AB16;
+    const int srcl = rowb + (inr ? oe : 0);
+    const int scv = __shfl(Mprev, srcl), eLv = __shfl(Oprev, srcl);
+    const unsigned kLv = (unsigned)__shfl((int)Kprev, srcl);
+    const int sc = inr ? scv : NEGV;
+    const int valid = (sc > NEGV / 2 && sc >= Ld) ? 1 : 0;
+    __threadfence_block();
+    if (l == 0 && use) {
+        P.ascore[r] = sc; P.avalid[r] = (uint8_t)valid;
+        if (valid) {
+            int32_t *ent = P.ent + P.ent_off[r];
+            uint32_t *dm = P.dmask + P.ent_off[r];
+            int e = eLv;
+            ent[nneed - 1] = e;
+            unsigned carry = kLv >> 31;
+            for (int k2 = nneed - 1; k2 >= 1; --k2) {
+                const int cell = e - lo_need[k2 * 4 + h];
+                const int2 om = OMsave[(size_t)k2 * 64 + rowb + cell];
+                unsigned mk = (unsigned)om.y;
+                const int cend = (k2 == nneed - 1) ? Ld : wb[(k2 + 1) >> 1] + ((k2 & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG);
+                const int cbeg = (k2 == 1) ? 0 : wb[k2 >> 1] + (((k2 - 1) & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG);
+                if (carry) mk |= 1u << (cend - cbeg - 1);
+                carry = mk >> 31;
+                dm[k2] = mk & 0x7fffffffu;
+                if (k2 >= 2) { e = om.x; ent[k2 - 1] = e; }
+            }
+            ent[0] = 0; dm[0] = 0u;
+        } else {
+            const int idx = atomicAdd(&P.align_retry[0], 1);        // -> the 64-row retry
+            P.align_retry[16 + idx] = r;
+        }
+    }
+}
+
+// The 64-row retry of the alignment cascade: the passes k_align16 could not align in its 16-row band (a list it appended to),
+// one wave per pass over a grid-stride loop.
+__global__ __launch_bounds__(64) void k_align(KParams P, int pass)
 {
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
     int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] then lo_need[need]
-    if (rbase + (int)blockIdx.x >= P.n_reads) return;   // launched in chunks of align_slots reads: slot = block
-    const int r = rfl(P.read_perm[rbase + blockIdx.x]); // longest reads first
+    const int nretry = rfl(P.align_retry[0]);
+    for (int it = blockIdx.x; it < nretry; it += gridDim.x) {
+    const int r = rfl(P.align_retry[16 + it]);
     const int z = rfl(P.read_zmw[r]);
     const int r0 = rfl(P.read_off[z]);
     const int zr = rfl(P.zref[z]);
-    if (pass == 1 && !(zr & ZREF_DONE)) return;        // second pass: only the ZMWs whose draft was redone
-    if (lane == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
-    if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z]) return;
+    __syncthreads();
     const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
     const uint8_t *d = P.draft + P.seq_off[z];
     const int32_t *wb = P.wbounds + P.wb_off[z];
@@ -947,6 +1095,7 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int rbase, int pass)
             }
             ent[0] = 0; dm[0] = 0u;
         }
+    }
     }
 }
 
@@ -2040,6 +2189,7 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
     if (hipFuncGetAttributes(&fa, (const void *)k_polish) != hipSuccess) return -1;
     const int static_bytes = (int)fa.sharedSizeBytes;
     if (hipFuncSetAttribute((const void *)k_polish, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES - static_bytes) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_align16, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4097 * 4 + 64) != hipSuccess) return -1;   // four 65 535-base passes
     if (max_reads > PW_MAXREADS) max_reads = PW_MAXREADS;
     if (max_reads < 1) max_reads = 1;
     *obs_bytes = ((max_reads * 68 * 2) + 15) & ~15;
@@ -2072,9 +2222,19 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* 
         }
         trace_sync(st, "k_poa");
         if (ev && pass == 0) (void)hipEventRecord(ev[2], st);
-        for (int rb = 0; rb < P.n_reads; rb += P.align_slots) {
-            const int nb = (P.n_reads - rb) < P.align_slots ? (P.n_reads - rb) : P.align_slots;
-            hipLaunchKernelGGL(k_align, dim3(nb), dim3(64), lds_read, st, P, rb, pass);
+        // alignment cascade: four passes per wave in 16-row bands, then the 64-row retry of the few that failed there
+        if (hipMemsetAsync(P.align_retry, 0, 64, st) != hipSuccess && !failed) failed = "hipMemsetAsync";
+        {
+            const size_t lds16 = 4 * ((((size_t)P.maxL_max + 15) >> 4) + 1) * sizeof(uint32_t);
+            for (int qb = 0; qb < P.n_quads; qb += P.align_slots) {
+                const int nb = (P.n_quads - qb) < P.align_slots ? (P.n_quads - qb) : P.align_slots;
+                hipLaunchKernelGGL(k_align16, dim3(nb), dim3(64), lds16, st, P, qb, pass);
+                LAUNCH_CHECK("k_align16");
+            }
+        }
+        {
+            const int g = P.align_slots < 1 ? 1 : (P.align_slots > 4096 ? 4096 : P.align_slots);
+            hipLaunchKernelGGL(k_align, dim3(g), dim3(64), lds_read, st, P, pass);
             LAUNCH_CHECK("k_align");
         }
         trace_sync(st, "k_align");

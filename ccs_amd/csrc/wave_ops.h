@@ -64,6 +64,24 @@ __device__ __forceinline__ int wave_scan_add_i32(int v)
     s = s + __builtin_amdgcn_update_dpp(0, s, DPP_ROW_BCAST31, 0xc, 0xf, false);
     return s;
 }
+// ---- the same primitives inside each 16-lane DPP row (four independent groups per wave: k_align16's four 16-row bands)
+#define DPP_ROW_SHL(n) (0x100 + (n))
+__device__ __forceinline__ int row_shr1_i32(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, DPP_ROW_SHR(1), 0xf, 0xf, false); }
+__device__ __forceinline__ int row_shl1_i32(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, DPP_ROW_SHL(1), 0xf, 0xf, false); }
+__device__ __forceinline__ int row_shl2_i32(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, DPP_ROW_SHL(2), 0xf, 0xf, false); }
+__device__ __forceinline__ int row_shr1_i32_z(int x) { return __builtin_amdgcn_mov_dpp(x, DPP_ROW_SHR(1), 0xf, 0xf, true); }
+__device__ __forceinline__ int row_shl1_i32_z(int x) { return __builtin_amdgcn_mov_dpp(x, DPP_ROW_SHL(1), 0xf, 0xf, true); }
+__device__ __forceinline__ int row_shl2_i32_z(int x) { return __builtin_amdgcn_mov_dpp(x, DPP_ROW_SHL(2), 0xf, 0xf, true); }
+// inclusive prefix maximum inside each 16-lane row: 4 VALU ops
+__device__ __forceinline__ int row_scan_max_i32(int v)
+{
+    int s = imax(v, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(2), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(4), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(8), 0xf, 0xf, false));
+    return s;
+}
+
 // wave-wide maximum, returned uniformly (scan + readlane 63)
 __device__ __forceinline__ int wave_reduce_max_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_max_i32(v), 63); }
 __device__ __forceinline__ int wave_reduce_add_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_add_i32(v), 63); }

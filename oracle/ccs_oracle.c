@@ -37,6 +37,8 @@
 
 /* ---------------- specification constants (same values as include/ccsx.h) -------------- */
 #define BAND      64
+#define ALIGN_BAND1 16      /* rows of the FIRST attempt of the subread -> draft alignment (step 3); BAND rows on failure */
+static __thread int g_bw = BAND;   /* rows of the band in use (the POA and the retry / split alignment use BAND) */
 #define MAXPRED   8
 #define WIN_CORE  22
 #define WIN_OVH   2
@@ -283,10 +285,10 @@ static void poa_renumber(poa_t *g) { int k = 0; for (int v = g->head; v >= 0; v 
 /* band start of a column whose best predecessor column has (lo_u, bestrow_u); I = read length */
 static inline int band_lo(int lo_u, int bestrow_u, int I)
 {
-    int lo = bestrow_u + 1 - BAND / 2;
+    int lo = bestrow_u + 1 - g_bw / 2;
     if (lo < lo_u) lo = lo_u;
     if (lo > lo_u + 2) lo = lo_u + 2;
-    int hi = I - (BAND - 1); if (hi < 0) hi = 0;
+    int hi = I - (g_bw - 1); if (hi < 0) hi = 0;
     if (lo > hi) lo = hi;
     if (lo < 0) lo = 0;
     return lo;
@@ -297,17 +299,17 @@ static inline int band_lo(int lo_u, int bestrow_u, int I)
 static void dp_column(int vbase, const uint8_t *r, int I, int lo, int npred, const int32_t *plo, const int32_t *const *pM,
                       int32_t *M, uint8_t *mv, int32_t *colmax, int32_t *bestrow)
 {
-    for (int l = 0; l < BAND; ++l) {
+    for (int l = 0; l < g_bw; ++l) {
         int i = lo + l;
         int32_t best = NEG; uint8_t bm = 0;
         if (i <= I) {
             for (int k = 0; k < npred; ++k) {
                 int o1 = i - 1 - plo[k], o0 = i - plo[k];
-                if (i >= 1 && o1 >= 0 && o1 < BAND) {
+                if (i >= 1 && o1 >= 0 && o1 < g_bw) {
                     int32_t x = pM[k][o1];
                     if (x > NEG / 2) { int32_t c = x + (vbase == r[i - 1] ? SC_MATCH : SC_MISMATCH); if (c > best) { best = c; bm = (uint8_t)(MV_DIAG | (k << 2)); } }
                 }
-                if (o0 >= 0 && o0 < BAND) {
+                if (o0 >= 0 && o0 < g_bw) {
                     int32_t y = pM[k][o0];
                     if (y > NEG / 2) { int32_t c = y + SC_DEL; if (c > best) { best = c; bm = (uint8_t)(MV_DEL | (k << 2)); } }
                 }
@@ -315,13 +317,13 @@ static void dp_column(int vbase, const uint8_t *r, int I, int lo, int npred, con
         }
         M[l] = best; mv[l] = bm;
     }
-    for (int l = 1; l < BAND; ++l) {
+    for (int l = 1; l < g_bw; ++l) {
         if (lo + l > I) break;
         int32_t c = M[l - 1] + SC_INS;
         if (c > M[l]) { M[l] = c; mv[l] = MV_INS; }
     }
     int32_t cm = NEG, br = lo;
-    for (int l = 0; l < BAND; ++l) {
+    for (int l = 0; l < g_bw; ++l) {
         if (M[l] < NEG / 2) M[l] = NEG;
         if (M[l] > cm) { cm = M[l]; br = lo + l; }
     }
@@ -330,7 +332,7 @@ static void dp_column(int vbase, const uint8_t *r, int I, int lo, int npred, con
 
 static void start_column(int I, int32_t *M)
 {
-    for (int l = 0; l < BAND; ++l) M[l] = (l <= I) ? l * SC_INS : NEG;
+    for (int l = 0; l < BAND; ++l) M[l] = (l <= I && l < g_bw) ? l * SC_INS : NEG;
 }
 
 /* Thread one read (draft orientation) into the graph.  Returns 1 if added, 0 if skipped, -1 on capacity overflow. */
@@ -461,7 +463,19 @@ int orc_poa_draft(int nreads, const int64_t *base_off, const uint8_t *bases, con
  * dirty (optional, [Ld]): the pile-up evidence of the candidate filter (docs/how-does-ccs-work.md:80-83) —
  * dirty[p] = 1 iff the optimal path does not pass draft position p by a plain matching DIAG step: a mismatch or a
  * deletion marks p; a read base inserted between positions p-1 and p marks both neighbours.                        */
+static int align_ev_band(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty);
+/* SPEC "alignment cascade": the banded global alignment is first tried with ALIGN_BAND1 rows (the band follows the best row, so
+ * this finds the same path as the wide band unless an indel run of more than ~ALIGN_BAND1/2 rows occurs); a pass that is not valid
+ * in the narrow band is aligned again with BAND rows (and, failing that, by the split alignment).                             */
 int orc_align_ev(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty)
+{
+    g_bw = ALIGN_BAND1;
+    int v = align_ev_band(r, I, d, Ld, rstart, score_out, dirty);
+    g_bw = BAND;
+    if (v) return 1;
+    return align_ev_band(r, I, d, Ld, rstart, score_out, dirty);
+}
+static int align_ev_band(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty)
 {
     int32_t *lo = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
     uint8_t *mv = (uint8_t *)malloc((size_t)(Ld + 1) * BAND);
@@ -476,7 +490,7 @@ int orc_align_ev(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rst
         int32_t *t = prevM; prevM = curM; curM = t;
     }
     int o = I - lo[Ld];
-    int valid = (o >= 0 && o < BAND && prevM[o] > NEG / 2);
+    int valid = (o >= 0 && o < g_bw && prevM[o] > NEG / 2);
     int32_t sc = valid ? prevM[o] : NEG;
     if (valid && sc < Ld) valid = 0;                        /* SPEC: alignment score must reach 1.0 per draft base */
     if (score_out) *score_out = sc;
