@@ -226,6 +226,22 @@ __device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t 
 {
     load_read_packed_mode(sread, bases, L, rev ? 3 : 0, lane);
 }
+// a CH16-base chunk [c0, c0 + CH16) of the oriented read, packed 2 bits per base into sread[0 .. CH16/16] (k_align16 keeps only the
+// part of each pass its band can reach in LDS: 0.5 KB instead of the whole pass, so the kernel's occupancy is not LDS-bound)
+#define CH16 2048
+__device__ __forceinline__ void load_read_chunk(uint32_t *sread, const uint8_t *bases, int L, int rev, int c0, int lane)
+{
+    for (int w = lane; w <= CH16 / 16; w += LANES) {
+        uint32_t v = 0;
+        const int i0 = c0 + (w << 4);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = i0 + k;
+            if (i < L) { uint32_t b = (uint32_t)bases[rev ? L - 1 - i : i]; if (rev) b = 3u - b; v |= (b & 3u) << (2 * k); }
+        }
+        sread[w] = v;
+    }
+}
 __device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { return (int)((sread[i >> 4] >> (2 * (i & 15))) & 3u); }
 // the band's next read base, wave-uniform index: 64 packed words (1024 bases) of the read sit in one VGPR, lane = word, loaded
 // at a point from which the band cannot advance past the window before the next load (<= 2 rows per column); a column takes
@@ -923,27 +939,32 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
     const uint8_t *d = P.draft + P.seq_off[z];
     const int32_t *wb = P.wbounds + P.wb_off[z];
-    const int wstride = ((P.maxL_max + 15) >> 4) + 1;   // LDS words per pass
+    const int wstride = CH16 / 16 + 2;                  // LDS words per pass: one chunk of the pass at a time
     const int fl0 = rfl(P.flags[r0 + (zr & 63)] & 1);
     for (int hh = 0; hh < nq; ++hh) {
         const int rr = rfirst + hh;
         const int Ih = rfl((int)(P.base_off[rr + 1] - P.base_off[rr]));
-        load_read_packed(sread + hh * wstride, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), lane);
+        load_read_chunk(sread + hh * wstride, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), 0, lane);
     }
     __syncthreads();
+    int c0 = 0;                                         // first base of the row's chunk in LDS (per lane, uniform inside a row)
     const int I = use ? (int)(P.base_off[r + 1] - P.base_off[r]) : 0;
     const uint32_t *myread = sread + h * wstride;
     const int nneed = 2 * nw;
     int2 *OMsave = (int2 *)Osave;
     int32_t *lo_need = Osave + (size_t)P.need_max * 128;        // [need][4]
     int kk = 1;
-    int next_need = rfl(need_col(wb, nw, Ld, 1));
+    // window-edge columns ahead: lane q holds column kkb + q of the list, refilled every 64 edges (a load + wait per edge otherwise)
+    int kkb = 1;
+    int needv = need_col(wb, nw, Ld, (kkb + lane < nneed) ? kkb + lane : nneed - 1);
+    int next_need = rl(needv, 0);
     int Mprev = (l <= I) ? l * SC_INS : NEGV;
     int Oprev = 0;
     unsigned Kprev = (l >= 1) ? 1u : 0u;
     int ecol = 0;
     int lo = 0, br = 0;                                  // per lane, uniform inside a row
     const int hiI = I - (AB16 - 1) > 0 ? I - (AB16 - 1) : 0;
+    const int Iclamp = I > 0 ? I - 1 : 0;
     for (int jb = 0; jb < Ld; jb += LANES) {
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
         asm volatile("" :: "v"(dL));
@@ -961,7 +982,23 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int sh = lo - plo;                    // 0..2, per row
             const int i = lo + l;
             const int vb = rl(dL, jj);
-            const int rbv = (i >= 1 && i <= I) ? read_base_packed(myread, i - 1) : 4;
+            if (__any(lo + AB16 + 2 > c0 + CH16)) {           // (every ~2000 columns per pass) the band reaches the end of a chunk: next chunk
+                for (int hh = 0; hh < nq; ++hh) {
+                    const int src = hh << 4;
+                    if (rl(lo, src) + AB16 + 2 > rl(c0, src) + CH16) {
+                        const int rr = rfirst + hh;
+                        const int Ih = rfl((int)(P.base_off[rr + 1] - P.base_off[rr]));
+                        const int nc0 = rl(lo, src) - 16 > 0 ? rl(lo, src) - 16 : 0;
+                        __syncthreads();
+                        load_read_chunk(sread + hh * wstride, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), nc0, lane);
+                        __syncthreads();
+                        if (h == hh) c0 = nc0;
+                    }
+                }
+            }
+            // the read base of row i-1: an unconditional (clamped) LDS read issued here, consumed after the shifts below
+            const int bi = (i - 1 < 0 ? 0 : (i - 1 > Iclamp ? Iclamp : i - 1)) - c0;
+            const uint32_t bw = myread[bi >> 4];
             // rows of the previous column in the new band position: the three possible shifts, selected per row
             const int mR = row_shr1_i32(Mprev, NEGV), m1 = row_shl1_i32(Mprev, NEGV), m2 = row_shl2_i32(Mprev, NEGV);
             const int oR = row_shr1_i32_z(Oprev), o1 = row_shl1_i32_z(Oprev), o2 = row_shl2_i32_z(Oprev);
@@ -971,6 +1008,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int ox = s0 ? oR : (s1 ? Oprev : o1), oy = s0 ? Oprev : (s1 ? o1 : o2);
             const unsigned kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1)), ky = (unsigned)(s0 ? (int)Kprev : (s1 ? k1 : k2));
             const unsigned bitj = 1u << (j - ecol - 1);
+            const int rbv = (i >= 1 && i <= I) ? (int)((bw >> (2 * (bi & 15))) & 3u) : 4;
             const bool match = (vb == rbv);
             int best = x + (match ? SC_MATCH : SC_MISMATCH), org = ox;
             unsigned kd = match ? kx : (kx | bitj);
@@ -1001,7 +1039,8 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             Mprev = best; Oprev = org; Kprev = kd;
             if (need) {
                 ++kk;
-                next_need = (kk >= nneed) ? -1 : rfl(need_col(wb, nw, Ld, kk));
+                if (kk - kkb >= LANES) { kkb = kk; needv = need_col(wb, nw, Ld, (kkb + lane < nneed) ? kkb + lane : nneed - 1); }
+                next_need = (kk >= nneed) ? -1 : rl(needv, kk - kkb);
             }
         }
     }
@@ -2189,7 +2228,6 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
     if (hipFuncGetAttributes(&fa, (const void *)k_polish) != hipSuccess) return -1;
     const int static_bytes = (int)fa.sharedSizeBytes;
     if (hipFuncSetAttribute((const void *)k_polish, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES - static_bytes) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void *)k_align16, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4097 * 4 + 64) != hipSuccess) return -1;   // four 65 535-base passes
     if (max_reads > PW_MAXREADS) max_reads = PW_MAXREADS;
     if (max_reads < 1) max_reads = 1;
     *obs_bytes = ((max_reads * 68 * 2) + 15) & ~15;
@@ -2225,7 +2263,7 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* 
         // alignment cascade: four passes per wave in 16-row bands, then the 64-row retry of the few that failed there
         if (hipMemsetAsync(P.align_retry, 0, 64, st) != hipSuccess && !failed) failed = "hipMemsetAsync";
         {
-            const size_t lds16 = 4 * ((((size_t)P.maxL_max + 15) >> 4) + 1) * sizeof(uint32_t);
+            const size_t lds16 = 4 * (CH16 / 16 + 2) * sizeof(uint32_t);
             for (int qb = 0; qb < P.n_quads; qb += P.align_slots) {
                 const int nb = (P.n_quads - qb) < P.align_slots ? (P.n_quads - qb) : P.align_slots;
                 hipLaunchKernelGGL(k_align16, dim3(nb), dim3(64), lds16, st, P, qb, pass);
