@@ -1000,13 +1000,19 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int bi = (i - 1 < 0 ? 0 : (i - 1 > Iclamp ? Iclamp : i - 1)) - c0;
             const uint32_t bw = myread[bi >> 4];
             // rows of the previous column in the new band position: the three possible shifts, selected per row
-            const int mR = row_shr1_i32(Mprev, NEGV), m1 = row_shl1_i32(Mprev, NEGV), m2 = row_shl2_i32(Mprev, NEGV);
-            const int oR = row_shr1_i32_z(Oprev), o1 = row_shl1_i32_z(Oprev), o2 = row_shl2_i32_z(Oprev);
-            const int kR = row_shr1_i32_z((int)Kprev), k1 = row_shl1_i32_z((int)Kprev), k2 = row_shl2_i32_z((int)Kprev);
-            const bool s0 = sh == 0, s1 = sh == 1;
-            const int x = s0 ? mR : (s1 ? Mprev : m1), y = s0 ? Mprev : (s1 ? m1 : m2);
-            const int ox = s0 ? oR : (s1 ? Oprev : o1), oy = s0 ? Oprev : (s1 ? o1 : o2);
-            const unsigned kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1)), ky = (unsigned)(s0 ? (int)Kprev : (s1 ? k1 : k2));
+            const int m1 = row_shl1_i32(Mprev, NEGV), o1 = row_shl1_i32_z(Oprev), k1 = row_shl1_i32_z((int)Kprev);
+            int x, y, ox, oy; unsigned kx, ky;
+            if (__all(sh == 1)) {                         // every band moves down by one row (the common column): no selects
+                x = Mprev; y = m1; ox = Oprev; oy = o1; kx = Kprev; ky = (unsigned)k1;
+            } else {
+                const int mR = row_shr1_i32(Mprev, NEGV), m2 = row_shl2_i32(Mprev, NEGV);
+                const int oR = row_shr1_i32_z(Oprev), o2 = row_shl2_i32_z(Oprev);
+                const int kR = row_shr1_i32_z((int)Kprev), k2 = row_shl2_i32_z((int)Kprev);
+                const bool s0 = sh == 0, s1 = sh == 1;
+                x = s0 ? mR : (s1 ? Mprev : m1); y = s0 ? Mprev : (s1 ? m1 : m2);
+                ox = s0 ? oR : (s1 ? Oprev : o1); oy = s0 ? Oprev : (s1 ? o1 : o2);
+                kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1)); ky = (unsigned)(s0 ? (int)Kprev : (s1 ? k1 : k2));
+            }
             const unsigned bitj = 1u << (j - ecol - 1);
             const int rbv = (i >= 1 && i <= I) ? (int)((bw >> (2 * (bi & 15))) & 3u) : 4;
             const bool match = (vb == rbv);
