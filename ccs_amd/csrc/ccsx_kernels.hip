@@ -917,6 +917,7 @@ __device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t 
 // (bit-identical consensus on the test sets); a pass that is not valid here goes on a list for the 64-row retry (k_align), and
 // from there to the split alignment.  Same cell recurrence, origin / dirty tracking and edge saves as align_pass.
 #define AB16 16
+#define AB16_ABOVE 6
 __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
 {
     const int lane = threadIdx.x, h = lane >> 4, l = lane & 15, rowb = lane & 48;
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int j = jb + jj + 1;
             const int plo = lo;
             {   // band_lo with 16 rows, per row
-                int t = br + 1 - AB16 / 2;
+                int t = br + 1 - AB16_ABOVE;              // 6 rows above the best row, 9 below: insertion bursts push the path down
                 t = t > plo ? t : plo;
                 t = t < plo + 2 ? t : plo + 2;
                 t = t < hiI ? t : hiI;
