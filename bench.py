@@ -9,13 +9,18 @@ path (weak scaling: per-GPU batch fixed).
 
 Timed region: from the first submit to the last result of K steps through the library's asynchronous
 boundary (ccsx_submit / ccsx_wait): batches start in page-locked HOST memory, go H2D, through every kernel, and their
-results come back D2H into page-locked host memory; up to three batches are in flight, so the copies of batch k+1 / k-1
-run under the kernels of batch k.  `value` is that PCIe-inclusive rate.  `resident_zmws_per_s` is the same work counted
-over the kernels alone (HIP events on the compute stream): the rate with inputs already in HBM.
+results come back D2H into page-locked host memory; up to three batches are in flight, so the copies of batch k+1 / k-1 and
+the draft stage of batch k+1 run under the polish stage of batch k (two compute streams; `--serial-stages` = one).  `value`
+is that PCIe-inclusive rate.  `resident_zmws_per_s` is the same work counted over the kernels alone (HIP events: first kernel
+of the first timed batch to the last kernel of the last): the rate with inputs already in HBM.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, its duration measured live with HIP events on the
-stream it is launched on (ccsx_ticket_timings); `cpu_baseline` times the CPU restatement (oracle, kind "port") on the host
-cores over a bounded sample of the same workload, and the reference `ccs` binary is probed for (command -v ccs).
+stream it is launched on (ccsx_ticket_timings); with `--pmc` (run under `rocprofv3 --pmc ...`) nothing but the headline steps
+runs, so a counter pass profiles exactly this workload and `tools/mk_traffic.py` turns the passes into profiles/rNN_traffic.json,
+whose `head` field ties it to a commit; `cpu_baseline` times the CPU restatement (oracle, kind "port") on the host cores over a
+bounded sample of the same workload, and the reference `ccs` binary is probed for (command -v ccs) and, when present, RUN on
+the same synthetic subreads (timing + identity against the truth: `reference_ccs`).  `extra` carries the other BASELINE shapes
+(c1 / c4 / c5) through the same pipeline, a few steps each.
 """
 from __future__ import annotations
 
@@ -23,12 +28,16 @@ import argparse
 import json
 import os
 import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+TRAFFIC_FILE = "r03_traffic.json"       # this round's committed PMC passes (tools/prof_round.sh -> tools/mk_traffic.py)
 
 
 def effective_cores() -> int:
@@ -62,13 +71,136 @@ def host_memory_budget() -> int:
     return max(0, avail // 2)
 
 
-# BASELINE.json configs (SURVEY.md §8 sizes): (passes, template length, ZMWs per GPU per step in the default run)
-WORKLOADS = {"c1": (3, 1000, 65536), "c2": (10, 10000, 8192), "c4": (30, 20000, 1024), "c5": ((3, 50), (1000, 25000), 4096)}
+def git_head() -> str | None:
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+# BASELINE.json configs (SURVEY.md §8 sizes): (passes, template length, ZMWs per GPU per step in the default run).  Every preset keeps
+# 8192 POA graphs resident where memory allows (one wave per graph: fewer leave SIMDs idle in the draft stage);
+# `fit_zmws` halves the batch until its page-locked copies fit the host.
+WORKLOADS = {"c1": (3, 1000, 65536), "c2": (10, 10000, 8192), "c4": (30, 20000, 8192), "c5": ((3, 50), (1000, 25000), 8192)}
 
 
 def _span(v):
     a = [int(x) for x in str(v).split("-")]
     return a[0] if len(a) == 1 else (a[0], a[1])
+
+
+def _mean(v):
+    return (v[0] + v[1]) / 2 if isinstance(v, tuple) else v
+
+
+def fit_zmws(zmws, passes, length, world, min_batches=2):
+    """largest batch (halving from `zmws`) of which `min_batches` page-locked copies (bases + pw + ipd + results) fit the host budget"""
+    per_zmw = 4.6 * _mean(passes) * _mean(length) * 1.02
+    budget = host_memory_budget()
+    while zmws > 256 and per_zmw * zmws * min_batches * world > budget:
+        zmws //= 2
+    return zmws
+
+
+class Job:
+    """one workload through the asynchronous boundary on this rank's GPU"""
+
+    def __init__(self, api, np, rank, world, local_rank, zmws, passes, length, distinct, steps, warmup, depth, opts, keep_sample=0):
+        self.api, self.np, self.zmws, self.depth = api, np, zmws, depth
+        t0 = time.time()
+        first = api.synth(zmws, passes, length, seed=0xC0FFEE, first_zmw_id=rank * zmws)
+        batch_bytes = 4 * first.bases.nbytes                 # bases + pw + ipd page-locked, plus slack for the result buffers
+        self.nb = max(1, min(distinct, steps + warmup, host_memory_budget() // max(1, batch_bytes * world)))
+        self.alg_bytes = first.algorithmic_bytes()           # SURVEY.md §8(d): 3*sum(len) + 48 + 2*L_out per ZMW
+        self.sample0 = first.slice(0, min(zmws, keep_sample)) if keep_sample else None   # CPU baseline sample (pageable copy)
+        self.batches = [first.pinned()]
+        del first
+        for i in range(1, self.nb):
+            b = api.synth(zmws, passes, length, seed=0xC0FFEE, first_zmw_id=(i * world + rank) * zmws)
+            self.batches.append(b.pinned())
+            del b
+        self.gen_s = time.time() - t0
+        self.h = api.Handle(local_rank, opts=opts)
+        kin = bool(opts.hifi_kinetics)
+
+        def layout_cap(b):
+            cb = b.c_struct()
+            return int(api.lib().ccsx_result_layout(api.C.byref(cb), api._ptr(np.zeros(b.n_zmw + 1, np.int64), api.C.c_int64)))
+        big = max(self.batches, key=layout_cap)
+        # the optional float QVs (raw_qv) are not requested in the pipelined job: the HiFi record needs seq + qual + rq/ec/np/status
+        self.results = [api.Results.allocate(big, kinetics=kin, pinned=True, raw=False) for _ in range(depth)]
+
+    def run(self, nsteps, collect):
+        """nsteps batches through the asynchronous boundary, `depth` in flight; returns (elapsed, per-ticket timings, stats)"""
+        h, depth, nb = self.h, self.depth, self.nb
+        tick, kt, ok, rqsum, rqn, checks = [], [], 0, 0.0, 0, 0
+        t_start = time.perf_counter()
+        for k in range(nsteps + depth):
+            if k >= depth:                                   # retire the oldest batch before its slot / result buffer is reused
+                t_old = tick[k - depth]
+                r = h.wait(t_old)
+                n = self.batches[(k - depth) % nb].n_zmw
+                good = r.status[:n] == 0
+                ok += int(good.sum()); rqsum += float(r.rq[:n][good].sum()); rqn += int(good.sum())
+                checks += int(r.seq_len[:n].sum())
+                if collect:
+                    kt.append(h.ticket_timings(t_old))
+                h.release(t_old)
+            if k < nsteps:
+                b = self.batches[k % nb]
+                res = self.results[k % depth]
+                if b.n_zmw != len(res.status):
+                    raise RuntimeError("batches must have equal ZMW counts")
+                tick.append(h.submit(b, res))
+        return time.perf_counter() - t_start, kt, (ok, rqsum, rqn, checks)
+
+    def close(self):
+        self.h.close()
+        self.batches, self.results = [], []
+
+
+STAGES = ("setup_ms", "draft_ms", "align_ms", "queue_ms", "polish_ms", "stitch_ms", "total_ms")
+
+
+def stage_means(np, kt):
+    return {k: float(np.mean([getattr(t, k) for t in kt])) for k in STAGES}
+
+
+def kernels_span_ms(kt):
+    """device time from the first kernel of the first timed batch to the last kernel of the last one (HIP events)"""
+    return max(t.end_ms for t in kt) - min(t.start_ms for t in kt)
+
+
+def reference_concordance(api, np, ccs_bin, sample, cores, seconds):
+    """the reference tool, when the box has it (bioconda pbccs), is RUN on the same synthetic subreads — written as
+    a PacBio subreads.bam by this repo's driver — and timed; its HiFi reads are compared with the truth templates and with this
+    library's reads.  Nothing here is exercised without `ccs` on PATH; it is the one code path that can pin parity."""
+    out = {"found": True, "path": ccs_bin}
+    try:
+        import bam_util
+        ours = os.path.join(ROOT, "ccs_amd", "bin", "ccs")
+        n = sample.n_zmw
+        with tempfile.TemporaryDirectory() as td:
+            sub, ref_out, our_out = os.path.join(td, "s.subreads.bam"), os.path.join(td, "ref.bam"), os.path.join(td, "ours.bam")
+            passes = int(np.diff(sample.read_off)[0]); length = int(np.diff(sample.tpl_off)[0])
+            subprocess.run([ours, "--write-synthetic", f"{n},{passes},{length},{0xC0FFEE}", sub], check=True, timeout=600)
+            out["version"] = subprocess.run([ccs_bin, "--version"], capture_output=True, text=True, timeout=60).stdout.strip()[:80]
+            t0 = time.perf_counter()
+            r = subprocess.run([ccs_bin, sub, ref_out, "-j", str(cores), "--min-rq", "0.99"], capture_output=True, text=True, timeout=max(600, 40 * seconds))
+            dt = time.perf_counter() - t0
+            out.update({"rc": r.returncode, "wall_s": round(dt, 2), "zmws": n, "zmws_per_s": round(n / dt, 3), "cores": cores,
+                        "stderr_tail": r.stderr[-300:]})
+            if r.returncode == 0:
+                subprocess.run([ours, sub, our_out], check=True, timeout=600)
+                ref_reads = {x["tags"]["zm"]: x["seq"] for x in bam_util.read_bam(ref_out)[1]}
+                our_reads = {x["tags"]["zm"]: x["seq"] for x in bam_util.read_bam(our_out)[1]}
+                both = sorted(set(ref_reads) & set(our_reads))
+                same = sum(1 for z in both if len(ref_reads[z]) == len(our_reads[z]) and np.array_equal(ref_reads[z], our_reads[z]))
+                out.update({"hifi_reads_reference": len(ref_reads), "hifi_reads_ours": len(our_reads), "zmws_in_both": len(both),
+                            "identical_sequences": same})
+    except Exception as e:                                   # the concordance leg must never take the benchmark down
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
 
 
 def main():
@@ -86,14 +218,21 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL; gloo for CPU-side tests)")
     ap.add_argument("--hifi-kinetics", action="store_true", help="also run the N4 kinetics kernel (not part of the headline metric)")
     ap.add_argument("--disable-heuristics", action="store_true", help="polish every position (no candidate filter): A/B for the filter's cost")
+    ap.add_argument("--serial-stages", action="store_true", help="draft and polish stage on ONE compute stream (A/B for the two-stage queue)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--extra", default="c1,c4,c5", help="other BASELINE shapes reported under `extra` (N=1 only; '' = none)")
+    ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--pmc", action="store_true", help="counter-pass mode (under rocprofv3 --pmc): only the headline steps, no CPU baseline, no extras")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     args.passes = wl[0] if args.passes is None else args.passes
     args.length = wl[1] if args.length is None else args.length
+    explicit_zmws = args.zmws > 0
     args.zmws = wl[2] if args.zmws <= 0 else args.zmws
     args.depth = max(1, min(3, args.depth))
+    if args.pmc:
+        args.no_cpu_baseline, args.extra = True, ""
 
     import numpy as np
     import torch
@@ -112,108 +251,76 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(local_rank)
+    if not explicit_zmws:
+        args.zmws = fit_zmws(args.zmws, args.passes, args.length, world)
 
     import __graft_entry__ as graft
     if not os.path.exists(graft.LIB):
         graft.build()
     from ccs_amd import api
 
-    # ---- synthetic shards of this rank: distinct batches with distinct ZMW ids (deterministic), in page-locked memory
-    t0 = time.time()
-    first = api.synth(args.zmws, args.passes, args.length, seed=0xC0FFEE, first_zmw_id=rank * args.zmws)
-    batch_bytes = 4 * first.bases.nbytes                     # bases + pw + ipd page-locked, plus slack for the result buffers
-    nb = max(1, min(args.distinct, args.steps + args.warmup, host_memory_budget() // max(1, batch_bytes * world)))
-    alg_bytes = first.algorithmic_bytes()                   # 3*sum(len) + 48 + 2*L_out per ZMW
-    sample0 = first.slice(0, min(args.zmws, 4096))          # CPU baseline sample (pageable copy)
-    batches = [first.pinned()]
-    del first
-    for i in range(1, nb):
-        b = api.synth(args.zmws, args.passes, args.length, seed=0xC0FFEE, first_zmw_id=(i * world + rank) * args.zmws)
-        batches.append(b.pinned())
-        del b
-    gen_s = time.time() - t0
-    opts = api.default_opts()
-    opts.hifi_kinetics = 1 if args.hifi_kinetics else 0
-    opts.disable_heuristics = 1 if args.disable_heuristics else 0
-    h = api.Handle(local_rank, opts=opts)
-    kin = bool(args.hifi_kinetics)
-    # result buffers: one per batch in flight, page-locked, sized for the largest batch
-    def layout_cap(b):
-        cb = b.c_struct()
-        return int(api.lib().ccsx_result_layout(api.C.byref(cb), api._ptr(np.zeros(b.n_zmw + 1, np.int64), api.C.c_int64)))
-    big = max(batches, key=layout_cap)
-    # the optional float QVs (raw_qv) are not requested in the pipelined job: the HiFi record needs seq + qual + rq/ec/np/status
-    results = [api.Results.allocate(big, kinetics=kin, pinned=True, raw=False) for _ in range(args.depth)]
+    def make_opts():
+        o = api.default_opts()
+        o.hifi_kinetics = 1 if args.hifi_kinetics else 0
+        o.disable_heuristics = 1 if args.disable_heuristics else 0
+        o.serial_stages = 1 if args.serial_stages else 0
+        return o
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_job(nsteps, collect):
-        """nsteps batches through the asynchronous boundary, `depth` in flight; returns (elapsed, per-ticket timings, stats)"""
-        tick = []
-        kt, ok, rqsum, rqn, checks = [], 0, 0.0, 0, 0
-        t_start = time.perf_counter()
-        for k in range(nsteps + args.depth):
-            if k >= args.depth:                              # retire the oldest batch before its slot / result buffer is reused
-                t_old = tick[k - args.depth]
-                r = h.wait(t_old)
-                n = batches[(k - args.depth) % nb].n_zmw
-                good = r.status[:n] == 0
-                ok += int(good.sum()); rqsum += float(r.rq[:n][good].sum()); rqn += int(good.sum())
-                checks += int(r.seq_len[:n].sum())
-                if collect:
-                    kt.append(h.ticket_timings(t_old))
-                h.release(t_old)
-            if k < nsteps:
-                b = batches[k % nb]
-                res = results[k % args.depth]
-                res_view = res if b.n_zmw == len(res.status) else None
-                if res_view is None:                         # ragged last batch cannot happen here (equal sizes); guard anyway
-                    raise RuntimeError("batches must have equal ZMW counts")
-                tick.append(h.submit(b, res))
-        return time.perf_counter() - t_start, kt, (ok, rqsum, rqn, checks)
-
+    # ---- the headline job: synthetic shards of this rank, distinct batches with distinct ZMW ids (deterministic), page-locked
+    job = Job(api, np, rank, world, local_rank, args.zmws, args.passes, args.length, args.distinct, args.steps, args.warmup, args.depth,
+              make_opts(), keep_sample=4096)
+    h = job.h
     t0 = time.time()
-    run_job(max(1, args.warmup), False)                      # untimed: every hipMalloc of the engine happens here
+    job.run(max(1, args.warmup), False)                      # untimed: every hipMalloc of the engine happens here
     warm_s = time.time() - t0
     barrier()
-    elapsed, kt, (ok, rqsum, rqn, checks) = run_job(args.steps, True)
+    elapsed, kt, (ok, rqsum, rqn, checks) = job.run(args.steps, True)
     barrier()
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # un-overlapped copy times of one batch (context for the pipeline: what the copies would cost in the open)
-    t0 = time.time(); h.upload(batches[0]); h.sync(); upload_s = time.time() - t0
-    h.run(); h.sync()
-    res0 = h.download()                                      # also the GPU side of the CPU-baseline comparison
+    res0, upload_s = None, None
+    if not args.pmc:
+        # un-overlapped copy times of one batch (context for the pipeline: what the copies would cost in the open)
+        t0 = time.time(); h.upload(job.batches[0]); h.sync(); upload_s = time.time() - t0
+        h.run(); h.sync()
+        res0 = h.download()                                  # also the GPU side of the CPU-baseline comparison
 
     if rank == 0:
         total_zmws = args.zmws * world * args.steps
         value = total_zmws / elapsed
-        stage_ms = {k: float(np.mean([getattr(t, k) for t in kt])) for k in
-                    ("setup_ms", "draft_ms", "align_ms", "polish_ms", "stitch_ms", "total_ms")}
-        names = {"draft_ms": "k_poa", "align_ms": "k_align", "polish_ms": "k_polish", "stitch_ms": "k_stitch", "setup_ms": "k_setup"}
+        stage_ms = stage_means(np, kt)
+        span_ms = kernels_span_ms(kt)
+        names = {"draft_ms": "k_poa", "align_ms": "k_align16", "polish_ms": "k_polish", "stitch_ms": "k_stitch", "setup_ms": "k_setup"}
         dom = max(names, key=lambda k: stage_ms[k])
+        alg_bytes = job.alg_bytes
         # dominant kernel: algorithmic bytes of one batch / that kernel's average launch duration in the timed region
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-        # HBM traffic and VALU issue of that kernel from this round's committed rocprofv3 PMC passes of the same workload
-        # (profiles/r02_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 with the calibrated FETCH_SIZE = bytes/2, per ZMW)
-        traffic, valu = None, None
+        # HBM traffic / VALU issue / counted work of that kernel from this round's committed rocprofv3 PMC passes of the SAME command
+        # (`bench.py --pmc`; (2*FETCH_SIZE + WRITE_SIZE)*1024 with the calibrated FETCH_SIZE = bytes/2, per ZMW); the file names
+        # the commit it was measured at
+        traffic, valu, traffic_head = None, None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
             kz = tj["kernels"][names[dom]]
+            traffic_head = tj.get("head")
             if args.passes == 10 and args.length == 10000 and not args.hifi_kinetics and not args.disable_heuristics:
                 traffic = int(kz["hbm_bytes_per_zmw"] * args.zmws)
-                valu = {k: kz[k] for k in ("valu_wave_instr_per_zmw", "valu_issue_frac_if_2cyc", "valu_issue_frac_if_4cyc", "lanes_active_frac") if k in kz}
+                valu = {k: kz[k] for k in ("valu_wave_instr_per_zmw", "valu_issue_frac_if_2cyc", "valu_issue_frac_if_4cyc", "lanes_active_frac",
+                                           "valu_frac_of_calibrated_peak", "cell_updates_per_zmw") if k in kz}
                 valu["calibration"] = "profiles/r02_valu_peak.txt: v_add/mul_f32, v_add_u32 issue in 2 SIMD cycles per wave64, v_fma_f32, v_max_i32, DPP ops in 4"
         except Exception:
             traffic, valu = None, None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic else None,
+                    "traffic_source": f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of `bench.py --pmc`, measured at commit {traffic_head})" if traffic else None,
                     "avg_launch_ms": round(stage_ms[dom], 3), "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                     "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d); "
                             "the kernel is bound by VALU issue and dependent-chain latency (DESIGN.md 4)"}
@@ -224,25 +331,36 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.passes} passes x {args.length} bp synthetic subreads (BASELINE configs[{int(args.workload[1]) - 1}] shape), "
-                                   f"{args.zmws} ZMWs per GPU per step, {nb} distinct batches, host-pinned -> H2D -> kernels -> D2H, {args.depth} batches in flight",
-                       "preset": args.workload, "zmws_per_gpu": args.zmws, "distinct_batches": nb, "in_flight": args.depth, "passes": args.passes,
+                                   f"{args.zmws} ZMWs per GPU per step, {job.nb} distinct batches, host-pinned -> H2D -> kernels -> D2H, {args.depth} batches in flight",
+                       "preset": args.workload, "zmws_per_gpu": args.zmws, "distinct_batches": job.nb, "in_flight": args.depth, "passes": args.passes,
                        "template_len": args.length, "parallelism": f"zmw-shard x{world}", "model": "SYN-1",
-                       "hifi_kinetics": kin, "candidate_filter": not args.disable_heuristics},
+                       "hifi_kinetics": bool(args.hifi_kinetics), "candidate_filter": not args.disable_heuristics,
+                       "stages": "serial (one compute stream)" if args.serial_stages else "draft stage of batch k+1 under the polish stage of batch k (two compute streams)",
+                       "spec_version": int(api.lib().ccsx_spec_version())},
             "timed_region": "first ccsx_submit to last ccsx_wait: pinned host -> H2D -> kernels -> D2H (PCIe-inclusive); downloaded per ZMW: status, sequence, phred QVs, rq, ec, np, fn/rn, iterations (the optional float QVs are not requested)",
-            "resident_zmws_per_s": round(args.zmws * world / (stage_ms["total_ms"] * 1e-3), 2),
+            "resident_zmws_per_s": round(args.zmws * args.steps / (span_ms * 1e-3), 2),
+            "kernels_ms_per_step": round(span_ms / args.steps, 3),
             "roofline": roofline,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "stage_ms_note": "per batch, HIP events on the stream of each stage; with two compute streams the stages of consecutive batches overlap, "
+                             "so ms_per_step < draft + align + polish + stitch; queue_ms = the batch waiting between the stages",
             "success_frac": ok / (args.zmws * args.steps), "mean_rq": rqsum / rqn if rqn else None, "consensus_bases": checks,
-            "host": {"synth_s": round(gen_s, 2), "warmup_s": round(warm_s, 2), "unoverlapped_upload_s": round(upload_s, 3),
-                     "copies_hidden_frac": round(min(1.0, stage_ms["total_ms"] * 1e-3 / (elapsed / args.steps)), 4)},
+            "host": {"synth_s": round(job.gen_s, 2), "warmup_s": round(warm_s, 2), "unoverlapped_upload_s": round(upload_s, 3) if upload_s else None,
+                     "copies_hidden_frac": round(min(1.0, span_ms * 1e-3 / elapsed), 4)},
+            "head": git_head(),
         }
-        # the reference tool, if the box has it (expected absent; bioconda pbccs)
+        cores = effective_cores()
+        # the reference tool, if the box has it (expected absent; bioconda pbccs): probed, and run when found
         ccs_bin = shutil.which("ccs")
-        out["reference_ccs"] = {"found": bool(ccs_bin), "path": ccs_bin,
-                                "note": "command -v ccs on this box; not timed" if not ccs_bin else "present: see DESIGN.md for the concordance run"}
+        if ccs_bin and os.path.realpath(ccs_bin) == os.path.realpath(os.path.join(ROOT, "ccs_amd", "bin", "ccs")):
+            ccs_bin = None                                   # this repo's own driver is not the reference
+        if ccs_bin and not args.pmc and c2:
+            out["reference_ccs"] = reference_concordance(api, np, ccs_bin, job.sample0.slice(0, min(job.sample0.n_zmw, 4 * cores)), cores, args.cpu_seconds)
+        else:
+            out["reference_ccs"] = {"found": bool(ccs_bin), "path": ccs_bin, "note": "command -v ccs on this box: absent, nothing to run" if not ccs_bin else "present; concordance runs with the default c2 workload"}
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             import oracle_lib
-            cores = effective_cores()
+            sample0 = job.sample0
             probe = sample0.slice(0, 1)
             pr = api.Results.allocate(probe)
             t1 = time.perf_counter()
@@ -257,16 +375,44 @@ def main():
             t2 = time.perf_counter() - t2
             same = all(np.array_equal(sr.sequence(z), res0.sequence(z)) for z in range(n_s))
             qv_max = max((float(np.max(np.abs(sr.raw(z) - res0.raw(z)))) if len(sr.raw(z)) else 0.0) for z in range(n_s)) if same else None
+            core_s = t2 * cores / n_s
             out["cpu_baseline"] = {"value": round(n_s / t2, 3), "unit": "ZMWs/s", "cores": cores, "kind": "port",
                                    "sample": f"first {n_s} ZMWs of batch 0, oracle/ccs_oracle.c with OpenMP over ZMWs "
                                              f"({t2:.1f} s wall; single-thread probe {t1:.2f} s/ZMW); reference ccs binary "
                                              f"{'found at ' + ccs_bin if ccs_bin else 'not on PATH (probed)'}",
                                    "gpu_matches_cpu_sequences": bool(same), "max_abs_qv_diff": qv_max,
-                                   "context": "the port does ~0.2 core-s per ZMW; docs/img/runtime.png shows ~1 core-s for ccs 4.2 at 10 kb x 7 passes, so this "
-                                              "ratio is not a statement about ccs (PacBio's own GPU claim: 10x over 128 cores, docs/faq/revio.md:23-25)"}
+                                   "core_seconds_per_zmw": round(core_s, 4),
+                                   "context": f"this SPEC's port costs {core_s:.3f} core-s per ZMW here; docs/img/runtime.png shows ~1 core-s for ccs 4.2 at "
+                                              "10 kb x 7 passes, i.e. the port does far less CPU work per ZMW than ccs, so the GPU/CPU ratio is not a "
+                                              "statement about ccs (PacBio's own GPU claim: 10x over 128 cores, docs/faq/revio.md:23-25)"}
             out["speedup_vs_cpu_all_cores"] = round(value / (n_s / t2), 2)
+        job.close()
+        # ---- the other BASELINE shapes through the same pipeline (N=1 only; a few steps each)
+        if world == 1 and args.extra:
+            extra = {}
+            for name in [x for x in args.extra.split(",") if x and x != args.workload]:
+                try:
+                    p_, l_, z_ = WORKLOADS[name]
+                    z_ = fit_zmws(z_, p_, l_, 1)
+                    j2 = Job(api, np, 0, 1, local_rank, z_, p_, l_, 2, args.extra_steps, 1, args.depth, make_opts())
+                    j2.run(1, False)
+                    torch.cuda.synchronize()
+                    el, kt2, (ok2, rs2, rn2, _) = j2.run(args.extra_steps, True)
+                    sm = stage_means(np, kt2)
+                    extra[name] = {"workload": f"{p_} passes x {l_} bp", "zmws_per_step": z_, "steps": args.extra_steps,
+                                   "value": round(z_ * args.extra_steps / el, 2), "unit": "ZMWs/s",
+                                   "resident_zmws_per_s": round(z_ * args.extra_steps / (kernels_span_ms(kt2) * 1e-3), 2),
+                                   "stage_ms": {k: round(v, 3) for k, v in sm.items()},
+                                   "success_frac": round(ok2 / (z_ * args.extra_steps), 4), "mean_rq": rs2 / rn2 if rn2 else None,
+                                   "algorithmic_bytes_per_launch": j2.alg_bytes}
+                    j2.close()
+                    del j2
+                except Exception as e:
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
-    h.close()
+    else:
+        job.close()
     if dist is not None:
         dist.destroy_process_group()
 

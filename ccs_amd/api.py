@@ -41,7 +41,7 @@ class Opts(C.Structure):
     _fields_ = [
         ("max_poa_cov", C.c_int32), ("min_passes", C.c_int32), ("top_passes", C.c_int32),
         ("min_length", C.c_int32), ("max_length", C.c_int32), ("min_rq", C.c_float),
-        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("disable_heuristics", C.c_int32), ("min_zscore", C.c_float), ("handles_per_device", C.c_int32), ("no_fallback_draft", C.c_int32), ("max_insertion_size", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("disable_heuristics", C.c_int32), ("min_zscore", C.c_float), ("handles_per_device", C.c_int32), ("no_fallback_draft", C.c_int32), ("max_insertion_size", C.c_int32), ("serial_stages", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -71,6 +71,7 @@ class Timings(C.Structure):
     _fields_ = [
         ("setup_ms", C.c_float), ("draft_ms", C.c_float), ("align_ms", C.c_float), ("polish_ms", C.c_float),
         ("stitch_ms", C.c_float), ("total_ms", C.c_float), ("polish_workgroups", C.c_int64),
+        ("queue_ms", C.c_float), ("reserved_", C.c_float), ("start_ms", C.c_double), ("end_ms", C.c_double),
     ]
 
 
@@ -80,7 +81,7 @@ class CSynth(C.Structure):
 
 # every symbol include/ccsx.h declares (tests/test_abi.py checks the library exports all of them)
 EXPORTS = [
-    "ccsx_abi_version", "ccsx_last_error", "ccsx_device_count", "ccsx_model_default", "ccsx_opts_default",
+    "ccsx_abi_version", "ccsx_spec_version", "ccsx_last_error", "ccsx_device_count", "ccsx_model_default", "ccsx_opts_default",
     "ccsx_create", "ccsx_destroy", "ccsx_result_layout", "ccsx_consensus_batch", "ccsx_upload", "ccsx_run",
     "ccsx_sync", "ccsx_download", "ccsx_get_timings", "ccsx_stage_draft", "ccsx_stage_align",
     "ccsx_stage_windows", "ccsx_synth_generate", "ccsx_synth_free", "ccsx_alloc_pinned", "ccsx_free_pinned",

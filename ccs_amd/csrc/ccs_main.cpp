@@ -534,15 +534,22 @@ int main(int argc, char **argv)
         std::string err_msg;
         auto fail = [&](const std::string &m) { std::lock_guard<std::mutex> l(err_m); if (!failed.exchange(1)) err_msg = m; };
 
-        // ---- IN.bam.pbi: random access for --chunk, and the number of ZMWs ahead for the progress line
+        // ---- IN.bam.pbi: random access for --chunk, and the number of ZMWs ahead for the progress line.  --chunk i/N with N > 1
+        // REQUIRES the index (docs/faq/parallelize.md:9-13): every job of a sharded run must partition the ZMWs the same way, so a
+        // missing, unreadable or stale index is fatal instead of a silent switch to another scheme
         bool have_pbi = false, chunk_done = false;
         int64_t chunk_zmws = 0, total_zmws = -1;
         int pbi_first_hole = -1;                              // the ZMW the index promises at the seek target (a stale index is an error)
+        int pbi_next_hole = -1;                               // ... and right after the chunk's last record (-1: the chunk ends the file)
+        int64_t pbi_chunk_records = -1, seen_records = 0;     // records the index counts inside the chunk
         {
             PbiIndex pbi;
             bool ok = false;
+            std::string why = "not found";
             try { ok = read_pbi(opt.in + ".pbi", pool, pbi); }
-            catch (const std::exception &e) { std::fprintf(stderr, "ccs: warning: ignoring %s.pbi: %s\n", opt.in.c_str(), e.what()); }
+            catch (const std::exception &e) { why = e.what(); if (opt.chunk_n <= 1) std::fprintf(stderr, "ccs: warning: ignoring %s.pbi: %s\n", opt.in.c_str(), e.what()); }
+            if (opt.chunk_n > 1 && !(ok && pbi.size() > 0))
+                throw std::runtime_error("--chunk needs a usable " + opt.in + ".pbi (" + why + "): generate the index first (docs/faq/parallelize.md:9-13)");
             if (ok && pbi.size() > 0) {
                 std::vector<size_t> first;                        // first record of every ZMW (consecutive records of one hole number)
                 for (size_t i = 0; i < pbi.size(); ++i) if (i == 0 || pbi.hole[i] != pbi.hole[i - 1]) first.push_back(i);
@@ -552,8 +559,12 @@ int main(int argc, char **argv)
                     const int64_t lo = (opt.chunk_i - 1) * Z / opt.chunk_n, hi = (int64_t)opt.chunk_i * Z / opt.chunk_n;
                     have_pbi = true; chunk_zmws = hi - lo; total_zmws = chunk_zmws;
                     if (chunk_zmws == 0) chunk_done = true;
-                    else { in.seek((uint64_t)pbi.file_offset[first[(size_t)lo]]); pbi_first_hole = pbi.hole[first[(size_t)lo]]; }
-                    if (opt.log_level >= 2) std::fprintf(stderr, "ccs: chunk %d/%d = ZMWs %" PRId64 "..%" PRId64 " of %" PRId64 " (%s.pbi)\n", opt.chunk_i, opt.chunk_n, lo, hi, Z, opt.in.c_str());
+                    else {
+                        in.seek((uint64_t)pbi.file_offset[first[(size_t)lo]]); pbi_first_hole = pbi.hole[first[(size_t)lo]];
+                        pbi_chunk_records = (int64_t)((hi < Z ? first[(size_t)hi] : pbi.size()) - first[(size_t)lo]);
+                        pbi_next_hole = hi < Z ? pbi.hole[first[(size_t)hi]] : -1;
+                    }
+                    std::fprintf(stderr, "ccs: chunk %d/%d = ZMWs %" PRId64 "..%" PRId64 " of %" PRId64 " by random access (%s.pbi)\n", opt.chunk_i, opt.chunk_n, lo, hi, Z, opt.in.c_str());
                 }
             }
         }
@@ -582,7 +593,7 @@ int main(int argc, char **argv)
                 if (!have) return;
                 // --chunk i/N: with IN.bam.pbi a contiguous range of ZMWs (the reader has seeked to its first record and stops after
                 // its last ZMW: docs/faq/parallelize.md:9-13); without an index round-robin over the ZMWs of the whole file
-                const bool mine = have_pbi ? (nz < chunk_zmws) : ((nz % opt.chunk_n) == (opt.chunk_i - 1));
+                const bool mine = have_pbi ? (nz < chunk_zmws) : true;
                 cur.order = nz++;
                 if (have_pbi && nz >= chunk_zmws) chunk_done = true;
                 if (mine) {
@@ -611,7 +622,16 @@ int main(int argc, char **argv)
                         pbi_first_hole = -1;
                     }
                     if (movie.empty()) movie = movie_of(rec.name);
-                    if (!have || rec.zm != cur.zm) { flush_zmw(); cur.zm = rec.zm; have = true; }
+                    if (chunk_done) break;                           // records of the next chunk that shared the last inflated run
+                    if (!have || rec.zm != cur.zm) {
+                        flush_zmw(); cur.zm = rec.zm; have = true;
+                        if (chunk_done) {                            // the chunk's last ZMW has just ended: the index must agree on where
+                            if (seen_records != pbi_chunk_records || rec.zm != pbi_next_hole)
+                                throw std::runtime_error(opt.in + ".pbi does not match the BAM (record count / next ZMW of the chunk differ: stale index?)");
+                            break;
+                        }
+                    }
+                    ++seen_records;
                     if (rec.has_snr) std::memcpy(cur.snr, rec.snr, 16);
                     cur.reads.push_back(std::move(rec));
                 }
@@ -633,7 +653,11 @@ int main(int argc, char **argv)
                 }
                 if (!more) break;
             }
-            if (!chunk_done) flush_zmw();                          // (a finished chunk ends inside the next chunk's first ZMW)
+            if (!chunk_done) {                                     // (a finished chunk ends inside the next chunk's first ZMW)
+                flush_zmw();
+                if (have_pbi && (seen_records != pbi_chunk_records || pbi_next_hole != -1 || !chunk_done))
+                    throw std::runtime_error(opt.in + ".pbi does not match the BAM (the file ends before the chunk does: stale index?)");
+            }
             if (!opt.dump && !batch->zmws.empty()) { batch->index = nb++; to_pack.push(batch); }
             } catch (const std::exception &e) { fail(std::string("reading ") + opt.in + ": " + e.what()); }
             to_pack.close();

@@ -1,11 +1,12 @@
 // ccsx_api.cpp — C ABI over the HIP kernels: handle lifecycle, HBM layout, the asynchronous batch pipeline.
 //
-// One handle = one GPU, three HIP streams (H2D, kernels, D2H) and CCSX_SLOTS batch slots.  A slot owns the device
-// copies of one batch (inputs, host-derived layout, per-ZMW state, outputs) and the page-locked host arrays its
-// asynchronous uploads read from; the large POA / alignment scratch is shared, because kernels of different batches
-// run back to back on the one compute stream.  ccsx_submit() enqueues upload -> kernels -> download of a batch and
-// returns; while batch k computes, batch k+1 uploads and batch k-1 downloads (submit/wait tickets,
-// double-buffered staging).  The synchronous entry points (upload / run / sync / download, consensus_batch) are the
+// One handle = one GPU, four HIP streams (H2D, draft stage, polish stage, D2H) and CCSX_SLOTS batch slots.  A slot owns
+// the device copies of one batch (inputs, host-derived layout, per-ZMW state, outputs) and the page-locked host arrays its
+// asynchronous uploads read from; the large POA / alignment scratch is shared: only the draft stage touches it, and the
+// draft stages of all batches run back to back on the draft stream.  ccsx_submit() enqueues upload -> draft stage ->
+// polish stage -> download of a batch and returns; while batch k is polished, batch k+1 uploads and is drafted / aligned
+// and batch k-1 downloads (submit/wait tickets, double-buffered staging; the two-stage queue of
+// docs/img/ccs-impl.png).  The synchronous entry points (upload / run / sync / download, consensus_batch) are the
 // same machinery on slot 0.  There is no CPU fallback: without a usable device every entry point fails with a
 // message (ccsx_last_error).
 #include <hip/hip_runtime.h>
@@ -41,12 +42,18 @@ struct DevBuf {
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        // the new block first: a failed growth leaves the old buffer (and every KParams that points into it) intact
         size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { ccsx_set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return -2; }
-        cap = want;
+        void *np_ = nullptr;
+        hipError_t e = hipMalloc(&np_, want);
+        if (e != hipSuccess && p) {                      // not enough room for both: give the old block back and try once more
+            (void)hipGetLastError();
+            (void)hipFree(p); p = nullptr; cap = 0;
+            e = hipMalloc(&np_, want);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); ccsx_set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return -2; }
+        if (p) (void)hipFree(p);
+        p = np_; cap = want;
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -96,7 +103,7 @@ struct Slot {
     PinVec<int32_t> read_zmw, vcap, dcap, wslot, zperm, rperm, wb_off, read_off, quads, qperm;
     PinVec<int64_t> seq_off, ent_off, base_off;
     KParams P;
-    hipEvent_t ev[6] = {}, ev_up = nullptr, ev_done = nullptr;
+    hipEvent_t ev[7] = {}, ev_up = nullptr, ev_done = nullptr;   // ev[0..5]: stage boundaries, ev[6]: start of the polish stage
     bool staged = false, ran = false, inflight = false;
     ccsx_results *res = nullptr;      // destination of an in-flight submit
     int64_t ticket = -1;
@@ -126,7 +133,9 @@ std::mutex g_scratch_mutex;
 
 struct ccsx_handle_s {
     int device = 0;
-    hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+    hipStream_t s_in = nullptr, s_draft = nullptr, s_comp = nullptr, s_out = nullptr;   // s_comp: polish stage (and the synchronous calls' copies)
+    hipEvent_t ev_epoch = nullptr;    // recorded at creation: origin of ccsx_timings.start_ms / end_ms
+    bool poisoned = false;            // a submit failed after work was enqueued: the handle refuses further batches
     ccsx_model model;
     ccsx_opts opts;
     DevBuf d_model, d_poa, d_align;   // shared by all slots
@@ -141,11 +150,14 @@ static void destroy_handle(ccsx_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
+    if (h->s_draft) (void)hipStreamSynchronize(h->s_draft);
     if (h->s_comp) (void)hipStreamSynchronize(h->s_comp);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
     for (auto &s : h->slot) s.release();
+    if (h->ev_epoch) (void)hipEventDestroy(h->ev_epoch);
     h->d_model.release(); h->d_poa.release(); h->d_align.release();
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_draft && h->s_draft != h->s_comp) (void)hipStreamDestroy(h->s_draft);
     if (h->s_comp) (void)hipStreamDestroy(h->s_comp);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     delete h;
@@ -177,7 +189,11 @@ static int create_impl(ccsx_handle h)
 {
     HIPTRY(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
     HIPTRY(hipStreamCreateWithFlags(&h->s_comp, hipStreamNonBlocking));
+    if (h->opts.serial_stages) h->s_draft = h->s_comp;
+    else HIPTRY(hipStreamCreateWithFlags(&h->s_draft, hipStreamNonBlocking));
     HIPTRY(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    HIPTRY(hipEventCreate(&h->ev_epoch));
+    HIPTRY(hipEventRecord(h->ev_epoch, h->s_comp));
     for (auto &s : h->slot) {
         for (auto &ev : s.ev) HIPTRY(hipEventCreate(&ev));
         HIPTRY(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
@@ -207,6 +223,7 @@ int ccsx_create(int device_ordinal, const ccsx_model *model, const ccsx_opts *op
     h->model = *model;
     h->opts = *opts;
     if (h->opts.max_poa_cov < 1) h->opts.max_poa_cov = 1;
+    if (const char *e = std::getenv("CCSX_SERIAL_STAGES")) h->opts.serial_stages = std::atoi(e) != 0;   // A/B switch without a rebuild
     h->handles_on_device = opts->handles_per_device > 1 ? opts->handles_per_device : 1;
     const int rc = create_impl(h);
     if (rc) { destroy_handle(h); return rc; }        // no leak on a failed create (streams, events, device memory)
@@ -369,10 +386,11 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         poa_slots = std::min(poa_slots, n);
         poa_slots = (int)std::min<size_t>((size_t)poa_slots, std::max<size_t>(1, (budget * 3 / 4) / S.poa_slot_bytes));
         align_slots = std::min(16384, std::max(R, 2));            // (the split alignment uses two slots per pass)
-        align_slots = (int)std::min<size_t>((size_t)align_slots, std::max<size_t>(1, (budget / 8) / (S.align_slot_i32 * 4)));
+        align_slots = (int)std::min<size_t>((size_t)align_slots, std::max<size_t>(2, (budget / 8) / (S.align_slot_i32 * 4)));
         const size_t need_align = (size_t)align_slots * S.align_slot_i32 * 4;
         if ((size_t)poa_slots * S.poa_slot_bytes > h->d_poa.cap || need_align > h->d_align.cap) {
-            HIPTRY(hipStreamSynchronize(h->s_comp));                 // kernels of an earlier batch may still use the old scratch
+            HIPTRY(hipStreamSynchronize(h->s_draft));                // kernels of an earlier batch may still use the old scratch
+            HIPTRY(hipStreamSynchronize(h->s_comp));
             for (int attempt = 0;; ++attempt) {                      // another process / handle may have taken the memory meanwhile
                 if (h->d_poa.reserve((size_t)poa_slots * S.poa_slot_bytes) == 0) break;
                 if (attempt >= 4 || poa_slots <= 1) return -2;
@@ -429,7 +447,8 @@ static int launch(ccsx_handle h, Slot &S)
     S.P.poa_scratch = (uint8_t *)h->d_poa.p; S.P.align_scratch = (int32_t *)h->d_align.p;
     if ((size_t)S.P.poa_slots * S.P.poa_slot_bytes > h->d_poa.cap) S.P.poa_slots = (int)std::max<size_t>(1, h->d_poa.cap / S.P.poa_slot_bytes);
     if ((size_t)S.P.align_slots * S.P.align_slot_i32 * 4 > h->d_align.cap) S.P.align_slots = (int)std::max<size_t>(1, h->d_align.cap / (S.P.align_slot_i32 * 4));
-    const char *failed = ccsx_launch_all(S.P, h->s_comp, S.ev);
+    if (!h->d_poa.p || !h->d_align.p) { ccsx_set_error("kernel launch refused: the POA / alignment scratch is not allocated (an earlier allocation failed)"); return -2; }
+    const char *failed = ccsx_launch_all(S.P, h->s_draft, h->s_comp, S.ev);
     if (failed) { ccsx_set_error(std::string("kernel launch failed: ") + failed); return -2; }
     S.ran = true;
     return 0;
@@ -476,24 +495,40 @@ static int enqueue_download(Slot &S, ccsx_results *res, hipStream_t s)
 int ccsx_submit(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, ccsx_ticket *ticket)
 {
     if (!h || !b || !res || !ticket) { ccsx_set_error("ccsx_submit: null argument"); return -1; }
+#ifdef CCSX_FAULT_INJECTION                                          // test builds only (tests/test_cli_bam.py builds its own copy of the library)
     if (const char *e = std::getenv("CCSX_TEST_FAIL_SUBMIT"))        // fault injection for the driver's error-path test
         if (std::atoll(e) == (long long)h->next_ticket) { ++h->next_ticket; ccsx_set_error("injected failure (CCSX_TEST_FAIL_SUBMIT)"); return -2; }
+#endif
+    if (h->poisoned) { ccsx_set_error("ccsx_submit: an earlier submit failed after work had been enqueued; destroy the handle"); return -2; }
     HIPTRY(hipSetDevice(h->device));
     Slot &S = h->slot[h->next_ticket % CCSX_SLOTS];
     if (S.inflight) {                                    // the slot's previous batch was never waited for: finish it first
         HIPTRY(hipEventSynchronize(S.ev_done));
         S.inflight = false;
     }
+    // A failure after the first enqueue must not leave copies or kernels running on a slot the next submit would rewrite
+    // (ADVICE r02): drain every stream, mark the slot unusable and refuse further batches on this handle.
+    auto fail = [&](int rc_) {
+        const std::string msg = ccsx_last_error();
+        (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->s_draft); (void)hipStreamSynchronize(h->s_comp); (void)hipStreamSynchronize(h->s_out);
+        (void)hipGetLastError();
+        S.staged = false; S.ran = false; S.inflight = false; S.ticket = -1;
+        h->poisoned = true;
+        ccsx_set_error(msg);
+        return rc_;
+    };
     int rc = stage(h, S, b, h->s_in);
-    if (rc) return rc;
-    if ((rc = check_results(S, res, S.P.out_kin != nullptr))) return rc;
-    HIPTRY(hipEventRecord(S.ev_up, h->s_in));
-    HIPTRY(hipStreamWaitEvent(h->s_comp, S.ev_up, 0));
-    if ((rc = launch(h, S))) return rc;
+    if (rc) return rc == -1 ? (S.staged = false, rc) : fail(rc);     // -1: rejected by validation before anything was enqueued
+    if ((rc = check_results(S, res, S.P.out_kin != nullptr))) { (void)hipStreamSynchronize(h->s_in); S.staged = false; return rc; }
+#define HIPTRY_F(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ccsx_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return fail(-2); } } while (0)
+    HIPTRY_F(hipEventRecord(S.ev_up, h->s_in));
+    HIPTRY_F(hipStreamWaitEvent(h->s_draft, S.ev_up, 0));
+    if ((rc = launch(h, S))) return fail(rc);
     // ev[5] (end of the last kernel) doubles as the "results ready" event of the download stream
-    HIPTRY(hipStreamWaitEvent(h->s_out, S.ev[5], 0));
-    if ((rc = enqueue_download(S, res, h->s_out))) return rc;
-    HIPTRY(hipEventRecord(S.ev_done, h->s_out));
+    HIPTRY_F(hipStreamWaitEvent(h->s_out, S.ev[5], 0));
+    if ((rc = enqueue_download(S, res, h->s_out))) return fail(rc);
+    HIPTRY_F(hipEventRecord(S.ev_done, h->s_out));
+#undef HIPTRY_F
     S.res = res; S.inflight = true; S.ticket = h->next_ticket;
     h->last = (int)(h->next_ticket % CCSX_SLOTS);
     *ticket = h->next_ticket++;
@@ -532,16 +567,32 @@ int ccsx_poll(ccsx_handle h, ccsx_ticket ticket)
     return -2;
 }
 
+// stage durations of a slot's last run.  draft_ms = the first POA pass, align_ms = alignment cascade + accounting + the whole
+// fallback round (POA included), polish_ms from the polish stage's own start event (it may have queued behind the previous batch)
+static int slot_timings(ccsx_handle h, Slot &S, ccsx_timings *t)
+{
+    HIPTRY(hipEventSynchronize(S.ev[5]));
+    std::memset(t, 0, sizeof(*t));
+    HIPTRY(hipEventElapsedTime(&t->setup_ms, S.ev[0], S.ev[1]));
+    HIPTRY(hipEventElapsedTime(&t->draft_ms, S.ev[1], S.ev[2]));
+    HIPTRY(hipEventElapsedTime(&t->align_ms, S.ev[2], S.ev[3]));
+    HIPTRY(hipEventElapsedTime(&t->queue_ms, S.ev[3], S.ev[6]));
+    HIPTRY(hipEventElapsedTime(&t->polish_ms, S.ev[6], S.ev[4]));
+    HIPTRY(hipEventElapsedTime(&t->stitch_ms, S.ev[4], S.ev[5]));
+    HIPTRY(hipEventElapsedTime(&t->total_ms, S.ev[0], S.ev[5]));
+    float a = 0.0f, b = 0.0f;
+    HIPTRY(hipEventElapsedTime(&a, h->ev_epoch, S.ev[0]));
+    HIPTRY(hipEventElapsedTime(&b, h->ev_epoch, S.ev[5]));
+    t->start_ms = a; t->end_ms = b;
+    return 0;
+}
+
 int ccsx_ticket_timings(ccsx_handle h, ccsx_ticket ticket, ccsx_timings *t)
 {
     Slot *S = slot_of(h, ticket);
     if (!S || !t || !S->ran) { ccsx_set_error("ccsx_ticket_timings: unknown ticket"); return -1; }
     HIPTRY(hipSetDevice(h->device));
-    HIPTRY(hipEventSynchronize(S->ev[5]));
-    float ms[5];
-    for (int i = 0; i < 5; ++i) HIPTRY(hipEventElapsedTime(&ms[i], S->ev[i], S->ev[i + 1]));
-    t->setup_ms = ms[0]; t->draft_ms = ms[1]; t->align_ms = ms[2]; t->polish_ms = ms[3]; t->stitch_ms = ms[4];
-    HIPTRY(hipEventElapsedTime(&t->total_ms, S->ev[0], S->ev[5]));
+    if (int rc = slot_timings(h, *S, t)) return rc;
     t->polish_workgroups = 0;
     if (!S->inflight && S->res && S->res->n_windows) for (int z = 0; z < S->P.n_zmw; ++z) t->polish_workgroups += S->res->n_windows[z];
     return 0;
@@ -573,6 +624,7 @@ int ccsx_sync(ccsx_handle h)
 {
     if (!h) return -1;
     HIPTRY(hipSetDevice(h->device));
+    HIPTRY(hipStreamSynchronize(h->s_draft));
     HIPTRY(hipStreamSynchronize(h->s_comp));
     Slot &S = h->slot[h->last];
 #ifdef CCSX_PROFILE_PHASES
@@ -628,11 +680,7 @@ int ccsx_get_timings(ccsx_handle h, ccsx_timings *t)
     Slot &S = h->slot[h->last];
     if (!S.ran) { ccsx_set_error("ccsx_get_timings: no completed run"); return -1; }
     HIPTRY(hipSetDevice(h->device));
-    HIPTRY(hipEventSynchronize(S.ev[5]));
-    float ms[5];
-    for (int i = 0; i < 5; ++i) HIPTRY(hipEventElapsedTime(&ms[i], S.ev[i], S.ev[i + 1]));
-    t->setup_ms = ms[0]; t->draft_ms = ms[1]; t->align_ms = ms[2]; t->polish_ms = ms[3]; t->stitch_ms = ms[4];
-    HIPTRY(hipEventElapsedTime(&t->total_ms, S.ev[0], S.ev[5]));
+    if (int rc = slot_timings(h, S, t)) return rc;
     std::vector<int32_t> nwin(S.P.n_zmw);
     HIPTRY(hipMemcpy(nwin.data(), S.P.out_nwin, nwin.size() * 4, hipMemcpyDeviceToHost));
     int64_t tw = 0;

@@ -18,6 +18,7 @@ void ccsx_set_error(const std::string &s) { g_last_error = s; }
 extern "C" {
 
 int ccsx_abi_version(void) { return CCSX_ABI_VERSION; }
+int ccsx_spec_version(void) { return CCSX_SPEC_VERSION; }
 const char *ccsx_last_error(void) { return g_last_error.c_str(); }
 
 // Synthetic parameter set "SYN-1".  The trained PacBio tables (docs/faq/chemistry.md:27-56,

@@ -74,5 +74,5 @@ struct KParams {
     long long kin_plane;       // plane stride = seq_off[n]
 };
 
-const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev);   // NULL, or the name of the launch that failed
+const char *ccsx_launch_all(const KParams &P, hipStream_t st_draft, hipStream_t st_polish, hipEvent_t *ev /* [7] */);   // NULL, or the name of the launch that failed
 int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats);

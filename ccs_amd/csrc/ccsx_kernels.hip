@@ -2244,11 +2244,17 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
 
 // every launch status is captured: returns NULL, or the name of the first launch that failed (ccsx_api.cpp reports it)
 #define LAUNCH_CHECK(name) do { if (hipGetLastError() != hipSuccess && !failed) failed = name; } while (0)
-const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* [6] or NULL */)
+const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */)
 {
+    // Two-stage queue of docs/img/ccs-impl.png ("Draft Stage" -> queue -> "Polish Stage"): the draft stage (tables, POA, alignment
+    // cascade, accounting) is enqueued on `st`, the polish stage (polish, kinetics, stitch) on `st_polish`, which waits for the
+    // draft stage's last kernel through ev[3].  With two different streams the draft stage of batch k+1 runs UNDER the polish
+    // stage of batch k (the register-only one-wave POA and the LDS-bound polish workgroups share the SIMDs); the shared POA /
+    // alignment scratch is touched by the draft stage only, so `st` alone orders its users.  st_polish == st: serial stages.
     const char *failed = nullptr;
     if (ev && hipEventRecord(ev[0], st) != hipSuccess) failed = "hipEventRecord";
     if (hipMemsetAsync(P.ticket_poa, 0, 256, st) != hipSuccess && !failed) failed = "hipMemsetAsync";   // debug / phase-profile words (CCSX_DEBUG_CHECKS, CCSX_PROFILE_PHASES builds)
+    if (hipMemsetAsync(P.avalid, 0, (size_t)(P.n_reads > 0 ? P.n_reads : 1), st) != hipSuccess && !failed) failed = "hipMemsetAsync";   // passes beyond top_passes are never visited by a kernel
     {
         int n = P.n_zmw * CCSX_NCTX;
         hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, P);
@@ -2283,15 +2289,20 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipEvent_t *ev /* 
             LAUNCH_CHECK("k_align");
         }
         trace_sync(st, "k_align");
-        {
-            const int g = P.align_slots / 2 < 1 ? 1 : (P.align_slots / 2 > 2048 ? 2048 : P.align_slots / 2);
+        if (P.align_slots >= 2) {                          // the split alignment uses two scratch slots per workgroup
+            const int g = P.align_slots / 2 > 2048 ? 2048 : P.align_slots / 2;
             hipLaunchKernelGGL(k_rescue, dim3(g), dim3(64), lds_read, st, P, pass);
             LAUNCH_CHECK("k_rescue");
         }
         hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P, pass);
         LAUNCH_CHECK("k_post");
     }
-    if (ev) (void)hipEventRecord(ev[3], st);
+    if (ev) {
+        if (hipEventRecord(ev[3], st) != hipSuccess && !failed) failed = "hipEventRecord";
+        if (st_polish != st && hipStreamWaitEvent(st_polish, ev[3], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
+        (void)hipEventRecord(ev[6], st_polish);            // the polish stage starts here (after the queue between the stages)
+    } else if (st_polish != st && !failed) failed = "two streams need events";
+    st = st_polish;
     if (P.total_wslots > 0) {
         hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), (size_t)P.pw_obs_bytes + (size_t)P.pw_gb_floats * 4, st, P);
         LAUNCH_CHECK("k_polish");

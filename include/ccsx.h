@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define CCSX_ABI_VERSION 3
+#define CCSX_ABI_VERSION 4
+#define CCSX_SPEC_VERSION 2   /* DESIGN.md §2; bumped whenever a result-changing rule changes (oracle: ORC_SPEC_VERSION) */
 
 /* ---- fixed constants of the algorithm specification ---- */
 #define CCSX_BAND          64   /* DP band rows of the POA / alignment kernels (one wave64)      */
@@ -88,7 +89,9 @@ typedef struct ccsx_opts {
     int32_t max_insertion_size; /* SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78, --max-insertion-size): a subread segment more
                                  * than this many bases longer than its window is cut down to the window's length before polishing;
                                  * 0 = the default 30, < 0 = never trim (such a segment then leaves the window when it exceeds 63 bases) */
-    int32_t reserved[2];
+    int32_t serial_stages;      /* 1: draft and polish stage of all batches on ONE compute stream (A/B switch; default 0: the draft stage
+                                 * of batch k+1 runs on its own stream under the polish stage of batch k, docs/img/ccs-impl.png)            */
+    int32_t reserved[1];
 } ccsx_opts;
 
 /* ---- input batch: SoA + CSR ---- */
@@ -137,12 +140,19 @@ typedef struct ccsx_results {
 typedef struct ccsx_timings {
     float setup_ms, draft_ms, align_ms, polish_ms, stitch_ms, total_ms;
     int64_t polish_workgroups;   /* launched polish workgroups that had work                     */
+    float queue_ms;              /* between the two stages: end of the draft stage -> start of the polish stage (the polish stream
+                                    was still busy with the previous batch); total_ms includes it               */
+    float reserved_;
+    double start_ms, end_ms;     /* device time of the batch's first / last kernel since the handle's creation: over a run of
+                                    tickets (end of the last - start of the first) is the time the kernels alone took     */
 } ccsx_timings;
 
 typedef struct ccsx_handle_s *ccsx_handle;
 
 /* library / device */
 int         ccsx_abi_version(void);
+int         ccsx_spec_version(void);                    /* version of the algorithm specification the kernels implement:
+                                                           golden vectors carry it, so SPEC drift fails loudly           */
 const char *ccsx_last_error(void);
 int         ccsx_device_count(void);
 
@@ -179,8 +189,8 @@ int64_t     ccsx_result_layout(const ccsx_batch *b, int64_t *seq_off);
 int         ccsx_consensus_batch(ccsx_handle h, const ccsx_batch *b, ccsx_results *res);
 
 /* asynchronous pipeline (submit / wait tickets).  ccsx_submit enqueues upload -> kernels -> download of one
- * batch on the handle's three streams (H2D, kernels, D2H) and returns; up to three batches are in flight, so the copies
- * of batch k+1 / k-1 run under the kernels of batch k.  The batch arrays and the result buffers must stay valid (and
+ * batch on the handle's streams (H2D, draft stage, polish stage, D2H) and returns; up to three batches are in flight, so the
+ * copies of batch k+1 / k-1 and the draft stage of batch k+1 run under the polish stage of batch k.  The batch arrays and the result buffers must stay valid (and
  * should be page-locked: ccsx_alloc_pinned) until ccsx_wait returns for that ticket.  Tickets complete in order.      */
 typedef int64_t ccsx_ticket;
 int         ccsx_submit(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, ccsx_ticket *ticket);

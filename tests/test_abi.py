@@ -23,7 +23,8 @@ def test_header_and_exports_agree(built):
     L = C.CDLL(api.LIB_PATH)
     for name in decl:
         assert hasattr(L, name), f"{name} declared in include/ccsx.h but not exported by libccsx.so"
-    assert L.ccsx_abi_version() == 3
+    assert L.ccsx_abi_version() == 4
+    assert L.ccsx_spec_version() >= 2
 
 
 def test_struct_layouts_match_header(built):
@@ -32,6 +33,7 @@ def test_struct_layouts_match_header(built):
     assert C.sizeof(api.Opts) == 4 * 7 + 4 * 8
     assert C.sizeof(api.CBatch) == 16 + 8 * 8
     assert C.sizeof(api.CResults) == 16 + 17 * 8
+    assert C.sizeof(api.Timings) == 6 * 4 + 8 + 2 * 4 + 2 * 8
     m = api.default_model()
     assert m.name == b"SYN-1" and m.snr_lo == 4.0 and m.snr_hi == 20.0
     o = api.default_opts()

@@ -419,7 +419,11 @@ def test_cli_engine_failure_leaves_no_output(built, tmp_path):
     ends with exit code 1, a message, and without the output file"""
     bam, out = tmp_path / "s.subreads.bam", tmp_path / "o.bam"
     _run("--write-synthetic", "12,5,500,9", bam)
-    env = dict(os.environ, CCSX_TEST_FAIL_SUBMIT="1")           # the second batch fails inside ccsx_submit
+    # the product library carries no fault injection: the test runs the driver against the -DCCSX_FAULT_INJECTION build of the
+    # same sources (ccs_amd/testlib/libccsx.so; the binary's RUNPATH yields to LD_LIBRARY_PATH)
+    import __graft_entry__ as graft
+    env = dict(os.environ, CCSX_TEST_FAIL_SUBMIT="1",           # the second batch fails inside ccsx_submit
+               LD_LIBRARY_PATH=os.path.dirname(graft.LIB_FI) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([CCS, str(bam), str(out), "--batch-size", "4"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 1 and "injected failure" in r.stderr and "removed" in r.stderr
     assert not os.path.exists(out)
@@ -430,9 +434,9 @@ def test_cli_engine_failure_leaves_no_output(built, tmp_path):
 
 def test_pbi_index_and_chunking_by_random_access(built, tmp_path):
     """docs/faq/parallelize.md:9-13 (--chunk uses the .pbi): the synthetic subreads.bam comes with IN.bam.pbi (one entry per
-    subread: hole number, BGZF virtual offset); with it --chunk i/N seeks to a contiguous range of ZMWs, without it the chunks are
-    round-robin over the whole file; either way the chunks partition the ZMWs and every ZMW's content is unchanged (--dump-zmws
-    hashes bases / pw / ip, no GPU)"""
+    subread: hole number, BGZF virtual offset); with it --chunk i/N seeks to a contiguous range of ZMWs; the chunks partition the
+    ZMWs and every ZMW's content is unchanged (--dump-zmws hashes bases / pw / ip, no GPU).  Without a usable index --chunk is an
+    error, as in the reference: the jobs of a sharded run must never partition the ZMWs in different ways"""
     bam = tmp_path / "s.subreads.bam"
     _run("--write-synthetic", "157,5,1500,9", bam)                 # ~2 MB: dozens of BGZF blocks, records straddle them
     x = bam_util.read_pbi(str(bam) + ".pbi")
@@ -450,15 +454,21 @@ def test_pbi_index_and_chunking_by_random_access(built, tmp_path):
         assert all(abs(len(q) - 157 / n) < 1 for q in parts)
     assert _run("--dump-zmws", "--chunk", "1/400", bam).stdout == ""   # more chunks than ZMWs: some are empty
     os.rename(str(bam) + ".pbi", str(bam) + ".pbi.off")
-    parts = [_run("--dump-zmws", "--chunk", f"{i}/3", bam).stdout.splitlines() for i in (1, 2, 3)]
-    assert sorted(sum(parts, [])) == sorted(full) and parts[1][0] == full[1]      # round-robin without the index
+    p = _run("--dump-zmws", "--chunk", "2/3", bam, check=False)      # no index: refused
+    assert p.returncode != 0 and "--chunk needs a usable" in p.stderr and p.stdout == ""
+    assert _run("--dump-zmws", bam).stdout.splitlines() == full      # (the whole file needs no index)
     _run("--write-synthetic", "157,5,1500,10", tmp_path / "other.bam")   # an index of a DIFFERENT file: refused, not silently wrong
     os.replace(str(tmp_path / "other.bam") + ".pbi", str(bam) + ".pbi")
     p = _run("--dump-zmws", "--chunk", "2/3", bam, check=False)
     assert p.returncode != 0 and ("does not match" in p.stderr or "BGZF" in p.stderr)   # (its offsets point into the middle of blocks)
-    open(str(bam) + ".pbi", "wb").write(b"garbage")                 # a broken index is reported and ignored
-    p = _run("--dump-zmws", "--chunk", "2/3", bam)
-    assert p.stdout.splitlines() == parts[1] and "ignoring" in p.stderr
+    # an index whose seek target is right but whose chunk END disagrees (one ZMW dropped from the index) is caught as well
+    good = bam_util.read_pbi(str(bam) + ".pbi.off")
+    open(str(bam) + ".pbi", "wb").write(b"garbage")                 # a broken index: fatal with --chunk, a warning without
+    p = _run("--dump-zmws", "--chunk", "2/3", bam, check=False)
+    assert p.returncode != 0 and "--chunk needs a usable" in p.stderr
+    p = _run("--dump-zmws", bam)
+    assert p.stdout.splitlines() == full and "ignoring" in p.stderr
+    del good
 
 
 @pytest.mark.gpu

@@ -543,7 +543,6 @@ def test_split_alignment_keeps_passes_with_large_blocks(handle):
         assert abs(int(res.seq_len[z]) - int(clean.seq_len[z])) <= 2 and res.ec[z] > 7.5
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("maxins,kin", [(10, 0), (6, 1), (-1, 0)])
 def test_large_insertion_trimming_matches_oracle(built, maxins, kin):
     """SPEC "trim large insertions" (docs/how-does-ccs-work.md:74-78, opts.max_insertion_size): passes with 8-30 base blocks of
@@ -577,33 +576,3 @@ def test_large_insertion_trimming_matches_oracle(built, maxins, kin):
         h2.close()
         ok = (res.status == 0) & (off_.status == 0)
         assert ok.sum() >= 5 and res.ec[ok].sum() > off_.ec[ok].sum()
-
-
-@pytest.mark.gpu
-def test_fallback_draft_matches_oracle(built):
-    """the second draft attempt (median-length backbone, twice the passes, orientation of the new backbone) on the GPU: ZMWs whose
-    pass 0 is junk, next to ZMWs that need no fallback, with and without opts.no_fallback_draft, and with kinetics"""
-    rng = np.random.default_rng(21)
-    batch = api.synth(12, (5, 9), (500, 1600), seed=97)
-    for z in (1, 3, 4, 6, 7, 9, 10):
-        r = int(batch.read_off[z])
-        a, b = int(batch.base_off[r]), int(batch.base_off[r + 1])
-        batch.bases[a:b] = rng.integers(0, 4, b - a, dtype=np.uint8)
-    seen_rescue = False
-    for nofb, kin in ((0, 0), (1, 0), (0, 1)):
-        o = api.default_opts(); o.no_fallback_draft = nofb; o.hifi_kinetics = kin
-        h = api.Handle(0, opts=o)
-        res = h.consensus(batch)
-        ref = api.Results.allocate(batch, kinetics=bool(kin))
-        O.consensus_batch(h.model, o, batch, ref, nthreads=4)
-        _compare(res, ref, batch)
-        assert np.array_equal(res.fn, ref.fn) and np.array_equal(res.rn, ref.rn)
-        if kin:
-            for z in range(batch.n_zmw):
-                assert np.array_equal(res.kinetics(z), ref.kinetics(z))
-        if nofb:
-            lost = set(np.nonzero(res.status == 3)[0].tolist())
-        else:
-            ok = set(np.nonzero((res.status == 0) | (res.status == 7))[0].tolist())
-        h.close()
-    assert len(lost) >= 2 and lost <= ok                      # what is lost without the fallback gets a consensus with it (HiFi or LOW_RQ)

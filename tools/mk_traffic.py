@@ -4,6 +4,7 @@ Counters are summed over every dispatch of a kernel in the run; one bench run = 
 taken from the number of k_polish dispatches (one per pass)."""
 import glob, json, os, sqlite3, sys
 root, n = sys.argv[1], int(sys.argv[2])
+head = sys.argv[3] if len(sys.argv) > 3 else None
 val, cnt = {}, {}
 for db in glob.glob(os.path.join(root, "pmc_*", "pmc_results.db")):
     c = sqlite3.connect(db)
@@ -11,7 +12,8 @@ for db in glob.glob(os.path.join(root, "pmc_*", "pmc_results.db")):
         val.setdefault(kn.split("(")[0], {})[cn] = v
         cnt.setdefault(kn.split("(")[0], {})[cn] = k
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ_* (separate passes), python bench.py "
-                 f"--zmws {n} --steps 1 --warmup 1 --distinct 1, tools/prof_round.sh",
+                 f"--pmc --zmws {n} --steps 1 --warmup 1 --distinct 1, tools/prof_round.sh",
+       "head": head,
        "note": "hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on this gfx950 stack FETCH_SIZE reports exactly half of the bytes of a "
                "coalesced streaming read at 1, 4 and 16 bytes per lane and WRITE_SIZE is exact (profiles/r01_counter_calibration.txt, "
                "tools/calib; MI355X_MICROARCH.md HBM section)",
