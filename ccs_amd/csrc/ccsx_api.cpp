@@ -372,7 +372,9 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
 
     // ---- resident POA graphs / alignment slots: as many as fit this handle's share of the free memory, never more than
     // the work.  The scratch is shared by the handle's batch slots; it only grows, and growing waits for the compute stream.
-    S.poa_slot_bytes = (((size_t)vcap_max + 64) * 393 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
+    // per vertex (ccsx_kernels.hip poa_slot): the 32-row score column of far-read columns 128, three 16-byte records, 32 move bytes,
+    // 5 overflow in-edges, 5 words of order / rank / consensus state, one flag byte = 249
+    S.poa_slot_bytes = (((size_t)vcap_max + 64) * 249 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
     S.align_slot_i32 = (size_t)need_max * 128 + 4 * (size_t)need_max + 64;   // (origin, dirty bits) per cell and edge + band starts + best cell (score, row, entry row) per edge
     int poa_slots, align_slots;
     {
@@ -382,7 +384,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         freeb /= (size_t)h->handles_on_device;
         freeb += h->d_poa.cap + h->d_align.cap;                      // what we already hold is reusable
         const size_t budget = freeb > (size_t)6 << 30 ? freeb - ((size_t)4 << 30) : freeb / 2;
-        poa_slots = h->opts.poa_slots > 0 ? h->opts.poa_slots : 8192;
+        poa_slots = h->opts.poa_slots > 0 ? h->opts.poa_slots : 16384;   // four graphs per wave: 16384 = 4 waves per SIMD
         poa_slots = std::min(poa_slots, n);
         poa_slots = (int)std::min<size_t>((size_t)poa_slots, std::max<size_t>(1, (budget * 3 / 4) / S.poa_slot_bytes));
         align_slots = std::min(16384, std::max(R, 2));            // (the split alignment uses two slots per pass)
@@ -403,7 +405,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
 
     KParams &P = S.P;
     std::memset(&P, 0, sizeof(P));
-    P.n_zmw = n; P.n_reads = R; P.maxL_max = (int32_t)maxL_max; P.vcap_max = (int32_t)vcap_max; P.need_max = need_max;
+    P.n_zmw = n; P.n_reads = R; P.maxL_max = (int32_t)maxL_max; P.vcap_max = (int32_t)vcap_max; P.need_max = need_max; P.max_reads = nr_max;
     P.opts = h->opts;
     P.model = (const ccsx_model *)h->d_model.p;
     P.snr = (const float *)S.d_snr.p; P.read_off = (const int32_t *)S.d_read_off.p; P.base_off = (const int64_t *)S.d_base_off.p;

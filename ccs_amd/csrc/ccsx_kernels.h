@@ -10,6 +10,7 @@ struct KParams {
     int32_t maxL_max;          // longest subread of the batch
     int32_t vcap_max;          // POA vertex capacity of the largest ZMW
     int32_t need_max;          // max window-edge columns per read (2 * window slots)
+    int32_t max_reads;         // most passes of a ZMW in the batch (after the top_passes cap)
     ccsx_opts opts;
     const ccsx_model *model;   // device copy
     // ---- inputs (HBM resident after ccsx_upload)

@@ -259,41 +259,62 @@ __device__ __forceinline__ int base_at(const BaseCursor &c, int t)
 }
 
 // ------------------------------------------------------------------------------------------------
-// D2/D3: sparse POA.  One wave per resident graph ("slot"); the kernel is launched per chunk of poa_slots ZMWs, longest first.
+// D2/D3: sparse POA (docs/how-does-ccs-work.md:34-51; SPEC: POA_BAND = 32 rows, a pass is threaded only if it passes the gate).
 //
-// v2 layout.  By vertex id: vrec {base | npred<<8 | reads<<16, pred0, pred1, pred2}, predx (in-edges 3..7),
-// rank (topological position).  By topological position: order (ping-pong), the score column Mk[64] and move
-// row mvK[64] of the current DP pass, kinfo {lo, colmax, bestrow, position of in-edge 0}.
-// The DP walks positions in blocks of 64: the block's vertex records are fetched with one coalesced load and
-// handed out with v_readlane, the previous column stays in registers, per-column metadata is captured in lane
-// registers and stored once per block, so the common chain step touches no memory on its critical path and
-// needs few scalar instructions (the kernel is scalar-issue bound).  Columns stream to HBM fire-and-forget.
+// Round 3: the POA is a pipeline of four kernels per threaded pass instead of one wave per graph doing everything —
+//   k_poa_init    one wave per graph: pass selection, the backbone chain, the column records of the first DP
+//   k_poa_dp      ONE WAVE = FOUR GRAPHS: the banded DP of one pass over four graphs in lockstep.  Each graph owns a 16-lane DPP
+//                 row; a lane holds TWO band rows (2l, 2l+1), so the 32-row band's insertion chain is a lane-local step plus a
+//                 4-step row scan, and the column maximum / best row one packed 4-step row scan.  Every column a graph finishes
+//                 goes into an LDS ring (the last PRING columns + the START column, guard cells on both sides): in-edges read
+//                 their source column from there at any band offset with plain ds_reads — no register shifting, no per-column
+//                 branch on the edge type; only sources more than PRING positions back come from HBM (flagged by the prepass).
+//                 Per column 32 move bytes + one 16-byte record go to HBM (round 2: 64 move bytes + the 256-byte score column
+//                 of every column an in-edge skipped to + the record).
+//   k_poa_thread  one wave per graph: the gate, traceback, threading of the pass into the graph (wave-parallel list insertion),
+//                 and the prepass for the next DP: column records by topological position {base, in-edge count, positions of
+//                 in-edges 0..2, "a far in-edge reads this column back"}
+//   k_poa_finish  heaviest path, draft, window bounds
+// Layout by vertex id: vrec {base | npred<<8 | reads<<16, pred0, pred1, pred2}, predx (in-edges 3..7), rank (topological
+// position).  By topological position: order (ping-pong), crec (the DP's column record), kinfo {lo, colmax, bestrow, position of
+// in-edge 0} and the move row mvK[32] of the current DP pass, M[32] for the far-read columns.
+#define PB CCSX_POA_BAND              // rows of the POA band
+#define PRING 8                       // columns of a graph the DP keeps in LDS (+ the START column in slot PRING)
+#define PGS 40                        // words per ring column: 4 guards, 32 rows, 4 guards
+#define CREC_NEED (1 << 16)            // column record: a far in-edge reads this column back from HBM
+#define CREC_FAR0 (1 << 17)            //                in-edge 0 comes from more than PRING positions back
+enum { ST_N, ST_NADDED, ST_OK, ST_PAR, ST_KEND, ST_BS, ST_NPOA, ST_BB, ST_NREADS, ST_REV0, ST_LIVE, ST_WORDS = 16 };
 struct PoaSlot {
-    int4 *vrec, *kinfo;
+    int32_t *st;                      // [ST_WORDS] per-graph state that travels between the kernels
+    int4 *vrec, *kinfo, *crec;
     int32_t *predx, *M, *rank, *order0, *order1, *bestK, *bpK, *pathv;
     uint8_t *mvK, *needK;
 };
+#define POA_BYTES_PER_VERTEX (PB * 4 + 16 * 3 + PB + 5 * 4 + 5 * 4 + 1)
 
 __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
 {
     PoaSlot s;
     const size_t vc = (size_t)P.vcap_max + 64;
     uint8_t *p = P.poa_scratch + (size_t)slot * P.poa_slot_bytes;
-    s.M = (int32_t *)p;       p += vc * 64 * 4;
+    s.st = (int32_t *)p;      p += 256;
+    s.M = (int32_t *)p;       p += vc * PB * 4;
     s.vrec = (int4 *)p;       p += vc * 16;
     s.kinfo = (int4 *)p;      p += vc * 16;
-    s.mvK = p;                p += vc * 64;
+    s.crec = (int4 *)p;       p += vc * 16;
+    s.mvK = p;                p += vc * PB;
     s.predx = (int32_t *)p;   p += vc * 5 * 4;
     s.rank = (int32_t *)p;    p += vc * 4;
     s.order0 = (int32_t *)p;  p += vc * 4;
     s.order1 = (int32_t *)p;  p += vc * 4;
     s.bestK = (int32_t *)p;   p += vc * 4;      // also the run-count / shift array while threading a read
     s.bpK = (int32_t *)p;     p += vc * 4;
-    s.needK = p;              p += vc;          // by topological position: 1 = some in-edge reaches this column from more than 3 positions ahead
+    s.needK = p;              p += (vc + 3) & ~(size_t)3;   // by topological position: 1 = some in-edge reaches this column from more than PRING positions ahead
     s.pathv = (int32_t *)p;
     return s;
 }
 
+__device__ __forceinline__ int imed3(int x, int lo, int hi) { x = x > lo ? x : lo; return x < hi ? x : hi; }   // clamp (v_med3_i32)
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -314,482 +335,629 @@ __device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to
 }
 
 extern __shared__ uint32_t dyn_lds[];
-#define TB_BLOCK 32                   // positions cached per traceback block (LDS per wave bounds the POA occupancy)
+#define TB_BLOCK 64                   // positions cached per traceback block (64 move rows of 32 bytes)
 
 #define ZREF_RETRY 256                  // k_post: this ZMW's first draft failed or most passes do not map to it
 #define ZREF_DONE 512                   // the fallback draft has been made
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa(KParams P, int z0, int pass)
+
+// the prepass of a DP: column records by topological position.  `order` = the graph's current topological order, n vertices.
+__device__ __forceinline__ void poa_column_records(const PoaSlot &g, const int32_t *order, int n, int lane)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sMv[TB_BLOCK * 64];   // move rows of the traceback's current block
+    for (int q = lane; q < n; q += LANES) g.needK[q] = 0;
+    __threadfence_block();
+    for (int kb = 0; kb < n; kb += LANES) {                // which score columns will be read back from HBM?
+        const int kk = kb + lane;
+        if (kk < n) {
+            const int v = order[kk];
+            const int4 rec = g.vrec[v];
+            const int np = (rec.x >> 8) & 255;
+            for (int q = 0; q < np; ++q) {
+                const int pu = g.rank[poa_pred(g, rec, v, q)];
+                if (kk - pu > PRING) g.needK[pu] = 1;
+            }
+        }
+    }
+    __threadfence_block();
+    for (int kb = 0; kb < n; kb += LANES) {
+        const int kk = kb + lane;
+        if (kk < n) {
+            const int v = order[kk];
+            const int4 rec = g.vrec[v];
+            const int np = (rec.x >> 8) & 255;
+            int4 c = make_int4((rec.x & 255) | (np << 8) | (g.needK[kk] ? CREC_NEED : 0), -1, -1, -1);
+            if (np >= 1) { c.y = g.rank[rec.y]; if (kk - c.y > PRING) c.x |= CREC_FAR0; }
+            if (np >= 2) c.z = g.rank[rec.z];
+            if (np >= 3) c.w = g.rank[rec.w];
+            g.crec[kk] = c;
+        }
+    }
+    __threadfence_block();
+}
+
+// ---- k_poa_init: which passes, the backbone chain, the first column records.  One wave per graph (slot = block).
+__global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
+{
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
-    PoaSlot g = poa_slot(P, blockIdx.x);                   // launched in chunks of poa_slots ZMWs: slot = block
+    PoaSlot g = poa_slot(P, blockIdx.x);
     if (z0 + (int)blockIdx.x >= P.n_zmw) return;
     const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);     // longest ZMWs first
-    PHASE_T0();
-    {
-        const int r0 = rfl(P.read_off[z]);
-        int nreads = rfl(P.read_off[z + 1]) - r0;
-        {   // SPEC: at most 64 passes are used (the polish kernel keeps per-read state for 64 reads)
-            const int top = (P.opts.top_passes <= 0 || P.opts.top_passes > PW_MAXREADS_SPEC) ? PW_MAXREADS_SPEC : P.opts.top_passes;
-            if (nreads > top) nreads = top;
-        }
-        // SPEC "fallback draft" (docs/faq/accuracy-vs-passes.md:41-46: a cascade from fast to robust draft generators): pass 1
-        // (only for ZMWs k_post marked) takes the pass whose length is closest to the median as backbone and threads twice as
-        // many passes, starting at the backbone and wrapping around
-        int bb = 0;
-        if (pass == 1) {
-            if (rfl(P.zref[z]) != ZREF_RETRY) return;
-            const int len = lane < nreads ? (int)(P.base_off[r0 + lane + 1] - P.base_off[r0 + lane]) : 0x7fffffff;
-            int rank = 0;                                   // position of my length in the sorted order (ties by index)
-            for (int q = 0; q < nreads; ++q) { const int lq = __shfl(len, q); rank += (lq < len || (lq == len && q < lane)) ? 1 : 0; }
-            const int med = rfl(__shfl(len, __ffsll((long long)__ballot(lane < nreads && rank == nreads / 2)) - 1));
-            int dist = len - med; dist = dist < 0 ? -dist : dist;
-            const int key = lane < nreads ? ((dist > 0xffffff ? 0xffffff : dist) << 6) | lane : 0x7fffffff;
-            bb = rfl(wave_min_i32(key)) & 63;
-        }
-        if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_DONE : 0); }
-        const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
-        if (!enough && lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES;
-        if (enough) {
-        const int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
-        const int npoa = nreads < cov ? nreads : cov;
-        const int vcap = rfl(P.vcap[z]);
-        const int rev0 = rfl(P.flags[r0 + bb] & 1);
-        int n = 0, nadded = 0, ok = 1;
-        int32_t *order = g.order0, *order_nx = g.order1;
-        for (int rr = 0; rr < npoa && ok; ++rr) {
-            const int r = r0 + (bb + rr < nreads ? bb + rr : bb + rr - nreads);
-            const uint8_t *rb = P.bases + P.base_off[r];
-            const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
-            const int rev = rfl(((P.flags[r] & 1) != rev0) ? 1 : 0);
-            __syncthreads();
-            load_read_packed(sread, rb, I, rev, lane);
-            __syncthreads();
-            if (n == 0) {                                   // first read: backbone chain
-                if (I > vcap) ok = 0;
-                else {
-                for (int i = lane; i < I; i += LANES) {
-                    g.vrec[i] = make_int4(read_base_packed(sread, i) | ((i > 0 ? 1 : 0) << 8) | (1 << 16), i - 1, -1, -1);
-                    g.rank[i] = i; order[i] = i;
-                }
-                n = I; nadded = 1;
-                __threadfence_block();
-                }
-            } else {
-            PHASE(8);
-            const int n0 = n;
-            // ---- which score columns will be read back?  Columns k-1..k-3 stay in registers, so only the source of an in-edge that
-            // spans more than 3 positions has to be stored (a few per cent of the vertices): the other 256-byte columns were the
-            // bulk of this kernel's HBM writes.  One pass over the graph marks them by topological position.
-            for (int q = lane; q < n0; q += LANES) g.needK[q] = 0;
-            __threadfence_block();
-            for (int kb = 0; kb < n0; kb += LANES) {
-                const int kk = kb + lane;
-                if (kk < n0) {
-                    const int v = order[kk];
-                    const int4 rec = g.vrec[v];
-                    const int np = (rec.x >> 8) & 255;
-                    for (int q = 0; q < np; ++q) {
-                        const int pu = g.rank[poa_pred(g, rec, v, q)];
-                        if (kk - pu > 3) g.needK[pu] = 1;
-                    }
-                }
-            }
-            __threadfence_block();
-            // ---- DP over the graph in topological order
-            int Mprev = NEGV, lo_prev = 0, cm_prev = NEGV, br_prev = 0;
-            int M2 = NEGV, M3 = NEGV, lo2 = 0, lo3 = 0;             // columns k-2, k-3: most branch in-edges end there
-            int rbK = 4;                                            // read base of row lo + lane - 1 of the current band position
-            int kend = -1, bs = NEGV;
-            const int hiI = I - (CCSX_BAND - 1) > 0 ? I - (CCSX_BAND - 1) : 0;
-            const int lane4 = 4 * lane;
-            __threadfence_block();
-            for (int kb = 0; kb < n0; kb += LANES) {
-                const int kkL = kb + lane;
-                const int vL = kkL < n0 ? order[kkL] : 0;
-                int4 rL = make_int4(0, 0, 0, 0);
-                int needL = 0;
-                if (kkL < n0) { rL = g.vrec[vL]; needL = g.needK[kkL]; }
-                // topological positions of in-edges 0..2 of the block's columns (ranks are fixed during a DP pass): gathered
-                // once per block, so a branch column needs no dependent rank[] load on its critical path
-                int pLx = -1, pLy = -1, pLz = -1;
-                {
-                    const int npL = (rL.x >> 8) & 255;
-                    if (npL >= 1) pLx = g.rank[rL.y];
-                    if (npL >= 2) pLy = g.rank[rL.z];
-                    if (npL >= 3) pLz = g.rank[rL.w];
-                }
-                const int nblk = (n0 - kb) < LANES ? (n0 - kb) : LANES;
-                int4 myInfo = make_int4(0, NEGV, 0, -1);                   // (lo, colmax, bestrow, pp) of column kb + lane
-                // consume the block loads here, so the compiler waits for them once per block and not at the top of
-                // every column (a vmcnt(0) there would also drain each column's streaming stores)
-                asm volatile("" :: "v"(vL), "v"(rL.x), "v"(rL.y), "v"(rL.z), "v"(rL.w), "v"(pLx), "v"(pLy), "v"(pLz), "v"(needL));
-                int32_t *Mrow = g.M + (size_t)kb * 64 + lane;
-                uint8_t *mvrow = g.mvK + (size_t)kb * 64 + lane;
-                for (int j = 0; j < nblk; ++j, Mrow += 64, mvrow += 64) {
-                    const int k = kb + j;
-                    const int v = rl(vL, j);
-                    const int meta = rl(rL.x, j), q0 = rl(pLx, j);         // q0: position of in-edge 0
-                    const int vb = meta & 255, np = (meta >> 8) & 255;
-                    int lo, best = NEGV, bm = 0, pp, i, rbv;
-                    if (np == 1 && q0 == k - 1) {                          // chain step: registers only, no branches
-                        lo = smin(smin(smax(br_prev + 1 - CCSX_BAND / 2, lo_prev), lo_prev + 2), hiI);   // wave-uniform: scalar unit
-                        const int sh = lo - lo_prev;                       // 0..2: the band follows the best row of the previous column
-                        // rows of the previous column by wave shifts (no LDS crossbar on the chain); the read base of row i-1
-                        // travels with the band, only the top lane(s) fetch a new one.  Invalid cells carry NEGV, lose every
-                        // comparison and are reset at the end of the column.
-                        int x, y;
-                        if (sh == 0) { x = wave_shr1_i32(Mprev, NEGV); y = Mprev; }
-                        else {
-                            const int top = lo + 62;
-                            int tc = top >= I ? I - 1 : top; tc = tc < 0 ? 0 : tc;   // clamped: the value only matters for valid rows
-                            if (sh == 1) { const int nb = read_base_packed(sread, tc); x = Mprev; y = wave_shl1_i32(Mprev, NEGV); rbK = wave_shl1_i32(rbK, nb); }
-                            else {
-                                x = wave_shl1_i32(Mprev, NEGV); y = wave_shl1_i32(x, NEGV);
-                                int tc1 = top - 1 >= I ? I - 1 : top - 1; tc1 = tc1 < 0 ? 0 : tc1;
-                                const int nb1 = read_base_packed(sread, tc1);
-                                const int nb = read_base_packed(sread, tc);
-                                rbK = wave_shl1_i32(wave_shl1_i32(rbK, nb1), nb);
-                            }
-                        }
-                        i = lo + lane;
-                        rbv = rbK;
-                        best = x + (vb == rbv ? SC_MATCH : SC_MISMATCH);   // bm = MV_DIAG = 0
-                        const int cdel = y + SC_DEL;
-                        const bool vdel = cdel > best;
-                        best = vdel ? cdel : best; bm = vdel ? MV_DEL : MV_DIAG;
-                        pp = k - 1;
-                    } else {                                               // source vertex or several / far in-edges
-                        // in-edge positions: 0..2 from the block prefetch, 3..7 (rare) through predx + rank
-                        const int q1 = rl(pLy, j), q2 = rl(pLz, j);
-                        int ulo = 0, ubr = 0;
-                        pp = np > 0 ? q0 : -1;
-                        if (np > 0) {
-                            bool far = false;                              // some column comes back from HBM/L2: order our stores first
-                            for (int q = 0; q < np; ++q) {
-                                const int pu = q == 0 ? q0 : (q == 1 ? q1 : (q == 2 ? q2 : rfl(g.rank[g.predx[v * 5 + (q - 3)]])));
-                                far |= (pu < k - 3) || (pu < kb);
-                            }
-                            if (far) __threadfence_block();
-                            int bestcm = NEGV - 1;
-                            for (int q = 0; q < np; ++q) {                 // pass 1: band placement from the best in-edge column
-                                const int pu = q == 0 ? q0 : (q == 1 ? q1 : (q == 2 ? q2 : rfl(g.rank[g.predx[v * 5 + (q - 3)]])));
-                                int l, cm, b;
-                                if (pu == k - 1) { l = lo_prev; cm = cm_prev; b = br_prev; }
-                                else if (pu >= kb) { l = rl(myInfo.x, pu - kb); cm = rl(myInfo.y, pu - kb); b = rl(myInfo.z, pu - kb); }
-                                else { const int4 ki = g.kinfo[pu]; l = rfl(ki.x); cm = rfl(ki.y); b = rfl(ki.z); }
-                                if (cm > bestcm) { bestcm = cm; ulo = l; ubr = b; }
-                            }
-                        }
-                        lo = rfl(band_lo(ulo, ubr, I));
-                        i = lo + lane;
-                        rbv = (i >= 1 && i <= I) ? read_base_packed(sread, i - 1) : 4;
-                        rbK = rbv;                                         // the chain step continues from this band position
-                        const int npp = np == 0 ? 1 : np;
-                        for (int q = 0; q < npp; ++q) {                    // pass 2: candidates (in-edge data is re-derived: no arrays)
-                            int x, y;
-                            if (np == 0) {
-                                const int o1 = i - 1, o0 = i;
-                                x = (o1 >= 0 && o1 < LANES && o1 <= I) ? o1 * SC_INS : NEGV;
-                                y = (o0 >= 0 && o0 < LANES && o0 <= I) ? o0 * SC_INS : NEGV;
-                            } else {
-                                const int pu = q == 0 ? q0 : (q == 1 ? q1 : (q == 2 ? q2 : rfl(g.rank[g.predx[v * 5 + (q - 3)]])));
-                                if (pu >= k - 3) {                         // the last three columns are still in registers
-                                    const int plo = pu == k - 1 ? lo_prev : (pu == k - 2 ? lo2 : lo3);
-                                    const int srcM = pu == k - 1 ? Mprev : (pu == k - 2 ? M2 : M3);
-                                    const int o1 = i - 1 - plo, o0 = i - plo;
-                                    const int xs = __shfl(srcM, o1 & 63), ys = __shfl(srcM, o0 & 63);
-                                    x = (o1 >= 0 && o1 < LANES) ? xs : NEGV;
-                                    y = (o0 >= 0 && o0 < LANES) ? ys : NEGV;
-                                } else {
-                                    const int plo = (pu >= kb) ? rl(myInfo.x, pu - kb) : rfl(g.kinfo[pu].x);
-                                    const int o1 = i - 1 - plo, o0 = i - plo;
-                                    const int32_t *Mu = g.M + (size_t)pu * 64;
-                                    x = (o1 >= 0 && o1 < LANES) ? Mu[o1] : NEGV;
-                                    y = (o0 >= 0 && o0 < LANES) ? Mu[o0] : NEGV;
-                                }
-                            }
-                            if (i >= 1 && i <= I && x > NEGV / 2) { int c = x + (vb == rbv ? SC_MATCH : SC_MISMATCH); if (c > best) { best = c; bm = MV_DIAG | (q << 2); } }
-                            if (i <= I && y > NEGV / 2) { int c = y + SC_DEL; if (c > best) { best = c; bm = MV_DEL | (q << 2); } }
-                        }
-                    }
-                    // insertion chain: x_l = max_k<=l (c_k + (l-k)*INS): exact integer max-plus prefix scan (6 fused DPP ops)
-                    const int d = wave_scan_max_i32(best + lane4);
-                    const int xi = d - lane4;
-                    if (xi > best) { best = xi; bm = MV_INS; }
-                    if (i > I || best < NEGV / 2) best = NEGV;
-                    const int cm = wave_reduce_max_i32(best);
-                    const unsigned long long bal = __ballot(best == cm);
-                    const int br = lo + (__ffsll((long long)bal) - 1);
-                    if (rl(needL, j)) *Mrow = best;                            // wave-uniform: only columns a far in-edge will read
-                    *mvrow = (uint8_t)bm;
-                    if (lane == j) myInfo = make_int4(lo, cm, br, pp);
-                    const int oe = I - lo;
-                    if ((unsigned)oe < (unsigned)LANES) { const int xe = rl(best, oe); if (xe > NEGV / 2 && xe > bs) { bs = xe; kend = k; } }
-                    M3 = M2; lo3 = lo2; M2 = Mprev; lo2 = lo_prev;
-                    Mprev = best; lo_prev = lo; cm_prev = cm; br_prev = br;
-                }
-                if (kkL < n0) g.kinfo[kkL] = myInfo;
-            }
-            __threadfence_block();
-            PHASE(9);
-            if (kend >= 0) {                                // else: read not added
-            // ---- traceback: lane 0 walks, the block of 64 positions it is in is cached in LDS
-            {
-                int k = kend, i = I;
-                while (k >= 0) {
-                    const int kb = (k / TB_BLOCK) * TB_BLOCK;
-                    __syncthreads();
-                    // block cache: the TB_BLOCK move rows go to LDS, the per-position words (band start, position of in-edge 0,
-                    // vertex id, record word) stay in lane registers and are handed out with v_readlane
-                    int4 kiL = make_int4(0, 0, 0, -1);
-                    int vLt = 0, metaL = 0;
-                    {
-                        const int kk = kb + lane;
-                        if (lane < TB_BLOCK && kk < n0) { kiL = g.kinfo[kk]; vLt = order[kk]; metaL = g.vrec[vLt].x; }
-                        const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb * 64);
-                        uint4 *dst = (uint4 *)sMv;
-#pragma unroll
-                        for (int q = 0; q < TB_BLOCK / 16; ++q) dst[q * 64 + lane] = src[q * 64 + lane];
-                    }
-                    asm volatile("" :: "v"(kiL.x), "v"(kiL.w), "v"(vLt), "v"(metaL));
-                    __syncthreads();
-                    while (k >= kb) {                                  // uniform walk: every lane follows the same (k, i)
-                        const int kl = k - kb;
-                        {
-                            // a run of plain DIAG steps along the chain (in-edge 0 is the previous position): lane s tests
-                            // step s of the run, one ballot gives its length, the path entries are stored by the lanes
-                            const int kls = kl - lane;
-                            const int src = kls & 63;
-                            const int lo_s = __shfl(kiL.x, src), pp_s = __shfl(kiL.w, src);
-                            const int off = i - lane - lo_s;
-                            const bool inb = kls >= 0 && i - lane >= 1 && (unsigned)off < 64u;
-                            const int m_s = inb ? sMv[kls * 64 + off] : 255;
-                            const unsigned long long simple = __ballot(m_s == 0 && pp_s == k - lane - 1);
-                            const int R = (simple == ~0ull) ? 64 : __ffsll((long long)~simple) - 1;
-                            if (R > 0) {
-                                const int meta_s = __shfl(metaL, src), v_s = __shfl(vLt, src);
-                                if (lane < R) {
-                                    const int ir = i - lane - 1;
-                                    g.pathv[ir] = ((meta_s & 255) == read_base_packed(sread, ir)) ? v_s : -1;
-                                }
-                                k -= R; i -= R;
-                                continue;
-                            }
-                        }
-                        const int lo_k = rl(kiL.x, kl);
-                        CHK(i - lo_k >= 0 && i - lo_k < 64 && i >= 0, 101);
-                        const int m = rfl(sMv[kl * 64 + (i - lo_k)]);
-                        const int t = m & 3, slot = m >> 2;
-                        CHK(i >= 1 || t == MV_DEL, 102);
-                        if (t == MV_INS) { if (lane == 0) g.pathv[i - 1] = -1; --i; continue; }
-                        const int meta = rl(metaL, kl);
-                        const int np = (meta >> 8) & 255;
-                        int up;
-                        if (np == 0) up = -1;
-                        else if (slot == 0) up = rl(kiL.w, kl);
-                        else { const int v = rl(vLt, kl); const int4 rec = g.vrec[v]; up = rfl(g.rank[poa_pred(g, rec, v, slot)]); }
-                        if (t == MV_DIAG) {
-                            if (lane == 0) g.pathv[i - 1] = ((meta & 255) == read_base_packed(sread, i - 1)) ? rl(vLt, kl) : -1;
-                            --i;
-                        }
-                        CHK(up < k && up >= -1, 103);
-                        k = up;
-                    }
-                    k = rfl(k); i = rfl(i);
-                }
-                for (int q = lane; q < i; q += LANES) g.pathv[q] = -1;     // leading insertions at START
-            }
-            __threadfence_block();
-            PHASE(10);
-            // ---- thread the read into the graph (wave-parallel; identical result to the serial list insertion)
-            int32_t *cnt = g.bestK;
-            int carry = 0;
-            for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 1: vertex ids of the path
-                const int i = c0 + lane;
-                const int pv = i < I ? g.pathv[i] : 0;
-                const int isnew = (i < I && pv < 0) ? 1 : 0;
-                const int incl = wave_scan_add_i32(isnew);
-                if (i < I) g.pathv[i] = isnew ? n0 + carry + incl - 1 : pv;
-                carry += rl(incl, 63);
-            }
-            const int nnew = carry;
-            if (n0 + nnew > vcap) ok = 0;
-            else {
-            for (int q = lane; q <= n0; q += LANES) cnt[q] = 0;
-            __threadfence_block();
-            int lastEx = -1;
-            for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 2: records, edges, run counts
-                const int i = c0 + lane;
-                const bool valid = i < I;
-                const int w = valid ? g.pathv[i] : 0;
-                const int pw = (valid && i > 0) ? g.pathv[i - 1] : -1;
-                const bool isnew = valid && w >= n0;
-                const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
-                int ex = wave_shr1_i32(incl, -1);
-                ex = ex > lastEx ? ex : lastEx;                            // last existing path element before i
-                if (valid) {
-                    int4 rec;
-                    if (!isnew) { rec = g.vrec[w]; rec.x += 1 << 16; }
-                    else {
-                        rec = make_int4(read_base_packed(sread, i) | (1 << 16), -1, -1, -1);
-                        // the last vertex of a run of new vertices records the run length at its anchor (plain store, one writer)
-                        const bool lastOfRun = (i + 1 >= I) || (g.pathv[i + 1] < n0);
-                        if (lastOfRun) {
-                            const int apos = ex >= 0 ? g.rank[g.pathv[ex]] : -1;
-                            CHK(apos >= -1 && apos < n0, 106);
-                            cnt[apos + 1] = i - ex;
-                        }
-                    }
-                    if (pw >= 0) poa_add_edge(g, rec, w, pw);
-                    g.vrec[w] = rec;
-                }
-                const int li = rl(incl, 63);
-                lastEx = li > lastEx ? li : lastEx;
-            }
-            __threadfence_block();
-            carry = 0;
-            for (int c0 = 0; c0 <= n0; c0 += LANES) {                      // inclusive prefix sum of run counts
-                const int q = c0 + lane;
-                const int incl = wave_scan_add_i32(q <= n0 ? cnt[q] : 0);
-                if (q <= n0) cnt[q] = carry + incl;
-                carry += rl(incl, 63);
-            }
-            __threadfence_block();
-            lastEx = -1;
-            for (int c0 = 0; c0 < I; c0 += LANES) {                        // new vertices: position right after their anchor
-                const int i = c0 + lane;
-                const bool valid = i < I;
-                const int w = valid ? g.pathv[i] : 0;
-                const bool isnew = valid && w >= n0;
-                const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
-                int ex = wave_shr1_i32(incl, -1);
-                ex = ex > lastEx ? ex : lastEx;
-                if (isnew) {
-                    int pos = i - ex - 1;
-                    if (ex >= 0) { const int apos = g.rank[g.pathv[ex]]; pos += apos + cnt[apos] + 1; }
-                    CHK(pos >= 0 && pos < n0 + nnew && w < vcap, 104);
-                    order_nx[pos] = w; g.rank[w] = pos;
-                }
-                const int li = rl(incl, 63);
-                lastEx = li > lastEx ? li : lastEx;
-            }
-            __threadfence_block();
-            for (int q = lane; q < n0; q += LANES) {                       // existing vertices shift right
-                const int v = order[q];
-                const int np2 = q + cnt[q];
-                CHK(np2 >= 0 && np2 < n0 + nnew && v >= 0 && v < n0, 105);
-                order_nx[np2] = v; g.rank[v] = np2;
-            }
-            { int32_t *t = order; order = order_nx; order_nx = t; }
-            n = n0 + nnew;
-            nadded += 1;
-            __threadfence_block();
-            PHASE(11);
-            }   // capacity ok
-            }   // kend >= 0
-            }   // not the first read
-        }
-        PHASE(12);
-        // ---- consensus: heaviest path (uniform walk, block records via readlane)
-        int Ld = 0, nw = 0, stat = -1;
-        if (ok && n > 0) {
-            int kbest = -1, sb = NEGV, best_prev = 0, vprev = -2;
-            for (int kb = 0; kb < n; kb += LANES) {
-                const int kkL = kb + lane;
-                const int vL = kkL < n ? order[kkL] : 0;
-                int4 rL = make_int4(0, 0, 0, 0);
-                if (kkL < n) rL = g.vrec[vL];
-                const int nblk = (n - kb) < LANES ? (n - kb) : LANES;
-                int myBest = 0, myBp = -1;
-                for (int j = 0; j < nblk; ++j) {
-                    const int k = kb + j;
-                    const int v = rl(vL, j);
-                    const int4 rec = make_int4(rl(rL.x, j), rl(rL.y, j), rl(rL.z, j), rl(rL.w, j));
-                    const int np = (rec.x >> 8) & 255, nr = rec.x >> 16;
-                    int b = 0, p = -1;
-                    for (int q = 0; q < np; ++q) {
-                        const int u = rfl(poa_pred(g, rec, v, q));
-                        int bu, pu;
-                        CHK(u >= 0 && u < n, 108);
-                        if (u == vprev) { bu = best_prev; pu = k - 1; }
-                        else { pu = rfl(g.rank[u]); bu = (pu >= kb) ? rl(myBest, pu - kb) : rfl(g.bestK[pu]); }
-                        if (bu > b) { b = bu; p = pu; }
-                    }
-                    const int bv = b + 2 * nr - nadded;
-                    if (lane == j) { myBest = bv; myBp = p; }
-                    if (bv > sb) { sb = bv; kbest = k; }
-                    best_prev = bv; vprev = v;
-                }
-                if (kkL < n) { g.bestK[kkL] = myBest; g.bpK[kkL] = myBp; }
-                __threadfence_block();
-            }
-            // backtrack (uniform), bases collected in reverse into scratch
-            uint8_t *tmp = (uint8_t *)g.pathv;
-            int len = 0, k = kbest;
-            while (k >= 0) {
-                const int kb = (k >> 6) << 6;
-                const int kk = kb + lane;
-                const int bpL = kk < n ? g.bpK[kk] : -1;
-                const int bL = kk < n ? (g.vrec[order[kk]].x & 255) : 0;
-                while (k >= kb) {
-                    const int kl = k - kb;
-                    CHK(len < n, 107);
-                    if (lane == 0) tmp[len] = (uint8_t)rl(bL, kl);
-                    ++len;
-                    k = rl(bpL, kl);
-                }
-            }
-            __threadfence_block();
-            if (len <= P.dcap[z]) {
-                uint8_t *draft = P.draft + P.seq_off[z];
-                for (int q = lane; q < len; q += LANES) draft[q] = tmp[len - 1 - q];
-                Ld = len;
-            }
-            __threadfence_block();
-        }
-        if (Ld <= 0) stat = CCSX_DRAFT_FAILURE;
-        else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
-        else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
-        else {
-            // step 4 windows.  SPEC: a break nb is bad when for some period p in 1..4 the p-mer before it equals the p-mer
-            // after it ("avoid breaking windows at simple repeats", docs/how-does-ccs-work.md:58-60); the target cur+22 moves by
-            // 0,+1,-1,+2,-2,+3,-3 to the first good position.  Lane l holds draft[cur+14+l]; E_p = ballot(d[i] == d[i+p]).
-            const uint8_t *d = P.draft + P.seq_off[z];
-            int32_t *b = P.wbounds + P.wb_off[z];
-            int cur = 0;
-            if (lane == 0) b[0] = 0;
-            while (cur < Ld) {
-                int nb;
-                if (Ld - cur <= CCSX_WIN_CORE + 6) nb = Ld;
-                else {
-                    const int base = cur + CCSX_WIN_CORE - 8;                 // positions base .. base+15 cover every p-mer examined
-                    const int pos = base + lane;
-                    const int x = (lane < 16 && pos < Ld) ? (int)d[pos] : 8 + lane;
-                    unsigned e[4];
-#pragma unroll
-                    for (int p = 1; p <= 4; ++p) e[p - 1] = (unsigned)__ballot(x == __shfl(x, (lane + p) & 63)) & 0xffffu;
-                    nb = cur + CCSX_WIN_CORE;
-                    const int offs[7] = {0, 1, -1, 2, -2, 3, -3};
-#pragma unroll
-                    for (int k = 6; k >= 0; --k) {                            // last assignment wins: scan the preference order backwards
-                        const int c = 8 + offs[k];                            // bit index of the candidate break
-                        bool bad = false;
-#pragma unroll
-                        for (int p = 1; p <= 4; ++p) bad |= ((e[p - 1] >> (c - p)) & ((1u << p) - 1u)) == ((1u << p) - 1u);
-                        if (!bad) nb = cur + CCSX_WIN_CORE + offs[k];
-                    }
-                }
-                ++nw;
-                if (lane == 0) b[nw] = nb;
-                cur = nb;
-            }
-        }
-        if (lane == 0) { P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat; }
-        PHASE(13);
-        }   // enough
+    if (lane < ST_WORDS) g.st[lane] = 0;                // (ST_LIVE = 0: the other kernels skip this graph unless it is set below)
+    __threadfence_block();
+    const int r0 = rfl(P.read_off[z]);
+    int nreads = rfl(P.read_off[z + 1]) - r0;
+    {   // SPEC: at most 64 passes are used (the polish kernel keeps per-read state for 64 reads)
+        const int top = (P.opts.top_passes <= 0 || P.opts.top_passes > PW_MAXREADS_SPEC) ? PW_MAXREADS_SPEC : P.opts.top_passes;
+        if (nreads > top) nreads = top;
     }
+    // SPEC "fallback draft" (docs/faq/accuracy-vs-passes.md:41-46: a cascade from fast to robust draft generators): pass 1
+    // (only for ZMWs k_post marked) takes the pass whose length is closest to the median as backbone and threads twice as
+    // many passes, starting at the backbone and wrapping around
+    int bb = 0;
+    if (pass == 1) {
+        if (rfl(P.zref[z]) != ZREF_RETRY) return;
+        const int len = lane < nreads ? (int)(P.base_off[r0 + lane + 1] - P.base_off[r0 + lane]) : 0x7fffffff;
+        int rank = 0;                                   // position of my length in the sorted order (ties by index)
+        for (int q = 0; q < nreads; ++q) { const int lq = __shfl(len, q); rank += (lq < len || (lq == len && q < lane)) ? 1 : 0; }
+        const int med = rfl(__shfl(len, __ffsll((long long)__ballot(lane < nreads && rank == nreads / 2)) - 1));
+        int dist = len - med; dist = dist < 0 ? -dist : dist;
+        const int key = lane < nreads ? ((dist > 0xffffff ? 0xffffff : dist) << 6) | lane : 0x7fffffff;
+        bb = rfl(wave_min_i32(key)) & 63;
+    }
+    if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_DONE : 0); }
+    const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
+    if (!enough) { if (lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES; return; }
+    const int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
+    const int npoa = nreads < cov ? nreads : cov;
+    const int vcap = rfl(P.vcap[z]);
+    const int rev0 = rfl(P.flags[r0 + bb] & 1);
+    const int r = r0 + bb;
+    const uint8_t *rb = P.bases + P.base_off[r];
+    const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
+    load_read_packed(sread, rb, I, 0, lane);
+    __syncthreads();
+    int ok = 1, n = 0;
+    if (I > vcap) ok = 0;
+    else {                                              // first read: backbone chain; its column records are trivial
+        for (int i = lane; i < I; i += LANES) {
+            const int b = read_base_packed(sread, i);
+            g.vrec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8) | (1 << 16), i - 1, -1, -1);
+            g.rank[i] = i; g.order0[i] = i;
+            g.crec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8), i - 1, -1, -1);
+        }
+        n = I;
+    }
+    __threadfence_block();
+    if (lane == 0) {
+        g.st[ST_N] = n; g.st[ST_NADDED] = 1; g.st[ST_OK] = ok; g.st[ST_PAR] = 0; g.st[ST_KEND] = -1; g.st[ST_BS] = NEGV;
+        g.st[ST_NPOA] = npoa; g.st[ST_BB] = bb; g.st[ST_NREADS] = nreads; g.st[ST_REV0] = rev0; g.st[ST_LIVE] = 1;
+    }
+}
+
+// a CH16-base chunk of the oriented read for one 16-lane group, packed 2 bits per base, shifted by ONE base: word w holds the bases
+// c0 - 1 + 16 w .. (index -1 = a dummy), so that the base of row i - 1 for row i = c0 + x sits at packed position x
+__device__ __forceinline__ void load_read_chunk_m1(uint32_t *sread, const uint8_t *bases, int L, int rev, int c0, int l16)
+{
+    for (int w = l16; w <= CH16 / 16 + 1; w += 16) {
+        uint32_t v = 0;
+        const int i0 = c0 - 1 + (w << 4);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = i0 + k;
+            if (i >= 0 && i < L) { uint32_t b = (uint32_t)bases[rev ? L - 1 - i : i]; if (rev) b = 3u - b; v |= (b & 3u) << (2 * k); }
+        }
+        sread[w] = v;
+    }
+}
+
+// ---- k_poa_dp: the banded DP of pass rr over FOUR graphs per wave (see the header of this section)
+__global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int rr)
+{
+    __shared__ __attribute__((aligned(16))) int32_t sRing[4][PRING + 1][PGS];
+    __shared__ __attribute__((aligned(16))) int4 sKin[4][PRING + 1];
+    __shared__ __attribute__((aligned(16))) int4 sCrec[4][16];
+    __shared__ uint32_t sRead[4][CH16 / 16 + 2];
+    const int lane = threadIdx.x, gq = lane >> 4, l = lane & 15;
+    const int zi = z0 + 4 * (int)blockIdx.x + gq;
+    const bool have = zi < P.n_zmw && 4 * (int)blockIdx.x + gq < P.poa_slots;
+    const PoaSlot G = poa_slot(P, have ? 4 * (int)blockIdx.x + gq : 4 * (int)blockIdx.x);   // per lane, uniform inside a 16-lane group
+    int32_t *st = G.st;
+    int32_t *Mcol = G.M;
+    int4 *kinfo = G.kinfo;
+    const int4 *crec = G.crec;
+    uint8_t *mvK = G.mvK;
+    bool live = have && st[ST_LIVE] && st[ST_OK] && rr < st[ST_NPOA];
+    if (!__any(live)) return;
+    const int z = have ? P.zmw_perm[zi] : 0;
+    const int r0 = P.read_off[z];
+    const int n0 = live ? st[ST_N] : 0;
+    int I = 0, rev = 0;
+    const uint8_t *rb = P.bases;
+    if (live) {
+        const int bb = st[ST_BB], nr = st[ST_NREADS];
+        const int r = r0 + (bb + rr < nr ? bb + rr : bb + rr - nr);
+        rb = P.bases + P.base_off[r];
+        I = (int)(P.base_off[r + 1] - P.base_off[r]);
+        rev = ((P.flags[r] & 1) != st[ST_REV0]) ? 1 : 0;
+    }
+    // ---- LDS: guards and unused cells = NEGV, the START column M[l] = l * INS (l <= I), its record (lo 0, colmax 0, best row 0)
+    for (int e = l; e < (PRING + 1) * PGS; e += 16) (&sRing[gq][0][0])[e] = NEGV;
+    __syncthreads();
+    sRing[gq][PRING][4 + 2 * l] = (2 * l <= I) ? 2 * l * SC_INS : NEGV;
+    sRing[gq][PRING][5 + 2 * l] = (2 * l + 1 <= I) ? (2 * l + 1) * SC_INS : NEGV;
+    if (l == 0) sKin[gq][PRING] = make_int4(0, 0, 0, 0);
+    int c0 = 0;                                         // first base of the group's read chunk in LDS
+    load_read_chunk_m1(sRead[gq], rb, I, rev, 0, l);
+    __syncthreads();
+    const int hiI = I - (PB - 1) > 0 ? I - (PB - 1) : 0;
+    const int nmax = wave_max_i32(n0);
+    int bs = NEGV, kend = -1;
+    // per-lane constants of the column step
+    const int l2 = 2 * l, l8 = 8 * l;
+    const int kRow0 = 63 - 2 * l, kRow1 = 62 - 2 * l;
+    typedef int32_t __attribute__((address_space(3))) *lds_i32;
+    const uint32_t ringBase = (uint32_t)(uintptr_t)(lds_i32)&sRing[gq][0][0];      // 32-bit LDS addresses
+    const uint32_t readBase = (uint32_t)(uintptr_t)(lds_i32)(int32_t *)&sRead[gq][0];
+    const int bcastAddr = (lane | 15) << 2;                                        // ds_bpermute: the row's last lane
+    // running per-lane output pointers (one 64-bit add per column instead of an index multiply)
+    uint8_t *mvp = mvK + 2 * l;
+    int4 *kip = kinfo;
+    int32_t *Mp = Mcol + 2 * l;
+    int4 recN = make_int4(0, -1, -1, -1);               // the NEXT block of 16 column records (lane l: column kb + 16 + l)
+    if (l < n0) recN = crec[l];
+#define LDS_I32(addr) (*(lds_i32)(uintptr_t)(addr))
+    // wave masks of per-lane conditions straight from the compare (a bool that goes through ballot costs two extra VALU ops)
+#define M_NE0(a) __builtin_amdgcn_uicmp((unsigned)(a), 0u, 33)
+#define M_SLT(a, b) __builtin_amdgcn_sicmp((int)(a), (int)(b), 40)
+#define M_SGT(a, b) __builtin_amdgcn_sicmp((int)(a), (int)(b), 38)
+#define M_UGT(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 34)
+    const uint32_t kinBase = (uint32_t)(uintptr_t)(lds_i32)(int32_t *)&sKin[gq][0];
+    const unsigned long long livem = M_NE0(live ? 1 : 0);
+    for (int k = 0; k < nmax; ++k, mvp += PB, ++kip, Mp += PB) {
+        if ((k & 15) == 0) {                            // hand the prefetched block to LDS, start fetching the one after it
+            sCrec[gq][l] = recN;
+            recN = make_int4(0, -1, -1, -1);
+            if (k + 16 + l < n0) recN = crec[k + 16 + l];
+            __syncthreads();
+        }
+        const unsigned long long actm = livem & M_SLT(k, n0);
+        const int4 rec = sCrec[gq][k & 15];
+        const int vb = rec.x & 3;
+        const int p0 = rec.y;
+        const unsigned long long multim = actm & M_NE0(rec.x & 0xe00);         // two or more in-edges
+        const unsigned long long far0m = actm & M_NE0(rec.x & CREC_FAR0);      // in-edge 0 comes from more than PRING positions back
+        // ---- band placement: from the in-edge column with the largest column maximum (first on ties); START for a source
+        const uint32_t slot0 = p0 < 0 ? PRING : (uint32_t)(p0 & (PRING - 1));
+        int k0x, k0y, k0z;
+        { const uint32_t ka = kinBase + slot0 * 16; k0x = LDS_I32(ka); k0y = LDS_I32(ka + 4); k0z = LDS_I32(ka + 8); }
+        if (far0m) { if (rec.x & CREC_FAR0) { const int4 t = kinfo[p0]; k0x = t.x; k0y = t.y; k0z = t.z; } }
+        int ulo = k0x, ubr = k0z;
+        int plo1 = 0, plo2 = 0;
+        if (multim) {
+            const int np = (rec.x >> 8) & 15;
+            const bool act = live && k < n0;
+            int bestcm = k0y;
+            for (int q = 1; q < CCSX_MAXPRED; ++q) {
+                if ((actm & M_SGT(np, q)) == 0ull) break;
+                int pq = q == 1 ? rec.z : rec.w;
+                if (q >= 3 && act && np > q) {          // in-edges 3..7 (rare): through the vertex id
+                    const int32_t *order = st[ST_PAR] ? G.order1 : G.order0;
+                    pq = G.rank[G.predx[order[k] * 5 + (q - 3)]];
+                }
+                const bool on = act && np > q;
+                const bool farq = on && k - pq > PRING;
+                const uint32_t ka = kinBase + (on ? (uint32_t)(pq & (PRING - 1)) : (uint32_t)PRING) * 16;
+                int qx = LDS_I32(ka), qy = LDS_I32(ka + 4), qz = LDS_I32(ka + 8);
+                if (M_NE0(farq ? 1 : 0)) { if (farq) { const int4 t = kinfo[pq]; qx = t.x; qy = t.y; qz = t.z; } }
+                if (q == 1) plo1 = qx; else if (q == 2) plo2 = qx;
+                if (on && qy > bestcm) { bestcm = qy; ulo = qx; ubr = qz; }
+            }
+        }
+        int lo = imed3(ubr + (1 - PB / 2), ulo, ulo + 2);                        // clamp(best row + 1 - 16, ulo, ulo + 2)
+        lo = lo < hiI ? lo : hiI;
+        lo = lo > 0 ? lo : 0;
+        // ---- the read bases of rows r0 - 1 and r0 (r0 = lo + 2l): the chunk follows the band
+        if (actm & M_UGT(lo - c0, CH16 - PB - 2)) {
+            __syncthreads();
+            if (live && k < n0 && (unsigned)(lo - c0) > (unsigned)(CH16 - PB - 2)) {
+                c0 = lo - 128 > 0 ? lo - 128 : 0;
+                load_read_chunk_m1(sRead[gq], rb, I, rev, c0, l);
+            }
+            __syncthreads();
+        }
+        const int r0w = lo + l2;
+        int s0, s1;
+        {
+            const uint32_t idx = (uint32_t)(r0w - c0) & (CH16 - 1);              // (inactive groups: any in-range index)
+            const uint32_t wa = readBase + ((idx >> 4) << 2);
+            const uint32_t wlo = (uint32_t)LDS_I32(wa), whi = (uint32_t)LDS_I32(wa + 4);
+            const uint32_t t = __builtin_amdgcn_alignbit(whi, wlo, (idx & 15u) << 1);
+            s0 = (vb == (int)(t & 3u)) ? SC_MATCH : SC_MISMATCH;
+            s1 = (vb == (int)((t >> 2) & 3u)) ? SC_MATCH : SC_MISMATCH;
+        }
+        // ---- in-edge 0 (or START): diagonal then deletion; three consecutive rows of the source column at the band offset
+        int b0, b1, m0, m1;
+        {
+            const int w = imed3(r0w - k0x + 3, 1, PGS - 3);   // word of row (r0 - plo) - 1 behind the 4 guard words
+            const uint32_t src = ringBase + slot0 * (PGS * 4) + ((uint32_t)w << 2);
+            int x0 = LDS_I32(src), y0 = LDS_I32(src + 4), y1 = LDS_I32(src + 8);
+            if (far0m) {
+                if (rec.x & CREC_FAR0) {                // the source column comes from HBM
+                    const int32_t *Mu = Mcol + (size_t)p0 * PB;
+                    const int o = r0w - k0x - 1;
+                    x0 = (unsigned)o < (unsigned)PB ? Mu[o] : NEGV;
+                    y0 = (unsigned)(o + 1) < (unsigned)PB ? Mu[o + 1] : NEGV;
+                    y1 = (unsigned)(o + 2) < (unsigned)PB ? Mu[o + 2] : NEGV;
+                }
+            }
+            const int d0 = x0 + s0, e0 = y0 + SC_DEL, d1 = y0 + s1, e1 = y1 + SC_DEL;
+            const bool t0 = e0 > d0, t1 = e1 > d1;
+            b0 = t0 ? e0 : d0; m0 = t0 ? MV_DEL : MV_DIAG;
+            b1 = t1 ? e1 : d1; m1 = t1 ? MV_DEL : MV_DIAG;
+        }
+        if (multim) {                                    // further in-edges, in list order: a later candidate wins only if strictly greater
+            const int np = (rec.x >> 8) & 15;
+            const bool act = live && k < n0;
+            for (int q = 1; q < CCSX_MAXPRED; ++q) {
+                if ((actm & M_SGT(np, q)) == 0ull) break;
+                const bool on = act && np > q;
+                int pq = q == 1 ? rec.z : rec.w, plo = q == 1 ? plo1 : plo2;
+                if (q >= 3 && on) {
+                    const int32_t *order = st[ST_PAR] ? G.order1 : G.order0;
+                    pq = G.rank[G.predx[order[k] * 5 + (q - 3)]];
+                    if (k - pq > PRING) plo = kinfo[pq].x; else plo = LDS_I32(kinBase + (uint32_t)(pq & (PRING - 1)) * 16);
+                }
+                const bool farq = on && k - pq > PRING;
+                const int off = r0w - plo;
+                const int w = imed3(off + 3, 1, PGS - 3);
+                const uint32_t src = ringBase + (on ? (uint32_t)(pq & (PRING - 1)) : (uint32_t)PRING) * (PGS * 4) + ((uint32_t)w << 2);
+                int x0 = LDS_I32(src), y0 = LDS_I32(src + 4), y1 = LDS_I32(src + 8);
+                if (M_NE0(farq ? 1 : 0)) {
+                    if (farq) {
+                        const int32_t *Mu = Mcol + (size_t)pq * PB;
+                        const int o = off - 1;
+                        x0 = (unsigned)o < (unsigned)PB ? Mu[o] : NEGV;
+                        y0 = (unsigned)(o + 1) < (unsigned)PB ? Mu[o + 1] : NEGV;
+                        y1 = (unsigned)(o + 2) < (unsigned)PB ? Mu[o + 2] : NEGV;
+                    }
+                }
+                const int mq = q << 2;
+                int c;
+                c = x0 + s0;     if (on && c > b0) { b0 = c; m0 = mq | MV_DIAG; }
+                c = y0 + SC_DEL; if (on && c > b0) { b0 = c; m0 = mq | MV_DEL; }
+                c = y0 + s1;     if (on && c > b1) { b1 = c; m1 = mq | MV_DIAG; }
+                c = y1 + SC_DEL; if (on && c > b1) { b1 = c; m1 = mq | MV_DEL; }
+            }
+        }
+        // ---- insertion chain x_i = max(c_i, x_{i-1} + INS) over the 32 rows: lane-local (row 2l -> 2l+1), an exclusive 4-step
+        // row scan of the lanes' outgoing values, then the incoming value applied to both rows
+        { const int c = b0 + SC_INS; if (c > b1) { b1 = c; m1 = MV_INS; } }
+        {
+            const int S = row_scan_max_i32(b1 + l8);
+            const int Sp = __builtin_amdgcn_update_dpp(-(1 << 30), S, DPP_ROW_SHR(1), 0xf, 0xf, false);
+            const int c0v = Sp - (l8 - 8 - SC_INS);     // (final value of row 2l - 1) + INS ; lane 0: very negative
+            const int c1v = Sp - (l8 - 8 - 2 * SC_INS);
+            if (c0v > b0) { b0 = c0v; m0 = MV_INS; }
+            if (c1v > b1) { b1 = c1v; m1 = MV_INS; }
+        }
+        if (r0w > I || b0 < NEGV / 2) b0 = NEGV;
+        if (r0w >= I || b1 < NEGV / 2) b1 = NEGV;
+        // ---- column maximum and the first row that attains it: one packed row scan (value << 6 | 63 - row).  A column without a
+        // valid cell reports -2^24 as its maximum (it loses every comparison a valid column takes part in, like the SPEC's NEG)
+        int cm, br;
+        {
+            const int f = -(1 << 24);
+            const int k0_ = ((b0 > f ? b0 : f) * 64) | kRow0, k1_ = ((b1 > f ? b1 : f) * 64) | kRow1;
+            const int key = __builtin_amdgcn_ds_bpermute(bcastAddr, row_scan_max_i32(k0_ > k1_ ? k0_ : k1_));
+            cm = key >> 6; br = (lo + 63) - (key & 63);
+        }
+        // ---- the read's last row: best end cell over all columns (first in topological order)
+        if (actm & M_SGT(lo + PB, I)) {
+            const int e = r0w == I ? b0 : (r0w + 1 == I ? b1 : NEGV);
+            const int ev = __builtin_amdgcn_ds_bpermute(bcastAddr, row_scan_max_i32(e));
+            if (live && k < n0 && ev > NEGV / 2 && ev > bs) { bs = ev; kend = k; }
+        }
+        // ---- out: ring (LDS), moves + column record (HBM), the score column if a far in-edge will read it
+        if (live && k < n0) {
+            *(int2 *)&sRing[gq][k & (PRING - 1)][4 + l2] = make_int2(b0, b1);
+            *(uint16_t *)mvp = (uint16_t)(m0 | (m1 << 8));
+            if (l == 0) {
+                sKin[gq][k & (PRING - 1)] = make_int4(lo, cm, br, 0);
+                *kip = make_int4(lo, cm, br, p0);
+            }
+            if (rec.x & CREC_NEED) *(int2 *)Mp = make_int2(b0, b1);
+        }
+    }
+#undef M_NE0
+#undef M_SLT
+#undef M_SGT
+#undef M_UGT
+#undef LDS_I32
+    __threadfence_block();
+    if (live && l == 0) { st[ST_KEND] = kend; st[ST_BS] = bs; }
+}
+
+// ---- k_poa_thread: gate, traceback and threading of pass rr, then the column records of the next DP.  One wave per graph.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa_thread(KParams P, int z0, int pass, int rr)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sMv[TB_BLOCK * PB];   // move rows of the traceback's current block
+    const int lane = threadIdx.x;
+    uint32_t *sread = dyn_lds;
+    PoaSlot g = poa_slot(P, blockIdx.x);
+    if (z0 + (int)blockIdx.x >= P.n_zmw) return;
+    if (!g.st[ST_LIVE] || !g.st[ST_OK] || rr >= g.st[ST_NPOA]) return;
+    const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);
+    const int r0 = rfl(P.read_off[z]);
+    const int bb = rfl(g.st[ST_BB]), nreads = rfl(g.st[ST_NREADS]), npoa = rfl(g.st[ST_NPOA]);
+    const int r = r0 + (bb + rr < nreads ? bb + rr : bb + rr - nreads);
+    const uint8_t *rb = P.bases + P.base_off[r];
+    const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
+    const int kend = rfl(g.st[ST_KEND]), bsc = rfl(g.st[ST_BS]);
+    // SPEC "POA gate": a pass is threaded only if its alignment reaches the read's last row with a score of at least 1.0 per base
+    if (kend < 0 || bsc < I) return;
+    const int rev = rfl(((P.flags[r] & 1) != g.st[ST_REV0]) ? 1 : 0);
+    const int vcap = rfl(P.vcap[z]);
+    const int n0 = rfl(g.st[ST_N]);
+    int32_t *order = g.st[ST_PAR] ? g.order1 : g.order0, *order_nx = g.st[ST_PAR] ? g.order0 : g.order1;
+    load_read_packed(sread, rb, I, rev, lane);
+    __syncthreads();
+    // ---- traceback: lane 0 walks, the block of TB_BLOCK positions it is in is cached in LDS
+    {
+        int k = kend, i = I;
+        while (k >= 0) {
+            const int kb = (k / TB_BLOCK) * TB_BLOCK;
+            __syncthreads();
+            // block cache: the TB_BLOCK move rows go to LDS, the per-position words (band start, position of in-edge 0,
+            // vertex id, record word) stay in lane registers and are handed out with v_readlane
+            int4 kiL = make_int4(0, 0, 0, -1);
+            int vLt = 0, metaL = 0;
+            {
+                const int kk = kb + lane;
+                if (lane < TB_BLOCK && kk < n0) { kiL = g.kinfo[kk]; vLt = order[kk]; metaL = g.vrec[vLt].x; }
+                const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb * PB);
+                uint4 *dst = (uint4 *)sMv;
+#pragma unroll
+                for (int q = 0; q < TB_BLOCK * PB / 16 / 64; ++q) dst[q * 64 + lane] = src[q * 64 + lane];
+            }
+            asm volatile("" :: "v"(kiL.x), "v"(kiL.w), "v"(vLt), "v"(metaL));
+            __syncthreads();
+            while (k >= kb) {                                  // uniform walk: every lane follows the same (k, i)
+                const int kl = k - kb;
+                {
+                    // a run of plain DIAG steps along the chain (in-edge 0 is the previous position): lane s tests
+                    // step s of the run, one ballot gives its length, the path entries are stored by the lanes
+                    const int kls = kl - lane;
+                    const int src = kls & 63;
+                    const int lo_s = __shfl(kiL.x, src), pp_s = __shfl(kiL.w, src);
+                    const int off = i - lane - lo_s;
+                    const bool inb = kls >= 0 && i - lane >= 1 && (unsigned)off < (unsigned)PB;
+                    const int m_s = inb ? sMv[kls * PB + off] : 255;
+                    const unsigned long long simple = __ballot(m_s == 0 && pp_s == k - lane - 1);
+                    const int R = (simple == ~0ull) ? 64 : __ffsll((long long)~simple) - 1;
+                    if (R > 0) {
+                        const int meta_s = __shfl(metaL, src), v_s = __shfl(vLt, src);
+                        if (lane < R) {
+                            const int ir = i - lane - 1;
+                            g.pathv[ir] = ((meta_s & 255) == read_base_packed(sread, ir)) ? v_s : -1;
+                        }
+                        k -= R; i -= R;
+                        continue;
+                    }
+                }
+                const int lo_k = rl(kiL.x, kl);
+                CHK(i - lo_k >= 0 && i - lo_k < PB && i >= 0, 101);
+                const int m = rfl(sMv[kl * PB + (i - lo_k)]);
+                const int t = m & 3, slot = m >> 2;
+                CHK(i >= 1 || t == MV_DEL, 102);
+                if (t == MV_INS) { if (lane == 0) g.pathv[i - 1] = -1; --i; continue; }
+                const int meta = rl(metaL, kl);
+                const int np = (meta >> 8) & 255;
+                int up;
+                if (np == 0) up = -1;
+                else if (slot == 0) up = rl(kiL.w, kl);
+                else { const int v = rl(vLt, kl); const int4 rec = g.vrec[v]; up = rfl(g.rank[poa_pred(g, rec, v, slot)]); }
+                if (t == MV_DIAG) {
+                    if (lane == 0) g.pathv[i - 1] = ((meta & 255) == read_base_packed(sread, i - 1)) ? rl(vLt, kl) : -1;
+                    --i;
+                }
+                CHK(up < k && up >= -1, 103);
+                k = up;
+            }
+            k = rfl(k); i = rfl(i);
+        }
+        for (int q = lane; q < i; q += LANES) g.pathv[q] = -1;     // leading insertions at START
+    }
+    __threadfence_block();
+    // ---- thread the read into the graph (wave-parallel; identical result to the serial list insertion)
+    int32_t *cnt = g.bestK;
+    int carry = 0;
+    for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 1: vertex ids of the path
+        const int i = c0 + lane;
+        const int pv = i < I ? g.pathv[i] : 0;
+        const int isnew = (i < I && pv < 0) ? 1 : 0;
+        const int incl = wave_scan_add_i32(isnew);
+        if (i < I) g.pathv[i] = isnew ? n0 + carry + incl - 1 : pv;
+        carry += rl(incl, 63);
+    }
+    const int nnew = carry;
+    if (n0 + nnew > vcap) { if (lane == 0) g.st[ST_OK] = 0; return; }
+    for (int q = lane; q <= n0; q += LANES) cnt[q] = 0;
+    __threadfence_block();
+    int lastEx = -1;
+    for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 2: records, edges, run counts
+        const int i = c0 + lane;
+        const bool valid = i < I;
+        const int w = valid ? g.pathv[i] : 0;
+        const int pw = (valid && i > 0) ? g.pathv[i - 1] : -1;
+        const bool isnew = valid && w >= n0;
+        const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
+        int ex = wave_shr1_i32(incl, -1);
+        ex = ex > lastEx ? ex : lastEx;                            // last existing path element before i
+        if (valid) {
+            int4 rec;
+            if (!isnew) { rec = g.vrec[w]; rec.x += 1 << 16; }
+            else {
+                rec = make_int4(read_base_packed(sread, i) | (1 << 16), -1, -1, -1);
+                // the last vertex of a run of new vertices records the run length at its anchor (plain store, one writer)
+                const bool lastOfRun = (i + 1 >= I) || (g.pathv[i + 1] < n0);
+                if (lastOfRun) {
+                    const int apos = ex >= 0 ? g.rank[g.pathv[ex]] : -1;
+                    CHK(apos >= -1 && apos < n0, 106);
+                    cnt[apos + 1] = i - ex;
+                }
+            }
+            if (pw >= 0) poa_add_edge(g, rec, w, pw);
+            g.vrec[w] = rec;
+        }
+        const int li = rl(incl, 63);
+        lastEx = li > lastEx ? li : lastEx;
+    }
+    __threadfence_block();
+    carry = 0;
+    for (int c0 = 0; c0 <= n0; c0 += LANES) {                      // inclusive prefix sum of run counts
+        const int q = c0 + lane;
+        const int incl = wave_scan_add_i32(q <= n0 ? cnt[q] : 0);
+        if (q <= n0) cnt[q] = carry + incl;
+        carry += rl(incl, 63);
+    }
+    __threadfence_block();
+    lastEx = -1;
+    for (int c0 = 0; c0 < I; c0 += LANES) {                        // new vertices: position right after their anchor
+        const int i = c0 + lane;
+        const bool valid = i < I;
+        const int w = valid ? g.pathv[i] : 0;
+        const bool isnew = valid && w >= n0;
+        const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
+        int ex = wave_shr1_i32(incl, -1);
+        ex = ex > lastEx ? ex : lastEx;
+        if (isnew) {
+            int pos = i - ex - 1;
+            if (ex >= 0) { const int apos = g.rank[g.pathv[ex]]; pos += apos + cnt[apos] + 1; }
+            CHK(pos >= 0 && pos < n0 + nnew && w < vcap, 104);
+            order_nx[pos] = w; g.rank[w] = pos;
+        }
+        const int li = rl(incl, 63);
+        lastEx = li > lastEx ? li : lastEx;
+    }
+    __threadfence_block();
+    for (int q = lane; q < n0; q += LANES) {                       // existing vertices shift right
+        const int v = order[q];
+        const int np2 = q + cnt[q];
+        CHK(np2 >= 0 && np2 < n0 + nnew && v >= 0 && v < n0, 105);
+        order_nx[np2] = v; g.rank[v] = np2;
+    }
+    __threadfence_block();
+    const int n = n0 + nnew;
+    if (lane == 0) { g.st[ST_N] = n; g.st[ST_NADDED] += 1; g.st[ST_PAR] ^= 1; }
+    // ---- the column records of the next pass's DP (none after the last pass)
+    if (rr + 1 < npoa) poa_column_records(g, order_nx, n, lane);
+}
+
+// ---- k_poa_finish: consensus (heaviest path), draft, window bounds.  One wave per graph.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa_finish(KParams P, int z0, int pass)
+{
+    const int lane = threadIdx.x;
+    PoaSlot g = poa_slot(P, blockIdx.x);
+    if (z0 + (int)blockIdx.x >= P.n_zmw) return;
+    if (!g.st[ST_LIVE]) return;
+    const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);
+    const int ok = rfl(g.st[ST_OK]), n = rfl(g.st[ST_N]), nadded = rfl(g.st[ST_NADDED]);
+    const int32_t *order = g.st[ST_PAR] ? g.order1 : g.order0;
+    // ---- consensus: heaviest path (uniform walk, block records via readlane)
+    int Ld = 0, nw = 0, stat = -1;
+    if (ok && n > 0) {
+        int kbest = -1, sb = NEGV, best_prev = 0, vprev = -2;
+        for (int kb = 0; kb < n; kb += LANES) {
+            const int kkL = kb + lane;
+            const int vL = kkL < n ? order[kkL] : 0;
+            int4 rL = make_int4(0, 0, 0, 0);
+            if (kkL < n) rL = g.vrec[vL];
+            const int nblk = (n - kb) < LANES ? (n - kb) : LANES;
+            int myBest = 0, myBp = -1;
+            for (int j = 0; j < nblk; ++j) {
+                const int k = kb + j;
+                const int v = rl(vL, j);
+                const int4 rec = make_int4(rl(rL.x, j), rl(rL.y, j), rl(rL.z, j), rl(rL.w, j));
+                const int np = (rec.x >> 8) & 255, nr = rec.x >> 16;
+                int b = 0, p = -1;
+                for (int q = 0; q < np; ++q) {
+                    const int u = rfl(poa_pred(g, rec, v, q));
+                    int bu, pu;
+                    CHK(u >= 0 && u < n, 108);
+                    if (u == vprev) { bu = best_prev; pu = k - 1; }
+                    else { pu = rfl(g.rank[u]); bu = (pu >= kb) ? rl(myBest, pu - kb) : rfl(g.bestK[pu]); }
+                    if (bu > b) { b = bu; p = pu; }
+                }
+                const int bv = b + 2 * nr - nadded;
+                if (lane == j) { myBest = bv; myBp = p; }
+                if (bv > sb) { sb = bv; kbest = k; }
+                best_prev = bv; vprev = v;
+            }
+            if (kkL < n) { g.bestK[kkL] = myBest; g.bpK[kkL] = myBp; }
+            __threadfence_block();
+        }
+        // backtrack (uniform), bases collected in reverse into scratch
+        uint8_t *tmp = (uint8_t *)g.pathv;
+        int len = 0, k = kbest;
+        while (k >= 0) {
+            const int kb = (k >> 6) << 6;
+            const int kk = kb + lane;
+            const int bpL = kk < n ? g.bpK[kk] : -1;
+            const int bL = kk < n ? (g.vrec[order[kk]].x & 255) : 0;
+            while (k >= kb) {
+                const int kl = k - kb;
+                CHK(len < n, 107);
+                if (lane == 0) tmp[len] = (uint8_t)rl(bL, kl);
+                ++len;
+                k = rl(bpL, kl);
+            }
+        }
+        __threadfence_block();
+        if (len <= P.dcap[z]) {
+            uint8_t *draft = P.draft + P.seq_off[z];
+            for (int q = lane; q < len; q += LANES) draft[q] = tmp[len - 1 - q];
+            Ld = len;
+        }
+        __threadfence_block();
+    }
+    if (Ld <= 0) stat = CCSX_DRAFT_FAILURE;
+    else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
+    else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
+    else {
+        // step 4 windows.  SPEC: a break nb is bad when for some period p in 1..4 the p-mer before it equals the p-mer
+        // after it ("avoid breaking windows at simple repeats", docs/how-does-ccs-work.md:58-60); the target cur+22 moves by
+        // 0,+1,-1,+2,-2,+3,-3 to the first good position.  Lane l holds draft[cur+14+l]; E_p = ballot(d[i] == d[i+p]).
+        const uint8_t *d = P.draft + P.seq_off[z];
+        int32_t *b = P.wbounds + P.wb_off[z];
+        int cur = 0;
+        if (lane == 0) b[0] = 0;
+        while (cur < Ld) {
+            int nb;
+            if (Ld - cur <= CCSX_WIN_CORE + 6) nb = Ld;
+            else {
+                const int base = cur + CCSX_WIN_CORE - 8;                 // positions base .. base+15 cover every p-mer examined
+                const int pos = base + lane;
+                const int x = (lane < 16 && pos < Ld) ? (int)d[pos] : 8 + lane;
+                unsigned e[4];
+#pragma unroll
+                for (int p = 1; p <= 4; ++p) e[p - 1] = (unsigned)__ballot(x == __shfl(x, (lane + p) & 63)) & 0xffffu;
+                nb = cur + CCSX_WIN_CORE;
+                const int offs[7] = {0, 1, -1, 2, -2, 3, -3};
+#pragma unroll
+                for (int k = 6; k >= 0; --k) {                            // last assignment wins: scan the preference order backwards
+                    const int c = 8 + offs[k];                            // bit index of the candidate break
+                    bool bad = false;
+#pragma unroll
+                    for (int p = 1; p <= 4; ++p) bad |= ((e[p - 1] >> (c - p)) & ((1u << p) - 1u)) == ((1u << p) - 1u);
+                    if (!bad) nb = cur + CCSX_WIN_CORE + offs[k];
+                }
+            }
+            ++nw;
+            if (lane == 0) b[nw] = nb;
+            cur = nb;
+        }
+    }
+    if (lane == 0) { P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2266,10 +2434,21 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
     // pass 0 = the draft; pass 1 = the fallback draft of the ZMWs k_post marked (their waves run, all others leave at once:
     // the second round of launches costs microseconds unless something failed)
     for (int pass = 0; pass < (P.opts.no_fallback_draft ? 1 : 2); ++pass) {
+        int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
+        if (cov > PW_MAXREADS_SPEC) cov = PW_MAXREADS_SPEC;
+        if (cov > P.max_reads) cov = P.max_reads;          // no ZMW of the batch has more passes
         for (int z0 = 0; z0 < P.n_zmw; z0 += P.poa_slots) {
             const int nb = (P.n_zmw - z0) < P.poa_slots ? (P.n_zmw - z0) : P.poa_slots;
-            hipLaunchKernelGGL(k_poa, dim3(nb), dim3(64), lds_read, st, P, z0, pass);
-            LAUNCH_CHECK("k_poa");
+            hipLaunchKernelGGL(k_poa_init, dim3(nb), dim3(64), lds_read, st, P, z0, pass);
+            LAUNCH_CHECK("k_poa_init");
+            for (int rr = 1; rr < cov; ++rr) {             // one DP (four graphs per wave) + one threading kernel per pass of the POA
+                hipLaunchKernelGGL(k_poa_dp, dim3((nb + 3) / 4), dim3(64), 0, st, P, z0, pass, rr);
+                LAUNCH_CHECK("k_poa_dp");
+                hipLaunchKernelGGL(k_poa_thread, dim3(nb), dim3(64), lds_read, st, P, z0, pass, rr);
+                LAUNCH_CHECK("k_poa_thread");
+            }
+            hipLaunchKernelGGL(k_poa_finish, dim3(nb), dim3(64), 0, st, P, z0, pass);
+            LAUNCH_CHECK("k_poa_finish");
         }
         trace_sync(st, "k_poa");
         if (ev && pass == 0) (void)hipEventRecord(ev[2], st);

@@ -30,10 +30,11 @@ extern "C" {
 #endif
 
 #define CCSX_ABI_VERSION 4
-#define CCSX_SPEC_VERSION 2   /* DESIGN.md §2; bumped whenever a result-changing rule changes (oracle: ORC_SPEC_VERSION) */
+#define CCSX_SPEC_VERSION 3   /* DESIGN.md §2; bumped whenever a result-changing rule changes (oracle: ORC_SPEC_VERSION) */
 
 /* ---- fixed constants of the algorithm specification ---- */
-#define CCSX_BAND          64   /* DP band rows of the POA / alignment kernels (one wave64)      */
+#define CCSX_BAND          64   /* DP band rows of the wide alignment (retry of the cascade, split alignment: one wave64) */
+#define CCSX_POA_BAND      32   /* DP band rows of the POA (four graphs per wave64, two rows per lane)                    */
 #define CCSX_MAXPRED       8    /* POA in-edge cap per vertex                                    */
 #define CCSX_WIN_CORE      22   /* target window core size, docs/how-does-ccs-work.md:57-59      */
 #define CCSX_WIN_OVERHANG  2    /* +-2 bp overlap, same citation                                 */

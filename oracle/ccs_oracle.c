@@ -36,11 +36,37 @@
 #endif
 
 /* ---------------- specification constants (same values as include/ccsx.h) -------------- */
+#define ORC_SPEC_VERSION 3  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
+int orc_spec_version(void) { return ORC_SPEC_VERSION; }
 #define BAND      64
 #define ALIGN_BAND1 16      /* rows of the FIRST attempt of the subread -> draft alignment (step 3); BAND rows on failure */
 #define ALIGN_OFF1  6       /* rows of the narrow band ABOVE the best row: 6 above, 9 below — insertion bursts push the path DOWN, a deleted
                              * stretch leaves it where it is (2.2 % of the 10 kb passes lose a symmetric 16-row band, 0.2 % this one)     */
-static __thread int g_bw = BAND;   /* rows of the band in use (the POA and the retry / split alignment use BAND) */
+#define POA_BAND  32        /* rows of the POA's band (step 2): on the device four graphs share a wave, each in a 16-lane DPP row with two rows
+                             * per lane.  Drafts equal those of a 64-row band on every test set (tools/acc_eval.py, profiles/r03_spec_studies.txt) */
+static __thread int g_bw = BAND;   /* rows of the band in use (alignment retry / split alignment: BAND) */
+static __thread int g_poa_band = POA_BAND;
+void orc_set_poa_band(int bw) { g_poa_band = bw; }     /* test hook (accuracy studies of the band width; the SPEC value is POA_BAND) */
+/* ---- path / work counters of the tests and of bench.py's counted-work figure (SURVEY.md §8d "algorithmic work per ZMW: counted on an
+ * instrumented CPU path, not estimated"); per-thread tallies are flushed into the global sums once per ZMW ---- */
+enum { CNT_TRIM, CNT_SPLIT, CNT_SPLIT_S0, CNT_SPLIT_SLD, CNT_FALLBACK, CNT_RETRY64, CNT_ZDROP, CNT_NONCONV_WIN, CNT_POA_WIDE, CNT_THIRD_DRAFT,
+       CNT_PARTIAL_USED, CNT_CELLS_POA, CNT_CELLS_ALIGN, CNT_CELLS_FILL, CNT_CELLS_SCORE, CNT_ZMWS, CNT_SPLIT2, CNT_N };
+static int64_t orc_cnt_global[CNT_N];
+static __thread int64_t orc_cnt[CNT_N];
+static __thread int g_cells_kind = CNT_CELLS_ALIGN;         /* which tally dp_column feeds */
+void orc_counts_reset(void) { memset(orc_cnt_global, 0, sizeof(orc_cnt_global)); }
+void orc_counts_get(int64_t *out) { memcpy(out, orc_cnt_global, sizeof(orc_cnt_global)); }
+int orc_counts_n(void) { return CNT_N; }
+static void orc_counts_flush(void)
+{
+    for (int k = 0; k < CNT_N; ++k) if (orc_cnt[k]) {
+#pragma omp atomic
+        orc_cnt_global[k] += orc_cnt[k];
+        orc_cnt[k] = 0;
+    }
+}
+static __thread int g_poa_scores[64], g_poa_nscores = 0;   /* test hook: end scores of the passes threaded into the last POA */
+int orc_poa_last_scores(int *out) { for (int i = 0; i < g_poa_nscores; ++i) out[i] = g_poa_scores[i]; return g_poa_nscores; }
 #define MAXPRED   8
 #define WIN_CORE  22
 #define WIN_OVH   2
@@ -301,6 +327,7 @@ static inline int band_lo(int lo_u, int bestrow_u, int I)
 static void dp_column(int vbase, const uint8_t *r, int I, int lo, int npred, const int32_t *plo, const int32_t *const *pM,
                       int32_t *M, uint8_t *mv, int32_t *colmax, int32_t *bestrow)
 {
+    orc_cnt[g_cells_kind] += (int64_t)g_bw * (npred > 0 ? npred : 1);
     for (int l = 0; l < g_bw; ++l) {
         int i = lo + l;
         int32_t best = NEG; uint8_t bm = 0;
@@ -375,9 +402,12 @@ static int poa_add_read(poa_t *g, const uint8_t *r, int I, int32_t *pathv /* scr
     int vend = -1; int32_t bs = NEG;
     for (int k = 0; k < n0; ++k) {
         int v = g->order[k]; int o = I - g->lo[v];
-        if (o >= 0 && o < BAND) { int32_t x = g->M[(size_t)v * BAND + o]; if (x > NEG / 2 && x > bs) { bs = x; vend = v; } }
+        if (o >= 0 && o < g_bw) { int32_t x = g->M[(size_t)v * BAND + o]; if (x > NEG / 2 && x > bs) { bs = x; vend = v; } }
     }
-    if (vend < 0) return 0;
+    if (g_poa_nscores < 64) g_poa_scores[g_poa_nscores++] = bs;
+    /* SPEC "POA gate": a pass is threaded only if its alignment reaches the read's last row with a score of at least 1.0 per base
+     * (the gate of step 3): a pass the band has lost, or junk, adds nothing to the graph                                        */
+    if (vend < 0 || bs < I) return 0;   /* EXPERIMENT: lost band -> retry wide */
     /* traceback: pathv[i] = matched vertex of read base i, or -1 (new vertex) */
     int v = vend, i = I;
     while (v >= 0) {
@@ -444,11 +474,14 @@ int orc_poa_draft_bb(int nreads, const int64_t *base_off, const uint8_t *bases, 
     uint8_t *ob = (uint8_t *)malloc(maxL + 1);
     int32_t *pathv = (int32_t *)malloc(sizeof(int32_t) * (maxL + 1));
     int rev0 = flags[bb] & 1, ok = 1;
+    g_poa_nscores = 0;
     for (int rr = 0; rr < npoa && ok; ++rr) {
         int r = bb + rr < nreads ? bb + rr : bb + rr - nreads;
         int L = (int)(base_off[r + 1] - base_off[r]);
         orient(bases + base_off[r], NULL, L, (flags[r] & 1) != rev0, ob, NULL);
+        g_bw = g_poa_band; g_cells_kind = CNT_CELLS_POA;            /* SPEC: the POA runs in a POA_BAND-row band */
         if (poa_add_read(g, ob, L, pathv) < 0) ok = 0;
+        g_bw = BAND; g_cells_kind = CNT_CELLS_ALIGN;
     }
     int len = ok ? poa_consensus(g, draft, draft_cap) : 0;
     if (len < 0) len = 0;
@@ -475,6 +508,7 @@ int orc_align_ev(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rst
     int v = align_ev_band(r, I, d, Ld, rstart, score_out, dirty);
     g_bw = BAND;
     if (v) return 1;
+    orc_cnt[CNT_RETRY64] += 1;
     return align_ev_band(r, I, d, Ld, rstart, score_out, dirty);
 }
 static int align_ev_band(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty)
@@ -580,6 +614,7 @@ int orc_align_rescue(const uint8_t *r, int I, const uint8_t *d, int Ld, const in
     if (ks >= 0 && best >= Ld) {
         valid = 1;
         int s = need[ks];
+        orc_cnt[CNT_SPLIT] += 1; if (s == 0) orc_cnt[CNT_SPLIT_S0] += 1; if (s == Ld) orc_cnt[CNT_SPLIT_SLD] += 1;
         for (int j = 0; j <= Ld; ++j) rstart[j] = -1;
         trace_entries(mvF, loF, s, brF[s], rstart);
         for (int j = 0; j <= Ld - s; ++j) rsR[j] = -1;
@@ -635,6 +670,7 @@ static void fill(const float *ME, const float *INS, const float *DL, const uint8
                  const uint8_t *o, int I, float *gam, float *bet, float *aIJ, float *b00)
 {
     int k[JMAX + 1]; tpl_ctx(t, J, lf, k);
+    orc_cnt[CNT_CELLS_FILL] += 2 * (int64_t)(I + 1) * (J + 1);
     float acol[IMAX + 2], pcol[IMAX + 2];
     memset(pcol, 0, sizeof(pcol));
     for (int j = 0; j <= J; ++j) {
@@ -695,6 +731,7 @@ static float score_mut(const float *ME, const float *INS, const float *DL, const
     int nrows = (I < 2 * Wr ? I : 2 * Wr) + 1;
     int rc = (J > 0) ? (2 * c * I + J) / (2 * J) : 0;
     int i0 = rc - Wr; if (i0 < 0) i0 = 0; if (i0 > I + 1 - nrows) i0 = I + 1 - nrows;
+    orc_cnt[CNT_CELLS_SCORE] += (type == MT_DEL ? 1 : 2) * (int64_t)nrows;
     for (int i = i0; i < i0 + nrows; ++i) {
         float insA = 0.0f, meA = 0.0f, insB = 0.0f;
         if (i > 0) {
@@ -819,7 +856,7 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
                 float d = (la - (float)(2 * I[r])) - M;
                 if (orc_dbg.stats == 3) { float z = d / sqrtf(V); int bin = (int)floorf(z * 2.0f) + 32; if (bin < 0) bin = 0; if (bin > 63) bin = 63;
                     _Pragma("omp atomic") orc_dbg.cal_cnt[bin] += 1; }
-                if (d < 0.0f && d * d > (zmin * zmin) * V) { zdrop[r] = 1; continue; }
+                if (d < 0.0f && d * d > (zmin * zmin) * V) { zdrop[r] = 1; orc_cnt[CNT_ZDROP] += 1; continue; }
             }
             base[r] = la; valid[r] = 1; ++nvalid;
         }
@@ -923,6 +960,7 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
         out_seq[len] = w.t[c]; out_perr[len] = p; out_qv[len] = qv; ++len;
     }
     *out_len = len; *out_nvalid = nvalid; *out_nonconv = nonconv;
+    orc_cnt[CNT_NONCONV_WIN] += nonconv;
     if (out_delta) memcpy(out_delta, delta, sizeof(delta));
     if (wfinal) *wfinal = w;
     if (out_nscored) *out_nscored = nscored;
@@ -1182,7 +1220,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                 if (best < 0 || d < best) { best = d; bb = r; }
             }
         }
-        attempt = 1;
+        attempt = 1; orc_cnt[CNT_FALLBACK] += 1;
     }
     {
         /* step 4 */
@@ -1229,7 +1267,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                         if (m > best) { best = m; sb = s; }
                     }
                     for (int i = 0; i < J; ++i) { int src = i < sb ? i : n - J + i; oo[i] = (uint8_t)obs_of(bb[src], pp[src]); }
-                    Iw[r] = J;
+                    Iw[r] = J; orc_cnt[CNT_TRIM] += 1;
                     continue;
                 }
                 if (n > IMAX) continue;
@@ -1340,6 +1378,8 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         free(wb); free(obuf); free(obs); free(Iw); free(Ikin);
     }
 done:
+    orc_cnt[CNT_ZMWS] += 1;
+    orc_counts_flush();
     for (int r = 0; r < nreads; ++r) { free(rstart[r]); free(dirty[r]); }
     free(rstart); free(dirty); free(strand); free(avalid); free(draft);
     return ret;

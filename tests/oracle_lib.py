@@ -175,3 +175,30 @@ def kinetics_read(tpl_read_orient, read_bases, ipd, pw, strand):
     lib().orc_kinetics_read(_p(t, C.c_uint8), len(t), _p(rb, C.c_uint8), _p(ip, C.c_uint8), _p(pwc, C.c_uint8), len(rb),
                             int(strand), _p(si, C.c_uint32), _p(sp, C.c_uint32), _p(cn, C.c_uint32))
     return si[: len(t)], sp[: len(t)], cn[: len(t)]
+
+
+COUNT_NAMES = ["trim", "split", "split_s0", "split_sLd", "fallback", "retry64", "zdrop", "nonconv_win", "poa_wide", "third_draft",
+               "partial_used", "cells_poa", "cells_align", "cells_fill", "cells_score", "zmws", "split2"]
+
+
+def counts_reset():
+    lib().orc_counts_reset()
+
+
+def counts():
+    """path / work counters since the last counts_reset(): which SPEC paths fired (trim, split alignment, fallback draft, 64-row
+    retry, z-score drop, ...) and the DP cell updates per stage (SURVEY.md §8d secondary figure)"""
+    n = lib().orc_counts_n()
+    a = np.zeros(n, np.int64)
+    lib().orc_counts_get(_p(a, C.c_int64))
+    return dict(zip(COUNT_NAMES, a.tolist()))
+
+
+def edit_distance(a, b, band=400):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().orc_edit_distance(_p(a, C.c_uint8), len(a), _p(b, C.c_uint8), len(b), int(band)))
+
+
+def spec_version():
+    return int(lib().orc_spec_version())
