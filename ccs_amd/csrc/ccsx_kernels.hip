@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
     __shared__ uint8_t sZdrop[PW_MAXREADS];                  // z-score gate: decided on the draft window (round 0), then kept
-    __shared__ float sBase[PW_MAXREADS];
+    __shared__ float sBase[PW_MAXREADS], sB00[PW_MAXREADS];   // alpha(I,J) / beta(0,0) of the chunk's reads (the fill's two halves meet here)
     __shared__ short2 sTask[PW_MAXREADS];                    // fill tasks: (read A, read B or -1)
     __shared__ int sDeltaI[256];                             // fixed-point sums of the per-read gains; converted in place to float
     float *sDelta = (float *)sDeltaI;                        // (each thread converts its own entry after the scoring barrier)
@@ -1833,12 +1833,21 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 rend = rfl(rend_); ntask = rfl(nl + ((ns + 1) >> 1));
             }
             PHASE(2);
-            // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals
+            // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals.  Work units: a task = a pair of
+            // short reads (or one long read) per wave.  When the last round of tasks would leave half of the waves idle (ntask mod 4
+            // = 1 or 2: e.g. five pairs on four waves), those tasks are SPLIT into an alpha-only and a beta-only unit on two waves —
+            // the same arithmetic per cell, the sweep of a unit is as long but issues half the instructions: 5 tasks cost 1.55
+            // task-times instead of 2.  alpha(I,J) / beta(0,0) of a read therefore meet in LDS, and every wave derives the reads'
+            // validity from them after the barrier (lane = read; identical values in every wave: no second barrier).
 #ifdef CCSX_EXP_NO_FILL
-            for (int tk = wave; tk < 0; tk += PW_WAVES) {
+            const int nsplit = 0, nfull = 0, nunit_f = 0;
 #else
-            for (int tk = wave; tk < ntask; tk += PW_WAVES) {
+            const int nsplit = ((ntask % PW_WAVES) == 1 || (ntask % PW_WAVES) == 2) ? (ntask % PW_WAVES) : 0;
+            const int nfull = ntask - nsplit, nunit_f = nfull + 2 * nsplit;
 #endif
+            for (int fu = wave; fu < nunit_f; fu += PW_WAVES) {
+                const int tk = fu < nfull ? fu : nfull + ((fu - nfull) >> 1);
+                const int mode = fu < nfull ? 0 : 1 + ((fu - nfull) & 1);      // 0: alpha and beta, 1: alpha only, 2: beta only
                 const short2 task = sTask[tk];
                 const bool paired = rfl((int)task.y) >= 0;
                 const int myr = paired ? (half ? task.y : task.x) : task.x;
@@ -1868,64 +1877,80 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 float acur = one0, updiag = 0.0f, mePrev = 0.0f, dlPrev = 1.0f;
                 float bcur = oneI, dndiag = 0.0f;
                 const unsigned uJ = (unsigned)J;
-#define CCSX_FILL_STEP(T, AOFF, BOFF)                                                                                      \
+#define CCSX_FILL_STEP(T, AOFF, BOFF, DOA, DOB)                                                                            \
                 {                                                                                                          \
-                    const float up = wave_shr1_f32_z(acur);          /* all rows of the read shift together (full exec) */     \
-                    const float dn = wave_shl1_f32_z(bcur);                                                                    \
-                    if ((unsigned)((T) - tA0) <= uJ) {               /* alpha, column j = T - row */                          \
-                        const float2 pr = pA[(AOFF) * MI_STRIDE];                                                            \
-                        const float dlc = dA[(AOFF)];                                                                        \
-                        const float m = updiag * mePrev, dl = acur * dlPrev;                                                  \
-                        const float gmm = m + dl;                                                                            \
-                        const float st = up * pr.y;                  /* row 0 and column J read zero entries: +0 */           \
-                        gA[(AOFF)] = gmm;                                                                                    \
-                        acur = gmm + st;                                                                                     \
-                        mePrev = pr.x; dlPrev = dlc;                                                                         \
+                    if (DOA) {                                                                                               \
+                        const float up = wave_shr1_f32_z(acur);      /* all rows of the read shift together (full exec) */     \
+                        if ((unsigned)((T) - tA0) <= uJ) {           /* alpha, column j = T - row */                          \
+                            const float2 pr = pA[(AOFF) * MI_STRIDE];                                                        \
+                            const float dlc = dA[(AOFF)];                                                                    \
+                            const float m = updiag * mePrev, dl = acur * dlPrev;                                              \
+                            const float gmm = m + dl;                                                                        \
+                            const float st = up * pr.y;              /* row 0 and column J read zero entries: +0 */           \
+                            gA[(AOFF)] = gmm;                                                                                \
+                            acur = gmm + st;                                                                                 \
+                            mePrev = pr.x; dlPrev = dlc;                                                                     \
+                        }                                                                                                    \
+                        updiag = up;                                                                                         \
                     }                                                                                                        \
-                    updiag = up;                                                                                             \
-                    if ((unsigned)((T) - tB0) <= uJ) {               /* beta, column jb = J - (T - (I - row)) */              \
-                        const float2 pr = pB[(BOFF) * MI_STRIDE];                                                            \
-                        const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                                       \
-                        const float t3 = dB[(BOFF)] * bcur;                                                                  \
-                        const float bv = (t1 + t2) + t3;                                                                     \
-                        bB[(BOFF)] = bv;                                                                                     \
-                        bcur = bv;                                                                                           \
+                    if (DOB) {                                                                                               \
+                        const float dn = wave_shl1_f32_z(bcur);                                                                \
+                        if ((unsigned)((T) - tB0) <= uJ) {           /* beta, column jb = J - (T - (I - row)) */              \
+                            const float2 pr = pB[(BOFF) * MI_STRIDE];                                                        \
+                            const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                                   \
+                            const float t3 = dB[(BOFF)] * bcur;                                                              \
+                            const float bv = (t1 + t2) + t3;                                                                 \
+                            bB[(BOFF)] = bv;                                                                                 \
+                            bcur = bv;                                                                                       \
+                        }                                                                                                    \
+                        dndiag = dn;                                                                                         \
                     }                                                                                                        \
-                    dndiag = dn;                                                                                             \
                 }
-                for (int t = 0; t <= Tmax; t += 2, pA += 2 * MI_STRIDE, dA += 2, gA += 2, pB -= 2 * MI_STRIDE, dB -= 2, bB -= 2) {
-                    CCSX_FILL_STEP(t, 0, 1)
-                    CCSX_FILL_STEP(t + 1, 1, 0)                      // an odd extra step past Tmax is inactive in every lane
+#define CCSX_FILL_LOOP(DOA, DOB)                                                                                            \
+                for (int t = 0; t <= Tmax; t += 2, pA += 2 * MI_STRIDE, dA += 2, gA += 2, pB -= 2 * MI_STRIDE, dB -= 2, bB -= 2) { \
+                    CCSX_FILL_STEP(t, 0, 1, DOA, DOB)                                                                        \
+                    CCSX_FILL_STEP(t + 1, 1, 0, DOA, DOB)            /* an odd extra step past Tmax is inactive in every lane */ \
                 }
+                if (mode == 0) { CCSX_FILL_LOOP(1, 1) }
+                else if (mode == 1) { CCSX_FILL_LOOP(1, 0) }
+                else { CCSX_FILL_LOOP(0, 1) }
+#undef CCSX_FILL_LOOP
 #undef CCSX_FILL_STEP
-                // zero row I+1 of beta, validity
-                if (row < S && (paired || lane < 32) ) sGB[sBoff[myr] + (I + 1) * S + row] = 0.0f;
-                if (!paired && lane >= 32 && lane < S) sGB[sBoff[myr] + (I + 1) * S + lane] = 0.0f;   // S can reach 33
                 const int basel = paired ? (half << 5) : 0;
-                const float aIJ = __shfl(acur, basel + I);
-                const float b00 = __shfl(bcur, basel);
-                if (row == 0 && (paired || lane == 0)) {
-                    int v = 0; float la = 0.0f;
-                    if (aIJ > TINY_P && b00 > TINY_P) {
-                        la = det_log2f(aIJ); const float lb = det_log2f(b00);
-                        float df = la - lb; if (df < 0.0f) df = -df;
-                        v = !(df > AB_TOL);
-                        if (sZdrop[myr]) v = 0;
-                        else if (v && it == 0 && P.opts.min_zscore != 0.0f) {   // A7 z-score gate, round 0 only (x4 per emitted base = 2 bits per read base)
-                            const float zd = (la - (float)(2 * I)) - sZS[2 * sd];
-                            const float zm = P.opts.min_zscore;
-                            if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) { v = 0; sZdrop[myr] = 1; }
-                        }
-                    }
-                    sValid[myr] = (uint8_t)v; sBase[myr] = la;
+                if (mode != 1) {                                     // zero row I+1 of beta; beta(0,0)
+                    if (row < S && (paired || lane < 32) ) sGB[sBoff[myr] + (I + 1) * S + row] = 0.0f;
+                    if (!paired && lane >= 32 && lane < S) sGB[sBoff[myr] + (I + 1) * S + lane] = 0.0f;   // S can reach 33
+                    const float b00 = __shfl(bcur, basel);
+                    if (row == 0 && (paired || lane == 0)) sB00[myr] = b00;
+                }
+                if (mode != 2) {
+                    const float aIJ = __shfl(acur, basel + I);
+                    if (row == 0 && (paired || lane == 0)) sBase[myr] = aIJ;   // (alpha(I,J) itself; its log2 is taken after the barrier)
                 }
             }
             __syncthreads();
+            // read validity (lane = read; every wave computes the same values): alpha/beta agreement, the z-score gate of round 0
+            int vOk = 0; float vLa = 0.0f;
+            if (lane >= rbeg && lane < rend && sGoff[lane] >= 0) {
+                const float aIJ = sBase[lane], b00 = sB00[lane];
+                const int I = sI[lane], sd = sStrand[lane];
+                if (aIJ > TINY_P && b00 > TINY_P) {
+                    vLa = det_log2f(aIJ); const float lb = det_log2f(b00);
+                    float df = vLa - lb; if (df < 0.0f) df = -df;
+                    vOk = !(df > AB_TOL);
+                    if (sZdrop[lane]) vOk = 0;
+                    else if (vOk && it == 0 && P.opts.min_zscore != 0.0f) {   // A7 z-score gate, round 0 only (x4 per emitted base = 2 bits per read base)
+                        const float zd = (vLa - (float)(2 * I)) - sZS[2 * sd];
+                        const float zm = P.opts.min_zscore;
+                        if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) { vOk = 0; sZdrop[lane] = 1; }   // (every wave writes the same 1)
+                    }
+                }
+            }
             // usable reads of the chunk, in read order: every wave builds the list in a register (lane k = the k-th usable read) with one
             // ds_permute (valid lane r sends r to lane rank(r), the others fill the remaining lanes): no LDS list, no second barrier
             int vRlist, nv_chunk;
             {
-                const bool v = lane >= rbeg && lane < rend && sValid[lane];
+                const bool v = vOk != 0;
                 const unsigned long long bv = __ballot(v), lower = (1ull << lane) - 1ull;
                 nv_chunk = rfl(__popcll(bv));
                 const int dest = v ? __popcll(bv & lower) : nv_chunk + __popcll(~bv & lower);
@@ -1950,7 +1975,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 int vR, vI, vSt, vG, vB; float vBase;
                 {
                     vR = lane < nv ? vRlist : rl(vRlist, 0);
-                    vI = sI[vR]; vSt = (int)sStrand[vR]; vG = sGoff[vR]; vB = sBoff[vR]; vBase = sBase[vR];
+                    vI = sI[vR]; vSt = (int)sStrand[vR]; vG = sGoff[vR]; vB = sBoff[vR]; vBase = __shfl(vLa, vR);
                 }
                 const int u_end = ((wave + 1) * nunits) / PW_WAVES;
                 for (int u = (wave * nunits) / PW_WAVES; u < u_end;) {
