@@ -337,8 +337,12 @@ __device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to
 extern __shared__ uint32_t dyn_lds[];
 #define TB_BLOCK 64                   // positions cached per traceback block (64 move rows of 32 bytes)
 
+// zref[z]: bits 0-5 = backbone pass of the current draft, plus the state of the draft cascade (SPEC "fallback draft", "last resort")
 #define ZREF_RETRY 256                  // k_post: this ZMW's first draft failed or most passes do not map to it
-#define ZREF_DONE 512                   // the fallback draft has been made
+#define ZREF_DONE 512                   // the fallback draft (pass 1) has been made
+#define ZREF_RETRY2 1024                // k_post: the fallback draft failed as well (bits 0-5: its backbone)
+#define ZREF_DONE2 2048                 // the last-resort draft (pass 2: the backbone pass itself) has been made
+#define ZREF_PASSBIT(pass) ((pass) == 1 ? ZREF_DONE : ZREF_DONE2)
 
 // the prepass of a DP: column records by topological position.  `order` = the graph's current topological order, n vertices.
 __device__ __forceinline__ void poa_column_records(const PoaSlot &g, const int32_t *order, int n, int lane)
@@ -374,6 +378,47 @@ __device__ __forceinline__ void poa_column_records(const PoaSlot &g, const int32
     __threadfence_block();
 }
 
+// step 4: window bounds of a draft of Ld bases (one wave); returns the number of windows
+__device__ __forceinline__ int poa_windows(const KParams &P, int z, int Ld, int lane)
+{
+    int nw = 0;
+    {
+        // step 4 windows.  SPEC: a break nb is bad when for some period p in 1..4 the p-mer before it equals the p-mer
+        // after it ("avoid breaking windows at simple repeats", docs/how-does-ccs-work.md:58-60); the target cur+22 moves by
+        // 0,+1,-1,+2,-2,+3,-3 to the first good position.  Lane l holds draft[cur+14+l]; E_p = ballot(d[i] == d[i+p]).
+        const uint8_t *d = P.draft + P.seq_off[z];
+        int32_t *b = P.wbounds + P.wb_off[z];
+        int cur = 0;
+        if (lane == 0) b[0] = 0;
+        while (cur < Ld) {
+            int nb;
+            if (Ld - cur <= CCSX_WIN_CORE + 6) nb = Ld;
+            else {
+                const int base = cur + CCSX_WIN_CORE - 8;                 // positions base .. base+15 cover every p-mer examined
+                const int pos = base + lane;
+                const int x = (lane < 16 && pos < Ld) ? (int)d[pos] : 8 + lane;
+                unsigned e[4];
+#pragma unroll
+                for (int p = 1; p <= 4; ++p) e[p - 1] = (unsigned)__ballot(x == __shfl(x, (lane + p) & 63)) & 0xffffu;
+                nb = cur + CCSX_WIN_CORE;
+                const int offs[7] = {0, 1, -1, 2, -2, 3, -3};
+#pragma unroll
+                for (int k = 6; k >= 0; --k) {                            // last assignment wins: scan the preference order backwards
+                    const int c = 8 + offs[k];                            // bit index of the candidate break
+                    bool bad = false;
+#pragma unroll
+                    for (int p = 1; p <= 4; ++p) bad |= ((e[p - 1] >> (c - p)) & ((1u << p) - 1u)) == ((1u << p) - 1u);
+                    if (!bad) nb = cur + CCSX_WIN_CORE + offs[k];
+                }
+            }
+            ++nw;
+            if (lane == 0) b[nw] = nb;
+            cur = nb;
+        }
+    }
+    return nw;
+}
+
 // ---- k_poa_init: which passes, the backbone chain, the first column records.  One wave per graph (slot = block).
 __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
 {
@@ -393,18 +438,23 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
     // SPEC "fallback draft" (docs/faq/accuracy-vs-passes.md:41-46: a cascade from fast to robust draft generators): pass 1
     // (only for ZMWs k_post marked) takes the pass whose length is closest to the median as backbone and threads twice as
     // many passes, starting at the backbone and wrapping around
+    // SPEC "last resort" (pass 2, only for ZMWs whose fallback draft failed too): the pass closest to the median among the passes
+    // that have not been a backbone yet is the draft itself, no POA; the polish repairs its errors
     int bb = 0;
-    if (pass == 1) {
-        if (rfl(P.zref[z]) != ZREF_RETRY) return;
+    if (pass >= 1) {
+        const int zr = rfl(P.zref[z]);
+        if (!(zr & (pass == 1 ? ZREF_RETRY : ZREF_RETRY2))) return;
+        const int bb1 = pass == 2 ? (zr & 63) : -1;
         const int len = lane < nreads ? (int)(P.base_off[r0 + lane + 1] - P.base_off[r0 + lane]) : 0x7fffffff;
         int rank = 0;                                   // position of my length in the sorted order (ties by index)
         for (int q = 0; q < nreads; ++q) { const int lq = __shfl(len, q); rank += (lq < len || (lq == len && q < lane)) ? 1 : 0; }
         const int med = rfl(__shfl(len, __ffsll((long long)__ballot(lane < nreads && rank == nreads / 2)) - 1));
         int dist = len - med; dist = dist < 0 ? -dist : dist;
-        const int key = lane < nreads ? ((dist > 0xffffff ? 0xffffff : dist) << 6) | lane : 0x7fffffff;
+        const bool cand = lane < nreads && !(pass == 2 && ((lane == bb1 && nreads > 1) || (lane == 0 && nreads > 2)));   // not a backbone that failed
+        const int key = cand ? ((dist > 0xffffff ? 0xffffff : dist) << 6) | lane : 0x7fffffff;
         bb = rfl(wave_min_i32(key)) & 63;
     }
-    if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_DONE : 0); }
+    if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_PASSBIT(pass) : 0); }
     const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
     if (!enough) { if (lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES; return; }
     const int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
@@ -414,6 +464,18 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
     const int r = r0 + bb;
     const uint8_t *rb = P.bases + P.base_off[r];
     const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
+    if (pass == 2) {                                    // the backbone pass is the draft
+        int Ld = I <= P.dcap[z] ? I : 0, nw = 0, stat = -1;
+        uint8_t *draft = P.draft + P.seq_off[z];
+        for (int q = lane; q < Ld; q += LANES) draft[q] = rb[q] & 3;
+        __threadfence_block();
+        if (Ld <= 0) stat = CCSX_DRAFT_FAILURE;
+        else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
+        else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
+        else nw = poa_windows(P, z, Ld, lane);
+        if (lane == 0) { P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat; }
+        return;
+    }
     load_read_packed(sread, rb, I, 0, lane);
     __syncthreads();
     int ok = 1, n = 0;
@@ -924,38 +986,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
     else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
     else {
-        // step 4 windows.  SPEC: a break nb is bad when for some period p in 1..4 the p-mer before it equals the p-mer
-        // after it ("avoid breaking windows at simple repeats", docs/how-does-ccs-work.md:58-60); the target cur+22 moves by
-        // 0,+1,-1,+2,-2,+3,-3 to the first good position.  Lane l holds draft[cur+14+l]; E_p = ballot(d[i] == d[i+p]).
-        const uint8_t *d = P.draft + P.seq_off[z];
-        int32_t *b = P.wbounds + P.wb_off[z];
-        int cur = 0;
-        if (lane == 0) b[0] = 0;
-        while (cur < Ld) {
-            int nb;
-            if (Ld - cur <= CCSX_WIN_CORE + 6) nb = Ld;
-            else {
-                const int base = cur + CCSX_WIN_CORE - 8;                 // positions base .. base+15 cover every p-mer examined
-                const int pos = base + lane;
-                const int x = (lane < 16 && pos < Ld) ? (int)d[pos] : 8 + lane;
-                unsigned e[4];
-#pragma unroll
-                for (int p = 1; p <= 4; ++p) e[p - 1] = (unsigned)__ballot(x == __shfl(x, (lane + p) & 63)) & 0xffffu;
-                nb = cur + CCSX_WIN_CORE;
-                const int offs[7] = {0, 1, -1, 2, -2, 3, -3};
-#pragma unroll
-                for (int k = 6; k >= 0; --k) {                            // last assignment wins: scan the preference order backwards
-                    const int c = 8 + offs[k];                            // bit index of the candidate break
-                    bool bad = false;
-#pragma unroll
-                    for (int p = 1; p <= 4; ++p) bad |= ((e[p - 1] >> (c - p)) & ((1u << p) - 1u)) == ((1u << p) - 1u);
-                    if (!bad) nb = cur + CCSX_WIN_CORE + offs[k];
-                }
-            }
-            ++nw;
-            if (lane == 0) b[nw] = nb;
-            cur = nb;
-        }
+        nw = poa_windows(P, z, Ld, lane);
     }
     if (lane == 0) { P.draft_len[z] = Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat; }
 }
@@ -1097,7 +1128,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const int z = rfl(P.read_zmw[rfirst]);
     const int r0 = rfl(P.read_off[z]);
     const int zr = rfl(P.zref[z]);
-    if (pass == 1 && !(zr & ZREF_DONE)) return;        // second pass: only the ZMWs whose draft was redone
+    if (pass && !(zr & ZREF_PASSBIT(pass))) return;    // later passes: only the ZMWs whose draft was redone in that pass
     const bool live = h < nq;
     const int r = rfirst + (live ? h : 0);
     if (live && l == 0) { P.avalid[r] = 0; P.ascore[r] = NEGV; }
@@ -1335,7 +1366,7 @@ __global__ __launch_bounds__(64) void k_rescue(KParams P, int pass)
         const int z = rfl(P.read_zmw[r]);
         const int r0 = rfl(P.read_off[z]);
         const int zr = rfl(P.zref[z]);
-        if (pass == 1 && !(zr & ZREF_DONE)) continue;
+        if (pass && !(zr & ZREF_PASSBIT(pass))) continue;
         if (P.zstat[z] != CCSX_SUCCESS || r - r0 >= P.nreads_used[z] || P.avalid[r]) continue;
         const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
         const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
@@ -1394,10 +1425,14 @@ __global__ void k_post(KParams P, int pass)
     int z = blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= P.n_zmw) return;
     const int zr = P.zref[z];
-    if (pass == 1 && !(zr & ZREF_DONE)) return;
+    if (pass && !(zr & ZREF_PASSBIT(pass))) return;
+    // the draft cascade: a failed draft, or one most passes do not map to, is retried — pass 0 -> the fallback draft (pass 1), pass 1 ->
+    // the last resort (pass 2); the last attempt's outcome is final
+    const bool may_retry = !P.opts.no_fallback_draft && pass < 2;
+    const int retry = pass == 0 ? ZREF_RETRY : ((zr & 63) | ZREF_RETRY2);
     if (P.zstat[z] != CCSX_SUCCESS) {
         P.np[z] = 0; P.out_fn[z] = 0; P.out_rn[z] = 0;
-        if (pass == 0 && P.zstat[z] == CCSX_DRAFT_FAILURE && !P.opts.no_fallback_draft) P.zref[z] = ZREF_RETRY;
+        if (may_retry && P.zstat[z] == CCSX_DRAFT_FAILURE) P.zref[z] = retry;
         return;
     }
     int r0 = P.read_off[z], nr = P.nreads_used[z], np = 0, rn = 0;
@@ -1409,7 +1444,7 @@ __global__ void k_post(KParams P, int pass)
     }
     P.np[z] = np; P.out_fn[z] = np - rn; P.out_rn[z] = rn;
     if (2 * np <= nr) {
-        if (pass == 0 && !P.opts.no_fallback_draft) P.zref[z] = ZREF_RETRY;      // try the fallback draft before giving up
+        if (may_retry) P.zref[z] = retry;                  // try the next draft generator before giving up
         else { P.zstat[z] = CCSX_TOO_MANY_UNUSABLE; P.nwin[z] = 0; }
     }
 }
@@ -2458,7 +2493,7 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
     const size_t lds_read = (((size_t)P.maxL_max + 15) / 16) * 4 + 64;
     // pass 0 = the draft; pass 1 = the fallback draft of the ZMWs k_post marked (their waves run, all others leave at once:
     // the second round of launches costs microseconds unless something failed)
-    for (int pass = 0; pass < (P.opts.no_fallback_draft ? 1 : 2); ++pass) {
+    for (int pass = 0; pass < (P.opts.no_fallback_draft ? 1 : 3); ++pass) {
         int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
         if (cov > PW_MAXREADS_SPEC) cov = PW_MAXREADS_SPEC;
         if (cov > P.max_reads) cov = P.max_reads;          // no ZMW of the batch has more passes
@@ -2466,14 +2501,16 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
             const int nb = (P.n_zmw - z0) < P.poa_slots ? (P.n_zmw - z0) : P.poa_slots;
             hipLaunchKernelGGL(k_poa_init, dim3(nb), dim3(64), lds_read, st, P, z0, pass);
             LAUNCH_CHECK("k_poa_init");
-            for (int rr = 1; rr < cov; ++rr) {             // one DP (four graphs per wave) + one threading kernel per pass of the POA
+            for (int rr = 1; rr < cov && pass < 2; ++rr) { // one DP (four graphs per wave) + one threading kernel per pass of the POA
                 hipLaunchKernelGGL(k_poa_dp, dim3((nb + 3) / 4), dim3(64), 0, st, P, z0, pass, rr);
                 LAUNCH_CHECK("k_poa_dp");
                 hipLaunchKernelGGL(k_poa_thread, dim3(nb), dim3(64), lds_read, st, P, z0, pass, rr);
                 LAUNCH_CHECK("k_poa_thread");
             }
-            hipLaunchKernelGGL(k_poa_finish, dim3(nb), dim3(64), 0, st, P, z0, pass);
-            LAUNCH_CHECK("k_poa_finish");
+            if (pass < 2) {                                // (pass 2 = last resort: k_poa_init writes the draft itself)
+                hipLaunchKernelGGL(k_poa_finish, dim3(nb), dim3(64), 0, st, P, z0, pass);
+                LAUNCH_CHECK("k_poa_finish");
+            }
         }
         trace_sync(st, "k_poa");
         if (ev && pass == 0) (void)hipEventRecord(ev[2], st);

@@ -45,8 +45,13 @@ int orc_spec_version(void) { return ORC_SPEC_VERSION; }
 #define POA_BAND  32        /* rows of the POA's band (step 2): on the device four graphs share a wave, each in a 16-lane DPP row with two rows
                              * per lane.  Drafts equal those of a 64-row band on every test set (tools/acc_eval.py, profiles/r03_spec_studies.txt) */
 static __thread int g_bw = BAND;   /* rows of the band in use (alignment retry / split alignment: BAND) */
-static __thread int g_poa_band = POA_BAND;
-void orc_set_poa_band(int bw) { g_poa_band = bw; }     /* test hook (accuracy studies of the band width; the SPEC value is POA_BAND) */
+/* test hooks: the build-defined approximations of the SPEC as variables, so that tools/acc_eval.py can measure what each of them costs on
+ * off-model and low-complexity data (profiles/r03_spec_studies.txt).  The product implements the SPEC values only. */
+static int g_poa_band = POA_BAND, g_align_band1 = 16, g_score_band = 5, g_skip_margin = 6;
+void orc_set_poa_band(int bw) { g_poa_band = bw; }
+void orc_set_align_band1(int bw) { g_align_band1 = bw; }      /* 64: no narrow first attempt */
+void orc_set_score_band(int w) { g_score_band = w; }          /* >= 64: the full sum over alignments */
+void orc_set_skip_margin(int m) { g_skip_margin = m; }
 /* ---- path / work counters of the tests and of bench.py's counted-work figure (SURVEY.md §8d "algorithmic work per ZMW: counted on an
  * instrumented CPU path, not estimated"); per-thread tallies are flushed into the global sums once per ZMW ---- */
 enum { CNT_TRIM, CNT_SPLIT, CNT_SPLIT_S0, CNT_SPLIT_SLD, CNT_FALLBACK, CNT_RETRY64, CNT_ZDROP, CNT_NONCONV_WIN, CNT_POA_WIDE, CNT_THIRD_DRAFT,
@@ -313,7 +318,7 @@ static void poa_renumber(poa_t *g) { int k = 0; for (int v = g->head; v >= 0; v 
 /* band start of a column whose best predecessor column has (lo_u, bestrow_u); I = read length */
 static inline int band_lo(int lo_u, int bestrow_u, int I)
 {
-    int lo = bestrow_u + 1 - (g_bw == ALIGN_BAND1 ? ALIGN_OFF1 : g_bw / 2);
+    int lo = bestrow_u + 1 - (g_bw == ALIGN_BAND1 ? ALIGN_OFF1 : g_bw / 2);   /* (16 rows: 6 above the best row, 9 below) */
     if (lo < lo_u) lo = lo_u;
     if (lo > lo_u + 2) lo = lo_u + 2;
     int hi = I - (g_bw - 1); if (hi < 0) hi = 0;
@@ -504,7 +509,7 @@ static int align_ev_band(const uint8_t *r, int I, const uint8_t *d, int Ld, int3
  * in the narrow band is aligned again with BAND rows (and, failing that, by the split alignment).                             */
 int orc_align_ev(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty)
 {
-    g_bw = ALIGN_BAND1;
+    g_bw = g_align_band1;
     int v = align_ev_band(r, I, d, Ld, rstart, score_out, dirty);
     g_bw = BAND;
     if (v) return 1;
@@ -727,7 +732,7 @@ static float score_mut(const float *ME, const float *INS, const float *DL, const
      * probability mass off the band is below float resolution for every read the alpha/beta check accepts): half width SCORE_BAND, widened by
      * the part of the length difference a single indel could move the path off that line; rows outside contribute 0.   */
     int dIJ = I > J ? I - J : J - I;
-    int Wr = SCORE_BAND + (dIJ > 2 ? dIJ - 2 : 0);
+    int Wr = g_score_band + (dIJ > 2 ? dIJ - 2 : 0);
     int nrows = (I < 2 * Wr ? I : 2 * Wr) + 1;
     int rc = (J > 0) ? (2 * c * I + J) / (2 * J) : 0;
     int i0 = rc - Wr; if (i0 < 0) i0 = 0; if (i0 > I + 1 - nrows) i0 = I + 1 - nrows;
@@ -1166,7 +1171,12 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
     uint8_t *strand = (uint8_t *)malloc(nreads), *avalid = (uint8_t *)malloc(nreads);
     int ret = 0;
     for (;;) {
-        Ld = orc_poa_draft_bb(nreads, base_off, bases, flags, attempt ? 2 * opts->max_poa_cov : opts->max_poa_cov, vcap, draft, dcap, bb);
+        if (attempt < 2) Ld = orc_poa_draft_bb(nreads, base_off, bases, flags, attempt ? 2 * opts->max_poa_cov : opts->max_poa_cov, vcap, draft, dcap, bb);
+        else {                                              /* SPEC "draft cascade", last resort: the backbone pass itself is the draft */
+            Ld = (int)(base_off[bb + 1] - base_off[bb]);
+            if (Ld > dcap) Ld = 0;
+            else orient(bases + base_off[bb], NULL, Ld, 0, draft, NULL);
+        }
         if (draft_len_out) *draft_len_out = Ld;
         if (draft_out && Ld > 0) memcpy(draft_out, draft, Ld);
         int want_retry = 0;
@@ -1207,8 +1217,10 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
             if (2 * np <= nreads) { out->status = ST_UNUSABLE; want_retry = 1; }
         }
         if (!want_retry) break;
-        if (attempt || opts->no_fallback_draft) { if (out->status == ST_DRAFT_FAIL) { out->np = 0; out->fn = out->rn = 0; } goto done; }
-        {   /* backbone of the fallback draft */
+        if (attempt >= 2 || opts->no_fallback_draft) { if (out->status == ST_DRAFT_FAIL) { out->np = 0; out->fn = out->rn = 0; } goto done; }
+        {   /* backbone of the fallback draft: the pass whose length is closest to the median (ties: the first); the last resort takes
+             * the closest among the passes that have NOT been a backbone yet (pass 0 and the fallback's backbone may be the problem) */
+            const int bb1 = attempt ? bb : -1;
             int med = 0, best = -1;
             for (int r = 0; r < nreads; ++r) {
                 int len = (int)(base_off[r + 1] - base_off[r]), rank = 0;
@@ -1217,10 +1229,12 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
             }
             for (int r = 0; r < nreads; ++r) {
                 int d = (int)(base_off[r + 1] - base_off[r]) - med; if (d < 0) d = -d;
+                if (attempt && nreads > 1 && r == bb1) continue;
+                if (attempt && nreads > 2 && r == 0) continue;     /* ... and pass 0, the backbone of the first draft, failed as well */
                 if (best < 0 || d < best) { best = d; bb = r; }
             }
         }
-        attempt = 1; orc_cnt[CNT_FALLBACK] += 1;
+        attempt += 1; orc_cnt[attempt == 1 ? CNT_FALLBACK : CNT_THIRD_DRAFT] += 1;
     }
     {
         /* step 4 */
@@ -1287,7 +1301,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                     skp[c] = skip_perr(margin[c]);
                 }
                 for (int c = 0; c < J; ++c) {
-                    int ok = !opts->disable_heuristics && margin[c] >= SKIP_MARGIN;
+                    int ok = !opts->disable_heuristics && margin[c] >= g_skip_margin;
                     for (int q = c - SKIP_SPREAD; ok && q <= c + SKIP_SPREAD; ++q) if (q >= 0 && q < J && margin[q] < 0) ok = 0;
                     if (ok) ev0 |= 1u << c;
                 }

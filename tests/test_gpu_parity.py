@@ -576,3 +576,64 @@ def test_large_insertion_trimming_matches_oracle(built, maxins, kin):
         h2.close()
         ok = (res.status == 0) & (off_.status == 0)
         assert ok.sum() >= 5 and res.ec[ok].sum() > off_.ec[ok].sum()
+
+
+@pytest.mark.parametrize("passes,length,n,seed,disable", [(5, (800, 3000), 24, 301, 0), (10, (1500, 6000), 16, 302, 0), (30, (1000, 4000), 8, 303, 0),
+                                                            (10, (1500, 5000), 12, 304, 1)])
+def test_low_complexity_templates_bit_exact(built, passes, length, n, seed, disable):
+    """VERDICT r02 item 3b / docs/faq/low-complexity.md:11-18: templates made of homopolymer runs (5-60) and 2-4-mer tandem repeats
+    (20-500 bp) next to random stretches (tools/lowcx.py, a generator independent of the library's) — where the rarely taken
+    kernel branches live (JMAX / JMIN caps, cycle guard, NON_CONVERGENT, band placement ties in repeats): HIP == oracle bit for
+    bit at 5 / 10 / 30 passes, with the candidate filter and with --disable-heuristics"""
+    import lowcx
+    batch = lowcx.make(n, passes, length, seed, tpl="lowcx")
+    o = api.default_opts(); o.disable_heuristics = disable
+    h = api.Handle(0, opts=o)
+    try:
+        res = h.consensus(batch)
+        ref = api.Results.allocate(batch)
+        O.consensus_batch(h.model, o, batch, ref, nthreads=8)
+        _compare(res, ref, batch)
+        assert np.array_equal(res.np_, ref.np_) and np.array_equal(res.iters, ref.iters)
+        assert ((res.status == 0) | (res.status == 7) | (res.status == 4)).sum() >= n // 2
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("channel,hp_boost,seed", [(1.5, 1.0, 311), (1.0, 2.5, 312), (0.5, 1.0, 313)])
+def test_off_model_error_channels_bit_exact(built, channel, hp_boost, seed):
+    """reads from an error channel the parameter set was NOT matched to (rates x1.5 / x0.5, indels boosted
+    2.5x inside homopolymers) — more gate failures, 64-row retries, z-score drops and polish rounds than on-model data"""
+    import lowcx
+    batch = lowcx.make(16, (6, 12), (1500, 5000), seed, channel=channel, hp_boost=hp_boost)
+    h = api.Handle(0)
+    try:
+        res = h.consensus(batch)
+        ref = _oracle(h, batch)
+        _compare(res, ref, batch)
+    finally:
+        h.close()
+
+
+def test_last_resort_draft_matches_oracle(built):
+    """SPEC "draft cascade", third generator (pass 2: a pass is the draft itself): ZMWs whose pass 0 AND median-length pass are junk,
+    next to ZMWs that need no retry, with and without kinetics; bit-exact incl. np / fn / rn and the orientation of the new backbone"""
+    import test_oracle_draft as T
+    batch = T._junk_backbones_batch()
+    for kin in (0, 1):
+        o = api.default_opts(); o.hifi_kinetics = kin
+        h = api.Handle(0, opts=o)
+        try:
+            res = h.consensus(batch)
+            ref = api.Results.allocate(batch, kinetics=bool(kin))
+            O.counts_reset()
+            O.consensus_batch(h.model, o, batch, ref, nthreads=4)
+            assert O.counts()["third_draft"] >= 2
+            _compare(res, ref, batch)
+            assert np.array_equal(res.fn, ref.fn) and np.array_equal(res.rn, ref.rn) and np.array_equal(res.np_, ref.np_)
+            assert ((res.status == 0) | (res.status == 7)).all()
+            if kin:
+                for z in range(batch.n_zmw):
+                    assert np.array_equal(res.kinetics(z), ref.kinetics(z))
+        finally:
+            h.close()

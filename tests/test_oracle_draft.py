@@ -161,3 +161,44 @@ def test_accuracy_rises_with_passes(built):
     assert 12 <= q[4] <= 28 and 25 <= q[10] <= 45 and q[20] >= 30
     for p, (e_emp, e_pred) in emp.items():                     # rq is calibrated within a factor ~4 of the truth
         assert e_pred < 4 * max(e_emp, 2e-4) + 1e-4 and e_emp < 4 * e_pred + 2e-3, (p, e_emp, e_pred)
+
+
+def _junk_backbones_batch():
+    """7 passes per ZMW; pass 0 and the pass whose length is the median are junk, the other five are good: the first draft and the
+    fallback draft both start from junk, the last resort (SPEC "draft cascade") takes a good pass as the draft itself"""
+    from ccs_amd import api
+    rng = np.random.default_rng(11)
+    base = api.synth(6, 7, (900, 1400), seed=77)
+    for z in (1, 2, 4):
+        r0 = int(base.read_off[z])
+        lens = np.diff(base.base_off[r0:r0 + 8])
+        med = sorted((int(l), q) for q, l in enumerate(lens))[7 // 2][1]        # element n/2 of the sorted lengths
+        for q in {0, med}:
+            a, b = int(base.base_off[r0 + q]), int(base.base_off[r0 + q + 1])
+            base.bases[a:b] = rng.integers(0, 4, b - a, dtype=np.uint8)
+    return base
+
+
+def test_last_resort_draft_takes_a_pass_as_the_draft(built):
+    """docs/faq/accuracy-vs-passes.md:41-46 (a cascade of draft generators, from fast and unstable to slow and robust)"""
+    from ccs_amd import api
+    import oracle_lib as O
+    batch = _junk_backbones_batch()
+    o = api.default_opts()
+    res = api.Results.allocate(batch)
+    O.counts_reset()
+    O.consensus_batch(api.default_model(), o, batch, res)
+    c = O.counts()
+    assert c["third_draft"] >= 2 and c["fallback"] >= c["third_draft"]
+    ok = (res.status == 0) | (res.status == 7)
+    assert ok.all(), res.status                                   # with the cascade every ZMW gets a consensus
+    for z in (1, 2, 4):                                           # ... that is close to the truth, in the orientation of a good pass
+        t = batch.tpl[batch.tpl_off[z]:batch.tpl_off[z + 1]]
+        s = res.sequence(z)
+        d = min(O.edit_distance(s, t), O.edit_distance(s, (3 - t[::-1]).astype(np.uint8)))
+        assert d <= 12, (z, d)
+        assert res.np_[z] == 5
+    o.no_fallback_draft = 1
+    res2 = api.Results.allocate(batch)
+    O.consensus_batch(api.default_model(), o, batch, res2)
+    assert set(res2.status[[1, 2, 4]].tolist()) <= {2, 3}        # DRAFT_FAILURE / TOO_MANY_UNUSABLE without it

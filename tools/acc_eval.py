@@ -2,7 +2,7 @@
 """Accuracy of the SPEC on synthetic ZMWs with the CPU restatement (oracle): consensus errors against the true templates, rq, polish
 rounds, which paths fired, counted cell updates.  Used for every SPEC decision of DESIGN.md §2 and for the off-model sweeps
 (profiles/r03_offmodel.txt).   usage: acc_eval.py N PASSES LENGTH SEED [key=value ...]
-  keys: any ccsx_opts field; channel=<x>: error-channel multiplier applied to the reads (extra substitutions / indels on top of the
+  keys: any ccsx_opts field; poa_band / align_band1 / score_band / skip_margin = the SPEC's approximations (oracle test hooks); channel=<x>: error-channel multiplier applied to the reads (extra substitutions / indels on top of the
   generator's); tpl=lowcx: low-complexity templates (tools/lowcx.py); env:NAME=VALUE sets an oracle experiment variable."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,14 +33,16 @@ def evaluate(batch, opts, model=None, nthreads=8, label=""):
 if __name__ == "__main__":
     n, P, Ln, seed = (int(x) for x in sys.argv[1:5])
     opts = api.default_opts()
-    channel, tpl = 1.0, None
+    channel, tpl, hp_boost = 1.0, None, 1.0
     for kv in sys.argv[5:]:
         k, v = kv.split("=", 1)
         if k.startswith("env:"): os.environ[k[4:]] = v
+        elif k in ("poa_band", "align_band1", "score_band", "skip_margin"): getattr(O.lib(), "orc_set_" + k)(int(v))   # SPEC approximation knobs
         elif k == "channel": channel = float(v)
         elif k == "tpl": tpl = v
+        elif k == "hp_boost": hp_boost = float(v)
         else: setattr(opts, k, type(getattr(opts, k))(float(v)))
     sys.path.insert(0, os.path.join(R, "tools"))
     import lowcx
-    b = lowcx.make(n, P, Ln, seed, channel=channel, tpl=tpl)
+    b = lowcx.make(n, P, Ln, seed, channel=channel, tpl=tpl, hp_boost=hp_boost)
     evaluate(b, opts, label=" ".join(sys.argv[5:]) or "default")
