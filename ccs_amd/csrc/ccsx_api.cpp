@@ -252,6 +252,13 @@ static int validate(const ccsx_batch *b)
     for (int r = 0; r < R; ++r)
         if (b->base_off[r + 1] < b->base_off[r]) { ccsx_set_error("ccsx_upload: base_off not monotone"); return -1; }
     if (b->base_off[R] != b->n_bases) { ccsx_set_error("ccsx_upload: n_bases != base_off[n_reads]"); return -1; }
+    for (int z = 0; z < b->n_zmw; ++z) {                  // partial passes (flag bit 1) must follow the ZMW's full-length passes
+        bool partial = false;
+        for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) {
+            if (b->flags[r] & 2) partial = true;
+            else if (partial) { ccsx_set_error("ccsx_upload: a full-length pass follows a partial pass (flags bit 1) in a ZMW"); return -1; }
+        }
+    }
     return 0;
 }
 
@@ -307,7 +314,9 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         std::vector<int32_t> qpack; std::vector<int64_t> qlen;
         const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > 64) ? 64 : h->opts.top_passes;
         for (int z = 0; z < n; ++z) {
-            const int r0 = b->read_off[z], nr = std::min(b->read_off[z + 1] - r0, top);
+            const int r0 = b->read_off[z];
+            int nr = std::min(b->read_off[z + 1] - r0, top);
+            while (nr > 0 && (b->flags[r0 + nr - 1] & 2)) --nr;   // partial passes are aligned by k_rescue (anchored at one end), not here
             for (int g = 0; g < nr; g += 4) {
                 const int c = std::min(4, nr - g);
                 int64_t ml = 0;
@@ -355,7 +364,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
 #define RES(buf, bytes) do { if ((buf).reserve(bytes)) return -2; } while (0)
     RES(S.d_tabME, (size_t)n * 192 * 4); RES(S.d_tabINS, (size_t)n * 192 * 4); RES(S.d_tabDL, (size_t)n * 16 * 4); RES(S.d_tabZ, (size_t)n * 32 * 4);
     RES(S.d_draft, (size_t)cap_total);
-    RES(S.d_zmw_i32, (size_t)n * 4 * 6);   // draft_len, nwin, zstat, nreads_used, np, zref
+    RES(S.d_zmw_i32, (size_t)n * 4 * 7);   // draft_len, nwin, zstat, nreads_used, np, zref, nfull
     RES(S.d_wbounds, (size_t)S.wb_off[n] * 4);
     RES(S.d_ticket, 256);
     RES(S.d_avalid, (size_t)(R > 0 ? R : 1)); RES(S.d_ascore, (size_t)(R > 0 ? R : 1) * 4);
@@ -417,7 +426,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.tabME = (float *)S.d_tabME.p; P.tabINS = (float *)S.d_tabINS.p; P.tabDL = (float *)S.d_tabDL.p; P.tabZ = (float *)S.d_tabZ.p;
     P.draft = (uint8_t *)S.d_draft.p;
     int32_t *zi = (int32_t *)S.d_zmw_i32.p;
-    P.draft_len = zi; P.nwin = zi + n; P.zstat = zi + 2 * (size_t)n; P.nreads_used = zi + 3 * (size_t)n; P.np = zi + 4 * (size_t)n; P.zref = zi + 5 * (size_t)n;
+    P.draft_len = zi; P.nwin = zi + n; P.zstat = zi + 2 * (size_t)n; P.nreads_used = zi + 3 * (size_t)n; P.np = zi + 4 * (size_t)n; P.zref = zi + 5 * (size_t)n; P.nfull = zi + 6 * (size_t)n;
     P.wbounds = (int32_t *)S.d_wbounds.p;
     P.ticket_poa = (int32_t *)S.d_ticket.p; P.ticket_align = P.ticket_poa + 1; P.debug = P.ticket_poa + 4; P.phase = (unsigned long long *)(P.ticket_poa + 16);
     P.poa_scratch = (uint8_t *)h->d_poa.p; P.poa_slot_bytes = S.poa_slot_bytes; P.poa_slots = poa_slots;

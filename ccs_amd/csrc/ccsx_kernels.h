@@ -31,6 +31,7 @@ struct KParams {
     float *tabZ;               // [n][32] z-score parameters per context: MU[16], VAR[16]
     uint8_t *draft;
     int32_t *draft_len, *nwin, *zstat, *nreads_used, *wbounds, *np;
+    int32_t *nfull;            // [n] full-length passes among nreads_used (the partial passes follow them)
     int32_t *zref;             // [n] backbone pass (index within the ZMW) = orientation reference of draft and consensus; bit 8: a fallback
                                //     draft is requested (set by k_post), bit 9: the fallback draft has been made
     int32_t *ticket_poa, *ticket_align;   // 256-byte scratch block that also holds debug[] and phase[] (no tickets since the chunked launch)

@@ -435,6 +435,9 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
         const int top = (P.opts.top_passes <= 0 || P.opts.top_passes > PW_MAXREADS_SPEC) ? PW_MAXREADS_SPEC : P.opts.top_passes;
         if (nreads > top) nreads = top;
     }
+    // SPEC "partial passes" (flag bit 1; they follow the ZMW's full-length passes): not in the draft, not counted as passes
+    const int nall = nreads;
+    nreads = rfl(__popcll(__ballot(lane < nall && !(P.flags[r0 + (lane < nall ? lane : 0)] & 2))));
     // SPEC "fallback draft" (docs/faq/accuracy-vs-passes.md:41-46: a cascade from fast to robust draft generators): pass 1
     // (only for ZMWs k_post marked) takes the pass whose length is closest to the median as backbone and threads twice as
     // many passes, starting at the backbone and wrapping around
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
         const int key = cand ? ((dist > 0xffffff ? 0xffffff : dist) << 6) | lane : 0x7fffffff;
         bb = rfl(wave_min_i32(key)) & 63;
     }
-    if (lane == 0) { P.nreads_used[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_PASSBIT(pass) : 0); }
+    if (lane == 0) { P.nreads_used[z] = nall; P.nfull[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_PASSBIT(pass) : 0); }
     const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
     if (!enough) { if (lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES; return; }
     const int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
@@ -1371,10 +1374,59 @@ __global__ __launch_bounds__(64) void k_rescue(KParams P, int pass)
         const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
         const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
         const int nneed = 2 * nw;
-        if (I - Ld <= RESCUE_MIN_EXCESS || nneed < 3) continue;
         const uint8_t *d = P.draft + P.seq_off[z];
         const int32_t *wb = P.wbounds + P.wb_off[z];
-        const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0 + (zr & 63)] & 1)) ? 1 : 0);
+        const int fl = rfl((int)P.flags[r]);
+        const int rev = rfl(((fl & 1) != (P.flags[r0 + (zr & 63)] & 1)) ? 1 : 0);
+        if (fl & 2) {
+            // SPEC "partial passes": anchored at one end of the draft (flag bit 2 = the adapter is at the pass's end; in draft orientation
+            // that is the draft's end iff the pass is on the draft's strand).  The column loop runs from the anchored end; the pass covers
+            // the draft up to the window-edge column with the largest column maximum (first on ties), valid iff that score reaches 1.0 per
+            // covered base; uncovered edges get entry rows that give every window touching them a negative segment length
+            if (nneed < 2) continue;
+            const int from_end = ((fl >> 2) & 1) ^ rev;
+            __syncthreads();
+            load_read_packed_mode(sread, P.bases + P.base_off[r], I, from_end ? (rev ? 2 : 1) : (rev ? 3 : 0), lane);
+            __syncthreads();
+            if (from_end) (void)align_pass<1>(P, sread, I, d, Ld, wb, nw, OsF, lane);
+            else (void)align_pass<0>(P, sread, I, d, Ld, wb, nw, OsF, lane);
+            __threadfence_block();
+            const int32_t *loF = OsF + (size_t)P.need_max * 128, *cmF = loF + P.need_max + 64, *ebF = cmF + 2 * P.need_max;
+            int best = NEGV, bk = 1 << 30;
+            for (int k = 1 + lane; k < nneed; k += LANES) {          // edge columns in the direction of the DP
+                const int cf = cmF[k];
+                if (cf > NEGV / 2 && cf > best) { best = cf; bk = k; }
+            }
+            const int wbest = rfl(wave_max_i32(best));
+            const int ks = rfl(wave_min_i32(best == wbest ? bk : (1 << 30)));
+            if (wbest <= NEGV / 2) continue;
+            const int scol = from_end ? Ld - need_col(wb, nw, Ld, nneed - 1 - ks) : need_col(wb, nw, Ld, ks);   // covered draft columns
+            if (scol <= 0 || wbest < scol) continue;
+            if (lane == 0) {
+                int32_t *ent = P.ent + P.ent_off[r];
+                uint32_t *dm = P.dmask + P.ent_off[r];
+                const int2 *OM = (const int2 *)OsF;
+                int e = ebF[ks];
+                if (!from_end) {
+                    ent[ks] = e;
+                    for (int k2 = ks; k2 >= 2; --k2) { e = OM[(size_t)k2 * 64 + (e - loF[k2])].x; ent[k2 - 1] = e; }
+                    ent[0] = 0;
+                    for (int k2 = ks + 1; k2 < nneed; ++k2) ent[k2] = -(1 << 20) - 64 * k2;
+                } else {
+                    ent[nneed - 1 - ks] = I - e;
+                    for (int kq = ks; kq >= 1; --kq) {
+                        e = (kq >= 2) ? OM[(size_t)kq * 64 + (e - loF[kq])].x : 0;
+                        ent[nneed - kq] = I - e;
+                    }
+                    for (int k2 = 0; k2 < nneed - 1 - ks; ++k2) ent[k2] = (1 << 20) + 64 * (nneed - k2);
+                }
+                dm[0] = 0u;
+                for (int k2 = 1; k2 < nneed; ++k2) dm[k2] = 0x7fffffffu;
+                P.avalid[r] = 1; P.ascore[r] = wbest;
+            }
+            continue;
+        }
+        if (I - Ld <= RESCUE_MIN_EXCESS || nneed < 3) continue;
         __syncthreads();
         load_read_packed_mode(sread, P.bases + P.base_off[r], I, rev ? 3 : 0, lane);
         __syncthreads();
@@ -1435,7 +1487,7 @@ __global__ void k_post(KParams P, int pass)
         if (may_retry && P.zstat[z] == CCSX_DRAFT_FAILURE) P.zref[z] = retry;
         return;
     }
-    int r0 = P.read_off[z], nr = P.nreads_used[z], np = 0, rn = 0;
+    int r0 = P.read_off[z], nr = P.nfull[z], np = 0, rn = 0;     // full-length passes only: partial passes are not passes
     const int f0 = P.flags[r0 + (zr & 63)];
     for (int r = 0; r < nr; ++r) {
         const int v = P.avalid[r0 + r];
@@ -1747,7 +1799,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
 #endif
     int iters = 0, nonconv = 0;
     unsigned skmask = 0;                                     // positions skipped in the current round (wave-uniform)
-    int nvalid_last = 0;
+    int nvalid_last = 0, nvfull_last = 0;                    // usable reads of the last round: all / full-length passes only
+    const int nfull = P.nfull[z];
     for (int it = 0; it < CCSX_MAX_ITER; ++it) {
         __syncthreads();
         const int J = rfl(sCtl[0]);
@@ -1830,7 +1883,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         for (int q = 0; q < PW_WAVES; ++q) nvm += rfl(sCnt[q]);
         const int nblk = (nvm + 63) >> 6;
         PHASE(1);
-        int nvalid = 0;
+        int nvalid = 0, nvfull = 0;
         int curblk = -1;                                     // the block whose lane constants this wave holds (they survive the chunks of a round)
         LaneMut LF, LR;
         int myM = 0; bool mval = false;
@@ -1875,14 +1928,14 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             // task-times instead of 2.  alpha(I,J) / beta(0,0) of a read therefore meet in LDS, and every wave derives the reads'
             // validity from them after the barrier (lane = read; identical values in every wave: no second barrier).
 #ifdef CCSX_EXP_NO_FILL
-            const int nsplit = 0, nfull = 0, nunit_f = 0;
+            const int nsplit = 0, ntfull = 0, nunit_f = 0;
 #else
             const int nsplit = ((ntask % PW_WAVES) == 1 || (ntask % PW_WAVES) == 2) ? (ntask % PW_WAVES) : 0;
-            const int nfull = ntask - nsplit, nunit_f = nfull + 2 * nsplit;
+            const int ntfull = ntask - nsplit, nunit_f = ntfull + 2 * nsplit;
 #endif
             for (int fu = wave; fu < nunit_f; fu += PW_WAVES) {
-                const int tk = fu < nfull ? fu : nfull + ((fu - nfull) >> 1);
-                const int mode = fu < nfull ? 0 : 1 + ((fu - nfull) & 1);      // 0: alpha and beta, 1: alpha only, 2: beta only
+                const int tk = fu < ntfull ? fu : ntfull + ((fu - ntfull) >> 1);
+                const int mode = fu < ntfull ? 0 : 1 + ((fu - ntfull) & 1);      // 0: alpha and beta, 1: alpha only, 2: beta only
                 const short2 task = sTask[tk];
                 const bool paired = rfl((int)task.y) >= 0;
                 const int myr = paired ? (half ? task.y : task.x) : task.x;
@@ -1988,6 +2041,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const bool v = vOk != 0;
                 const unsigned long long bv = __ballot(v), lower = (1ull << lane) - 1ull;
                 nv_chunk = rfl(__popcll(bv));
+                nvfull += __popcll(bv & (nfull >= 64 ? ~0ull : (1ull << nfull) - 1ull));   // (partial passes sit behind the full ones)
                 const int dest = v ? __popcll(bv & lower) : nv_chunk + __popcll(~bv & lower);
                 vRlist = __builtin_amdgcn_ds_permute(dest << 2, lane);
             }
@@ -2081,7 +2135,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             PHASE(4);
         }
         ++iters;
-        nvalid_last = nvalid;
+        nvalid_last = nvalid; nvfull_last = nvfull;
         __syncthreads();
         float delta = 0.0f;
         if (tid < 256) { delta = (float)sDeltaI[tid] * (1.0f / DQ_SCALE); sDelta[tid] = delta; }   // same slot, same thread
@@ -2182,7 +2236,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         for (int k = 0; k < ce - cs; ++k) wsum = wsum + __int_as_float(rl(__float_as_int(pl), k));
       if (tid == 0) {
         P.wsum[wi] = wsum;
-        P.wmeta[wi] = make_int4(ce - cs, nvalid_last, nonconv, iters);
+        P.wmeta[wi] = make_int4(ce - cs, nvalid_last | (nvfull_last << 8), nonconv, iters);
         if (P.wtmeta) P.wtmeta[wi] = make_short2((short)J, (short)cs);
       }
     }
@@ -2390,7 +2444,7 @@ __global__ __launch_bounds__(64) void k_stitch(KParams P)
     for (int wbase = 0; wbase < nw; wbase += LANES) {
         const int w = wbase + lane;
         int4 mt = make_int4(0, 0, 0, 0);
-        if (w < nw) { mt = P.wmeta[w0 + w]; if ((unsigned)mt.y <= 64u) atomicAdd(&sHist[mt.y], 1); }
+        if (w < nw) { mt = P.wmeta[w0 + w]; if ((unsigned)(mt.y >> 8) <= 64u) atomicAdd(&sHist[mt.y >> 8], 1); mt.y &= 255; }   // np: full-length passes; ec: all
         int pre = mt.x;                                     // inclusive scan of lengths
 #pragma unroll
         for (int s = 1; s < LANES; s <<= 1) { int o = __shfl_up(pre, s); if (lane >= s) pre += o; }

@@ -110,7 +110,12 @@ typedef struct ccsx_batch {
                                     frame count, so the HMM's pulse-width bin min(pw,3) needs no decoding)        */
     const uint8_t *ipd;          /* [n_bases] inter-pulse duration, CodecV1 code (ip:B,C tag).  Unused by the HMM;
                                     may be NULL unless opts.hifi_kinetics is set                                   */
-    const uint8_t *flags;        /* [R] bit0: pass is on the reverse strand (cx REVERSE_PASS)   */
+    const uint8_t *flags;        /* [R] bit0: pass is on the reverse strand (cx REVERSE_PASS)
+                                        bit1: PARTIAL pass (not flanked by adapters on both sides: the first / last subread of the
+                                              polymerase read).  Not used for the draft, not counted in np; aligned to the draft anchored
+                                              at one end and used by the polish where it reaches (docs/faq/accuracy-vs-passes.md:26-29:
+                                              ec ~ np + 1).  A ZMW's partial passes must FOLLOW its full-length passes.
+                                        bit2: (partial only) the adapter is at the pass's END (cx ADAPTER_AFTER only), else at its start */
 } ccsx_batch;
 
 /* ---- results: caller-allocated; seq/qual/raw_qv are laid out at seq_off[z] (capacity layout

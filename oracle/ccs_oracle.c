@@ -631,6 +631,47 @@ int orc_align_rescue(const uint8_t *r, int I, const uint8_t *d, int Ld, const in
     return valid;
 }
 
+/* SPEC "partial passes" (docs/faq/accuracy-vs-passes.md:26-29: the first and last subread of a ZMW are not flanked by adapters on both
+ * sides; they are not used for the draft and do not count as passes, but the polish uses them where they reach: ec ~ np + 1).  A partial
+ * pass is anchored at ONE end of the draft — from_end = 0: it starts where the draft starts and stops somewhere, from_end = 1: it ends
+ * where the draft ends.  The banded recurrence of step 3 runs from the anchored end (on the reversed read and draft for from_end); the
+ * pass covers the draft up to the window-edge column with the largest column maximum (first on ties: the score rises while the pass
+ * lasts and falls by one deletion per column after its last base); valid iff that score reaches 1.0 per covered draft base.  Entry
+ * rows of the covered edge columns come from the path that ends in that column's best cell; uncovered columns get entry rows that
+ * make every window touching them unusable (a negative segment length); like a split pass it gives the candidate filter no evidence. */
+int orc_align_partial(const uint8_t *r, int I, const uint8_t *d, int Ld, const int32_t *need, int nneed, int from_end,
+                      int32_t *rstart, int32_t *score_out, uint8_t *dirty)
+{
+    uint8_t *rr = (uint8_t *)malloc(I + 1), *dr = (uint8_t *)malloc(Ld + 1);
+    for (int i = 0; i < I; ++i) rr[i] = from_end ? r[I - 1 - i] : r[i];
+    for (int j = 0; j < Ld; ++j) dr[j] = from_end ? d[Ld - 1 - j] : d[j];
+    int32_t *lo = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1) * 4), *cm = lo + (Ld + 1), *br = cm + (Ld + 1), *rs = br + (Ld + 1);
+    uint8_t *mv = (uint8_t *)malloc((size_t)(Ld + 1) * BAND);
+    dp_all_columns(rr, I, dr, Ld, lo, mv, cm, br);
+    int32_t best = NEG; int sb = -1;
+    for (int k = 1; k < nneed; ++k) {                        /* edge columns in the direction of the DP */
+        int s = from_end ? Ld - need[nneed - 1 - k] : need[k];
+        if (cm[s] > NEG / 2 && cm[s] > best) { best = cm[s]; sb = s; }
+    }
+    if (score_out) *score_out = best;
+    int valid = (sb > 0 && best >= sb);
+    if (valid) {
+        for (int j = 0; j <= Ld; ++j) rs[j] = -1;
+        trace_entries(mv, lo, sb, br[sb], rs);
+        if (!from_end) {
+            for (int c = 0; c <= sb; ++c) rstart[c] = rs[c];
+            for (int c = sb + 1; c <= Ld; ++c) rstart[c] = -(1 << 20) - c;
+        } else {
+            for (int c = Ld - sb; c <= Ld; ++c) rstart[c] = I - rs[Ld - c];
+            for (int c = 0; c < Ld - sb; ++c) rstart[c] = (1 << 20) + (Ld - c);
+        }
+        if (dirty) memset(dirty, 1, Ld);
+        orc_cnt[CNT_PARTIAL_USED] += 1;
+    }
+    free(rr); free(dr); free(lo); free(mv);
+    return valid;
+}
+
 /* step 4: window core boundaries b[0]=0 < ... < b[n]=Ld ; returns n (docs/how-does-ccs-work.md:57-61).
  * "Avoid breaking windows at simple repeats (homopolymers to 4-mer repeats)": a boundary nb is bad when for some
  * period p in 1..4 the p-mer before it equals the p-mer after it; the target boundary cur+22 is moved by
@@ -811,6 +852,9 @@ struct orc_dbg_s {
 } orc_dbg;
 
 static __thread uint32_t orc_dbg_calib_ev; static __thread int orc_dbg_margin[JMAX + 1];
+/* side channel of polish_window_impl for the whole-ZMW driver: reads [0, pw_nfull) are full-length passes; pw_nvalid_full = how many of
+ * them the window used (np counts full-length passes only, ec counts the partial ones too) */
+static __thread int pw_nfull = 1 << 30, pw_nvalid_full = 0;
 /* Polish one window.  obs[r] = native-orientation observation codes of read r's segment, I[r] its length
  * (I[r] < 0 or > IMAX: read unusable in this window), strand[r] = 1 if the read is reverse to the draft.
  * ev0 = candidate-filter evidence of the draft window (bit c: position c may be skipped), skip_p = error
@@ -965,6 +1009,8 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
         out_seq[len] = w.t[c]; out_perr[len] = p; out_qv[len] = qv; ++len;
     }
     *out_len = len; *out_nvalid = nvalid; *out_nonconv = nonconv;
+    pw_nvalid_full = 0;
+    for (int r = 0; r < nreads && r < pw_nfull; ++r) pw_nvalid_full += valid[r];
     orc_cnt[CNT_NONCONV_WIN] += nonconv;
     if (out_delta) memcpy(out_delta, delta, sizeof(delta));
     if (wfinal) *wfinal = w;
@@ -1155,7 +1201,10 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         int top = (opts->top_passes <= 0 || opts->top_passes > 64) ? 64 : opts->top_passes;
         if (nreads > top) nreads = top;
     }
-    if (nreads < opts->min_passes || nreads < 1) { out->status = ST_TOO_FEW; return 0; }
+    /* SPEC "partial passes": flag bit 1; a ZMW's partial passes follow its full-length passes (the batch is validated for that) */
+    int nfull = 0;
+    while (nfull < nreads && !(flags[nfull] & 2)) ++nfull;
+    if (nfull < opts->min_passes || nfull < 1) { out->status = ST_TOO_FEW; return 0; }
     int maxL = 0;
     for (int r = 0; r < nreads; ++r) { int L = (int)(base_off[r + 1] - base_off[r]); if (L > maxL) maxL = L; }
     int dcap = maxL + maxL / 4 + 64;
@@ -1171,7 +1220,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
     uint8_t *strand = (uint8_t *)malloc(nreads), *avalid = (uint8_t *)malloc(nreads);
     int ret = 0;
     for (;;) {
-        if (attempt < 2) Ld = orc_poa_draft_bb(nreads, base_off, bases, flags, attempt ? 2 * opts->max_poa_cov : opts->max_poa_cov, vcap, draft, dcap, bb);
+        if (attempt < 2) Ld = orc_poa_draft_bb(nfull, base_off, bases, flags, attempt ? 2 * opts->max_poa_cov : opts->max_poa_cov, vcap, draft, dcap, bb);
         else {                                              /* SPEC "draft cascade", last resort: the backbone pass itself is the draft */
             Ld = (int)(base_off[bb + 1] - base_off[bb]);
             if (Ld > dcap) Ld = 0;
@@ -1205,6 +1254,12 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                 rstart[r] = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
                 dirty[r] = (uint8_t *)malloc(Ld + 1);
                 int32_t sc;
+                if (r >= nfull) {                           /* partial pass: anchored at the draft's start or end (flag bit 2 = the adapter is at
+                                                               the pass's END; in draft orientation that end is the draft's end iff same strand) */
+                    int from_end = ((flags[r] >> 2) & 1) ^ strand[r];
+                    avalid[r] = (uint8_t)(nneed >= 2 ? orc_align_partial(ob, L, draft, Ld, need, nneed, from_end, rstart[r], &sc, dirty[r]) : 0);
+                    continue;                               /* not a pass: np / fn / rn count full-length passes */
+                }
                 avalid[r] = (uint8_t)orc_align_ev(ob, L, draft, Ld, rstart[r], &sc, dirty[r]);
                 /* a pass much longer than the draft that failed: look for ONE large insertion (SPEC "split alignment") */
                 if (!avalid[r] && L - Ld > RESCUE_MIN_EXCESS && nneed >= 3)
@@ -1214,7 +1269,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
             }
             free(ob); free(wb0); free(need);
             out->np = np;
-            if (2 * np <= nreads) { out->status = ST_UNUSABLE; want_retry = 1; }
+            if (2 * np <= nfull) { out->status = ST_UNUSABLE; want_retry = 1; }
         }
         if (!want_retry) break;
         if (attempt >= 2 || opts->no_fallback_draft) { if (out->status == ST_DRAFT_FAIL) { out->np = 0; out->fn = out->rn = 0; } goto done; }
@@ -1222,15 +1277,15 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
              * the closest among the passes that have NOT been a backbone yet (pass 0 and the fallback's backbone may be the problem) */
             const int bb1 = attempt ? bb : -1;
             int med = 0, best = -1;
-            for (int r = 0; r < nreads; ++r) {
+            for (int r = 0; r < nfull; ++r) {
                 int len = (int)(base_off[r + 1] - base_off[r]), rank = 0;
-                for (int q = 0; q < nreads; ++q) { int lq = (int)(base_off[q + 1] - base_off[q]); rank += (lq < len || (lq == len && q < r)) ? 1 : 0; }
-                if (rank == nreads / 2) med = len;
+                for (int q = 0; q < nfull; ++q) { int lq = (int)(base_off[q + 1] - base_off[q]); rank += (lq < len || (lq == len && q < r)) ? 1 : 0; }
+                if (rank == nfull / 2) med = len;
             }
-            for (int r = 0; r < nreads; ++r) {
+            for (int r = 0; r < nfull; ++r) {
                 int d = (int)(base_off[r + 1] - base_off[r]) - med; if (d < 0) d = -d;
-                if (attempt && nreads > 1 && r == bb1) continue;
-                if (attempt && nreads > 2 && r == 0) continue;     /* ... and pass 0, the backbone of the first draft, failed as well */
+                if (attempt && nfull > 1 && r == bb1) continue;
+                if (attempt && nfull > 2 && r == 0) continue;     /* ... and pass 0, the backbone of the first draft, failed as well */
                 if (best < 0 || d < best) { best = d; bb = r; }
             }
         }
@@ -1309,10 +1364,12 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
             uint8_t wseq[JMAX + 1]; float wperr[JMAX + 1], wqv[JMAX + 1]; int32_t wlen, wnv, wnc;
             wtpl_t wf; int64_t nsc = 0;
             orc_dbg_calib_ev = (orc_dbg.calib > 2) ? ev0 : 0u; memcpy(orc_dbg_margin, margin, sizeof(int) * J);
+            pw_nfull = nfull;
             int it = polish_window_impl(ME, INS, DL, draft + ws, J, cs, ce, lf, rf, nreads, obs, Iw, strand,
                                         orc_dbg.calib ? 0u : ev0, skp, MU, VAR, opts->min_zscore, wseq, wperr, wqv, &wlen, &wnv, &wnc, NULL, &wf, &nsc);
             out->iters += it; nvalid_sum += wnv; nonconv_any |= wnc;
-            if (wnv >= 0 && wnv <= 64) nv_hist[wnv] += 1;
+            pw_nfull = 1 << 30;
+            if (pw_nvalid_full >= 0 && pw_nvalid_full <= 64) nv_hist[pw_nvalid_full] += 1;
             if (orc_dbg.stats == 2) {
                 fprintf(stderr, "WIN %d ws %d we %d cs %d ce %d it %d nv %d ev %08x draft ", w, ws, we, cs, ce, it, wnv, ev0);
                 for (int q = 0; q < J; ++q) fputc("ACGT"[draft[ws + q]], stderr);

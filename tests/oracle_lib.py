@@ -56,6 +56,8 @@ def tables(model, snr):
 
 def poa_draft(batch, z, max_poa_cov=5):
     r0, r1 = int(batch.read_off[z]), int(batch.read_off[z + 1])
+    while r1 > r0 and (batch.flags[r1 - 1] & 2):           # partial passes (a suffix of the ZMW's reads) never enter the draft
+        r1 -= 1
     b0 = int(batch.base_off[r0])
     rel = (batch.base_off[r0:r1 + 1] - b0).astype(np.int64)
     bases = np.ascontiguousarray(batch.bases[b0:int(batch.base_off[r1])])

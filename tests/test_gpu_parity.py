@@ -637,3 +637,42 @@ def test_last_resort_draft_matches_oracle(built):
                     assert np.array_equal(res.kinetics(z), ref.kinetics(z))
         finally:
             h.close()
+
+
+@pytest.mark.parametrize("kin", [0, 1])
+def test_partial_passes_match_oracle(built, kin):
+    """SPEC "partial passes" (docs/faq/accuracy-vs-passes.md:26-29) on the GPU: k_rescue's anchored alignment of the passes that carry
+    flag bit 1 (start- and end-anchored, both strands), np counts full-length passes, ec the partial ones too; with fallback-draft
+    ZMWs (a junk pass 0 changes the draft's orientation, so the anchor side of the partial passes flips) and with kinetics"""
+    import test_oracle_draft as T
+    batch = T.partial_pass_batch(n=10, seed=56, nfull=6, length=(900, 3000))
+    rng = np.random.default_rng(3)
+    for z in (2, 7):                                         # junk pass 0 -> fallback draft with another backbone / orientation
+        r = int(batch.read_off[z]); a, b = int(batch.base_off[r]), int(batch.base_off[r + 1])
+        batch.bases[a:b] = rng.integers(0, 4, b - a, dtype=np.uint8)
+    o = api.default_opts(); o.hifi_kinetics = kin
+    h = api.Handle(0, opts=o)
+    try:
+        res = h.consensus(batch)
+        ref = api.Results.allocate(batch, kinetics=bool(kin))
+        O.counts_reset()
+        O.consensus_batch(h.model, o, batch, ref, nthreads=4)
+        assert O.counts()["partial_used"] >= 16
+        _compare(res, ref, batch)
+        assert np.array_equal(res.np_, ref.np_) and np.array_equal(res.fn, ref.fn) and np.array_equal(res.rn, ref.rn)
+        assert np.allclose(res.ec, ref.ec, atol=1e-6)
+        ok = (res.status == 0) | (res.status == 7)
+        assert ok.sum() >= 8 and (res.ec[ok] > res.np_[ok] + 0.5).all()
+        if kin:
+            for z in range(batch.n_zmw):
+                assert np.array_equal(res.kinetics(z), ref.kinetics(z))
+    finally:
+        h.close()
+    bad = T.partial_pass_batch(n=2, seed=57)
+    bad.flags[int(bad.read_off[1]) - 1] &= 1                 # a full-length pass after a partial one: refused, not misread
+    h = api.Handle(0)
+    try:
+        with pytest.raises(RuntimeError, match="follows a partial pass"):
+            h.consensus(bad)
+    finally:
+        h.close()

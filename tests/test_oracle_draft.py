@@ -202,3 +202,51 @@ def test_last_resort_draft_takes_a_pass_as_the_draft(built):
     res2 = api.Results.allocate(batch)
     O.consensus_batch(api.default_model(), o, batch, res2)
     assert set(res2.status[[1, 2, 4]].tolist()) <= {2, 3}        # DRAFT_FAILURE / TOO_MANY_UNUSABLE without it
+
+
+def partial_pass_batch(n=6, seed=55, nfull=6, length=(1200, 2500)):
+    """nfull full-length passes + two partial ones per ZMW (made by truncating two more passes): pass nfull keeps its first 60 % (it starts
+    at an adapter: the LAST subread of a polymerase read), pass nfull+1 its last 50 % (it ends at an adapter: the FIRST subread;
+    flag bit 2).  flags: bit 0 strand, bit 1 partial, bit 2 the adapter is at the pass's end."""
+    from ccs_amd import api
+    base = api.synth(n, nfull + 2, length, seed=seed)
+    bases, pw, ipd, off, flags = [], [], [], [0], base.flags.copy()
+    for r in range(int(base.read_off[-1])):
+        a, b = int(base.base_off[r]), int(base.base_off[r + 1])
+        z = int(np.searchsorted(base.read_off, r, side="right") - 1)
+        q = r - int(base.read_off[z])
+        if q == nfull: b = a + (6 * (b - a)) // 10; flags[r] |= 2
+        elif q == nfull + 1: a = b - (b - a) // 2; flags[r] |= 2 | 4
+        bases.append(base.bases[a:b]); pw.append(base.pw[a:b]); ipd.append(base.ipd[a:b]); off.append(off[-1] + (b - a))
+    return api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                     np.concatenate(ipd), flags, base.tpl_off, base.tpl)
+
+
+def test_partial_passes_serve_the_polish_but_are_not_passes(built):
+    """docs/faq/accuracy-vs-passes.md:26-29: np = full-length passes, ec ~ np + 1 because the polish also uses the partial ones"""
+    from ccs_amd import api
+    import oracle_lib as O
+    batch = partial_pass_batch()
+    full_only = api.synth(6, 8, (1200, 2500), seed=55)
+    keep = [r for z in range(6) for r in range(int(full_only.read_off[z]), int(full_only.read_off[z]) + 6)]
+    fo = api.Batch(full_only.zmw_id, full_only.snr, np.arange(0, 37, 6, dtype=np.int32),
+                   np.concatenate([[0], np.cumsum([int(full_only.base_off[r + 1] - full_only.base_off[r]) for r in keep])]).astype(np.int64),
+                   np.concatenate([full_only.bases[int(full_only.base_off[r]):int(full_only.base_off[r + 1])] for r in keep]),
+                   np.concatenate([full_only.pw[int(full_only.base_off[r]):int(full_only.base_off[r + 1])] for r in keep]),
+                   np.concatenate([full_only.ipd[int(full_only.base_off[r]):int(full_only.base_off[r + 1])] for r in keep]),
+                   full_only.flags[keep].copy(), full_only.tpl_off, full_only.tpl)
+    o, m = api.default_opts(), api.default_model()
+    res, ref = api.Results.allocate(batch), api.Results.allocate(fo)
+    O.counts_reset()
+    O.consensus_batch(m, o, batch, res)
+    assert O.counts()["partial_used"] == 12                       # both partial passes of every ZMW found their place
+    O.consensus_batch(m, o, fo, ref)
+    assert np.array_equal(res.np_, ref.np_) and (res.np_ == 6).all()          # they are not passes ...
+    assert np.array_equal(res.fn, ref.fn) and np.array_equal(res.rn, ref.rn)
+    assert (res.ec > ref.ec + 0.8).all() and (res.ec < ref.ec + 1.3).all()   # ... but 0.6 + 0.5 of a pass more coverage per window
+    assert ((res.status == 0) | (res.status == 7)).all()
+    for z in range(6):                                            # the draft does not see them
+        assert np.array_equal(O.poa_draft(batch, z), O.poa_draft(fo, z))
+    assert res.rq.mean() > ref.rq.mean()                          # more evidence, higher predicted accuracy
+    err = lambda r, b: sum(O.edit_distance(r.sequence(z), b.tpl[b.tpl_off[z]:b.tpl_off[z + 1]]) for z in range(6))
+    assert err(res, batch) <= err(ref, fo) + 1
