@@ -409,6 +409,7 @@ struct Subread {
     float snr[4] = {0, 0, 0, 0};
     bool has_snr = false, has_n = false;
     uint8_t strand = 0;         // 0 forward / 1 reverse pass (set by the driver: cx direction bits, else alternation)
+    uint8_t partial = 0;        // ccsx_batch.flags bits 1-2: 2 = partial pass with the adapter at its start, 6 = ... at its end
     std::vector<uint8_t> bases;  // 0..3
     std::vector<uint8_t> pw, ipd;
 };

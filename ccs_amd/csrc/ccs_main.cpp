@@ -51,6 +51,7 @@ struct Options {
     std::string write_synth;      // "N,P,L[,seed]" -> write a synthetic subreads.bam to `out`
     bool dump = false;            // print one line per ZMW after the step-1 filters, no GPU
     bool by_strand = false;       // --by-strand: one consensus per strand (docs/faq/mode-by-strand.md:8-23)
+    bool no_partial = false;      // --no-partial-passes: drop the subreads that are not flanked by adapters on both sides (as round 2 did)
     bool qv_binning = false;      // --qv-binning: 7-bin per-base QVs after rq is computed (docs/faq/qv-binning.md:19-31)
     bool suppress_reports = false;
     std::string metrics;          // --metrics-json (default <prefix>.zmw_metrics.json.gz)
@@ -157,6 +158,7 @@ void usage()
                  "      --min-rq F            minimum predicted accuracy [0.99]\n"
                  "      --maxPoaCoverage N    subreads used for the draft [5]\n"
                  "      --by-strand           one consensus per strand, read names end in /fwd or /rev\n"
+                 "      --no-partial-passes   do not use the first / last (one-adapter) subread of a ZMW in the polish\n"
                  "      --qv-binning          write 7-bin per-base QVs (Q3 Q10 Q17 Q22 Q27 Q35 Q40)\n"
                  "      --hifi-kinetics       averaged per-strand kinetics: tags fi fp fn ri rp rn (ip pw with --by-strand)\n"
                  "      --metrics-json F      per-ZMW metrics [<OUT prefix>.zmw_metrics.json.gz]\n"
@@ -198,6 +200,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--write-synthetic") o.write_synth = need(a.c_str());
         else if (a == "--dump-zmws") o.dump = true;
         else if (a == "--by-strand") o.by_strand = true;
+        else if (a == "--no-partial-passes") o.no_partial = true;
         else if (a == "--qv-binning") o.qv_binning = true;
         else if (a == "--hifi-kinetics") o.o.hifi_kinetics = 1;
         else if (a == "--suppress-reports") o.suppress_reports = true;
@@ -256,8 +259,9 @@ std::string movie_of(const std::string &qname) { const size_t p = qname.find('/'
 // ---- synthetic subreads.bam (test helper) ----------------------------------------------------------
 int write_synthetic(const Options &o, ThreadPool &pool)
 {
-    int n = 0, P = 0, L = 0; unsigned long long seed = 1;
-    if (std::sscanf(o.write_synth.c_str(), "%d,%d,%d,%llu", &n, &P, &L, &seed) < 3) { std::fprintf(stderr, "bad --write-synthetic\n"); return 2; }
+    int n = 0, P = 0, L = 0, partial = 0; unsigned long long seed = 1;   // n,passes,length[,seed[,1]]: a fifth field 1 = the first and the last
+    // subread of every ZMW are PARTIAL passes (one adapter only, truncated at the polymerase read's start / end)
+    if (std::sscanf(o.write_synth.c_str(), "%d,%d,%d,%llu,%d", &n, &P, &L, &seed, &partial) < 3) { std::fprintf(stderr, "bad --write-synthetic\n"); return 2; }
     ccsx_synth *s = nullptr;
     if (ccsx_synth_generate(n, 1000, P, P, L, L, seed, &s)) { std::fprintf(stderr, "%s\n", ccsx_last_error()); return 1; }
     BgzfWriter out(o.out, pool);
@@ -270,7 +274,12 @@ int write_synthetic(const Options &o, ThreadPool &pool)
     for (int z = 0; z < b.n_zmw; ++z) {
         int64_t q = 0;
         for (int r = b.read_off[z]; r < b.read_off[z + 1]; ++r) {
-            const int64_t a = b.base_off[r], len = b.base_off[r + 1] - a;
+            int64_t a = b.base_off[r], len = b.base_off[r + 1] - a;
+            int cxa = 3;                                                          // ADAPTER_BEFORE | ADAPTER_AFTER
+            if (partial && b.read_off[z + 1] - b.read_off[z] >= 3) {
+                if (r == b.read_off[z]) { a += len / 2; len -= len / 2; cxa = 2; }               // sequencing started inside the insert
+                else if (r == b.read_off[z + 1] - 1) { len = (6 * len) / 10; cxa = 1; }          // ... and ended inside it
+            }
             const std::string name = movie + "/" + std::to_string(b.zmw_id[z]) + "/" + std::to_string(q) + "_" + std::to_string(q + len);
             rb.begin(name, b.bases + a, nullptr, (uint32_t)len);
             rb.tagZ("RG", "synth001");
@@ -280,10 +289,10 @@ int write_synthetic(const Options &o, ThreadPool &pool)
             rb.tagBf("sn", b.snr + 4 * z, 4);
             rb.tagBC("ip", b.ipd + a, (uint32_t)len);
             rb.tagBC("pw", b.pw + a, (uint32_t)len);
-            rb.tagC("cx", (uint8_t)(3 | ((b.flags[r] & 1) ? 32 : 16)));      // ADAPTER_BEFORE|AFTER + FORWARD/REVERSE_PASS
+            rb.tagC("cx", (uint8_t)(cxa | ((b.flags[r] & 1) ? 32 : 16)));    // adapters + FORWARD/REVERSE_PASS
             marks.push_back(out.mark());
             pbi.rg_id.push_back(0); pbi.q_start.push_back((int32_t)q); pbi.q_end.push_back((int32_t)(q + len)); pbi.hole.push_back(b.zmw_id[z]);
-            pbi.read_qual.push_back(0.8f); pbi.ctxt.push_back(3);
+            pbi.read_qual.push_back(0.8f); pbi.ctxt.push_back((uint8_t)cxa);
             rb.finish(out);
             q += len + 45;
         }
@@ -315,13 +324,23 @@ void finish_zmw(ZmwIn &z, const Options &o)
     std::vector<size_t> s = lens;
     std::nth_element(s.begin(), s.begin() + s.size() / 2, s.end());
     const double med = (double)s[s.size() / 2];
-    std::vector<Subread> keep;
+    std::vector<Subread> keep, part;
     bool any_len_ok = false;
     for (auto &r : z.reads) {
         const double l = (double)r.bases.size();
+        const bool full = (r.cx < 0) || ((r.cx & 3) == 3);       // flanked by adapters (docs/faq/accuracy-vs-passes.md:17-18)
+        // partial passes (one adapter only: the first / last subread of the polymerase read) are not passes, but the polish uses them
+        // where they reach (docs/faq/accuracy-vs-passes.md:26-29: ec ~ np + 1); they are shorter by nature: no lower length bound
+        const bool partial = !full && r.cx >= 0 && (r.cx & 3) != 0 && l >= 50.0 && l <= 2.0 * med && !o.no_partial;
+        if (partial && !r.has_n) {
+            r.partial = (uint8_t)((r.cx & 3) == 2 ? 6 : 2);      // cx ADAPTER_AFTER only: the adapter is at the pass's end
+            if (r.pw.size() != r.bases.size()) r.pw.assign(r.bases.size(), 2);
+            if (r.ipd.size() != r.bases.size()) r.ipd.assign(r.bases.size(), 1);
+            part.push_back(std::move(r));
+            continue;
+        }
         if (l < 0.5 * med || l > 2.0 * med) continue;            // length filter
         any_len_ok = true;
-        const bool full = (r.cx < 0) || ((r.cx & 3) == 3);       // flanked by adapters (docs/faq/accuracy-vs-passes.md:17-18)
         if (!full || r.has_n || r.bases.empty()) continue;
         if (r.pw.size() != r.bases.size()) r.pw.assign(r.bases.size(), 2);
         if (r.ipd.size() != r.bases.size()) r.ipd.assign(r.bases.size(), 1);
@@ -346,6 +365,8 @@ void finish_zmw(ZmwIn &z, const Options &o)
         for (size_t i : idx) sel.push_back(std::move(z.reads[i]));
         z.reads.swap(sel);
     }
+    // the engine wants a ZMW's partial passes behind its full-length passes; it uses at most 64 passes in all
+    for (auto &r : part) if (z.reads.size() < 64) z.reads.push_back(std::move(r));
 }
 
 struct ArenaPool {                          // free list of page-locked arenas: a batch holds its staging until its results are written
@@ -381,7 +402,7 @@ void pack(Batch &b, Arena &arena)
             const size_t L = r.bases.size();
             std::memcpy(bases + at, r.bases.data(), L); std::memcpy(pw + at, r.pw.data(), L); std::memcpy(ipd + at, r.ipd.data(), L);
             at += (int64_t)L;
-            b.flags.push_back(r.strand);
+            b.flags.push_back((uint8_t)(r.strand | r.partial));
             b.base_off.push_back(at);
             std::vector<uint8_t>().swap(r.bases); std::vector<uint8_t>().swap(r.pw); std::vector<uint8_t>().swap(r.ipd);
         }

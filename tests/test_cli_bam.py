@@ -492,3 +492,42 @@ def test_cli_chunks_and_output_index(built, tmp_path):
     assert [r["name"] for r in got] == [r["name"] for r in full]
     for a, b in zip(got, full):
         assert np.array_equal(a["seq"], b["seq"]) and np.array_equal(a["qual"], b["qual"]) and a["tags"]["rq"] == b["tags"]["rq"]
+
+
+@pytest.mark.gpu
+def test_cli_partial_passes(built, tmp_path):
+    """docs/faq/accuracy-vs-passes.md:26-29: the first and last subread of a ZMW carry one adapter only (cx 2 / 1); they are not
+    passes (np, --min-passes count full-length ones) but the polish uses them: ec ~ np + 1.  --no-partial-passes drops them."""
+    bam, out, out2 = tmp_path / "s.subreads.bam", tmp_path / "o.bam", tmp_path / "o2.bam"
+    _run("--write-synthetic", "10,8,1200,31,1", bam)
+    _, sub = bam_util.read_bam(bam)
+    cx = [r["tags"]["cx"] & 3 for r in sub if r["tags"]["zm"] == 1000]
+    assert cx == [2, 3, 3, 3, 3, 3, 3, 1]
+    _run(bam, out, "--min-rq", 0.9)
+    _run(bam, out2, "--min-rq", 0.9, "--no-partial-passes")
+    a, b = bam_util.read_bam(out)[1], bam_util.read_bam(out2)[1]
+    assert len(a) == len(b) == 10
+    for x, y in zip(a, b):
+        assert x["tags"]["np"] == y["tags"]["np"] == 6
+        assert y["tags"]["ec"] <= 6.0 + 1e-6 and 6.7 < x["tags"]["ec"] < 7.3
+    assert np.mean([x["tags"]["rq"] for x in a]) > np.mean([y["tags"]["rq"] for y in b])
+    # the library gives the same through the ABI: full-length passes first, then the partial ones with flag bits 1 / 2
+    full = api.synth(10, 8, 1200, seed=31, first_zmw_id=1000)
+    order, flags, bases, pw, ipd, off = [], [], [], [], [], [0]
+    for z in range(10):
+        r0 = int(full.read_off[z])
+        for q in list(range(1, 7)) + [0, 7]:
+            r = r0 + q
+            s, e = int(full.base_off[r]), int(full.base_off[r + 1]); ln = e - s
+            fl = int(full.flags[r])
+            if q == 0: s += ln // 2; fl |= 2 | 4
+            if q == 7: e = s + (6 * ln) // 10; fl |= 2
+            bases.append(full.bases[s:e]); pw.append(full.pw[s:e]); ipd.append(full.ipd[s:e]); off.append(off[-1] + (e - s)); flags.append(fl)
+    batch = api.Batch(full.zmw_id, full.snr, full.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                      np.concatenate(ipd), np.array(flags, np.uint8), full.tpl_off, full.tpl)
+    o = api.default_opts(); o.min_rq = 0.9
+    h = api.Handle(0, opts=o)
+    res = h.consensus(batch)
+    h.close()
+    for z, x in enumerate(a):
+        assert np.array_equal(res.sequence(z), x["seq"]) and abs(float(res.ec[z]) - x["tags"]["ec"]) < 1e-5
