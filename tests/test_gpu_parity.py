@@ -125,13 +125,15 @@ def test_recovers_truth_at_full_size(handle):
 
 @pytest.mark.parametrize("n,passes,length,seed", [
     (256, 3, 1000, 30),               # BASELINE config 1 shape: the CPU-runnable case (every ZMW ends LOW_RQ at 3 passes)
-    (12, 30, 20000, 31),              # BASELINE config 4 shape: deep coverage, long template
-    (48, (3, 50), (1000, 25000), 32), # BASELINE config 5 shape: Sequel-II-like mix
+    (32, 30, 20000, 31),              # BASELINE config 4 shape: deep coverage, long template (the oracle needs ~1 core-s per ZMW here)
+    (128, (3, 50), (1000, 25000), 32), # BASELINE config 5 shape: Sequel-II-like mix
 ])
 def test_baseline_config_shapes_bit_exact(handle, n, passes, length, seed):
+    import os
     batch = api.synth(n, passes, length, seed=seed)
     res = handle.consensus(batch)
-    ref = _oracle(handle, batch)
+    ref = api.Results.allocate(batch)
+    O.consensus_batch(handle.model, handle.opts, batch, ref, nthreads=min(16, len(os.sched_getaffinity(0))))
     _compare(res, ref, batch)
 
 
