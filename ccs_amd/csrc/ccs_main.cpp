@@ -430,7 +430,7 @@ const char *fail_label(int st)
         case CCSX_TOO_LONG: case HS_TOO_LONG: return "Draft above --max-length";
         case CCSX_LOW_RQ: return "CCS below minimum RQ";
         case CCSX_EMPTY_WINDOW: return "Empty coverage windows";
-        case CCSX_CAPACITY: return "Draft above --max-length";
+        case CCSX_CAPACITY: return "Consensus outgrew its buffer";
         default: return "Unknown error";
     }
 }
@@ -449,7 +449,7 @@ const char *status_name(int st)
         case CCSX_TOO_LONG: case HS_TOO_LONG: return "TOO_LONG";
         case CCSX_LOW_RQ: return "POOR_QUALITY";
         case CCSX_EMPTY_WINDOW: return "EMPTY_WINDOW_DURING_POLISHING";
-        case CCSX_CAPACITY: return "TOO_LONG";
+        case CCSX_CAPACITY: return "CAPACITY";
         default: return "EXCEPTION_THROWN";
     }
 }

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -159,10 +160,28 @@ int parse_model(const std::string &text, ccsx_model *m, std::vector<Triple> *che
     }
     m->snr_lo = snr[0]; m->snr_hi = snr[1];
     if (!(m->snr_lo > 0.0f) || !(m->snr_hi >= m->snr_lo)) { ccsx_set_error("model json: SnrRange must be 0 < lo <= hi"); return -1; }
+    if (!std::isfinite(m->snr_lo) || !std::isfinite(m->snr_hi)) { ccsx_set_error("model json: SnrRange must be finite"); return -1; }
+    // every table entry is finite; emission tables are probabilities in (0, 1] (they go through log2 in the z-score parameters), their
+    // rows sum to 1; polynomial coefficients are only required to be finite (the weights are clamped at 1e-6 on the device)
     for (int k = 0; k < CCSX_NCTX; ++k) {
+        for (int mv = 0; mv < 3; ++mv) for (int c = 0; c < 4; ++c)
+            if (!std::isfinite(m->trans_poly[k][mv][c])) { ccsx_set_error("model json: TransitionPolynomials must be finite"); return -1; }
         float s = 0.0f;
-        for (int o = 0; o < CCSX_NOBS; ++o) { if (!(m->em_match[k][o] >= 0.0f)) { ccsx_set_error("model json: negative emission probability"); return -1; } s += m->em_match[k][o]; }
+        for (int o = 0; o < CCSX_NOBS; ++o) {
+            const float p = m->em_match[k][o];
+            if (!std::isfinite(p) || !(p > 0.0f) || p > 1.0f) { ccsx_set_error("model json: EmissionMatch entries must be probabilities in (0, 1]"); return -1; }
+            s += p;
+        }
         if (s < 0.98f || s > 1.02f) { ccsx_set_error("model json: EmissionMatch rows must sum to 1"); return -1; }
+        float sb = 0.0f, ss = 0.0f;
+        for (int b = 0; b < 3; ++b) {
+            const float pb = m->em_branch[k][b], ps = m->em_stick[k][b];
+            if (!std::isfinite(pb) || !(pb > 0.0f) || pb > 1.0f || !std::isfinite(ps) || !(ps > 0.0f) || ps > 1.0f) {
+                ccsx_set_error("model json: EmissionBranch / EmissionStick entries must be probabilities in (0, 1]"); return -1;
+            }
+            sb += pb; ss += ps;
+        }
+        if (sb < 0.98f || sb > 1.02f || ss < 0.98f || ss > 1.02f) { ccsx_set_error("model json: EmissionBranch / EmissionStick rows must sum to 1"); return -1; }
     }
     if (chems) {
         chems->clear();
@@ -217,14 +236,23 @@ int64_t ccsx_model_to_json(const ccsx_model *m, const char *binding_kit, const c
     std::string s = "{\n  \"ConsensusModelVersion\": \"ccsx-1\",\n  \"ChemistryName\": \"";
     char name[sizeof(m->name) + 1] = {0};
     std::memcpy(name, m->name, sizeof(m->name));
-    s += name;
+    auto esc = [](const char *t) {                       // JSON string escaping (quotes, backslashes, control characters)
+        std::string o;
+        for (const unsigned char *p = (const unsigned char *)t; *p; ++p) {
+            if (*p == '"' || *p == '\\') { o += '\\'; o += (char)*p; }
+            else if (*p < 0x20) { char u[8]; std::snprintf(u, sizeof(u), "\\u%04x", (unsigned)*p); o += u; }
+            else o += (char)*p;
+        }
+        return o;
+    };
+    s += esc(name);
     s += "\",\n  \"ModelForm\": \"PwSnr\",\n";
     char tmp[64];
     auto num = [&](float v) { std::snprintf(tmp, sizeof(tmp), "%.9g", (double)v); s += tmp; };
     s += "  \"Chemistries\": [";
     if (binding_kit && sequencing_kit && basecaller_version) {
-        s += "{\"BindingKit\": \""; s += binding_kit; s += "\", \"SequencingKit\": \""; s += sequencing_kit;
-        s += "\", \"BasecallerVersion\": \""; s += basecaller_version; s += "\"}";
+        s += "{\"BindingKit\": \""; s += esc(binding_kit); s += "\", \"SequencingKit\": \""; s += esc(sequencing_kit);
+        s += "\", \"BasecallerVersion\": \""; s += esc(basecaller_version); s += "\"}";
     }
     s += "],\n  \"SnrRange\": ["; num(m->snr_lo); s += ", "; num(m->snr_hi); s += "],\n";
     s += "  \"TransitionPolynomials\": [\n";
@@ -274,7 +302,13 @@ int ccsx_model_for_chemistry(const char *binding_kit, const char *sequencing_kit
             std::string text;
             ccsx_model cand;
             std::vector<Triple> chems;
-            if (!read_file(f, text) || parse_model(text, &cand, &chems)) continue;    // unreadable / foreign json files are skipped
+            if (!read_file(f, text)) { std::fprintf(stderr, "ccsx: warning: cannot read %s\n", f.c_str()); continue; }
+            if (parse_model(text, &cand, &chems)) {
+                // a file that claims to be one of ours but does not validate is reported (an injected model with a typo must not
+                // silently fall back to the built-in set: ADVICE r02); foreign json files in the bundle are skipped quietly
+                if (text.find("\"ccsx-1\"") != std::string::npos) std::fprintf(stderr, "ccsx: warning: ignoring %s: %s\n", f.c_str(), ccsx_last_error());
+                continue;
+            }
             for (const Triple &t : chems) if (triple_matches(t, binding_kit, sequencing_kit, basecaller_version)) { *m = cand; return 0; }
         }
     }

@@ -76,7 +76,9 @@ typedef struct ccsx_model {
 typedef struct ccsx_opts {
     int32_t max_poa_cov;     /* --maxPoaCoverage (docs/changelog.md:114): subreads threaded into the POA */
     int32_t min_passes;      /* --min-passes                                                    */
-    int32_t top_passes;      /* --top-passes; at most 64 passes are ever used (0 or >64 = 64)   */
+    int32_t top_passes;      /* at most this many of a ZMW's passes are used, the FIRST ones in batch order (0 or > 64 = 64).  The reference's
+                                --top-passes ("closest to the median length", docs/faq/accuracy-vs-passes.md:49-52) is a selection the
+                                caller makes when it builds the batch: the `ccs` driver does (ccs_main.cpp finish_zmw)             */
     int32_t min_length;      /* --min-length                                                    */
     int32_t max_length;      /* --max-length                                                    */
     float   min_rq;          /* --min-rq                                                        */

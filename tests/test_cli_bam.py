@@ -531,3 +531,23 @@ def test_cli_partial_passes(built, tmp_path):
     h.close()
     for z, x in enumerate(a):
         assert np.array_equal(res.sequence(z), x["seq"]) and abs(float(res.ec[z]) - x["tags"]["ec"]) < 1e-5
+
+
+def test_bgzf_crc_is_verified(built, tmp_path):
+    """a BGZF block whose payload does not match its CRC32 is an error (both inflate back ends), not silently accepted"""
+    bam = tmp_path / "s.subreads.bam"
+    _run("--write-synthetic", "20,4,800,5", bam)
+    raw = bytearray(open(bam, "rb").read())
+    # second BGZF block: BSIZE sits in the BC extra field; flip one bit of the stored CRC32 (the 4 bytes before ISIZE)
+    bsize0 = (raw[16] | (raw[17] << 8)) + 1
+    b1 = bsize0
+    assert bytes(raw[b1:b1 + 4]) == bytes([0x1f, 0x8b, 8, 4])
+    bsize1 = (raw[b1 + 16] | (raw[b1 + 17] << 8)) + 1
+    raw[b1 + bsize1 - 8] ^= 0x10
+    bad = tmp_path / "bad.bam"
+    open(bad, "wb").write(bytes(raw))
+    for env in ({}, {"CCS_NO_LIBDEFLATE": "1"}):
+        p = subprocess.run([CCS, "--dump-zmws", str(bad)], capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
+        assert p.returncode != 0 and "CRC32" in p.stderr, p.stderr
+        p = subprocess.run([CCS, "--dump-zmws", str(bam)], capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
+        assert p.returncode == 0 and len(p.stdout.splitlines()) == 20

@@ -678,3 +678,39 @@ def test_partial_passes_match_oracle(built, kin):
             h.consensus(bad)
     finally:
         h.close()
+
+
+def test_scratch_grows_while_tickets_are_in_flight(built):
+    """the shared POA / alignment scratch is re-allocated when a later batch needs more (longer reads, more ZMWs)
+    while earlier tickets are still in flight on the other slots — every batch must still equal its synchronous result"""
+    small = api.synth(64, 5, 600, seed=401)
+    big = api.synth(96, 8, 6000, seed=402)                   # ~10x the vertex capacity per graph and more graphs
+    mid = api.synth(80, 6, 2500, seed=403)
+    seq = [small, big, small, mid, big, small]
+    h = api.Handle(0)
+    try:
+        want = {id(b): h.consensus(b) for b in (small, mid)}      # synchronous references first, on a handle whose scratch is still small
+    finally:
+        h.close()
+    h2 = api.Handle(0)
+    try:
+        want[id(big)] = h2.consensus(big)
+    finally:
+        h2.close()
+    h = api.Handle(0)                                        # fresh handle: its scratch starts at the size of `small`
+    try:
+        res = [api.Results.allocate(b, pinned=True) for b in seq]
+        ticks = [None] * len(seq)
+        for k, b in enumerate(seq):
+            if k >= 3:
+                h.wait(ticks[k - 3])
+            ticks[k] = h.submit(b.pinned(), res[k])
+        for k in range(len(seq) - 3, len(seq)):
+            h.wait(ticks[k])
+        for k, b in enumerate(seq):
+            w = want[id(b)]
+            assert np.array_equal(res[k].status, w.status) and np.array_equal(res[k].seq_len, w.seq_len), k
+            for z in range(b.n_zmw):
+                assert np.array_equal(res[k].sequence(z), w.sequence(z)) and np.array_equal(res[k].quals(z), w.quals(z)), (k, z)
+    finally:
+        h.close()

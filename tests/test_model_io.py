@@ -12,7 +12,7 @@ def test_json_roundtrip_is_exact(built):
     assert '"ConsensusModelVersion": "ccsx-1"' in t and '"ChemistryName": "SYN-1"' in t
     assert bytes(api.model_from_json(t)) == bytes(m)
     # a perturbed set with awkward floats survives file -> blob -> file unchanged
-    api.set_model_name(m, "X-1"); m.snr_lo = 3.3333333; m.trans_poly[5][2][3] = 1.0 / 3.0; m.em_stick[9][1] = 0.1 + 1e-8
+    api.set_model_name(m, "X-1"); m.snr_lo = 3.3333333; m.trans_poly[5][2][3] = 1.0 / 3.0; m.em_stick[9][1] = 0.25 + 1e-8
     t2 = api.model_to_json(m)
     m2 = api.model_from_json(t2)
     assert bytes(m2) == bytes(m) and api.model_to_json(m2) == t2
@@ -46,3 +46,22 @@ def test_chemistry_lookup(built, tmp_path, monkeypatch):
     got = api.model_for_chemistry("102-000-000", "102-111-111", "6.0.1")
     assert got.name == b"EARLY-ACCESS" and got.snr_hi == 25.0
     assert api.model_for_chemistry("101-789-500", "101-826-100", "5.0").name == b"SYN-1"
+
+
+def test_model_json_is_validated_and_escaped(built):
+    """every table entry must be finite and a probability where it is one; names / kits are JSON-escaped"""
+    import json
+    m = api.default_model()
+    api.set_model_name(m, 'we"ird\\name')
+    text = api.model_to_json(m, ('kit"1', "s\\k", "5.0"))
+    d = json.loads(text)                                          # valid JSON despite the quotes / backslashes
+    assert d["ChemistryName"] == 'we"ird\\name' and d["Chemistries"][0]["BindingKit"] == 'kit"1'
+    back = api.model_from_json(text)
+    assert bytes(back) == bytes(m)
+    for key, bad in (("EmissionStick", -0.25), ("EmissionBranch", float("inf")), ("EmissionMatch", 0.0), ("TransitionPolynomials", float("nan"))):
+        d2 = json.loads(text)
+        row = d2[key][3]
+        while isinstance(row[0], list): row = row[0]
+        row[1] = bad
+        with pytest.raises(RuntimeError, match="model json"):
+            api.model_from_json(json.dumps(d2).replace("NaN", "1e999").replace("Infinity", "1e999"))
