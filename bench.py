@@ -370,9 +370,11 @@ def main():
             n_s = min(sample0.n_zmw, max(cores, (n_s // cores) * cores))    # whole rounds of one ZMW per thread
             sample = sample0.slice(0, n_s)
             sr = api.Results.allocate(sample)
+            oracle_lib.counts_reset()
             t2 = time.perf_counter()
             oracle_lib.consensus_batch(h.model, h.opts, sample, sr, nthreads=cores)
             t2 = time.perf_counter() - t2
+            cnt = oracle_lib.counts()
             same = all(np.array_equal(sr.sequence(z), res0.sequence(z)) for z in range(n_s))
             qv_max = max((float(np.max(np.abs(sr.raw(z) - res0.raw(z)))) if len(sr.raw(z)) else 0.0) for z in range(n_s)) if same else None
             core_s = t2 * cores / n_s
@@ -386,6 +388,23 @@ def main():
                                               "10 kb x 7 passes, i.e. the port does far less CPU work per ZMW than ccs, so the GPU/CPU ratio is not a "
                                               "statement about ccs (PacBio's own GPU claim: 10x over 128 cores, docs/faq/revio.md:23-25)"}
             out["speedup_vs_cpu_all_cores"] = round(value / (n_s / t2), 2)
+            # SURVEY.md §8d secondary figure: COUNTED DP cell updates per ZMW (the oracle's instrumented path on the same ZMWs), the rate the
+            # GPU sustains over them, and the VALU lane-operations the kernels spend per cell (PMC passes, when the traffic file has them)
+            cells = {k: cnt[k] / max(1, cnt["zmws"]) for k in ("cells_poa", "cells_align", "cells_fill", "cells_score")}
+            tot = sum(cells.values())
+            work = {"cell_updates_per_zmw": {k[6:]: int(v) for k, v in cells.items()}, "cell_updates_per_zmw_total": int(tot),
+                    "gpu_cell_updates_per_s": round(tot * value, 1),
+                    "note": "cells of the banded DP columns (POA: 32 rows x in-edges, alignment: 16 / 64 rows), of the alpha + beta matrices of every "
+                            "(read, window, round), and of the banded mutation links; counted, not estimated"}
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+                vt = sum(kz.get("valu_wave_instr_per_zmw", 0) for kz in tj["kernels"].values())
+                if vt:
+                    work["valu_lane_ops_per_cell"] = round(vt * 64 / tot, 1)
+                    work["valu_frac_of_calibrated_peak"] = tj.get("valu_frac_of_calibrated_peak_whole_step")
+            except Exception:
+                pass
+            out["roofline"]["work"] = work
         job.close()
         # ---- the other BASELINE shapes through the same pipeline (N=1 only; a few steps each)
         if world == 1 and args.extra:

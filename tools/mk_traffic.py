@@ -21,6 +21,10 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ
        "valu_note": "valu_issue_frac_if_{2,4}cyc = SQ_INSTS_VALU x {2,4} SIMD cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the bounds of the "
                     "VALU pipe occupancy (profiles/r02_valu_peak.txt: v_add/mul_f32 and v_add_u32 issue in 2 cycles per wave64, v_fma_f32, "
                     "v_max_i32, DPP ops in 4); lanes_active_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)"}
+# SIMD cycles one wave64 VALU instruction of each kernel's dominant mix occupies (profiles/r02_valu_peak.txt): float add / mul 2.5, fma 3.7,
+# integer max / cmp / cndmask / DPP 4.2 — k_polish mixes float multiply-adds with selects and DPP shifts, the DP kernels are DPP / max heavy
+CYC = {"k_polish": 3.2, "k_poa_dp": 4.2, "k_align16": 4.2, "k_align": 4.2, "k_rescue": 4.2, "k_kinetics": 4.2}
+tot_busy = tot_cycles = 0.0
 for k, d in sorted(val.items()):
     runs = max(1, cnt.get("k_polish", {}).get(next(iter(d)), 1))
     e = {}
@@ -34,10 +38,16 @@ for k, d in sorted(val.items()):
             simd_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 1024
             e["valu_issue_frac_if_2cyc"] = round(d["SQ_INSTS_VALU"] * 2 / simd_cycles, 3)
             e["valu_issue_frac_if_4cyc"] = round(d["SQ_INSTS_VALU"] * 4 / simd_cycles, 3)
+            e["valu_cycles_per_instr_calibrated"] = CYC.get(k, 4.0)
+            e["valu_frac_of_calibrated_peak"] = round(d["SQ_INSTS_VALU"] * CYC.get(k, 4.0) / simd_cycles, 3)
+            if k.startswith("k_"): tot_busy += d["SQ_INSTS_VALU"] * CYC.get(k, 4.0); tot_cycles += simd_cycles
         if d.get("SQ_THREAD_CYCLES_VALU"):
             e["lanes_active_frac"] = round(d["SQ_THREAD_CYCLES_VALU"] / (64 * d["SQ_INSTS_VALU"]), 3)
     if d.get("GRBM_GUI_ACTIVE"): e["gpu_active_ms_per_pass"] = round(d["GRBM_GUI_ACTIVE"] / 8 / 2.4e6 / runs, 3)
     if "SQ_WAIT_ANY" in d and d.get("SQ_WAVE_CYCLES"): e["wave_wait_frac"] = round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 3)
     if "SQ_LDS_BANK_CONFLICT" in d and d.get("SQ_LDS_IDX_ACTIVE"): e["lds_bank_conflict_frac"] = round(d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"], 3)
     out["kernels"][k] = e
+out["valu_frac_of_calibrated_peak_whole_step"] = round(tot_busy / tot_cycles, 3) if tot_cycles else None
+out["valu_frac_note"] = ("valu_frac_of_calibrated_peak = SQ_INSTS_VALU x (calibrated SIMD cycles per instruction of the kernel's dominant opcode mix) / "
+                         "(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of the VALU issue slots the kernel fills; whole_step = the same over every k_* kernel")
 print(json.dumps(out, indent=1))
