@@ -207,7 +207,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=13, help="timed steps (one batch each); the default 13 x 8192 ZMWs = the 100k-ZMW job of configs[1]")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3, help="untimed steps; at least one per batch slot (3), so that every hipMalloc of the engine happens before the timed region")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="BASELINE.json config shape: c2 (default, the "
                     "one the metric is quoted on) 10 x 10 kb; c1 3 x 1 kb; c4 30 x 20 kb; c5 3-50 passes x 1-25 kb (log-uniform)")
     ap.add_argument("--zmws", type=int, default=0, help="ZMWs per GPU per step [workload default]")
@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--extra", default="c1,c4,c5", help="other BASELINE shapes reported under `extra` (N=1 only; '' = none)")
-    ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--extra-steps", type=int, default=4)
     ap.add_argument("--pmc", action="store_true", help="counter-pass mode (under rocprofv3 --pmc): only the headline steps, no CPU baseline, no extras")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -413,8 +413,8 @@ def main():
                 try:
                     p_, l_, z_ = WORKLOADS[name]
                     z_ = fit_zmws(z_, p_, l_, 1)
-                    j2 = Job(api, np, 0, 1, local_rank, z_, p_, l_, 2, args.extra_steps, 1, args.depth, make_opts())
-                    j2.run(1, False)
+                    j2 = Job(api, np, 0, 1, local_rank, z_, p_, l_, 2, args.extra_steps, args.depth, args.depth, make_opts())
+                    j2.run(args.depth, False)            # one untimed step per batch slot: all device buffers exist before the timed steps
                     torch.cuda.synchronize()
                     el, kt2, (ok2, rs2, rn2, _) = j2.run(args.extra_steps, True)
                     sm = stage_means(np, kt2)

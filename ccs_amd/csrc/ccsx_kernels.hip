@@ -1518,12 +1518,14 @@ __global__ void k_post(KParams P, int pass)
 #define PW_THREADS 256                // 4 waves.  Measured on the 10 x 10 kb workload (ms per 2048 ZMWs): 256 threads x 3 workgroups/CU 95,
 #endif                                //   512 x 2 (all ten reads in one LDS chunk) 101-103, 256 x 2 141, 320 x 2 208: resident waves per CU decide
 #ifndef PW_MINWAVES
-#define PW_MINWAVES 3
+#define PW_MINWAVES 4
 #endif
 #define PW_WAVES (PW_THREADS / 64)
 #define PW_MAXREADS 64
 #ifndef PW_LDS_BYTES
-#define PW_LDS_BYTES 52992            // static + dynamic LDS of one workgroup: 3 workgroups per CU (160 KB) with allocation slack
+#define PW_LDS_BYTES 40960            // static + dynamic LDS of one workgroup: FOUR workgroups per CU fill its 160 KB exactly.  Round 3 sweep (ms of
+                                      // k_polish per 8192 ZMWs 10 x 10 kb, alone / under the draft stage of the next batch): 52992 (3 per CU) 217.9 / 305.3,
+                                      // 40960 184.6 / 264.8, 40448 189.6 / 273.3, 38912 195.0 / 279.3, 36864 199.7 / 281.1, 32256 (5 per CU) 225.6 / 307.8
 #endif
 #define MI_STRIDE 13
 
