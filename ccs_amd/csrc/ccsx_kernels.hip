@@ -283,6 +283,7 @@ __device__ __forceinline__ int base_at(const BaseCursor &c, int t)
 #define PGS 40                        // words per ring column: 4 guards, 32 rows, 4 guards
 #define CREC_NEED (1 << 16)            // column record: a far in-edge reads this column back from HBM
 #define CREC_FAR0 (1 << 17)            //                in-edge 0 comes from more than PRING positions back
+#define CREC_NREADS_SHIFT 20           //                bits 20..26: passes that go through the vertex (k_poa_finish)
 enum { ST_N, ST_NADDED, ST_OK, ST_PAR, ST_KEND, ST_BS, ST_NPOA, ST_BB, ST_NREADS, ST_REV0, ST_LIVE, ST_WORDS = 16 };
 struct PoaSlot {
     int32_t *st;                      // [ST_WORDS] per-graph state that travels between the kernels
@@ -368,7 +369,7 @@ __device__ __forceinline__ void poa_column_records(const PoaSlot &g, const int32
             const int v = order[kk];
             const int4 rec = g.vrec[v];
             const int np = (rec.x >> 8) & 255;
-            int4 c = make_int4((rec.x & 255) | (np << 8) | (g.needK[kk] ? CREC_NEED : 0), -1, -1, -1);
+            int4 c = make_int4((rec.x & 255) | (np << 8) | (g.needK[kk] ? CREC_NEED : 0) | ((rec.x >> 16) << CREC_NREADS_SHIFT), -1, -1, -1);
             if (np >= 1) { c.y = g.rank[rec.y]; if (kk - c.y > PRING) c.x |= CREC_FAR0; }
             if (np >= 2) c.z = g.rank[rec.z];
             if (np >= 3) c.w = g.rank[rec.w];
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
             const int b = read_base_packed(sread, i);
             g.vrec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8) | (1 << 16), i - 1, -1, -1);
             g.rank[i] = i; g.order0[i] = i;
-            g.crec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8), i - 1, -1, -1);
+            g.crec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8) | (1 << CREC_NREADS_SHIFT), i - 1, -1, -1);
         }
         n = I;
     }
@@ -766,25 +767,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     int32_t *order = g.st[ST_PAR] ? g.order1 : g.order0, *order_nx = g.st[ST_PAR] ? g.order0 : g.order1;
     load_read_packed(sread, rb, I, rev, lane);
     __syncthreads();
-    // ---- traceback: lane 0 walks, the block of TB_BLOCK positions it is in is cached in LDS
+    // ---- traceback: lane 0 walks, the block of TB_BLOCK positions it is in is cached in LDS.  Round 3: the per-position words come
+    // from the DP's column record (base, in-edge count and the positions of in-edges 0..2 by position: no vertex-record gather), and
+    // the NEXT block (the walk goes down the positions) is fetched into registers while the current one is walked
     {
         int k = kend, i = I;
+        int4 kiN = make_int4(0, 0, 0, -1), crN = make_int4(0, -1, -1, -1);
+        int vN = 0, kbN = -1;
+        uint4 mvN0 = make_uint4(0, 0, 0, 0), mvN1 = mvN0;
+        auto fetch = [&](int kb_) {
+            const int kk = kb_ + lane;
+            kbN = kb_;
+            kiN = make_int4(0, 0, 0, -1); crN = make_int4(0, -1, -1, -1); vN = 0;
+            if (kb_ >= 0) {
+                if (kk < n0) { kiN = g.kinfo[kk]; vN = order[kk]; crN = g.crec[kk]; }
+                const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb_ * PB);
+                mvN0 = src[lane]; mvN1 = src[64 + lane];
+            }
+        };
+        fetch((k / TB_BLOCK) * TB_BLOCK);
         while (k >= 0) {
             const int kb = (k / TB_BLOCK) * TB_BLOCK;
+            if (kbN != kb) fetch(kb);                          // (an in-edge that skipped a whole block: rare)
             __syncthreads();
             // block cache: the TB_BLOCK move rows go to LDS, the per-position words (band start, position of in-edge 0,
-            // vertex id, record word) stay in lane registers and are handed out with v_readlane
-            int4 kiL = make_int4(0, 0, 0, -1);
-            int vLt = 0, metaL = 0;
-            {
-                const int kk = kb + lane;
-                if (lane < TB_BLOCK && kk < n0) { kiL = g.kinfo[kk]; vLt = order[kk]; metaL = g.vrec[vLt].x; }
-                const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb * PB);
-                uint4 *dst = (uint4 *)sMv;
-#pragma unroll
-                for (int q = 0; q < TB_BLOCK * PB / 16 / 64; ++q) dst[q * 64 + lane] = src[q * 64 + lane];
-            }
-            asm volatile("" :: "v"(kiL.x), "v"(kiL.w), "v"(vLt), "v"(metaL));
+            // vertex id, record words) stay in lane registers and are handed out with v_readlane
+            const int4 kiL = kiN, crL = crN;
+            const int vLt = vN, metaL = crN.x;
+            ((uint4 *)sMv)[lane] = mvN0; ((uint4 *)sMv)[64 + lane] = mvN1;
+            fetch(kb - TB_BLOCK);                              // in flight while this block is walked
             __syncthreads();
             while (k >= kb) {                                  // uniform walk: every lane follows the same (k, i)
                 const int kl = k - kb;
@@ -803,7 +814,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         const int meta_s = __shfl(metaL, src), v_s = __shfl(vLt, src);
                         if (lane < R) {
                             const int ir = i - lane - 1;
-                            g.pathv[ir] = ((meta_s & 255) == read_base_packed(sread, ir)) ? v_s : -1;
+                            g.pathv[ir] = ((meta_s & 3) == read_base_packed(sread, ir)) ? v_s : -1;
                         }
                         k -= R; i -= R;
                         continue;
@@ -816,13 +827,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 CHK(i >= 1 || t == MV_DEL, 102);
                 if (t == MV_INS) { if (lane == 0) g.pathv[i - 1] = -1; --i; continue; }
                 const int meta = rl(metaL, kl);
-                const int np = (meta >> 8) & 255;
+                const int np = (meta >> 8) & 15;
                 int up;
                 if (np == 0) up = -1;
                 else if (slot == 0) up = rl(kiL.w, kl);
-                else { const int v = rl(vLt, kl); const int4 rec = g.vrec[v]; up = rfl(g.rank[poa_pred(g, rec, v, slot)]); }
+                else if (slot == 1) up = rl(crL.z, kl);
+                else if (slot == 2) up = rl(crL.w, kl);
+                else { const int v = rl(vLt, kl); up = rfl(g.rank[g.predx[v * 5 + (slot - 3)]]); }
                 if (t == MV_DIAG) {
-                    if (lane == 0) g.pathv[i - 1] = ((meta & 255) == read_base_packed(sread, i - 1)) ? rl(vLt, kl) : -1;
+                    if (lane == 0) g.pathv[i - 1] = ((meta & 3) == read_base_packed(sread, i - 1)) ? rl(vLt, kl) : -1;
                     --i;
                 }
                 CHK(up < k && up >= -1, 103);
@@ -914,8 +927,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     __threadfence_block();
     const int n = n0 + nnew;
     if (lane == 0) { g.st[ST_N] = n; g.st[ST_NADDED] += 1; g.st[ST_PAR] ^= 1; }
-    // ---- the column records of the next pass's DP (none after the last pass)
-    if (rr + 1 < npoa) poa_column_records(g, order_nx, n, lane);
+    // ---- the column records of the next pass's DP; after the last pass k_poa_finish walks them
+    (void)npoa;
+    poa_column_records(g, order_nx, n, lane);
 }
 
 // ---- k_poa_finish: consensus (heaviest path), draft, window bounds.  One wave per graph.
@@ -928,35 +942,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);
     const int ok = rfl(g.st[ST_OK]), n = rfl(g.st[ST_N]), nadded = rfl(g.st[ST_NADDED]);
     const int32_t *order = g.st[ST_PAR] ? g.order1 : g.order0;
-    // ---- consensus: heaviest path (uniform walk, block records via readlane)
+    // ---- consensus: heaviest path (uniform walk).  The column records of the last prepass give every column's base, pass count and the
+    // topological positions of its in-edges 0..2 by position: one coalesced load per 64 columns, no order -> vertex record -> rank
+    // chain of dependent gathers (round 3; in-edges 3..7 still go through the vertex id)
     int Ld = 0, nw = 0, stat = -1;
     if (ok && n > 0) {
-        int kbest = -1, sb = NEGV, best_prev = 0, vprev = -2;
+        int kbest = -1, sb = NEGV, best_prev = 0;
         for (int kb = 0; kb < n; kb += LANES) {
             const int kkL = kb + lane;
-            const int vL = kkL < n ? order[kkL] : 0;
-            int4 rL = make_int4(0, 0, 0, 0);
-            if (kkL < n) rL = g.vrec[vL];
+            int4 cL = make_int4(0, -1, -1, -1);
+            if (kkL < n) cL = g.crec[kkL];
             const int nblk = (n - kb) < LANES ? (n - kb) : LANES;
             int myBest = 0, myBp = -1;
             for (int j = 0; j < nblk; ++j) {
                 const int k = kb + j;
-                const int v = rl(vL, j);
-                const int4 rec = make_int4(rl(rL.x, j), rl(rL.y, j), rl(rL.z, j), rl(rL.w, j));
-                const int np = (rec.x >> 8) & 255, nr = rec.x >> 16;
+                const int cx = rl(cL.x, j);
+                const int np = (cx >> 8) & 15, nr = (cx >> CREC_NREADS_SHIFT) & 127;
                 int b = 0, p = -1;
                 for (int q = 0; q < np; ++q) {
-                    const int u = rfl(poa_pred(g, rec, v, q));
-                    int bu, pu;
-                    CHK(u >= 0 && u < n, 108);
-                    if (u == vprev) { bu = best_prev; pu = k - 1; }
-                    else { pu = rfl(g.rank[u]); bu = (pu >= kb) ? rl(myBest, pu - kb) : rfl(g.bestK[pu]); }
+                    int pu;
+                    if (q < 3) pu = q == 0 ? rl(cL.y, j) : (q == 1 ? rl(cL.z, j) : rl(cL.w, j));
+                    else { const int v = rfl(order[k]); pu = rfl(g.rank[g.predx[v * 5 + (q - 3)]]); }
+                    CHK(pu >= 0 && pu < k, 108);
+                    const int bu = pu == k - 1 ? best_prev : ((pu >= kb) ? rl(myBest, pu - kb) : rfl(g.bestK[pu]));
                     if (bu > b) { b = bu; p = pu; }
                 }
                 const int bv = b + 2 * nr - nadded;
                 if (lane == j) { myBest = bv; myBp = p; }
                 if (bv > sb) { sb = bv; kbest = k; }
-                best_prev = bv; vprev = v;
+                best_prev = bv;
             }
             if (kkL < n) { g.bestK[kkL] = myBest; g.bpK[kkL] = myBp; }
             __threadfence_block();
@@ -968,7 +982,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int kb = (k >> 6) << 6;
             const int kk = kb + lane;
             const int bpL = kk < n ? g.bpK[kk] : -1;
-            const int bL = kk < n ? (g.vrec[order[kk]].x & 255) : 0;
+            const int bL = kk < n ? (g.crec[kk].x & 255) : 0;
             while (k >= kb) {
                 const int kl = k - kb;
                 CHK(len < n, 107);
