@@ -382,8 +382,8 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     // ---- resident POA graphs / alignment slots: as many as fit this handle's share of the free memory, never more than
     // the work.  The scratch is shared by the handle's batch slots; it only grows, and growing waits for the compute stream.
     // per vertex (ccsx_kernels.hip poa_slot): the 32-row score column of far-read columns 128, three 16-byte records, 32 move bytes,
-    // 5 overflow in-edges, 5 words of order / rank / consensus state, one flag byte = 249
-    S.poa_slot_bytes = (((size_t)vcap_max + 64) * 249 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
+    // 16 move bytes (a nibble per band row), 5 overflow in-edges, 6 words of order / rank / consensus / band state, two flag bytes = 238
+    S.poa_slot_bytes = (((size_t)vcap_max + 64) * 238 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
     S.align_slot_i32 = (size_t)need_max * 128 + 4 * (size_t)need_max + 64;   // (origin, dirty bits) per cell and edge + band starts + best cell (score, row, entry row) per edge
     int poa_slots, align_slots;
     {

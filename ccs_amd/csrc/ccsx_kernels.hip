@@ -288,10 +288,11 @@ enum { ST_N, ST_NADDED, ST_OK, ST_PAR, ST_KEND, ST_BS, ST_NPOA, ST_BB, ST_NREADS
 struct PoaSlot {
     int32_t *st;                      // [ST_WORDS] per-graph state that travels between the kernels
     int4 *vrec, *kinfo, *crec;
-    int32_t *predx, *M, *rank, *order0, *order1, *bestK, *bpK, *pathv;
-    uint8_t *mvK, *needK;
+    int32_t *predx, *M, *rank, *order0, *order1, *bestK, *bpK, *pathv, *loK;
+    uint8_t *mvK, *needK, *nrV;
 };
-#define POA_BYTES_PER_VERTEX (PB * 4 + 16 * 3 + PB + 5 * 4 + 5 * 4 + 1)
+#define POA_MV_BYTES (PB / 2)         // a column's moves: one nibble per band row (0..13 = in-edge slot * 2 + [deletion], 15 = insertion)
+#define POA_BYTES_PER_VERTEX (PB * 4 + 16 * 3 + POA_MV_BYTES + 5 * 4 + 6 * 4 + 2)
 
 __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
 {
@@ -303,14 +304,16 @@ __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
     s.vrec = (int4 *)p;       p += vc * 16;
     s.kinfo = (int4 *)p;      p += vc * 16;
     s.crec = (int4 *)p;       p += vc * 16;
-    s.mvK = p;                p += vc * PB;
+    s.mvK = p;                p += vc * POA_MV_BYTES;
     s.predx = (int32_t *)p;   p += vc * 5 * 4;
     s.rank = (int32_t *)p;    p += vc * 4;
     s.order0 = (int32_t *)p;  p += vc * 4;
     s.order1 = (int32_t *)p;  p += vc * 4;
     s.bestK = (int32_t *)p;   p += vc * 4;      // also the run-count / shift array while threading a read
     s.bpK = (int32_t *)p;     p += vc * 4;
+    s.loK = (int32_t *)p;     p += vc * 4;      // by topological position: band start of the column in the current DP pass (the traceback's half of kinfo)
     s.needK = p;              p += (vc + 3) & ~(size_t)3;   // by topological position: 1 = some in-edge reaches this column from more than PRING positions ahead
+    s.nrV = p;                p += (vc + 3) & ~(size_t)3;   // by vertex id: passes through the vertex
     s.pathv = (int32_t *)p;
     return s;
 }
@@ -325,14 +328,15 @@ __device__ __forceinline__ int poa_pred(const PoaSlot &g, const int4 &rec, int v
 }
 
 // append edge from -> to (to's record in registers); SPEC: duplicates ignored, in-edge cap 8
-__device__ __forceinline__ void poa_add_edge(const PoaSlot &g, int4 &rec, int to, int from)
+__device__ __forceinline__ bool poa_add_edge(const PoaSlot &g, int4 &rec, int to, int from)
 {
     const int np = (rec.x >> 8) & 255;
     bool found = false;
     for (int q = 0; q < np; ++q) found |= (poa_pred(g, rec, to, q) == from);
-    if (found || np >= CCSX_MAXPRED) return;
+    if (found || np >= CCSX_MAXPRED) return false;
     if (np == 0) rec.y = from; else if (np == 1) rec.z = from; else if (np == 2) rec.w = from; else g.predx[to * 5 + (np - 3)] = from;
     rec.x += 1 << 8;
+    return true;                                        // the record changed: the caller writes it back
 }
 
 extern __shared__ uint32_t dyn_lds[];
@@ -345,23 +349,12 @@ extern __shared__ uint32_t dyn_lds[];
 #define ZREF_DONE2 2048                 // the last-resort draft (pass 2: the backbone pass itself) has been made
 #define ZREF_PASSBIT(pass) ((pass) == 1 ? ZREF_DONE : ZREF_DONE2)
 
-// the prepass of a DP: column records by topological position.  `order` = the graph's current topological order, n vertices.
+// the prepass of a DP: column records by topological position — {base | in-edges << 8 | flags | passes << 20, positions of in-edges
+// 0..2} — and the flags of the columns some in-edge reads back from more than PRING positions ahead (needK; the DP ORs them into the
+// record when it prefetches a block).  One pass over the graph: order -> vertex record -> ranks of its in-edges.
 __device__ __forceinline__ void poa_column_records(const PoaSlot &g, const int32_t *order, int n, int lane)
 {
     for (int q = lane; q < n; q += LANES) g.needK[q] = 0;
-    __threadfence_block();
-    for (int kb = 0; kb < n; kb += LANES) {                // which score columns will be read back from HBM?
-        const int kk = kb + lane;
-        if (kk < n) {
-            const int v = order[kk];
-            const int4 rec = g.vrec[v];
-            const int np = (rec.x >> 8) & 255;
-            for (int q = 0; q < np; ++q) {
-                const int pu = g.rank[poa_pred(g, rec, v, q)];
-                if (kk - pu > PRING) g.needK[pu] = 1;
-            }
-        }
-    }
     __threadfence_block();
     for (int kb = 0; kb < n; kb += LANES) {
         const int kk = kb + lane;
@@ -369,10 +362,12 @@ __device__ __forceinline__ void poa_column_records(const PoaSlot &g, const int32
             const int v = order[kk];
             const int4 rec = g.vrec[v];
             const int np = (rec.x >> 8) & 255;
-            int4 c = make_int4((rec.x & 255) | (np << 8) | (g.needK[kk] ? CREC_NEED : 0) | ((rec.x >> 16) << CREC_NREADS_SHIFT), -1, -1, -1);
-            if (np >= 1) { c.y = g.rank[rec.y]; if (kk - c.y > PRING) c.x |= CREC_FAR0; }
-            if (np >= 2) c.z = g.rank[rec.z];
-            if (np >= 3) c.w = g.rank[rec.w];
+            int4 c = make_int4((rec.x & 255) | (np << 8) | ((int)g.nrV[v] << CREC_NREADS_SHIFT), -1, -1, -1);
+            for (int q = 0; q < np; ++q) {
+                const int pu = g.rank[poa_pred(g, rec, v, q)];
+                if (kk - pu > PRING) { g.needK[pu] = 1; if (q == 0) c.x |= CREC_FAR0; }
+                if (q == 0) c.y = pu; else if (q == 1) c.z = pu; else if (q == 2) c.w = pu;
+            }
             g.crec[kk] = c;
         }
     }
@@ -487,8 +482,8 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
     else {                                              // first read: backbone chain; its column records are trivial
         for (int i = lane; i < I; i += LANES) {
             const int b = read_base_packed(sread, i);
-            g.vrec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8) | (1 << 16), i - 1, -1, -1);
-            g.rank[i] = i; g.order0[i] = i;
+            g.vrec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8), i - 1, -1, -1);
+            g.rank[i] = i; g.order0[i] = i; g.nrV[i] = 1;
             g.crec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8) | (1 << CREC_NREADS_SHIFT), i - 1, -1, -1);
         }
         n = I;
@@ -531,6 +526,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
     int32_t *Mcol = G.M;
     int4 *kinfo = G.kinfo;
     const int4 *crec = G.crec;
+    const uint8_t *needK = G.needK;
     uint8_t *mvK = G.mvK;
     bool live = have && st[ST_LIVE] && st[ST_OK] && rr < st[ST_NPOA];
     if (!__any(live)) return;
@@ -566,11 +562,12 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
     const uint32_t readBase = (uint32_t)(uintptr_t)(lds_i32)(int32_t *)&sRead[gq][0];
     const int bcastAddr = (lane | 15) << 2;                                        // ds_bpermute: the row's last lane
     // running per-lane output pointers (one 64-bit add per column instead of an index multiply)
-    uint8_t *mvp = mvK + 2 * l;
+    uint8_t *mvp = mvK + l;                             // one byte per lane and column: the nibbles of rows 2l and 2l+1
     int4 *kip = kinfo;
+    int32_t *lop = G.loK;
     int32_t *Mp = Mcol + 2 * l;
     int4 recN = make_int4(0, -1, -1, -1);               // the NEXT block of 16 column records (lane l: column kb + 16 + l)
-    if (l < n0) recN = crec[l];
+    if (l < n0) { recN = crec[l]; if (needK[l]) recN.x |= CREC_NEED; }
 #define LDS_I32(addr) (*(lds_i32)(uintptr_t)(addr))
     // wave masks of per-lane conditions straight from the compare (a bool that goes through ballot costs two extra VALU ops)
 #define M_NE0(a) __builtin_amdgcn_uicmp((unsigned)(a), 0u, 33)
@@ -579,11 +576,11 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
 #define M_UGT(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 34)
     const uint32_t kinBase = (uint32_t)(uintptr_t)(lds_i32)(int32_t *)&sKin[gq][0];
     const unsigned long long livem = M_NE0(live ? 1 : 0);
-    for (int k = 0; k < nmax; ++k, mvp += PB, ++kip, Mp += PB) {
+    for (int k = 0; k < nmax; ++k, mvp += POA_MV_BYTES, ++kip, ++lop, Mp += PB) {
         if ((k & 15) == 0) {                            // hand the prefetched block to LDS, start fetching the one after it
             sCrec[gq][l] = recN;
             recN = make_int4(0, -1, -1, -1);
-            if (k + 16 + l < n0) recN = crec[k + 16 + l];
+            if (k + 16 + l < n0) { recN = crec[k + 16 + l]; if (needK[k + 16 + l]) recN.x |= CREC_NEED; }
             __syncthreads();
         }
         const unsigned long long actm = livem & M_SLT(k, n0);
@@ -657,9 +654,9 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                 }
             }
             const int d0 = x0 + s0, e0 = y0 + SC_DEL, d1 = y0 + s1, e1 = y1 + SC_DEL;
-            const bool t0 = e0 > d0, t1 = e1 > d1;
-            b0 = t0 ? e0 : d0; m0 = t0 ? MV_DEL : MV_DIAG;
-            b1 = t1 ? e1 : d1; m1 = t1 ? MV_DEL : MV_DIAG;
+            const bool t0 = e0 > d0, t1 = e1 > d1;              // move codes (a nibble): in-edge slot * 2 + [deletion], 15 = insertion
+            b0 = t0 ? e0 : d0; m0 = t0 ? 1 : 0;
+            b1 = t1 ? e1 : d1; m1 = t1 ? 1 : 0;
         }
         if (multim) {                                    // further in-edges, in list order: a later candidate wins only if strictly greater
             const int np = (rec.x >> 8) & 15;
@@ -687,24 +684,24 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                         y1 = (unsigned)(o + 2) < (unsigned)PB ? Mu[o + 2] : NEGV;
                     }
                 }
-                const int mq = q << 2;
+                const int mq = q << 1;
                 int c;
-                c = x0 + s0;     if (on && c > b0) { b0 = c; m0 = mq | MV_DIAG; }
-                c = y0 + SC_DEL; if (on && c > b0) { b0 = c; m0 = mq | MV_DEL; }
-                c = y0 + s1;     if (on && c > b1) { b1 = c; m1 = mq | MV_DIAG; }
-                c = y1 + SC_DEL; if (on && c > b1) { b1 = c; m1 = mq | MV_DEL; }
+                c = x0 + s0;     if (on && c > b0) { b0 = c; m0 = mq; }
+                c = y0 + SC_DEL; if (on && c > b0) { b0 = c; m0 = mq | 1; }
+                c = y0 + s1;     if (on && c > b1) { b1 = c; m1 = mq; }
+                c = y1 + SC_DEL; if (on && c > b1) { b1 = c; m1 = mq | 1; }
             }
         }
         // ---- insertion chain x_i = max(c_i, x_{i-1} + INS) over the 32 rows: lane-local (row 2l -> 2l+1), an exclusive 4-step
         // row scan of the lanes' outgoing values, then the incoming value applied to both rows
-        { const int c = b0 + SC_INS; if (c > b1) { b1 = c; m1 = MV_INS; } }
+        { const int c = b0 + SC_INS; if (c > b1) { b1 = c; m1 = 15; } }
         {
             const int S = row_scan_max_i32(b1 + l8);
             const int Sp = __builtin_amdgcn_update_dpp(-(1 << 30), S, DPP_ROW_SHR(1), 0xf, 0xf, false);
             const int c0v = Sp - (l8 - 8 - SC_INS);     // (final value of row 2l - 1) + INS ; lane 0: very negative
             const int c1v = Sp - (l8 - 8 - 2 * SC_INS);
-            if (c0v > b0) { b0 = c0v; m0 = MV_INS; }
-            if (c1v > b1) { b1 = c1v; m1 = MV_INS; }
+            if (c0v > b0) { b0 = c0v; m0 = 15; }
+            if (c1v > b1) { b1 = c1v; m1 = 15; }
         }
         if (r0w > I || b0 < NEGV / 2) b0 = NEGV;
         if (r0w >= I || b1 < NEGV / 2) b1 = NEGV;
@@ -726,12 +723,15 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
         // ---- out: ring (LDS), moves + column record (HBM), the score column if a far in-edge will read it
         if (live && k < n0) {
             *(int2 *)&sRing[gq][k & (PRING - 1)][4 + l2] = make_int2(b0, b1);
-            *(uint16_t *)mvp = (uint16_t)(m0 | (m1 << 8));
+            *mvp = (uint8_t)(m0 | (m1 << 4));
             if (l == 0) {
                 sKin[gq][k & (PRING - 1)] = make_int4(lo, cm, br, 0);
-                *kip = make_int4(lo, cm, br, p0);
+                *lop = lo;                                  // all the traceback needs of a column (in-edge 0's position is in its record)
             }
-            if (rec.x & CREC_NEED) *(int2 *)Mp = make_int2(b0, b1);
+            if (rec.x & CREC_NEED) {                        // a far in-edge will read this column back: its scores and its record
+                *(int2 *)Mp = make_int2(b0, b1);
+                if (l == 0) *kip = make_int4(lo, cm, br, p0);
+            }
         }
     }
 #undef M_NE0
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
 // ---- k_poa_thread: gate, traceback and threading of pass rr, then the column records of the next DP.  One wave per graph.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa_thread(KParams P, int z0, int pass, int rr)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sMv[TB_BLOCK * PB];   // move rows of the traceback's current block
+    __shared__ __attribute__((aligned(16))) uint8_t sMv[TB_BLOCK * POA_MV_BYTES];   // move rows (a nibble per cell) of the traceback's current block
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
     PoaSlot g = poa_slot(P, blockIdx.x);
@@ -774,15 +774,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         int k = kend, i = I;
         int4 kiN = make_int4(0, 0, 0, -1), crN = make_int4(0, -1, -1, -1);
         int vN = 0, kbN = -1;
-        uint4 mvN0 = make_uint4(0, 0, 0, 0), mvN1 = mvN0;
+        uint4 mvN0 = make_uint4(0, 0, 0, 0);
         auto fetch = [&](int kb_) {
             const int kk = kb_ + lane;
             kbN = kb_;
             kiN = make_int4(0, 0, 0, -1); crN = make_int4(0, -1, -1, -1); vN = 0;
             if (kb_ >= 0) {
-                if (kk < n0) { kiN = g.kinfo[kk]; vN = order[kk]; crN = g.crec[kk]; }
-                const uint4 *src = (const uint4 *)(g.mvK + (size_t)kb_ * PB);
-                mvN0 = src[lane]; mvN1 = src[64 + lane];
+                if (kk < n0) { crN = g.crec[kk]; kiN = make_int4(g.loK[kk], 0, 0, crN.y); vN = order[kk]; }
+                mvN0 = ((const uint4 *)(g.mvK + (size_t)kb_ * POA_MV_BYTES))[lane];     // 64 columns x 16 bytes
             }
         };
         fetch((k / TB_BLOCK) * TB_BLOCK);
@@ -794,7 +793,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             // vertex id, record words) stay in lane registers and are handed out with v_readlane
             const int4 kiL = kiN, crL = crN;
             const int vLt = vN, metaL = crN.x;
-            ((uint4 *)sMv)[lane] = mvN0; ((uint4 *)sMv)[64 + lane] = mvN1;
+            ((uint4 *)sMv)[lane] = mvN0;
             fetch(kb - TB_BLOCK);                              // in flight while this block is walked
             __syncthreads();
             while (k >= kb) {                                  // uniform walk: every lane follows the same (k, i)
@@ -807,7 +806,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const int lo_s = __shfl(kiL.x, src), pp_s = __shfl(kiL.w, src);
                     const int off = i - lane - lo_s;
                     const bool inb = kls >= 0 && i - lane >= 1 && (unsigned)off < (unsigned)PB;
-                    const int m_s = inb ? sMv[kls * PB + off] : 255;
+                    const int m_s = inb ? ((sMv[kls * POA_MV_BYTES + (off >> 1)] >> ((off & 1) << 2)) & 15) : 255;
                     const unsigned long long simple = __ballot(m_s == 0 && pp_s == k - lane - 1);
                     const int R = (simple == ~0ull) ? 64 : __ffsll((long long)~simple) - 1;
                     if (R > 0) {
@@ -822,8 +821,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 }
                 const int lo_k = rl(kiL.x, kl);
                 CHK(i - lo_k >= 0 && i - lo_k < PB && i >= 0, 101);
-                const int m = rfl(sMv[kl * PB + (i - lo_k)]);
-                const int t = m & 3, slot = m >> 2;
+                const int mo = i - lo_k;
+                const int m = rfl((sMv[kl * POA_MV_BYTES + (mo >> 1)] >> ((mo & 1) << 2)) & 15);
+                const int t = m == 15 ? MV_INS : (m & 1), slot = m >> 1;   // (MV_DIAG = 0, MV_DEL = 1)
                 CHK(i >= 1 || t == MV_DEL, 102);
                 if (t == MV_INS) { if (lane == 0) g.pathv[i - 1] = -1; --i; continue; }
                 const int meta = rl(metaL, kl);
@@ -873,9 +873,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         ex = ex > lastEx ? ex : lastEx;                            // last existing path element before i
         if (valid) {
             int4 rec;
-            if (!isnew) { rec = g.vrec[w]; rec.x += 1 << 16; }
+            bool dirty = isnew;
+            if (!isnew) { rec = g.vrec[w]; g.nrV[w] += 1; }        // (a vertex is on the path once: one writer)
             else {
-                rec = make_int4(read_base_packed(sread, i) | (1 << 16), -1, -1, -1);
+                g.nrV[w] = 1;
+                rec = make_int4(read_base_packed(sread, i), -1, -1, -1);
                 // the last vertex of a run of new vertices records the run length at its anchor (plain store, one writer)
                 const bool lastOfRun = (i + 1 >= I) || (g.pathv[i + 1] < n0);
                 if (lastOfRun) {
@@ -884,8 +886,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     cnt[apos + 1] = i - ex;
                 }
             }
-            if (pw >= 0) poa_add_edge(g, rec, w, pw);
-            g.vrec[w] = rec;
+            if (pw >= 0) dirty |= poa_add_edge(g, rec, w, pw);
+            if (dirty) g.vrec[w] = rec;                          // most path vertices match and keep their record
         }
         const int li = rl(incl, 63);
         lastEx = li > lastEx ? li : lastEx;
@@ -1542,6 +1544,11 @@ __global__ void k_post(KParams P, int pass)
                                       // 40960 184.6 / 264.8, 40448 189.6 / 273.3, 38912 195.0 / 279.3, 36864 199.7 / 281.1, 32256 (5 per CU) 225.6 / 307.8
 #endif
 #define MI_STRIDE 13
+#ifndef CTXS
+#define CTXS 33                       // entries per observation row of sCTX
+#endif
+#define OBS_CODE(o) ((o) * (CTXS * 8))        // an observation code as stored in sObs: the byte offset of its row in sCTX
+#define OBS_OF_CODE(c) ((unsigned)(c) / (unsigned)(CTXS * 8))   // ... and back (a multiply + shift)
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
     int c, q, kA, kB, isdel, fin;    // kA / kB index sCTX; +16 selects the copy whose INS component is zero
@@ -1639,13 +1646,16 @@ __device__ __forceinline__ float skip_perr(int g)
 
 __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
 {
-    __shared__ float2 sCTX[(CCSX_NOBS + 1) * 32];            // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0); row 12 = zeros ("no base")
+    // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0); row 12 = zeros ("no base").  Row stride CTXS = 33 entries: with the banded link every
+    // lane looks up its OWN observation row, and with 32 entries per row all lanes of one context hit the same bank pair whatever
+    // their rows (35 % of the LDS cycles were bank conflicts in round 2); 33 spreads them by (obs + ctx) mod 16
+    __shared__ float2 sCTX[(CCSX_NOBS + 1) * CTXS];
     __shared__ float sDL[16], sZP[32];                       // sZP: z-score MU[16], VAR[16]
     __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
     __shared__ float sDLJ[2][32];
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
     // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
-    // A code is stored as obs * 256 = the byte offset of its row in sCTX, so the scoring loop adds it to a per-lane base.
+    // A code is stored as obs * 264 = the byte offset of its row in sCTX (OBS_CODE), so the scoring loop adds it to a per-lane base.
     uint16_t (*sObs)[68] = (uint16_t (*)[68])dyn_lds;
     float *sGB = (float *)((uint8_t *)dyn_lds + P.pw_obs_bytes);
     const int GB_FLOATS = P.pw_gb_floats;
@@ -1711,9 +1721,10 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         const unsigned m1 = P.dmask[eo + idx_ws + 1];
         const unsigned m2 = (idx_ws + 2 <= idx_we) ? P.dmask[eo + idx_ws + 2] : 0u;
         const unsigned m3 = (idx_ws + 3 <= idx_we) ? P.dmask[eo + idx_ws + 3] : 0u;
-        sCTX[e0] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
-        if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[e1] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
-        if (tid < 32) sCTX[CCSX_NOBS * 32 + tid] = make_float2(0.0f, 0.0f);
+        sCTX[(e0 >> 5) * CTXS + (e0 & 31)] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
+        if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[(e1 >> 5) * CTXS + (e1 & 31)] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
+        if (tid < CTXS) sCTX[CCSX_NOBS * CTXS + tid] = make_float2(0.0f, 0.0f);
+        if (CTXS > 32 && tid < CCSX_NOBS) sCTX[tid * CTXS + 32] = make_float2(0.0f, 0.0f);     // (the padding entry of every row)
         if (tid < 16) sDL[tid] = dl;
         if (tid < 32) sZP[tid] = zp;
         if (tid < we - ws) sT[0][tid] = dr;
@@ -1752,7 +1763,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             const int r = rb + PW_WAVES * q + wave;
             if (r < nreads) {
                 const int n = sI[r];
-                sObs[r][lane] = (lane < n) ? (uint16_t)(obs_of(bq[q], pq[q]) << 8) : (uint16_t)(lane == n ? CCSX_NOBS << 8 : 0);   // row n: "no base"
+                sObs[r][lane] = (lane < n) ? (uint16_t)OBS_CODE(obs_of(bq[q], pq[q])) : (uint16_t)(lane == n ? OBS_CODE(CCSX_NOBS) : 0);   // row n: "no base"
                 if (lane < 4) sObs[r][64 + lane] = 0;
             }
         }
@@ -1774,7 +1785,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             const unsigned long long mp = __ballot(in && (bp & 3) == T), ms = __ballot(in && (bs & 3) == T);
             const int tot = (lane <= J0) ? __popcll(mp & ((1ull << lane) - 1ull)) + __popcll(ms >> lane) : -1;
             const int sb = 63 - (rfl(wave_max_i32((tot << 6) | (63 - lane))) & 63);
-            if (in && lane >= sb) sObs[r][lane] = (uint16_t)(obs_of(bs, ps) << 8);
+            if (in && lane >= sb) sObs[r][lane] = (uint16_t)OBS_CODE(obs_of(bs, ps));
         }
     }
     // ---- step 7, candidate filter: pile-up margin of every window position over the reads with a usable segment
@@ -1837,7 +1848,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 if (j < J) {
                     const int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
                     const int k = ctx_of(prev, sT[sd][j]);
-                    if (o < CCSX_NOBS) ent = sCTX[o * 32 + k];
+                    if (o < CCSX_NOBS) ent = sCTX[o * CTXS + k];
                     dlv = sDL[k];
                 }
                 sMI[sd][j * MI_STRIDE + o] = ent;
@@ -1963,8 +1974,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const float2 *MI = sMI[sd];
                 const float *DLJ = sDLJ[sd];
                 const bool rowok = row <= I;
-                const int op = (row >= 1 && rowok) ? (sObs[myr][row - 1] >> 8) : 12;           // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
-                const int oc = (row < I) ? (sObs[myr][row] >> 8) : 12;                          // o_i;     12 = no base: row I emits nothing more
+                const int op = (row >= 1 && rowok) ? OBS_OF_CODE((int)sObs[myr][row - 1]) : 12;   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                const int oc = (row < I) ? OBS_OF_CODE((int)sObs[myr][row]) : 12;                  // o_i;     12 = no base: row I emits nothing more
                 // activity windows: alpha computes column j = t - row for t in [row, row+J]; beta computes column
                 // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step; two steps per
                 // loop iteration, so the second step's addresses are immediates and no state has to be copied between registers.

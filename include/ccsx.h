@@ -35,7 +35,7 @@ extern "C" {
 /* ---- fixed constants of the algorithm specification ---- */
 #define CCSX_BAND          64   /* DP band rows of the wide alignment (retry of the cascade, split alignment: one wave64) */
 #define CCSX_POA_BAND      32   /* DP band rows of the POA (four graphs per wave64, two rows per lane)                    */
-#define CCSX_MAXPRED       8    /* POA in-edge cap per vertex                                    */
+#define CCSX_MAXPRED       7    /* POA in-edge cap per vertex (a move is a nibble: slot * 2 + [deletion], 15 = insertion) */
 #define CCSX_WIN_CORE      22   /* target window core size, docs/how-does-ccs-work.md:57-59      */
 #define CCSX_WIN_OVERHANG  2    /* +-2 bp overlap, same citation                                 */
 #define CCSX_JMAX          31   /* max template columns in a polish window                       */

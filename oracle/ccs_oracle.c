@@ -72,7 +72,7 @@ static void orc_counts_flush(void)
 }
 static __thread int g_poa_scores[64], g_poa_nscores = 0;   /* test hook: end scores of the passes threaded into the last POA */
 int orc_poa_last_scores(int *out) { for (int i = 0; i < g_poa_nscores; ++i) out[i] = g_poa_scores[i]; return g_poa_nscores; }
-#define MAXPRED   8
+#define MAXPRED   7         /* in-edge cap of a POA vertex (SPEC v3; the device stores a move in a nibble) */
 #define WIN_CORE  22
 #define WIN_OVH   2
 #define JMAX      31
