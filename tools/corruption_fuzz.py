@@ -1,11 +1,11 @@
-"""Fuzz of the robustness paths on the GPU box: HIP path vs CPU restatement (bit-exact or fail) on batches whose passes are
+"""Fuzz of the robustness paths on the GPU box (round 3: + partial passes, low-complexity templates, off-model channels): HIP path vs CPU restatement (bit-exact or fail) on batches whose passes are
 corrupted the way real subreads are — foreign blocks of 8..600 bases (one or several per pass, anywhere incl. the first / last
 bases), missing stretches, junk passes, truncated passes — under random option sets (max_insertion_size, fallback draft,
 candidate filter, kinetics).  Exercises k_rescue (split alignment), the large-insertion trim, the fallback draft and every gate.
 
 python tools/corruption_fuzz.py [n_batches] [seed0]"""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, os.path.join(R, "tools"))
 import numpy as np
 from ccs_amd import api
 import oracle_lib as O
@@ -17,10 +17,23 @@ for k in range(nb):
     rng = np.random.default_rng(seed0 + k)
     n = int(rng.integers(8, 40))
     lmax = int(rng.choice([300, 1500, 4000, 12000]))
-    base = api.synth(n, (int(rng.integers(1, 6)), int(rng.integers(6, 24))), (max(40, lmax // 4), lmax), seed=seed0 + 31 * k)
+    if rng.random() < 0.25:                                 # round 3: low-complexity templates / off-model channels (tools/lowcx.py)
+        import lowcx
+        base = lowcx.make(n, (int(rng.integers(3, 6)), int(rng.integers(6, 24))), (max(60, lmax // 4), lmax), seed0 + 31 * k,
+                          channel=float(rng.choice([0.6, 1.0, 1.5])), tpl=("lowcx" if rng.random() < 0.6 else None), hp_boost=float(rng.choice([1.0, 2.5])))
+    else:
+        base = api.synth(n, (int(rng.integers(1, 6)), int(rng.integers(6, 24))), (max(40, lmax // 4), lmax), seed=seed0 + 31 * k)
     base.ipd = rng.integers(0, 256, len(base.bases)).astype(np.uint8)
     bases, pw, ipd, off = [], [], [], [0]
     ncorr = 0
+    flags = base.flags.copy()
+    # round 3: partial passes — the last one or two passes of some ZMWs are truncated at one end and flagged (bit 1, bit 2 = adapter at the end)
+    part = {}
+    for z in range(n):
+        nr = int(base.read_off[z + 1] - base.read_off[z])
+        if nr >= 4 and rng.random() < 0.35:
+            for q in range(nr - int(rng.integers(1, 3)), nr):
+                part[int(base.read_off[z]) + q] = int(rng.integers(0, 2))
     for r in range(int(base.read_off[-1])):
         a, b = int(base.base_off[r]), int(base.base_off[r + 1])
         bb, pp, ii = base.bases[a:b].copy(), base.pw[a:b].copy(), base.ipd[a:b].copy()
@@ -42,9 +55,14 @@ for k in range(nb):
         elif u < 0.47 and len(bb) > 60:                     # truncated
             cut = int(rng.integers(20, len(bb)))
             bb, pp, ii = bb[:cut], pp[:cut], ii[:cut]; ncorr += 1
+        if r in part and len(bb) > 120:
+            keep = int(len(bb) * rng.uniform(0.2, 0.9))
+            if part[r]: bb, pp, ii = bb[len(bb) - keep:], pp[len(pp) - keep:], ii[len(ii) - keep:]; flags[r] |= 2 | 4
+            else: bb, pp, ii = bb[:keep], pp[:keep], ii[:keep]; flags[r] |= 2
+        elif r in part: flags[r] |= 2 | (4 if part[r] else 0)
         bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
     batch = api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
-                      np.concatenate(ipd), base.flags, base.tpl_off, base.tpl)
+                      np.concatenate(ipd), flags, base.tpl_off, base.tpl)
     o = api.default_opts()
     o.max_insertion_size = int(rng.choice([0, 30, 10, 5, -1])); o.no_fallback_draft = int(rng.random() < 0.25)
     o.disable_heuristics = int(rng.random() < 0.2); o.hifi_kinetics = int(rng.random() < 0.4); o.max_poa_cov = int(rng.choice([3, 5, 7]))
