@@ -454,6 +454,9 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
         bb = rfl(wave_min_i32(key)) & 63;
     }
     if (lane == 0) { P.nreads_used[z] = nall; P.nfull[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_PASSBIT(pass) : 0); }
+    // a new draft invalidates the partial passes' alignments of the previous generator (k_align16 resets the full-length passes it
+    // realigns; the partial ones are aligned by k_rescue, which only looks at passes that are not valid)
+    if (lane >= nreads && lane < nall) { P.avalid[r0 + lane] = 0; P.ascore[r0 + lane] = NEGV; }
     const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
     if (!enough) { if (lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES; return; }
     const int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
@@ -1735,6 +1738,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             int n = -1, na = 0;
             if (av) {
                 n = b - a;
+                if (n > L) n = -1;                           // (entry rows are rows of this pass: anything else is not a segment)
                 // SPEC "trim large insertions": a segment more than max_insertion_size bases longer than the window is cut down
                 // to the window's length below (sBoff keeps the full length until the chunk plan re-uses it)
                 if (n >= 0 && maxins > 0 && n > (we - ws) + maxins) { trimflag = 1; sBoff[tid] = n; n = we - ws; }

@@ -714,3 +714,40 @@ def test_scratch_grows_while_tickets_are_in_flight(built):
                 assert np.array_equal(res[k].sequence(z), w.sequence(z)) and np.array_equal(res[k].quals(z), w.quals(z)), (k, z)
     finally:
         h.close()
+
+
+def test_partial_passes_are_realigned_after_a_redraft(built):
+    """found by tools/corruption_fuzz.py in round 3: a partial pass that was valid against the FIRST draft kept its entry rows when the
+    fallback draft replaced that draft (k_rescue only looks at passes that are not valid).  Pass 0 and the two partial passes come
+    from molecule B, the six other passes from molecule A: the first draft is B (most passes do not map -> fallback), the partial
+    passes map to it; against the fallback draft (A) they must be aligned again and drop out."""
+    A = api.synth(3, 7, 1500, seed=611)
+    B = api.synth(3, 7, 1500, seed=612)
+    bases, pw, ipd, off, flags = [], [], [], [0], []
+    read_off = [0]
+    for z in range(3):
+        src = [(B, 0, None)] + [(A, q, None) for q in range(1, 7)] + [(B, 2, "head"), (B, 3, "tail")]
+        for S, q, cut in src:
+            r = int(S.read_off[z]) + q
+            a, b = int(S.base_off[r]), int(S.base_off[r + 1])
+            fl = int(S.flags[r])
+            if cut == "head": b = a + (6 * (b - a)) // 10; fl |= 2
+            if cut == "tail": a = b - (b - a) // 2; fl |= 2 | 4
+            bases.append(S.bases[a:b]); pw.append(S.pw[a:b]); ipd.append(S.ipd[a:b]); off.append(off[-1] + (b - a)); flags.append(fl)
+        read_off.append(len(flags))
+    batch = api.Batch(A.zmw_id, A.snr, np.array(read_off, np.int32), np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                      np.concatenate(ipd), np.array(flags, np.uint8), A.tpl_off, A.tpl)
+    for kin in (0, 1):
+        o = api.default_opts(); o.hifi_kinetics = kin
+        h = api.Handle(0, opts=o)
+        try:
+            res = h.consensus(batch)
+            ref = api.Results.allocate(batch, kinetics=bool(kin))
+            O.counts_reset()
+            O.consensus_batch(h.model, o, batch, ref, nthreads=4)
+            assert O.counts()["fallback"] == 3
+            _compare(res, ref, batch)
+            assert np.allclose(res.ec, ref.ec, atol=1e-6) and np.array_equal(res.np_, ref.np_)
+            assert (res.np_ == 6).all() and (res.ec < 6.01).all()     # the B passes serve no window of the A consensus
+        finally:
+            h.close()

@@ -12,8 +12,10 @@ import oracle_lib as O
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+k0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # first batch (to reproduce one batch of a longer run)
+verbose = len(sys.argv) > 4
 bad = 0
-for k in range(nb):
+for k in range(k0, k0 + nb):
     rng = np.random.default_rng(seed0 + k)
     n = int(rng.integers(8, 40))
     lmax = int(rng.choice([300, 1500, 4000, 12000]))
@@ -76,6 +78,14 @@ for k in range(nb):
         if not ok: break
         ok = np.array_equal(res.sequence(z), ref.sequence(z)) and np.array_equal(res.quals(z), ref.quals(z)) and np.array_equal(res.raw(z), ref.raw(z))
         if ok and o.hifi_kinetics: ok = np.array_equal(res.kinetics(z), ref.kinetics(z))
+    if verbose and not ok:
+        for f in ("status", "seq_len", "np_", "iters", "fn", "rn", "rq", "ec"):
+            a, b = getattr(res, f), getattr(ref, f)
+            if not np.array_equal(a, b): print("  ", f, "gpu", a[a != b][:8], "cpu", b[a != b][:8], "zmws", np.nonzero(a != b)[0][:8])
+        for z in range(n):
+            if not np.array_equal(res.sequence(z), ref.sequence(z)):
+                nr = int(batch.read_off[z + 1] - batch.read_off[z]); r0 = int(batch.read_off[z])
+                print("   zmw", z, "seq differs; passes", nr, "lens", np.diff(batch.base_off[r0:r0 + nr + 1]).tolist(), "flags", batch.flags[r0:r0 + nr].tolist(), "status", res.status[z], ref.status[z])
     st = np.bincount(res.status, minlength=10)
     print(f"batch {k} n {n} lmax {lmax} corrupted passes {ncorr}/{int(base.read_off[-1])} maxins {o.max_insertion_size} nofb {o.no_fallback_draft} "
           f"noheur {o.disable_heuristics} kin {o.hifi_kinetics} cov {o.max_poa_cov}: {'OK ' if ok else 'MISMATCH'} status {st.tolist()} gpu {tg:.2f}s cpu {tc:.1f}s", flush=True)
