@@ -1546,7 +1546,6 @@ __global__ void k_post(KParams P, int pass)
                                       // k_polish per 8192 ZMWs 10 x 10 kb, alone / under the draft stage of the next batch): 52992 (3 per CU) 217.9 / 305.3,
                                       // 40960 184.6 / 264.8, 40448 189.6 / 273.3, 38912 195.0 / 279.3, 36864 199.7 / 281.1, 32256 (5 per CU) 225.6 / 307.8
 #endif
-#define MI_STRIDE 13
 #ifndef CTXS
 #define CTXS 33                       // entries per observation row of sCTX
 #endif
@@ -1654,8 +1653,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     // their rows (35 % of the LDS cycles were bank conflicts in round 2); 33 spreads them by (obs + ctx) mod 16
     __shared__ float2 sCTX[(CCSX_NOBS + 1) * CTXS];
     __shared__ float sDL[16], sZP[32];                       // sZP: z-score MU[16], VAR[16]
-    __shared__ float2 sMI[2][32 * MI_STRIDE];                // [strand][column][obs] = (ME[k_j], INS[k_j])
-    __shared__ float sDLJ[2][32];
+    __shared__ int2 sColJ[2][32];                            // [strand][column j] = (DL[k_j] as float bits, byte offset of context k_j in a row of sCTX)
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
     // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
     // A code is stored as obs * 264 = the byte offset of its row in sCTX (OBS_CODE), so the scoring loop adds it to a per-lane base.
@@ -1841,22 +1839,23 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
         __syncthreads();
         const int lfr = (rf < 4) ? 3 - rf : 4;
-        // per-column copies of the tables for the fill.  Two extra entries make the sweep branch-free: slot 12 of every column is
-        // (0, 0) (the "no base" code of row 0 / row I: the SPEC's "no diagonal / no stay there" becomes an exact +0 product), and
-        // column J is all zeros with DL = 1 (no stay in the final column; beta's start value passes through 1 * beta).
-        for (int e = tid; e < 2 * 32 * MI_STRIDE; e += PW_THREADS) {
-            const int sd = e / (32 * MI_STRIDE), rem = e - sd * (32 * MI_STRIDE), j = rem / MI_STRIDE, o = rem - j * MI_STRIDE;
+        // per-column table of the fill: column j's deletion weight and WHERE its context sits in a row of sCTX — the fill's lane
+        // (= read row, fixed observation) looks (ME, INS) up in its own sCTX row.  Round 3: a per-column copy of the tables
+        // ([strand][column][obs], 6.6 KB) made this one load instead of two dependent ones, but those 6.6 KB are worth a fourth
+        // / fifth read per gamma/beta chunk.  Two conventions make the sweep branch-free: observation code 12 is the all-zero row of
+        // sCTX ("no base" of row 0 / row I: the SPEC's "no diagonal / no stay there" becomes an exact +0 product), and column J
+        // points at the zero padding entry of every row with DL = 1 (no stay in the final column; beta's start value passes through
+        // 1 * beta).
+        if (tid < 64) {
+            const int sd = tid >> 5, j = tid & 31;
             if (j <= J) {
-                float2 ent = make_float2(0.0f, 0.0f);
-                float dlv = 1.0f;
+                int k = 32; float dlv = 1.0f;
                 if (j < J) {
                     const int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
-                    const int k = ctx_of(prev, sT[sd][j]);
-                    if (o < CCSX_NOBS) ent = sCTX[o * CTXS + k];
+                    k = ctx_of(prev, sT[sd][j]);
                     dlv = sDL[k];
                 }
-                sMI[sd][j * MI_STRIDE + o] = ent;
-                if (o == 0) sDLJ[sd][j] = dlv;
+                sColJ[sd][j] = make_int2(__float_as_int(dlv), k * 8);
             }
         }
         // z-score expectation of the window template on each strand, summed in column order (SPEC); the gate is decided in round 0
@@ -1975,21 +1974,20 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const int Ia = rfl(sI[task.x]), Ib = paired ? rfl(sI[task.y]) : -1;
                 const int Tmax = (Ia > Ib ? Ia : Ib) + J;
                 const int sd = sStrand[myr];
-                const float2 *MI = sMI[sd];
-                const float *DLJ = sDLJ[sd];
+                const int2 *CJ = sColJ[sd];
                 const bool rowok = row <= I;
-                const int op = (row >= 1 && rowok) ? OBS_OF_CODE((int)sObs[myr][row - 1]) : 12;   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
-                const int oc = (row < I) ? OBS_OF_CODE((int)sObs[myr][row]) : 12;                  // o_i;     12 = no base: row I emits nothing more
+                // the lane's rows of sCTX, as byte offsets (sObs holds them in that form)
+                const int op = (row >= 1 && rowok) ? (int)sObs[myr][row - 1] : OBS_CODE(12);   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                const int oc = (row < I) ? (int)sObs[myr][row] : OBS_CODE(12);                  // o_i;     12 = no base: row I emits nothing more
+                const char *rowA = (const char *)sCTX + op, *rowB = (const char *)sCTX + oc;
                 // activity windows: alpha computes column j = t - row for t in [row, row+J]; beta computes column
                 // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step; two steps per
                 // loop iteration, so the second step's addresses are immediates and no state has to be copied between registers.
                 const int tA0 = rowok ? row : (1 << 20), tB0 = rowok ? I - row : (1 << 20);
                 const float one0 = (row == 0) ? 1.0f : 0.0f, oneI = (row == I) ? 1.0f : 0.0f;
-                const float2 *pA = MI + op - row * MI_STRIDE;
-                const float *dA = DLJ - row;
+                const int2 *cA = CJ - row;
                 float *gA = sGB + sGoff[myr] + row * S - row;
-                const float2 *pB = MI + oc + (J + I - row - 1) * MI_STRIDE;               // the SECOND step of an iteration; the first is one column up
-                const float *dB = DLJ + (J + I - row - 1);
+                const int2 *cB = CJ + (J + I - row - 1);                                   // the SECOND step of an iteration; the first is one column up
                 float *bB = sGB + sBoff[myr] + row * S + (J + I - row - 1);
                 // start values chosen so that the general recurrence yields the boundary cells: gamma(i,0) = 0*x + one0*1,
                 // beta(i,J) = (0 + 0) + 1*oneI (column J of the tables is zero with DL = 1)
@@ -2001,8 +1999,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     if (DOA) {                                                                                               \
                         const float up = wave_shr1_f32_z(acur);      /* all rows of the read shift together (full exec) */     \
                         if ((unsigned)((T) - tA0) <= uJ) {           /* alpha, column j = T - row */                          \
-                            const float2 pr = pA[(AOFF) * MI_STRIDE];                                                        \
-                            const float dlc = dA[(AOFF)];                                                                    \
+                            const int2 cj = cA[(AOFF)];                                                                      \
+                            const float2 pr = *(const float2 *)(rowA + cj.y);                                                \
+                            const float dlc = __int_as_float(cj.x);                                                          \
                             const float m = updiag * mePrev, dl = acur * dlPrev;                                              \
                             const float gmm = m + dl;                                                                        \
                             const float st = up * pr.y;              /* row 0 and column J read zero entries: +0 */           \
@@ -2015,9 +2014,10 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     if (DOB) {                                                                                               \
                         const float dn = wave_shl1_f32_z(bcur);                                                                \
                         if ((unsigned)((T) - tB0) <= uJ) {           /* beta, column jb = J - (T - (I - row)) */              \
-                            const float2 pr = pB[(BOFF) * MI_STRIDE];                                                        \
+                            const int2 cj = cB[(BOFF)];                                                                      \
+                            const float2 pr = *(const float2 *)(rowB + cj.y);                                                \
                             const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                                   \
-                            const float t3 = dB[(BOFF)] * bcur;                                                              \
+                            const float t3 = __int_as_float(cj.x) * bcur;                                                    \
                             const float bv = (t1 + t2) + t3;                                                                 \
                             bB[(BOFF)] = bv;                                                                                 \
                             bcur = bv;                                                                                       \
@@ -2026,7 +2026,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     }                                                                                                        \
                 }
 #define CCSX_FILL_LOOP(DOA, DOB)                                                                                            \
-                for (int t = 0; t <= Tmax; t += 2, pA += 2 * MI_STRIDE, dA += 2, gA += 2, pB -= 2 * MI_STRIDE, dB -= 2, bB -= 2) { \
+                for (int t = 0; t <= Tmax; t += 2, cA += 2, gA += 2, cB -= 2, bB -= 2) {                                      \
                     CCSX_FILL_STEP(t, 0, 1, DOA, DOB)                                                                        \
                     CCSX_FILL_STEP(t + 1, 1, 0, DOA, DOB)            /* an odd extra step past Tmax is inactive in every lane */ \
                 }
