@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const int need = cand ? (2 * n + 3) * S : 0;
                 const int incl = wave_scan_add_i32(need);
                 const unsigned long long over = __ballot(cand && incl > GB_FLOATS);
-                const int rend_ = over ? (int)__ffsll((long long)over) - 1 : nreads;   // the first read that does not fit any more
+                const int rend_ = over ? (int)__ffsll((long long)over) - 1 : nreads;         // the first read that does not fit any more
                 if (r >= rbeg && r < rend_) {
                     if (!cand) { sGoff[r] = -1; sValid[r] = 0; }
                     else { const int off = incl - need; sGoff[r] = off; sBoff[r] = off + (n + 1) * S; }
@@ -1994,14 +1994,13 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 float acur = one0, updiag = 0.0f, mePrev = 0.0f, dlPrev = 1.0f;
                 float bcur = oneI, dndiag = 0.0f;
                 const unsigned uJ = (unsigned)J;
-#define CCSX_FILL_STEP(T, AOFF, BOFF, DOA, DOB)                                                                            \
+#define CCSX_FILL_STEP(T, AOFF, BOFF, DOA, DOB, CJA, CJB)                                                                  \
                 {                                                                                                          \
                     if (DOA) {                                                                                               \
                         const float up = wave_shr1_f32_z(acur);      /* all rows of the read shift together (full exec) */     \
                         if ((unsigned)((T) - tA0) <= uJ) {           /* alpha, column j = T - row */                          \
-                            const int2 cj = cA[(AOFF)];                                                                      \
-                            const float2 pr = *(const float2 *)(rowA + cj.y);                                                \
-                            const float dlc = __int_as_float(cj.x);                                                          \
+                            const float2 pr = *(const float2 *)(rowA + (CJA).y);                                             \
+                            const float dlc = __int_as_float((CJA).x);                                                       \
                             const float m = updiag * mePrev, dl = acur * dlPrev;                                              \
                             const float gmm = m + dl;                                                                        \
                             const float st = up * pr.y;              /* row 0 and column J read zero entries: +0 */           \
@@ -2014,10 +2013,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     if (DOB) {                                                                                               \
                         const float dn = wave_shl1_f32_z(bcur);                                                                \
                         if ((unsigned)((T) - tB0) <= uJ) {           /* beta, column jb = J - (T - (I - row)) */              \
-                            const int2 cj = cB[(BOFF)];                                                                      \
-                            const float2 pr = *(const float2 *)(rowB + cj.y);                                                \
+                            const float2 pr = *(const float2 *)(rowB + (CJB).y);                                             \
                             const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                                   \
-                            const float t3 = __int_as_float(cj.x) * bcur;                                                    \
+                            const float t3 = __int_as_float((CJB).x) * bcur;                                                 \
                             const float bv = (t1 + t2) + t3;                                                                 \
                             bB[(BOFF)] = bv;                                                                                 \
                             bcur = bv;                                                                                       \
@@ -2025,10 +2023,17 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                         dndiag = dn;                                                                                         \
                     }                                                                                                        \
                 }
+                // the column entries (DL_j, context offset) of an iteration are loaded one iteration ahead (unconditionally: an entry
+                // outside 0..J is never used), so only ONE LDS round trip — the (ME, INS) look-up — sits between a step and its data
 #define CCSX_FILL_LOOP(DOA, DOB)                                                                                            \
-                for (int t = 0; t <= Tmax; t += 2, cA += 2, gA += 2, cB -= 2, bB -= 2) {                                      \
-                    CCSX_FILL_STEP(t, 0, 1, DOA, DOB)                                                                        \
-                    CCSX_FILL_STEP(t + 1, 1, 0, DOA, DOB)            /* an odd extra step past Tmax is inactive in every lane */ \
+                {                                                                                                          \
+                    int2 ca0 = cA[0], ca1 = cA[1], cb0 = cB[1], cb1 = cB[0];                                               \
+                    for (int t = 0; t <= Tmax; t += 2, cA += 2, gA += 2, cB -= 2, bB -= 2) {                               \
+                        const int2 na0 = cA[2], na1 = cA[3], nb0 = cB[-1], nb1 = cB[-2];                                   \
+                        CCSX_FILL_STEP(t, 0, 1, DOA, DOB, ca0, cb0)                                                        \
+                        CCSX_FILL_STEP(t + 1, 1, 0, DOA, DOB, ca1, cb1)                                                    \
+                        ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;                                                        \
+                    }                                                                                                      \
                 }
                 if (mode == 0) { CCSX_FILL_LOOP(1, 1) }
                 else if (mode == 1) { CCSX_FILL_LOOP(1, 0) }
