@@ -1540,6 +1540,13 @@ __global__ void k_post(KParams P, int pass)
 #define PW_MINWAVES 4
 #endif
 #define PW_WAVES (PW_THREADS / 64)
+#ifndef PW_CHUNK_READS
+#define PW_CHUNK_READS 4              // reads per gamma/beta chunk (0: as many as fit).  A chunk costs one fill sweep + one scoring pass however many
+                                      // reads it holds (ms of k_polish per 8192 ZMWs: 2 reads per chunk 234, 4 reads 169.5, as many as fit = 4-5 reads 175.7):
+                                      // four reads = two pair tasks = four alpha-only / beta-only units = every wave busy for ONE sweep, a fifth read
+                                      // adds a task and turns the units into full alpha+beta sweeps on three waves.  Eight-wave workgroups with 8 / 10
+                                      // reads per chunk (2 per CU, 80 KB each) ran 260 / 229 ms: profiles/r03_polish_fill_variants.txt
+#endif
 #define PW_MAXREADS 64
 #ifndef PW_LDS_BYTES
 #define PW_LDS_BYTES 40960            // static + dynamic LDS of one workgroup: FOUR workgroups per CU fill its 160 KB exactly.  Round 3 sweep (ms of
@@ -1705,7 +1712,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     const int maxins = P.opts.max_insertion_size == 0 ? 30 : P.opts.max_insertion_size;
     {
         // level 2: everything that needs only z / r0 / the window bounds
-        const int e0 = tid, e1 = tid + PW_THREADS < CCSX_NOBS * 32 ? tid + PW_THREADS : tid;
+        const int e0 = tid < CCSX_NOBS * 32 ? tid : 0, e1 = tid + PW_THREADS < CCSX_NOBS * 32 ? tid + PW_THREADS : e0;
         const size_t tz = (size_t)z * 192;
         const int i0 = (e0 & 15) * CCSX_NOBS + (e0 >> 5), i1 = (e1 & 15) * CCSX_NOBS + (e1 >> 5);
         const float me0 = P.tabME[tz + i0], in0 = P.tabINS[tz + i0], me1 = P.tabME[tz + i1], in1 = P.tabINS[tz + i1];
@@ -1722,7 +1729,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         const unsigned m1 = P.dmask[eo + idx_ws + 1];
         const unsigned m2 = (idx_ws + 2 <= idx_we) ? P.dmask[eo + idx_ws + 2] : 0u;
         const unsigned m3 = (idx_ws + 3 <= idx_we) ? P.dmask[eo + idx_ws + 3] : 0u;
-        sCTX[(e0 >> 5) * CTXS + (e0 & 31)] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
+        if (tid < CCSX_NOBS * 32) sCTX[(e0 >> 5) * CTXS + (e0 & 31)] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
         if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[(e1 >> 5) * CTXS + (e1 & 31)] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
         if (tid < CTXS) sCTX[CCSX_NOBS * CTXS + tid] = make_float2(0.0f, 0.0f);
         if (CTXS > 32 && tid < CCSX_NOBS) sCTX[tid * CTXS + 32] = make_float2(0.0f, 0.0f);     // (the padding entry of every row)
@@ -1929,7 +1936,12 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const bool cand = n >= 0;
                 const int need = cand ? (2 * n + 3) * S : 0;
                 const int incl = wave_scan_add_i32(need);
+#if PW_CHUNK_READS > 0
+                const unsigned long long bcand = __ballot(cand);
+                const unsigned long long over = __ballot(cand && (incl > GB_FLOATS || __popcll(bcand & ((1ull << lane) - 1ull)) >= PW_CHUNK_READS));
+#else
                 const unsigned long long over = __ballot(cand && incl > GB_FLOATS);
+#endif
                 const int rend_ = over ? (int)__ffsll((long long)over) - 1 : nreads;         // the first read that does not fit any more
                 if (r >= rbeg && r < rend_) {
                     if (!cand) { sGoff[r] = -1; sValid[r] = 0; }
@@ -1960,7 +1972,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
 #ifdef CCSX_EXP_NO_FILL
             const int nsplit = 0, ntfull = 0, nunit_f = 0;
 #else
-            const int nsplit = ((ntask % PW_WAVES) == 1 || (ntask % PW_WAVES) == 2) ? (ntask % PW_WAVES) : 0;
+            const int nrest = ntask % PW_WAVES, nsplit = (nrest > 0 && 2 * nrest <= PW_WAVES) ? nrest : 0;
             const int ntfull = ntask - nsplit, nunit_f = ntfull + 2 * nsplit;
 #endif
             for (int fu = wave; fu < nunit_f; fu += PW_WAVES) {

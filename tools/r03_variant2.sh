@@ -4,7 +4,7 @@ O=gpurun_out/r03_variant; rm -rf $O; mkdir -p $O
 for v in $VARIANTS; do
   name=${v%%:*}; flags=${v#*:}; flags=${flags//,/ }
   CCSX_EXTRA_FLAGS="$flags" python -c "import __graft_entry__ as g; g.build(force=True)" > $O/build_$name.log 2>&1 || { echo "build $name failed"; tail -5 $O/build_$name.log; continue; }
-  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -1
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q > $O/pytest_$name.txt 2>&1; tail -1 $O/pytest_$name.txt; grep -q " passed" $O/pytest_$name.txt && ! grep -q failed $O/pytest_$name.txt || { echo "parity $name FAILED"; grep -m3 "Error\|error\|FAILED" $O/pytest_$name.txt; continue; }
   for rep in 1 2; do
     timeout 300 python bench.py --no-cpu-baseline --extra '' --steps 8 --warmup 3 --serial-stages > $O/b.json 2> $O/b.err
     python -c "
