@@ -1556,6 +1556,10 @@ __global__ void k_post(KParams P, int pass)
 #ifndef CTXS
 #define CTXS 33                       // entries per observation row of sCTX
 #endif
+#define FE_ALO 35                     // sEA holds columns -35 .. 69, sEB columns -69 .. 66 (the reach of a pair's lanes, see the fill)
+#define FE_A 105
+#define FE_BLO 69
+#define FE_B 136
 #define OBS_CODE(o) ((o) * (CTXS * 8))        // an observation code as stored in sObs: the byte offset of its row in sCTX
 #define OBS_OF_CODE(c) ((unsigned)(c) / (unsigned)(CTXS * 8))   // ... and back (a multiply + shift)
 
@@ -1661,6 +1665,10 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __shared__ float2 sCTX[(CCSX_NOBS + 1) * CTXS];
     __shared__ float sDL[16], sZP[32];                       // sZP: z-score MU[16], VAR[16]
     __shared__ int2 sColJ[2][32];                            // [strand][column j] = (DL[k_j] as float bits, byte offset of context k_j in a row of sCTX)
+    // the same per column, staggered for the software-pipelined sweeps of a PAIR of short reads (rows 0..31 each): entry m of sEA =
+    // (DL of column m-1, context offset of column m+4), entry n of sEB = (DL of column n, context offset of column n-4); every index a
+    // lane can form before its first / after its last column exists and holds (1.0, the zero entry), so no look-up needs a guard
+    __shared__ int2 sEA[2][FE_A], sEB[2][FE_B];
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
     // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
     // A code is stored as obs * 264 = the byte offset of its row in sCTX (OBS_CODE), so the scoring loop adds it to a per-lane base.
@@ -1915,6 +1923,16 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             if (v0) sList[basew + __popcll(bal & ((1ull << lane) - 1ull))] = (short)tid;
             __syncthreads();
         }
+        for (int e = tid; e < 2 * (FE_A + FE_B); e += PW_THREADS) {          // (sColJ is complete: two barriers since)
+            const bool isa = e < 2 * FE_A;
+            const int e2 = isa ? e : e - 2 * FE_A, len = isa ? FE_A : FE_B;
+            const int sd = e2 >= len ? 1 : 0, idx = e2 - sd * len;
+            const int cd = isa ? idx - FE_ALO - 1 : idx - FE_BLO;           // the column whose DL the entry carries
+            const int cc = isa ? idx - FE_ALO + 4 : idx - FE_BLO - 4;       // the column whose context offset it carries
+            const int2 vd = sColJ[sd][cd >= 0 && cd <= J ? cd : 0], vc = sColJ[sd][cc >= 0 && cc <= J ? cc : 0];
+            const int2 ent = make_int2((cd >= 0 && cd <= J) ? vd.x : __float_as_int(1.0f), (cc >= 0 && cc <= J) ? vc.y : 32 * 8);
+            if (isa) sEA[sd][idx] = ent; else sEB[sd][idx] = ent;
+        }
         int nvm = 0;
 #pragma unroll
         for (int q = 0; q < PW_WAVES; ++q) nvm += rfl(sCnt[q]);
@@ -2047,9 +2065,70 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                         ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;                                                        \
                     }                                                                                                      \
                 }
-                if (mode == 0) { CCSX_FILL_LOOP(1, 1) }
-                else if (mode == 1) { CCSX_FILL_LOOP(1, 0) }
-                else { CCSX_FILL_LOOP(0, 1) }
+                if (!paired) {                                       // a long read (rows 0..63): the plain loop
+                    if (mode == 0) { CCSX_FILL_LOOP(1, 1) }
+                    else if (mode == 1) { CCSX_FILL_LOOP(1, 0) }
+                    else { CCSX_FILL_LOOP(0, 1) }
+                } else {
+                    // a pair of short reads: one sweep per direction, FOUR steps per iteration, software-pipelined look-ups.  Slot k of
+                    // the iteration holds what the step of column c needs — DL (alpha: of column c-1), the (ME, INS) pair of column c —
+                    // and, already, the context offset of the column four steps on; right after its use the slot is refilled for the
+                    // next iteration (the pair from that offset, DL and the offset after next from the staggered table), so a look-up
+                    // has four steps to arrive and nothing is copied between registers.  The only state a step changes under its
+                    // activity mask is the running cell: ME of the previous column is simply the previous slot's pair (the column
+                    // before column 0 is the zero entry with DL = 1, as the boundary cells want it).
+#define LDPR(ROWP, OFF) (*(const float2 *)((ROWP) + (OFF)))
+                    if (mode != 2) {
+                        const int2 *eA = sEA[sd] + (FE_ALO - row);                       // eA[x] = the entry of column x - row
+#define CCSX_A_INIT(K) const int2 ea##K = eA[K], fa##K = eA[(K) - 4]; float dl##K = __int_as_float(ea##K.x); int cx##K = ea##K.y; float2 p##K = LDPR(rowA, fa##K.y);
+                        CCSX_A_INIT(0) CCSX_A_INIT(1) CCSX_A_INIT(2) CCSX_A_INIT(3)
+#undef CCSX_A_INIT
+                        int cnt = -tA0;
+#define CCSX_A_STEP(K)                                                                                                     \
+                        {                                                                                                  \
+                            const float up = wave_shr1_f32_z(acur);                                                        \
+                            if ((unsigned)(cnt + (K)) <= uJ) {       /* alpha, column j = t + K - row */                   \
+                                const float m = updiag * mePrev, dl = acur * dl##K;                                        \
+                                const float gmm = m + dl;                                                                  \
+                                const float st = up * p##K.y;        /* row 0 and column J read zero entries: +0 */        \
+                                gA[(K)] = gmm;                                                                             \
+                                acur = gmm + st;                                                                           \
+                            }                                                                                              \
+                            updiag = up; mePrev = p##K.x;                                                                  \
+                            p##K = LDPR(rowA, cx##K);                                                                      \
+                            const int2 en = eA[(K) + 4];                                                                   \
+                            dl##K = __int_as_float(en.x); cx##K = en.y;                                                    \
+                        }
+                        for (int t = 0; t <= Tmax; t += 4, eA += 4, gA += 4, cnt += 4) { CCSX_A_STEP(0) CCSX_A_STEP(1) CCSX_A_STEP(2) CCSX_A_STEP(3) }
+#undef CCSX_A_STEP
+                    }
+                    if (mode != 1) {
+                        const int2 *eB = sEB[sd] + (FE_BLO + J + I - row);               // eB[-x] = the entry of column J + I - row - x
+                        float *bE = sGB + sBoff[myr] + row * S + (J + I - row);          // bE[-x] = beta(row, J + I - row - x)
+#define CCSX_B_INIT(K) const int2 eb##K = eB[-(K)], fb##K = eB[4 - (K)]; float dk##K = __int_as_float(eb##K.x); int cy##K = eb##K.y; float2 q##K = LDPR(rowB, fb##K.y);
+                        CCSX_B_INIT(0) CCSX_B_INIT(1) CCSX_B_INIT(2) CCSX_B_INIT(3)
+#undef CCSX_B_INIT
+                        int cnt = -tB0;
+#define CCSX_B_STEP(K)                                                                                                     \
+                        {                                                                                                  \
+                            const float dn = wave_shl1_f32_z(bcur);                                                        \
+                            if ((unsigned)(cnt + (K)) <= uJ) {       /* beta, column jb = J + I - row - (t + K) */         \
+                                const float t1 = q##K.x * dndiag, t2 = q##K.y * dn;                                        \
+                                const float t3 = dk##K * bcur;                                                             \
+                                const float bv = (t1 + t2) + t3;                                                           \
+                                bE[-(K)] = bv;                                                                             \
+                                bcur = bv;                                                                                 \
+                            }                                                                                              \
+                            dndiag = dn;                                                                                   \
+                            q##K = LDPR(rowB, cy##K);                                                                      \
+                            const int2 en = eB[-(K) - 4];                                                                  \
+                            dk##K = __int_as_float(en.x); cy##K = en.y;                                                    \
+                        }
+                        for (int t = 0; t <= Tmax; t += 4, eB -= 4, bE -= 4, cnt += 4) { CCSX_B_STEP(0) CCSX_B_STEP(1) CCSX_B_STEP(2) CCSX_B_STEP(3) }
+#undef CCSX_B_STEP
+                    }
+#undef LDPR
+                }
 #undef CCSX_FILL_LOOP
 #undef CCSX_FILL_STEP
                 const int basel = paired ? (half << 5) : 0;
