@@ -413,6 +413,9 @@ inline void write_pbi(const std::string &path, ThreadPool &pool, const PbiIndex 
 
 // ---------------------------------------------------------------------------------------------- BAM records
 struct Subread {
+    // Round 3: a subread is a VIEW of its record in the inflated BGZF bytes (kept alive by `keep`) — the filters need only lengths
+    // and tags; bases / pw / ip are decoded exactly once, straight into the page-locked staging of the batch (decode_* below).
+    // Decoding every record into three vectors first cost a third of the host time and a second copy at packing.
     std::string name;
     int32_t zm = -1;
     int32_t cx = -1;            // -1: tag absent
@@ -420,8 +423,16 @@ struct Subread {
     bool has_snr = false, has_n = false;
     uint8_t strand = 0;         // 0 forward / 1 reverse pass (set by the driver: cx direction bits, else alternation)
     uint8_t partial = 0;        // ccsx_batch.flags bits 1-2: 2 = partial pass with the adapter at its start, 6 = ... at its end
-    std::vector<uint8_t> bases;  // 0..3
-    std::vector<uint8_t> pw, ipd;
+    uint32_t len = 0;           // bases
+    const uint8_t *seq = nullptr;                              // BAM nibbles, two per byte
+    const uint8_t *pw_p = nullptr, *ip_p = nullptr;            // payload of the B arrays as stored
+    char pw_t = 0, ip_t = 0;                                   // their element types ('C': CodecV1 bytes pass through)
+    uint32_t pw_n = 0, ip_n = 0;
+    std::shared_ptr<const void> keep;
+    size_t size() const { return len; }
+    inline void decode_bases(uint8_t *dst) const;              // 0..3 (a non-ACGT nibble decodes as 0; has_n says so)
+    inline void decode_pw(uint8_t *dst) const;                 // CodecV1 codes; a missing / mismatched array = all 2
+    inline void decode_ip(uint8_t *dst) const;                 // ... = all 1
 };
 
 struct BamHeader {
@@ -474,6 +485,47 @@ inline size_t tag_value_size(char t)
     switch (t) { case 'c': case 'C': case 'A': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; }
 }
 
+// one table look-up per packed byte: two base codes + "contains a non-ACGT nibble"
+struct NibLut {
+    uint16_t v[256]; uint8_t bad[256];
+    NibLut()
+    {
+        static const int8_t nib2code[16] = {-1, 0, 1, -1, 2, -1, -1, -1, 3, -1, -1, -1, -1, -1, -1, -1};
+        for (int b = 0; b < 256; ++b) {
+            const int hi = nib2code[b >> 4], lo = nib2code[b & 15];
+            v[b] = (uint16_t)((hi < 0 ? 0 : hi) | ((lo < 0 ? 0 : lo) << 8)); bad[b] = (uint8_t)((hi < 0 ? 1 : 0) | (lo < 0 ? 2 : 0));
+        }
+    }
+};
+inline const NibLut &nib_lut() { static const NibLut lut; return lut; }
+
+inline void Subread::decode_bases(uint8_t *dst) const
+{
+    const NibLut &lut = nib_lut();
+    const uint32_t pairs = len >> 1;
+    for (uint32_t k = 0; k < pairs; ++k) std::memcpy(dst + 2 * k, &lut.v[seq[k]], 2);
+    if (len & 1) dst[len - 1] = (uint8_t)(lut.v[seq[pairs]] & 0xff);
+}
+
+inline void decode_codes(const uint8_t *q, char st, uint32_t n, uint32_t len, uint8_t deflt, uint8_t *dst)
+{
+    if (!q || n != len) { std::memset(dst, deflt, len); return; }      // (an array of the wrong length is ignored, as before)
+    if (st == 'c' || st == 'C') { std::memcpy(dst, q, n); return; }     // CodecV1 bytes pass through
+    const size_t es = tag_value_size(st);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t *e = q + (size_t)i * es;
+        int64_t f;
+        switch (st) {
+            case 's': f = (int16_t)(e[0] | (e[1] << 8)); break; case 'S': f = (uint16_t)(e[0] | (e[1] << 8)); break;
+            case 'i': f = (int32_t)rd32(e); break; case 'I': f = rd32(e); break;
+            default: f = 0;
+        }
+        dst[i] = codec_v1_encode(f);
+    }
+}
+inline void Subread::decode_pw(uint8_t *dst) const { decode_codes(pw_p, pw_t, pw_n, len, 2, dst); }
+inline void Subread::decode_ip(uint8_t *dst) const { decode_codes(ip_p, ip_t, ip_n, len, 1, dst); }
+
 // decode one record body (the bytes after block_size)
 // Every length field of the record is checked against the record's own size before it is used (a lying l_seq, tag count or
 // an unterminated string must end in "malformed BAM record", not in an out-of-bounds read on a pool thread).
@@ -486,18 +538,13 @@ inline void parse_subread(const uint8_t *p, uint32_t bs, Subread &r)
     r = Subread();
     r.name.assign((const char *)p + 32, l_name ? l_name - 1 : 0);
     const uint8_t *seq = p + 32 + l_name + 4 * n_cig;
-    r.bases.resize(l_seq);
-    static const int8_t nib2code[16] = {-1, 0, 1, -1, 2, -1, -1, -1, 3, -1, -1, -1, -1, -1, -1, -1};
-    // one table look-up per packed byte: two base codes + "contains a non-ACGT nibble" (record decode is ~a third of the host time)
-    struct Lut { uint16_t v[256]; uint8_t bad[256]; Lut() { for (int b = 0; b < 256; ++b) { const int hi = nib2code[b >> 4], lo = nib2code[b & 15];
-        v[b] = (uint16_t)((hi < 0 ? 0 : hi) | ((lo < 0 ? 0 : lo) << 8)); bad[b] = (uint8_t)((hi < 0 ? 1 : 0) | (lo < 0 ? 2 : 0)); } } };
-    static const Lut lut;
-    {
-        uint8_t *dst = r.bases.data();
+    r.len = l_seq; r.seq = seq;
+    {   // only "does it hold a non-ACGT nibble" is decided here (one table look-up per packed byte, no writes)
+        const NibLut &lut = nib_lut();
         const uint32_t pairs = l_seq >> 1;
         unsigned anybad = 0;
-        for (uint32_t k = 0; k < pairs; ++k) { const uint8_t b = seq[k]; std::memcpy(dst + 2 * k, &lut.v[b], 2); anybad |= lut.bad[b]; }
-        if (l_seq & 1) { const uint8_t b = seq[pairs]; dst[l_seq - 1] = (uint8_t)(lut.v[b] & 0xff); anybad |= (lut.bad[b] & 1); }
+        for (uint32_t k = 0; k < pairs; ++k) anybad |= lut.bad[seq[k]];
+        if (l_seq & 1) anybad |= (lut.bad[seq[pairs]] & 1);
         if (anybad) r.has_n = true;
     }
     const uint8_t *t = seq + (l_seq + 1) / 2 + l_seq, *end = p + bs;
@@ -521,12 +568,8 @@ inline void parse_subread(const uint8_t *p, uint32_t bs, Subread &r)
             const size_t es = tag_value_size(st);
             if (!es || (uint64_t)n * es > (uint64_t)(end - q)) bad();
             if (t0 == 's' && t1 == 'n' && st == 'f' && n == 4) { std::memcpy(r.snr, q, 16); r.has_snr = true; }
-            else if ((t0 == 'p' && t1 == 'w') || (t0 == 'i' && t1 == 'p')) {
-                std::vector<uint8_t> &dst = (t0 == 'p') ? r.pw : r.ipd;
-                dst.resize(n);
-                if (es == 1) { if (n) std::memcpy(dst.data(), q, n); }      // CodecV1 bytes pass through
-                else for (uint32_t i = 0; i < n; ++i) dst[i] = codec_v1_encode(rdint(st, q + i * es));
-            }
+            else if (t0 == 'p' && t1 == 'w') { r.pw_p = q; r.pw_t = st; r.pw_n = n; }
+            else if (t0 == 'i' && t1 == 'p') { r.ip_p = q; r.ip_t = st; r.ip_n = n; }
             t = q + (size_t)n * es;
             continue;
         }
@@ -578,10 +621,10 @@ inline bool read_raw_chunk(BgzfReader &in, RawChunk &c)
     return !c.recs.empty();
 }
 
-inline std::vector<Subread> decode_chunk(const RawChunk &c)
+inline std::vector<Subread> decode_chunk(const std::shared_ptr<const RawChunk> &c)
 {
-    std::vector<Subread> out(c.recs.size());
-    for (size_t i = 0; i < c.recs.size(); ++i) parse_subread(c.recs[i].first, c.recs[i].second, out[i]);
+    std::vector<Subread> out(c->recs.size());
+    for (size_t i = 0; i < c->recs.size(); ++i) { parse_subread(c->recs[i].first, c->recs[i].second, out[i]); out[i].keep = c; }   // the views live as long as the chunk
     return out;
 }
 
@@ -601,10 +644,11 @@ struct RecordBuilder {
         u32(n); u32((uint32_t)-1); u32((uint32_t)-1); u32(0);
         b.insert(b.end(), name.begin(), name.end()); b.push_back(0);
         static const uint8_t code2nib[4] = {1, 2, 4, 8};
-        for (uint32_t i = 0; i < n; i += 2) {
-            const uint8_t hi = code2nib[bases[i] & 3], lo = (i + 1 < n) ? code2nib[bases[i + 1] & 3] : 0;
-            b.push_back((uint8_t)((hi << 4) | lo));
-        }
+        const size_t at = b.size();
+        b.resize(at + (n + 1) / 2);                              // (one resize, plain stores: the writer thread packs ~10 kb per record)
+        uint8_t *dst = b.data() + at;
+        for (uint32_t i = 0; i + 1 < n; i += 2) dst[i >> 1] = (uint8_t)((code2nib[bases[i] & 3] << 4) | code2nib[bases[i + 1] & 3]);
+        if (n & 1) dst[n >> 1] = (uint8_t)(code2nib[bases[n - 1] & 3] << 4);
         if (qual) b.insert(b.end(), qual, qual + n); else b.insert(b.end(), n, 0xff);
     }
     void tagZ(const char *t, const std::string &v) { b.push_back(t[0]); b.push_back(t[1]); b.push_back('Z'); b.insert(b.end(), v.begin(), v.end()); b.push_back(0); }

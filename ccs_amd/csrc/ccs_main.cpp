@@ -50,6 +50,7 @@ struct Options {
     bool all_gpus = false;
     std::string write_synth;      // "N,P,L[,seed]" -> write a synthetic subreads.bam to `out`
     bool dump = false;            // print one line per ZMW after the step-1 filters, no GPU
+    bool host_only = false;       // reader -> filters -> packing into staging, no engine and no output: what the host side alone sustains
     bool by_strand = false;       // --by-strand: one consensus per strand (docs/faq/mode-by-strand.md:8-23)
     bool no_partial = false;      // --no-partial-passes: drop the subreads that are not flanked by adapters on both sides (as round 2 did)
     bool qv_binning = false;      // --qv-binning: 7-bin per-base QVs after rq is computed (docs/faq/qv-binning.md:19-31)
@@ -72,20 +73,24 @@ struct ZmwIn {
 };
 
 // page-locked staging of one GPU worker (bases / pw / ipd of the batch in flight), grown geometrically and reused
+static bool g_plain_arenas = false;        // --host-only: ordinary memory (there may be no device to pin for)
 struct Arena {
     uint8_t *p = nullptr;
     size_t cap = 0;
+    bool plain = false;
+    void release() { if (plain) std::free(p); else ccsx_free_pinned(p); p = nullptr; }
     uint8_t *reserve(size_t bytes)
     {
         if (bytes > cap) {
-            ccsx_free_pinned(p);
+            release();
             cap = bytes + bytes / 4 + (1u << 20);
-            p = (uint8_t *)ccsx_alloc_pinned(cap);
-            if (!p) { cap = 0; throw std::runtime_error(std::string("pinned staging: ") + ccsx_last_error()); }
+            plain = g_plain_arenas;
+            p = plain ? (uint8_t *)std::malloc(cap) : (uint8_t *)ccsx_alloc_pinned(cap);
+            if (!p) { cap = 0; throw std::runtime_error(plain ? std::string("staging: out of memory") : std::string("pinned staging: ") + ccsx_last_error()); }
         }
         return p;
     }
-    ~Arena() { ccsx_free_pinned(p); }
+    ~Arena() { release(); }
 };
 
 struct Batch {
@@ -171,7 +176,8 @@ void usage()
                  "      --log-level L         ERROR|WARN|INFO [WARN]\n"
                  "  test helpers (not in the reference):\n"
                  "      --write-synthetic N,P,L[,seed]  write a synthetic subreads.bam to OUT (no IN)\n"
-                 "      --dump-zmws                     list ZMWs after the step-1 filters (no GPU, no OUT)\n");
+                 "      --dump-zmws                     list ZMWs after the step-1 filters (no GPU, no OUT)\n"
+                 "      --host-only                     read, filter and pack IN into batch staging, no engine (no GPU, no OUT): host throughput\n");
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -199,6 +205,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--log-level") { std::string v = need(a.c_str()); o.log_level = v == "INFO" ? 2 : (v == "ERROR" ? 0 : 1); }
         else if (a == "--write-synthetic") o.write_synth = need(a.c_str());
         else if (a == "--dump-zmws") o.dump = true;
+        else if (a == "--host-only") o.host_only = true;
         else if (a == "--by-strand") o.by_strand = true;
         else if (a == "--no-partial-passes") o.no_partial = true;
         else if (a == "--qv-binning") o.qv_binning = true;
@@ -215,7 +222,7 @@ bool parse(int argc, char **argv, Options &o)
         o.o.top_passes = 64;
     }
     if (!o.write_synth.empty()) { if (pos.size() != 1) return false; o.out = pos[0]; return true; }
-    if (o.dump) { if (pos.size() != 1) return false; o.in = pos[0]; return true; }
+    if (o.dump || o.host_only) { if (pos.size() != 1) return false; o.in = pos[0]; if (o.batch < 1) o.batch = 1; return true; }
     if (pos.size() != 2) return false;
     o.in = pos[0]; o.out = pos[1];
     {
@@ -307,11 +314,11 @@ int write_synthetic(const Options &o, ThreadPool &pool)
 // ---- step-1 filters (docs/how-does-ccs-work.md:19-32) ----------------------------------------------
 void finish_zmw(ZmwIn &z, const Options &o)
 {
-    for (auto &r : z.reads) z.polymerase_len += (int64_t)r.bases.size() + 45;   // + adapter between consecutive subreads
+    for (auto &r : z.reads) z.polymerase_len += (int64_t)r.size() + 45;   // + adapter between consecutive subreads
     if (z.reads.empty()) { z.host_status = HS_NO_SUBREADS; return; }
     {
         std::vector<size_t> s0;
-        for (auto &r : z.reads) s0.push_back(r.bases.size());
+        for (auto &r : z.reads) s0.push_back(r.size());
         std::nth_element(s0.begin(), s0.begin() + s0.size() / 2, s0.end());
         z.median_len = (int32_t)s0[s0.size() / 2];
         for (auto &r : z.reads) z.n_full += ((r.cx < 0) || ((r.cx & 3) == 3)) ? 1 : 0;
@@ -320,36 +327,32 @@ void finish_zmw(ZmwIn &z, const Options &o)
     for (int c = 1; c < 4; ++c) mn = std::min(mn, z.snr[c]);
     if (mn < (float)o.min_snr) { z.host_status = HS_POOR_SNR; z.reads.clear(); return; }
     std::vector<size_t> lens;
-    for (auto &r : z.reads) lens.push_back(r.bases.size());
+    for (auto &r : z.reads) lens.push_back(r.size());
     std::vector<size_t> s = lens;
     std::nth_element(s.begin(), s.begin() + s.size() / 2, s.end());
     const double med = (double)s[s.size() / 2];
     std::vector<Subread> keep, part;
     bool any_len_ok = false;
     for (auto &r : z.reads) {
-        const double l = (double)r.bases.size();
+        const double l = (double)r.size();
         const bool full = (r.cx < 0) || ((r.cx & 3) == 3);       // flanked by adapters (docs/faq/accuracy-vs-passes.md:17-18)
         // partial passes (one adapter only: the first / last subread of the polymerase read) are not passes, but the polish uses them
         // where they reach (docs/faq/accuracy-vs-passes.md:26-29: ec ~ np + 1); they are shorter by nature: no lower length bound
         const bool partial = !full && r.cx >= 0 && (r.cx & 3) != 0 && l >= 50.0 && l <= 2.0 * med && !o.no_partial;
         if (partial && !r.has_n) {
             r.partial = (uint8_t)((r.cx & 3) == 2 ? 6 : 2);      // cx ADAPTER_AFTER only: the adapter is at the pass's end
-            if (r.pw.size() != r.bases.size()) r.pw.assign(r.bases.size(), 2);
-            if (r.ipd.size() != r.bases.size()) r.ipd.assign(r.bases.size(), 1);
             part.push_back(std::move(r));
             continue;
         }
         if (l < 0.5 * med || l > 2.0 * med) continue;            // length filter
         any_len_ok = true;
-        if (!full || r.has_n || r.bases.empty()) continue;
-        if (r.pw.size() != r.bases.size()) r.pw.assign(r.bases.size(), 2);
-        if (r.ipd.size() != r.bases.size()) r.ipd.assign(r.bases.size(), 1);
+        if (!full || r.has_n || r.size() == 0) continue;
         keep.push_back(std::move(r));
     }
     z.reads.swap(keep);
     if (!any_len_ok) { z.host_status = HS_NO_SUBREADS; z.reads.clear(); return; }
     // the engine handles subreads up to 65535 bases; longer inserts cannot pass --max-length (<= 50000) anyway
-    for (auto &r : z.reads) if (r.bases.size() > 65535 || (double)r.bases.size() > 1.3 * (double)o.o.max_length + 1000.0) { z.host_status = HS_TOO_LONG; z.reads.clear(); return; }
+    for (auto &r : z.reads) if (r.size() > 65535 || (double)r.size() > 1.3 * (double)o.o.max_length + 1000.0) { z.host_status = HS_TOO_LONG; z.reads.clear(); return; }
     if ((int)z.reads.size() < o.o.min_passes) { z.host_status = HS_TOO_FEW; z.reads.clear(); return; }
     // --top-passes: "at most the top 60 full-length passes after sorting by median length" (docs/faq/accuracy-vs-passes.md:49-52):
     // the N passes whose length is closest to the median are kept, in their original order
@@ -357,7 +360,7 @@ void finish_zmw(ZmwIn &z, const Options &o)
     if (z.reads.size() > top) {
         std::vector<size_t> idx(z.reads.size());
         for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
-        auto dist = [&](size_t i) { const double d = (double)z.reads[i].bases.size() - med; return d < 0 ? -d : d; };
+        auto dist = [&](size_t i) { const double d = (double)z.reads[i].size() - med; return d < 0 ? -d : d; };
         std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return dist(a) < dist(b); });
         idx.resize(top);
         std::sort(idx.begin(), idx.end());
@@ -387,7 +390,7 @@ void pack(Batch &b, Arena &arena)
     b.read_off.assign(1, 0); b.base_off.assign(1, 0);
     b.slot.assign(b.zmws.size(), -1);
     int64_t total = 0;
-    for (const ZmwIn &z : b.zmws) if (z.host_status == HS_OK) for (const Subread &r : z.reads) total += (int64_t)r.bases.size();
+    for (const ZmwIn &z : b.zmws) if (z.host_status == HS_OK) for (const Subread &r : z.reads) total += (int64_t)r.size();
     uint8_t *base = arena.reserve((size_t)3 * (size_t)total);
     uint8_t *bases = base, *pw = base + total, *ipd = base + 2 * total;
     int64_t at = 0;
@@ -399,12 +402,12 @@ void pack(Batch &b, Arena &arena)
         b.snr.insert(b.snr.end(), z.snr, z.snr + 4);
         for (size_t k = 0; k < z.reads.size(); ++k) {
             Subread &r = z.reads[k];
-            const size_t L = r.bases.size();
-            std::memcpy(bases + at, r.bases.data(), L); std::memcpy(pw + at, r.pw.data(), L); std::memcpy(ipd + at, r.ipd.data(), L);
+            const size_t L = r.size();
+            r.decode_bases(bases + at); r.decode_pw(pw + at); r.decode_ip(ipd + at);      // the one and only decode: record -> staging
             at += (int64_t)L;
             b.flags.push_back((uint8_t)(r.strand | r.partial));
             b.base_off.push_back(at);
-            std::vector<uint8_t>().swap(r.bases); std::vector<uint8_t>().swap(r.pw); std::vector<uint8_t>().swap(r.ipd);
+            r.keep.reset(); r.seq = r.pw_p = r.ip_p = nullptr;                              // the inflated bytes may go
         }
         b.read_off.push_back((int32_t)b.flags.size());
     }
@@ -507,7 +510,7 @@ int main(int argc, char **argv)
         // "Abort if chemistry information is missing in BAM header" (docs/changelog.md:66)
         ccsx_model model;
         std::string chem_desc;
-        if (!opt.dump) {
+        if (!opt.dump && !opt.host_only) {
             auto ds_value = [&](const char *key) -> std::string {
                 const size_t rg = hdr.text.find("@RG");
                 const size_t k = rg == std::string::npos ? rg : hdr.text.find(std::string(key) + "=", rg);
@@ -532,7 +535,7 @@ int main(int argc, char **argv)
 
         // ---- devices (not needed for --dump-zmws): one engine handle per device
         std::vector<ccsx_handle> handles;
-        if (!opt.dump) {
+        if (!opt.dump && !opt.host_only) {
             const int ndev = ccsx_device_count();
             if (ndev <= 0) { std::fprintf(stderr, "ccs: no gfx950 GPU available (this build has no CPU consensus path)\n"); return 1; }
             if (opt.all_gpus) for (int d = 0; d < ndev; ++d) opt.gpus.push_back(d);
@@ -544,6 +547,7 @@ int main(int argc, char **argv)
             }
         }
 
+        g_plain_arenas = opt.host_only;
         Channel<std::shared_ptr<Batch>> to_pack(2 * std::max<size_t>(1, handles.size())), to_gpu(2 * std::max<size_t>(1, handles.size())),
             to_writer(4 * std::max<size_t>(1, handles.size()));
         std::string movie;
@@ -601,7 +605,12 @@ int main(int argc, char **argv)
                 finish_zmw(zin, opt);
                 if (opt.dump) {
                     unsigned long long hsh = 1469598103934665603ull;       // FNV-1a over bases, pw, ip of the kept passes (reader self-check)
-                    for (const Subread &r : zin.reads) for (const std::vector<uint8_t> *v : {&r.bases, &r.pw, &r.ipd}) for (uint8_t x : *v) { hsh ^= x; hsh *= 1099511628211ull; }
+                    std::vector<uint8_t> tmp;
+                    for (const Subread &r : zin.reads) for (int a = 0; a < 3; ++a) {
+                        tmp.resize(r.size());
+                        if (a == 0) r.decode_bases(tmp.data()); else if (a == 1) r.decode_pw(tmp.data()); else r.decode_ip(tmp.data());
+                        for (uint8_t x : tmp) { hsh ^= x; hsh *= 1099511628211ull; }
+                    }
                     std::printf("%d%s\t%d\t%zu\t%.2f,%.2f,%.2f,%.2f\t%016llx\n", zin.zm, zin.strand_tag == 1 ? "/fwd" : (zin.strand_tag == 2 ? "/rev" : ""), zin.host_status,
                                 zin.reads.size(), zin.snr[0], zin.snr[1], zin.snr[2], zin.snr[3], hsh);
                 }
@@ -663,7 +672,7 @@ int main(int argc, char **argv)
                 const bool more = !chunk_done && read_raw_chunk(in, *raw);
                 rd_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
                 if (failed) break;                                  // an engine / writer failure ends the run: stop feeding it
-                if (more) pending.push_back(pool.submit([raw] { return decode_chunk(*raw); }));
+                if (more) pending.push_back(pool.submit([raw] { return decode_chunk(std::shared_ptr<const RawChunk>(raw)); }));
                 while (!pending.empty() && (!more || pending.size() > (size_t)(2 * pool.size() + 4))) {
                     t0 = std::chrono::steady_clock::now();
                     auto recs = pending.front().get();
@@ -700,8 +709,9 @@ int main(int argc, char **argv)
         auto us_since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
         const bool kin = opt.o.hifi_kinetics != 0;
         std::vector<std::thread> packers;
-        std::atomic<int> packers_left{(int)(handles.size() * (size_t)opt.workers_per_gpu)};
-        for (size_t pk = 0; pk < handles.size() * (size_t)opt.workers_per_gpu; ++pk) packers.emplace_back([&] {
+        const size_t n_packers = std::max<size_t>(1, handles.size()) * (size_t)opt.workers_per_gpu;
+        std::atomic<int> packers_left{(int)n_packers};
+        for (size_t pk = 0; pk < n_packers; ++pk) packers.emplace_back([&] {
             std::shared_ptr<Batch> b;
             while (to_pack.pop(b)) {
                 auto t0 = now();
@@ -710,7 +720,7 @@ int main(int argc, char **argv)
                     pack(*b, *b->in_arena);
                     const int n = (int)b->zmw_id.size();
                     b->n = n;
-                    if (n > 0) {
+                    if (n > 0 && !opt.host_only) {
                         b->cb = ccsx_batch{n, (int32_t)b->flags.size(), b->n_bases, b->zmw_id.data(), b->snr.data(), b->read_off.data(),
                                            b->base_off.data(), b->bases, b->pw, b->ipd, b->flags.data()};
                         b->seq_off.resize(n + 1);
@@ -738,6 +748,24 @@ int main(int argc, char **argv)
             }
             if (--packers_left == 0) to_gpu.close();
         });
+
+        if (opt.host_only) {                                  // no engine: count what arrives, hand the staging back
+            int64_t nz = 0, nzok = 0, nbases = 0;
+            std::thread sink([&] {
+                std::shared_ptr<Batch> b;
+                while (to_gpu.pop(b)) { nz += (int64_t)b->zmws.size(); if (b->n > 0) { nzok += b->n; nbases += b->n_bases; } in_pool.put(std::move(b->in_arena)); }
+            });
+            reader.join();
+            for (auto &w : packers) w.join();
+            sink.join();
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            std::fprintf(stderr, "ccs: reader thread: framing/inflate %.2f s, waiting for record decode %.2f s, grouping+filters+queue %.2f s; packing (sum over %zu threads) %.2f s\n",
+                         rd_us[0] * 1e-6, rd_us[1] * 1e-6, rd_us[2] * 1e-6, n_packers, us_pack.load() * 1e-6);
+            std::printf("host-only: %" PRId64 " ZMWs read, %" PRId64 " packed (%" PRId64 " bases) in %.2f s = %.1f ZMWs/s on %d host threads + %zu pack threads\n", nz, nzok, nbases, el,
+                        nz / el, nthreads, n_packers);
+            if (failed) std::fprintf(stderr, "ccs: %s\n", err_msg.c_str());
+            return failed ? 1 : 0;
+        }
 
         // ---- GPU workers: one per device; up to three batches in flight through the asynchronous boundary
         std::vector<std::thread> workers;

@@ -551,3 +551,15 @@ def test_bgzf_crc_is_verified(built, tmp_path):
         assert p.returncode != 0 and "CRC32" in p.stderr, p.stderr
         p = subprocess.run([CCS, "--dump-zmws", str(bam)], capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
         assert p.returncode == 0 and len(p.stdout.splitlines()) == 20
+
+
+def test_host_only_pipeline_without_gpu(built, tmp_path):
+    """--host-only drives reader -> filters -> packing (the zero-copy subread views decode straight into the batch staging) with
+    no engine: every ZMW arrives, the packed base count is the generator's, a filter still counts its ZMWs as read."""
+    bam = tmp_path / "s.subreads.bam"
+    _run("--write-synthetic", "40,5,700,11", bam)
+    b = api.synth(40, 5, 700, seed=11)
+    out = _run("--host-only", "--batch-size", 16, "-j", 3, bam).stdout
+    assert f"host-only: 40 ZMWs read, 40 packed ({len(b.bases)} bases)" in out
+    out = _run("--host-only", "--min-passes", 6, bam).stdout
+    assert "host-only: 40 ZMWs read, 0 packed (0 bases)" in out
