@@ -346,7 +346,10 @@ def main():
                              "so ms_per_step < draft + align + polish + stitch; queue_ms = the batch waiting between the stages",
             "success_frac": ok / (args.zmws * args.steps), "mean_rq": rqsum / rqn if rqn else None, "consensus_bases": checks,
             "host": {"synth_s": round(job.gen_s, 2), "warmup_s": round(warm_s, 2), "unoverlapped_upload_s": round(upload_s, 3) if upload_s else None,
-                     "copies_hidden_frac": round(min(1.0, span_ms * 1e-3 / elapsed), 4)},
+                     "copies_hidden_frac": round(min(1.0, span_ms * 1e-3 / elapsed), 4),
+                     "bam_pipeline_note": "this bench feeds the engine from memory; the `ccs` driver's BAM side costs 0.85-0.94 CPU-s per 1000 ZMWs "
+                                          "(BGZF inflate 0.57), i.e. ~28 host cores per MI355X at the engine's rate: 17.0-18.8k ZMWs/s BAM->BAM and 24-28k for "
+                                          "the host side alone on this box's 16 usable threads (profiles/r03_cli_host_pipeline.txt, DESIGN.md 7)"},
             "head": git_head(),
         }
         cores = effective_cores()
