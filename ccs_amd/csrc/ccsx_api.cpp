@@ -188,8 +188,15 @@ void ccsx_free_pinned(void *p)
 static int create_impl(ccsx_handle h)
 {
     HIPTRY(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
-    HIPTRY(hipStreamCreateWithFlags(&h->s_comp, hipStreamNonBlocking));
+    // experiment knob (tools/r03_prio.sh): CCSX_STAGE_PRIO=draft|polish gives that stage's stream the device's highest priority
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char *pe = getenv("CCSX_STAGE_PRIO");
+    const int p_draft = (pe && !strcmp(pe, "draft")) ? prio_hi : prio_lo, p_polish = (pe && !strcmp(pe, "polish")) ? prio_hi : prio_lo;
+    if (pe) HIPTRY(hipStreamCreateWithPriority(&h->s_comp, hipStreamNonBlocking, p_polish));
+    else HIPTRY(hipStreamCreateWithFlags(&h->s_comp, hipStreamNonBlocking));
     if (h->opts.serial_stages) h->s_draft = h->s_comp;
+    else if (pe) HIPTRY(hipStreamCreateWithPriority(&h->s_draft, hipStreamNonBlocking, p_draft));
     else HIPTRY(hipStreamCreateWithFlags(&h->s_draft, hipStreamNonBlocking));
     HIPTRY(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
     HIPTRY(hipEventCreate(&h->ev_epoch));
