@@ -653,7 +653,7 @@ int ccsx_sync(ccsx_handle h)
         unsigned long long tot = 0;
         for (int i = 0; i < 7; ++i) tot += ph[i];
         for (int i = 0; i < 7; ++i) std::fprintf(stderr, "[ccsx phase] %-14s %6.2f %%  (%llu cycles)\n", nm[i], tot ? 100.0 * ph[i] / tot : 0.0, ph[i]);
-        static const char *pn[6] = {"poa load/chain", "poa dp", "poa traceback", "poa thread", "(between reads)", "poa consensus"};
+        static const char *pn[6] = {"thr setup+read", "thr traceback", "thr ids+zero", "thr records", "thr order", "thr col records"};
         unsigned long long pt = 0;
         for (int i = 8; i < 14; ++i) pt += ph[i];
         for (int i = 8; i < 14; ++i) std::fprintf(stderr, "[ccsx phase] %-14s %6.2f %%  (%llu cycles)\n", pn[i - 8], pt ? 100.0 * ph[i] / pt : 0.0, ph[i]);

@@ -30,6 +30,13 @@
 #define PHASE_T0() do { } while (0)
 #define PHASE(idx) do { } while (0)
 #endif
+#ifdef CCSX_PROFILE_PHASES                  // one-wave kernels: lane 0's cycle counter between phases, summed over the graphs
+#define TPH_T0() unsigned long long tph_t = __builtin_readcyclecounter(); (void)tph_t
+#define TPH(idx) do { if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd((unsigned long long *)P.phase + (idx), n_ - tph_t); tph_t = n_; } } while (0)
+#else
+#define TPH_T0() do { } while (0)
+#define TPH(idx) do { } while (0)
+#endif
 #ifdef CCSX_DEBUG_CHECKS
 #ifndef CCSX_CHK_MASK
 #define CCSX_CHK_MASK 0xff
@@ -755,6 +762,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     PoaSlot g = poa_slot(P, blockIdx.x);
     if (z0 + (int)blockIdx.x >= P.n_zmw) return;
     if (!g.st[ST_LIVE] || !g.st[ST_OK] || rr >= g.st[ST_NPOA]) return;
+    TPH_T0();
     const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);
     const int r0 = rfl(P.read_off[z]);
     const int bb = rfl(g.st[ST_BB]), nreads = rfl(g.st[ST_NREADS]), npoa = rfl(g.st[ST_NPOA]);
@@ -770,6 +778,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     int32_t *order = g.st[ST_PAR] ? g.order1 : g.order0, *order_nx = g.st[ST_PAR] ? g.order0 : g.order1;
     load_read_packed(sread, rb, I, rev, lane);
     __syncthreads();
+    TPH(8);
     // ---- traceback: lane 0 walks, the block of TB_BLOCK positions it is in is cached in LDS.  Round 3: the per-position words come
     // from the DP's column record (base, in-edge count and the positions of in-edges 0..2 by position: no vertex-record gather), and
     // the NEXT block (the walk goes down the positions) is fetched into registers while the current one is walked
@@ -849,6 +858,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (int q = lane; q < i; q += LANES) g.pathv[q] = -1;     // leading insertions at START
     }
     __threadfence_block();
+    TPH(9);
     // ---- thread the read into the graph (wave-parallel; identical result to the serial list insertion)
     int32_t *cnt = g.bestK;
     int carry = 0;
@@ -864,6 +874,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (n0 + nnew > vcap) { if (lane == 0) g.st[ST_OK] = 0; return; }
     for (int q = lane; q <= n0; q += LANES) cnt[q] = 0;
     __threadfence_block();
+    TPH(10);
     int lastEx = -1;
     for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 2: records, edges, run counts
         const int i = c0 + lane;
@@ -896,6 +907,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         lastEx = li > lastEx ? li : lastEx;
     }
     __threadfence_block();
+    TPH(11);
     carry = 0;
     for (int c0 = 0; c0 <= n0; c0 += LANES) {                      // inclusive prefix sum of run counts
         const int q = c0 + lane;
@@ -934,7 +946,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (lane == 0) { g.st[ST_N] = n; g.st[ST_NADDED] += 1; g.st[ST_PAR] ^= 1; }
     // ---- the column records of the next pass's DP; after the last pass k_poa_finish walks them
     (void)npoa;
+    TPH(12);
     poa_column_records(g, order_nx, n, lane);
+    TPH(13);
 }
 
 // ---- k_poa_finish: consensus (heaviest path), draft, window bounds.  One wave per graph.
