@@ -2228,19 +2228,39 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                             LR = lane_mut(type, (type == 2) ? J - cpos : J - 1 - cpos, 3 - x, sT[1], J, lfr, sDL);
                         } else { LF = lane_mut(0, 0, 0, sT[0], J, lf, sDL); LR = LF; }
                     }
-                    const int k1 = two ? k0 + 1 : k0;
+                    int dq;
+                    if (!two) {
+                        // a single unit (the usual case with four reads per chunk and one block of lanes): one chain, and none of the
+                        // second chain's set-up
+                        const int ra = rl(vR, k0), Ia = rl(vI, k0);
+                        const LaneMut La = rl(vSt, k0) ? LR : LF;
+                        const int gA_ = rl(vG, k0), bA_ = rl(vB, k0);
+                        const int dA = Ia > J ? Ia - J : J - Ia, WrA = SCORE_BAND + (dA > 2 ? dA - 2 : 0);
+                        const int nrA = (Ia < 2 * WrA ? Ia : 2 * WrA) + 1;
+                        const int i0a = band_row0(La.c, Ia, 2 * J, invJ2, J, WrA, nrA);
+                        lds_cc tAa = (lds_cc)(sCTX + La.kA), tBa = (lds_cc)(sCTX + La.kB);
+                        ScoreChain ca;
+                        ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
+                        ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, S) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, S) + La.q); ca.bq = *ca.be; ca.be += S;
+                        ca.op = (lds_cu16)(&sObs[ra][0] + i0a);
+                        asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(tAa), "+v"(tBa), "+v"(ca.op));
+                        for (int ia = 0; ia < nrA; ++ia) score_step(ca, La, tAa, tBa, S);
+                        const float res = La.fin ? ca.b : ca.acc;
+                        dq = dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k0)));
+                    } else {
+                    const int k1 = k0 + 1;
                     const int ra = rl(vR, k0), rb = rl(vR, k1);
-                    const int Ia = rl(vI, k0), Ib = two ? rl(vI, k1) : -1;
+                    const int Ia = rl(vI, k0), Ib = rl(vI, k1);
                     const LaneMut La = rl(vSt, k0) ? LR : LF;
-                    const LaneMut Lb = (two && rl(vSt, k1)) ? LR : LF;
+                    const LaneMut Lb = rl(vSt, k1) ? LR : LF;
                     const int gA_ = rl(vG, k0), bA_ = rl(vB, k0), gB_ = rl(vG, k1), bB_ = rl(vB, k1);
                     // SPEC "banded link": every lane scores the rows around its column's point on the window diagonal only
                     const int dA = Ia > J ? Ia - J : J - Ia, WrA = SCORE_BAND + (dA > 2 ? dA - 2 : 0);
                     const int nrA = (Ia < 2 * WrA ? Ia : 2 * WrA) + 1;
                     const int dB = Ib > J ? Ib - J : J - Ib, WrB = SCORE_BAND + (dB > 2 ? dB - 2 : 0);
-                    const int nrB = two ? (Ib < 2 * WrB ? Ib : 2 * WrB) + 1 : 0;
+                    const int nrB = (Ib < 2 * WrB ? Ib : 2 * WrB) + 1;
                     const int i0a = band_row0(La.c, Ia, 2 * J, invJ2, J, WrA, nrA);
-                    const int i0b = two ? band_row0(Lb.c, Ib, 2 * J, invJ2, J, WrB, nrB) : 0;
+                    const int i0b = band_row0(Lb.c, Ib, 2 * J, invJ2, J, WrB, nrB);
                     lds_cc tAa = (lds_cc)(sCTX + La.kA), tBa = (lds_cc)(sCTX + La.kB);
                     lds_cc tAb = (lds_cc)(sCTX + Lb.kA), tBb = (lds_cc)(sCTX + Lb.kB);
                     ScoreChain ca, cb;
@@ -2260,14 +2280,14 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     }
                     for (int ia = i; ia < nrA; ++ia) score_step(ca, La, tAa, tBa, S);
                     for (int ib = i; ib < nrB; ++ib) score_step(cb, Lb, tAb, tBb, S);
-                    int dq;
                     {
                         const float res = La.fin ? ca.b : ca.acc;
                         dq = dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k0)));
                     }
-                    if (two) {
+                    {
                         const float res = Lb.fin ? cb.b : cb.acc;
                         dq += dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k1)));
+                    }
                     }
                     if (mval) atomicAdd(&sDeltaI[myM], dq);
                 }
