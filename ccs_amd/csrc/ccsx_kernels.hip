@@ -1537,16 +1537,16 @@ __global__ void k_post(KParams P, int pass)
 // ------------------------------------------------------------------------------------------------
 // A1-A7 + step 7: Arrow polish of one window per workgroup (PW_THREADS = 4 waves).
 //
-// v3.  LDS holds: sCTX[obs][ctx] = (ME, INS) as float2 — 16 contexts = 16 distinct 8-byte slots, so a wave's
-// ds_read_b64 with a uniform obs row is bank-conflict free by construction; per-column copies sMI[strand][j][obs]
-// (row stride 13) for the fill; gamma/beta of one chunk of reads (sGB, even row stride: the fill's lane = row stores step by
-// S - 1 words from lane to lane, the scoring's lane = column loads by 1: both conflict free).  Fill: two reads per wave (lanes 0-31 / 32-63, lane = read
-// row) when both have <= 31 bases, alpha and beta swept in the same anti-diagonal loop (two independent dependency
-// chains), neighbours via DPP wave shifts.  Candidate filter (docs/how-does-ccs-work.md:80-83): the step-3 alignments'
-// dirty bits give a per-position pile-up margin; unambiguous non-homopolymer positions enumerate no mutations.
-// Scoring: a pool of (64 compacted mutation lanes) x (pair of usable reads) tasks over the waves, serial over read rows
-// exactly as the SPEC orders the operations; per-read gains are summed in 2^-16 fixed point with LDS integer atomics, so
-// the sum does not depend on which wave scored which read.
+// v4 (round 3).  LDS holds: sCTX[obs][ctx] = (ME, INS) as float2, 33 entries per observation row (16 contexts, 16 copies with INS = 0,
+// one zero entry; row 12 = all zeros); per-column entries (DL, offset of the column's context in a row of sCTX) — plain (sColJ, for
+// a long read's sweep) and staggered for the software-pipelined sweeps of a pair (sEA / sEB); gamma/beta of one chunk of FOUR reads
+// (sGB, even row stride: the fill's lane = row stores step by S - 1 words from lane to lane, the scoring's lane = column loads by 1:
+// both conflict free).  Fill: lane = read row, anti-diagonal sweep, neighbours via DPP wave shifts; two short reads per wave (lanes
+// 0-31 / 32-63); a chunk's two pair tasks run as four alpha-only / beta-only sweeps, one per wave.  Candidate filter
+// (docs/how-does-ccs-work.md:80-83): the step-3 alignments' dirty bits give a per-position pile-up margin; unambiguous
+// non-homopolymer positions enumerate no mutations.  Scoring: a pool of (64 compacted mutation lanes) x (usable read) units over the
+// waves, serial over read rows exactly as the SPEC orders the operations; per-read gains are summed in 2^-16 fixed point with LDS
+// integer atomics, so the sum does not depend on which wave scored which read.
 #ifndef PW_THREADS
 #define PW_THREADS 256                // 4 waves.  Measured on the 10 x 10 kb workload (ms per 2048 ZMWs): 256 threads x 3 workgroups/CU 95,
 #endif                                //   512 x 2 (all ten reads in one LDS chunk) 101-103, 256 x 2 141, 320 x 2 208: resident waves per CU decide
@@ -2025,8 +2025,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const int oc = (row < I) ? (int)sObs[myr][row] : OBS_CODE(12);                  // o_i;     12 = no base: row I emits nothing more
                 const char *rowA = (const char *)sCTX + op, *rowB = (const char *)sCTX + oc;
                 // activity windows: alpha computes column j = t - row for t in [row, row+J]; beta computes column
-                // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step; two steps per
-                // loop iteration, so the second step's addresses are immediates and no state has to be copied between registers.
+                // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step, so the steps of
+                // an iteration address with immediates.
                 const int tA0 = rowok ? row : (1 << 20), tB0 = rowok ? I - row : (1 << 20);
                 const float one0 = (row == 0) ? 1.0f : 0.0f, oneI = (row == I) ? 1.0f : 0.0f;
                 const int2 *cA = CJ - row;
