@@ -751,3 +751,28 @@ def test_partial_passes_are_realigned_after_a_redraft(built):
             assert (res.np_ == 6).all() and (res.ec < 6.01).all()     # the B passes serve no window of the A consensus
         finally:
             h.close()
+
+
+def test_corruption_fuzz_sample(built):
+    """A fixed sample of tools/corruption_fuzz.py inside the suite (the 900-batch runs are in profiles/): passes damaged the way real
+    subreads are — foreign blocks, missing stretches, junk, truncation, partial passes, low-complexity / off-model templates — under
+    random option sets; every field bit-exact against the oracle.  Seeds 9000.. include the batch that exposed the stale partial-pass
+    alignment of round 3."""
+    import corruption_fuzz as F
+    seen_status = np.zeros(16, np.int64)
+    for k in range(28):
+        batch, o, n, lmax, ncorr, npass = F.make_batch(k, 9000)
+        h = api.Handle(0, opts=o)
+        try:
+            res = h.consensus(batch)
+            ref = api.Results.allocate(batch, kinetics=bool(o.hifi_kinetics))
+            O.consensus_batch(h.model, o, batch, ref, nthreads=8)
+            for f in ("status", "seq_len", "np_", "iters", "fn", "rn", "rq", "ec"):
+                assert np.array_equal(getattr(res, f), getattr(ref, f)), f"batch {k}: {f} differs"
+            for z in range(n):
+                assert np.array_equal(res.sequence(z), ref.sequence(z)) and np.array_equal(res.quals(z), ref.quals(z)) and np.array_equal(res.raw(z), ref.raw(z)), f"batch {k} zmw {z}"
+                if o.hifi_kinetics: assert np.array_equal(res.kinetics(z), ref.kinetics(z)), f"batch {k} zmw {z}: kinetics"
+            seen_status += np.bincount(res.status, minlength=16)[:16]
+        finally:
+            h.close()
+    assert seen_status[0] > 100 and (seen_status[1:] > 0).sum() >= 3       # successes and at least three kinds of failure were compared

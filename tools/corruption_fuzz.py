@@ -10,12 +10,9 @@ import numpy as np
 from ccs_amd import api
 import oracle_lib as O
 
-nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-k0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # first batch (to reproduce one batch of a longer run)
-verbose = len(sys.argv) > 4
-bad = 0
-for k in range(k0, k0 + nb):
+
+def make_batch(k, seed0):
+    """batch k of the fuzz with seed seed0: (batch, opts, ZMWs, lmax, corrupted passes, passes) - also used by tests/test_gpu_parity.py"""
     rng = np.random.default_rng(seed0 + k)
     n = int(rng.integers(8, 40))
     lmax = int(rng.choice([300, 1500, 4000, 12000]))
@@ -69,27 +66,42 @@ for k in range(k0, k0 + nb):
     o.max_insertion_size = int(rng.choice([0, 30, 10, 5, -1])); o.no_fallback_draft = int(rng.random() < 0.25)
     o.disable_heuristics = int(rng.random() < 0.2); o.hifi_kinetics = int(rng.random() < 0.4); o.max_poa_cov = int(rng.choice([3, 5, 7]))
     o.min_rq = float(rng.choice([0.99, 0.9, 0.0]))
-    h = api.Handle(0, opts=o)
-    t0 = time.time(); res = h.consensus(batch); tg = time.time() - t0
-    ref = api.Results.allocate(batch, kinetics=bool(o.hifi_kinetics))
-    t0 = time.time(); O.consensus_batch(h.model, o, batch, ref, nthreads=16); tc = time.time() - t0
-    ok = all(np.array_equal(getattr(res, f), getattr(ref, f)) for f in ("status", "seq_len", "np_", "iters", "fn", "rn", "rq", "ec"))
-    for z in range(n):
-        if not ok: break
-        ok = np.array_equal(res.sequence(z), ref.sequence(z)) and np.array_equal(res.quals(z), ref.quals(z)) and np.array_equal(res.raw(z), ref.raw(z))
-        if ok and o.hifi_kinetics: ok = np.array_equal(res.kinetics(z), ref.kinetics(z))
-    if verbose and not ok:
-        for f in ("status", "seq_len", "np_", "iters", "fn", "rn", "rq", "ec"):
-            a, b = getattr(res, f), getattr(ref, f)
-            if not np.array_equal(a, b): print("  ", f, "gpu", a[a != b][:8], "cpu", b[a != b][:8], "zmws", np.nonzero(a != b)[0][:8])
+    return batch, o, n, lmax, ncorr, int(base.read_off[-1])
+
+
+def main():
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+    k0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # first batch (to reproduce one batch of a longer run)
+    verbose = len(sys.argv) > 4
+    bad = 0
+    for k in range(k0, k0 + nb):
+        batch, o, n, lmax, ncorr, npass = make_batch(k, seed0)
+        h = api.Handle(0, opts=o)
+        t0 = time.time(); res = h.consensus(batch); tg = time.time() - t0
+        ref = api.Results.allocate(batch, kinetics=bool(o.hifi_kinetics))
+        t0 = time.time(); O.consensus_batch(h.model, o, batch, ref, nthreads=16); tc = time.time() - t0
+        ok = all(np.array_equal(getattr(res, f), getattr(ref, f)) for f in ("status", "seq_len", "np_", "iters", "fn", "rn", "rq", "ec"))
         for z in range(n):
-            if not np.array_equal(res.sequence(z), ref.sequence(z)):
-                nr = int(batch.read_off[z + 1] - batch.read_off[z]); r0 = int(batch.read_off[z])
-                print("   zmw", z, "seq differs; passes", nr, "lens", np.diff(batch.base_off[r0:r0 + nr + 1]).tolist(), "flags", batch.flags[r0:r0 + nr].tolist(), "status", res.status[z], ref.status[z])
-    st = np.bincount(res.status, minlength=10)
-    print(f"batch {k} n {n} lmax {lmax} corrupted passes {ncorr}/{int(base.read_off[-1])} maxins {o.max_insertion_size} nofb {o.no_fallback_draft} "
-          f"noheur {o.disable_heuristics} kin {o.hifi_kinetics} cov {o.max_poa_cov}: {'OK ' if ok else 'MISMATCH'} status {st.tolist()} gpu {tg:.2f}s cpu {tc:.1f}s", flush=True)
-    bad += 0 if ok else 1
-    h.close()
-print("FAILED" if bad else "ALL BIT-EXACT")
-sys.exit(1 if bad else 0)
+            if not ok: break
+            ok = np.array_equal(res.sequence(z), ref.sequence(z)) and np.array_equal(res.quals(z), ref.quals(z)) and np.array_equal(res.raw(z), ref.raw(z))
+            if ok and o.hifi_kinetics: ok = np.array_equal(res.kinetics(z), ref.kinetics(z))
+        if verbose and not ok:
+            for f in ("status", "seq_len", "np_", "iters", "fn", "rn", "rq", "ec"):
+                a, b = getattr(res, f), getattr(ref, f)
+                if not np.array_equal(a, b): print("  ", f, "gpu", a[a != b][:8], "cpu", b[a != b][:8], "zmws", np.nonzero(a != b)[0][:8])
+            for z in range(n):
+                if not np.array_equal(res.sequence(z), ref.sequence(z)):
+                    nr = int(batch.read_off[z + 1] - batch.read_off[z]); r0 = int(batch.read_off[z])
+                    print("   zmw", z, "seq differs; passes", nr, "lens", np.diff(batch.base_off[r0:r0 + nr + 1]).tolist(), "flags", batch.flags[r0:r0 + nr].tolist(), "status", res.status[z], ref.status[z])
+        st = np.bincount(res.status, minlength=10)
+        print(f"batch {k} n {n} lmax {lmax} corrupted passes {ncorr}/{npass} maxins {o.max_insertion_size} nofb {o.no_fallback_draft} "
+              f"noheur {o.disable_heuristics} kin {o.hifi_kinetics} cov {o.max_poa_cov}: {'OK ' if ok else 'MISMATCH'} status {st.tolist()} gpu {tg:.2f}s cpu {tc:.1f}s", flush=True)
+        bad += 0 if ok else 1
+        h.close()
+    print("FAILED" if bad else "ALL BIT-EXACT")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
