@@ -1480,7 +1480,45 @@ __global__ __launch_bounds__(64) void k_rescue(KParams P, int pass)
         }
         const int wbest = rfl(wave_max_i32(best));
         const int ks = rfl(wave_min_i32(best == wbest ? bk : (1 << 30)));
-        if (wbest <= NEGV / 2 || wbest < Ld) continue;            // no valid split
+        if (wbest <= NEGV / 2 || wbest < Ld) {
+            // SPEC "double split" (v4): no single split column carries the pass (two insertions the band cannot follow).  It is used
+            // as a prefix up to the edge column with the largest forward column maximum and a suffix from the edge column with the
+            // largest reverse one (first on ties in the direction of each DP, as for partial passes), iff there are edge columns in
+            // between, the parts share no read rows and each scores at least 1.0 per covered base; the edges in between get entry
+            // rows that make every window touching them unusable for this pass (negative, or longer than the pass)
+            int bF = NEGV, kF = 1 << 30, bR = NEGV, kR = 1 << 30;
+            for (int k = 1 + lane; k < nneed; k += LANES) {
+                const int cf = cmF[k], cr = cmR[k];
+                if (cf > NEGV / 2 && cf > bF) { bF = cf; kF = k; }
+                if (cr > NEGV / 2 && cr > bR) { bR = cr; kR = k; }
+            }
+            const int wF = rfl(wave_max_i32(bF)), wR = rfl(wave_max_i32(bR));
+            if (wF <= NEGV / 2 || wR <= NEGV / 2) continue;
+            const int k1 = rfl(wave_min_i32(bF == wF ? kF : (1 << 30))), kr = rfl(wave_min_i32(bR == wR ? kR : (1 << 30)));
+            const int k2 = nneed - 1 - kr;
+            const int s1 = need_col(wb, nw, Ld, k1), s2r = Ld - need_col(wb, nw, Ld, k2);
+            if (!(k1 < k2 && s1 > 0 && s2r > 0 && wF >= s1 && wR >= s2r && brF[k1] + brR[kr] <= I)) continue;
+            if (lane == 0) {
+                int32_t *ent = P.ent + P.ent_off[r];
+                uint32_t *dm = P.dmask + P.ent_off[r];
+                const int2 *OMF = (const int2 *)OsF, *OMR = (const int2 *)OsR;
+                int e = ebF[k1];
+                ent[k1] = e;
+                for (int kq = k1; kq >= 2; --kq) { e = OMF[(size_t)kq * 64 + (e - loF[kq])].x; ent[kq - 1] = e; }
+                ent[0] = 0;
+                int er = ebR[kr];
+                ent[k2] = I - er;
+                for (int kq = kr; kq >= 1; --kq) {
+                    er = (kq >= 2) ? OMR[(size_t)kq * 64 + (er - loR[kq])].x : 0;
+                    ent[nneed - kq] = I - er;
+                }
+                for (int kq = k1 + 1; kq < k2; ++kq) ent[kq] = -(1 << 20) - 64 * kq;
+                dm[0] = 0u;
+                for (int kq = 1; kq < nneed; ++kq) dm[kq] = 0x7fffffffu;
+                P.avalid[r] = 1; P.ascore[r] = wF + wR;
+            }
+            continue;
+        }
         if (lane == 0) {
             int32_t *ent = P.ent + P.ent_off[r];
             uint32_t *dm = P.dmask + P.ent_off[r];

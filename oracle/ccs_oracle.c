@@ -36,7 +36,7 @@
 #endif
 
 /* ---------------- specification constants (same values as include/ccsx.h) -------------- */
-#define ORC_SPEC_VERSION 3  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
+#define ORC_SPEC_VERSION 4  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
 int orc_spec_version(void) { return ORC_SPEC_VERSION; }
 #define BAND      64
 #define ALIGN_BAND1 16      /* rows of the FIRST attempt of the subread -> draft alignment (step 3); BAND rows on failure */
@@ -626,6 +626,30 @@ int orc_align_rescue(const uint8_t *r, int I, const uint8_t *d, int Ld, const in
         trace_entries(mvR, loR, Ld - s, brR[Ld - s], rsR);
         for (int c = s + 1; c <= Ld; ++c) rstart[c] = I - rsR[Ld - c];
         if (dirty) memset(dirty, 1, Ld);
+    } else {
+        /* SPEC "double split" (v4; docs/how-does-ccs-work.md:74-78 speaks of large insertionS): no single split column carries the
+         * pass — e.g. two insertions the band cannot follow.  The forward alignment is good up to its first large insertion, the
+         * reverse one back to the last: the pass is used as a PREFIX up to the window-edge column s1 with the largest forward column
+         * maximum and a SUFFIX from the edge column s2 with the largest reverse column maximum (first on ties in the direction of
+         * each DP, as for partial passes), iff s1 < s2, the two parts do not share read rows (bestrow_F(s1) + bestrow_R(Ld - s2) <= I)
+         * and each scores at least 1.0 per covered draft base.  The edge columns in between get entry rows that make every window
+         * touching them unusable for this pass (a negative segment, or one longer than the pass); every position counts as dirty. */
+        int32_t bF = NEG, bR = NEG; int s1 = -1, s2r = -1;
+        for (int k = 1; k < nneed; ++k) { int c = need[k]; if (cmF[c] > NEG / 2 && cmF[c] > bF) { bF = cmF[c]; s1 = c; } }
+        for (int k = 1; k < nneed; ++k) { int c = Ld - need[nneed - 1 - k]; if (cmR[c] > NEG / 2 && cmR[c] > bR) { bR = cmR[c]; s2r = c; } }
+        if (s1 > 0 && s2r > 0 && s1 < Ld - s2r && bF >= s1 && bR >= s2r && brF[s1] + brR[s2r] <= I) {
+            valid = 1;
+            const int s2 = Ld - s2r;
+            if (score_out) *score_out = bF + bR;
+            orc_cnt[CNT_SPLIT2] += 1;
+            for (int j = 0; j <= Ld; ++j) rstart[j] = -1;
+            trace_entries(mvF, loF, s1, brF[s1], rstart);
+            for (int j = 0; j <= s2r; ++j) rsR[j] = -1;
+            trace_entries(mvR, loR, s2r, brR[s2r], rsR);
+            for (int c = s2; c <= Ld; ++c) rstart[c] = I - rsR[Ld - c];
+            for (int c = s1 + 1; c < s2; ++c) rstart[c] = -(1 << 20) - c;
+            if (dirty) memset(dirty, 1, Ld);
+        }
     }
     free(rr); free(dr); free(loF); free(mvF); free(rsR);
     return valid;
@@ -1317,7 +1341,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                 if (!avalid[r]) continue;
                 int a = rstart[r][ws], b = rstart[r][we], L = (int)(base_off[r + 1] - base_off[r]);
                 int n = b - a;
-                if (n < 0) continue;
+                if (n < 0 || n > L) continue;                /* (entry rows are rows of this pass: anything else is not a segment) */
                 if (n <= IMAX) Ikin[r] = n;                  /* the kinetics always see the untrimmed segment */
                 int na = strand[r] ? L - b : a;              /* native start of the segment */
                 const uint8_t *bb = bases + base_off[r] + na, *pp = pw + base_off[r] + na;

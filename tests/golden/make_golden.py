@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/golden_v3.npz: inputs + expected outputs of the hot path at SPEC version 3.
+"""Generates tests/golden/golden_v4.npz: inputs + expected outputs of the hot path at SPEC version 4.
 
 The reference mount is documentation-only (no source, binary or test vectors: SURVEY.md §0/§8c), so these
 vectors come from this repository's own CPU restatement (oracle/ccs_oracle.c, "parity unpinned") at the
@@ -72,6 +72,11 @@ def cases():
     yield "retry64", with_blocks(api.synth(2, 6, 1500, seed=98), {(0, 5): (0.5, 12), (1, 3): (0.6, 14)}, rng), {"retry64": 1}
     yield "lowcx", lowcx.make(3, 10, (1500, 3000), 401, tpl="lowcx"), {"nonconv_win": 1}
     yield "partial", T.partial_pass_batch(n=2, seed=58, nfull=5, length=(800, 1500)), {"partial_used": 4}
+    import test_oracle_filter as TF
+    yield "split2", TF._two_block_batch(sizes=(250, 250, 250), fr=(0.2, 0.5, 0.8))[1], {"split2": 2}     # SPEC v4: three blocks per pass
+
+
+PATH_KEYS = O.COUNT_NAMES[:11] + ["split2"]          # = tests/golden_util.py PATHS
 
 
 def main():
@@ -92,14 +97,14 @@ def main():
         for k in ("seq_off", "status", "seq_len", "seq", "qual", "raw_qv", "rq", "np_", "ec", "iters", "n_windows", "fn", "rn"):
             out[f"{name}/out/{k}"] = getattr(r, k)
         out[f"{name}/draft0"] = O.poa_draft(b, 0, o.max_poa_cov)
-        out[f"{name}/paths"] = np.array([c[k] for k in O.COUNT_NAMES[:11]], np.int64)
+        out[f"{name}/paths"] = np.array([c[k] for k in PATH_KEYS], np.int64)
         names.append(name)
-        print(f"{name:12s} zmws {b.n_zmw} status {r.status.tolist()} paths {{{', '.join(f'{k} {c[k]}' for k in O.COUNT_NAMES[:11] if c[k])}}}")
+        print(f"{name:12s} zmws {b.n_zmw} status {r.status.tolist()} paths {{{', '.join(f'{k} {c[k]}' for k in PATH_KEYS if c[k])}}}")
     out["model_bytes"] = np.frombuffer(bytes(m), np.uint8)
     out["spec_version"] = np.array([O.spec_version()], np.int32)
     out["cases"] = np.array(names)
-    np.savez_compressed(os.path.join(HERE, "golden_v3.npz"), **out)
-    print("wrote golden_v3.npz with", len(out), "arrays, SPEC version", O.spec_version())
+    np.savez_compressed(os.path.join(HERE, "golden_v4.npz"), **out)
+    print("wrote golden_v4.npz with", len(out), "arrays, SPEC version", O.spec_version())
 
 
 if __name__ == "__main__":

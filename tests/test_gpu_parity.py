@@ -776,3 +776,31 @@ def test_corruption_fuzz_sample(built):
         finally:
             h.close()
     assert seen_status[0] > 100 and (seen_status[1:] > 0).sum() >= 3       # successes and at least three kinds of failure were compared
+
+
+def test_double_split_matches_oracle(handle):
+    """SPEC "double split" (v4) on the GPU (k_rescue): passes with three foreign blocks serve the windows before the first and after the
+    last block, ec shows the gap (two blocks: the ordinary split and the band's recovery); bit-exact against the oracle, with and
+    without kinetics (which see the same windows)"""
+    from test_oracle_filter import _two_block_batch
+    for sizes, fr, want in (((250, 250, 250), (0.2, 0.5, 0.8), "split2"), ((300, 200, 400), (0.15, 0.45, 0.75), "split2"), ((90, 140), (0.3, 0.7), "split")):
+        base, batch = _two_block_batch(sizes=sizes, fr=fr)
+        O.counts_reset()
+        ref = _oracle(handle, batch)
+        assert O.counts()[want] == 2
+        res = handle.consensus(batch)
+        _compare(res, ref, batch)
+        assert res.status[1] == 0 and res.np_[1] >= 6 and 6.2 < res.ec[1] < 7.8
+    o = api.default_opts(); o.hifi_kinetics = 1
+    hk = api.Handle(0, opts=o)
+    try:
+        base, batch = _two_block_batch(sizes=(250, 250, 250), fr=(0.2, 0.5, 0.8))
+        batch.ipd = np.random.default_rng(5).integers(0, 256, len(batch.bases)).astype(np.uint8)
+        res = hk.consensus(batch)
+        ref = api.Results.allocate(batch, kinetics=True)
+        O.consensus_batch(hk.model, o, batch, ref, nthreads=4)
+        _compare(res, ref, batch)
+        for z in range(batch.n_zmw):
+            assert np.array_equal(res.kinetics(z), ref.kinetics(z))
+    finally:
+        hk.close()

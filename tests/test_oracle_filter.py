@@ -285,3 +285,52 @@ def test_fallback_draft_rescues_a_zmw_whose_first_pass_is_junk(built):
     allj = api.synth(2, 5, 600, seed=96)
     allj.bases[:] = np.random.default_rng(3).integers(0, 4, len(allj.bases), dtype=np.uint8)
     assert set(int(s) for s in _run(allj).status) <= {2, 3}
+
+
+def _two_block_batch(seed=90, sizes=(90, 140), zmw=1, reads=(2, 5), fr=(0.3, 0.7)):
+    """ZMW `zmw` of a clean 8-pass batch: the given passes carry TWO foreign blocks each (at 30 % and 70 % of the pass)"""
+    rng = np.random.default_rng(seed + 7)
+    base = api.synth(3, 8, 2000, seed=seed)
+    bases, pw, ipd, off = [], [], [], [0]
+    for r in range(int(base.read_off[-1])):
+        a, b = int(base.base_off[r]), int(base.base_off[r + 1])
+        bb, pp, ii = base.bases[a:b], base.pw[a:b], base.ipd[a:b]
+        z = int(np.searchsorted(base.read_off, r, side="right") - 1)
+        if z == zmw and (r - int(base.read_off[z])) in reads:
+            L0 = len(bb)
+            for f, size in sorted(zip(fr, sizes), reverse=True):       # back to front: the first position stays valid
+                at = int(L0 * f)
+                blk = rng.integers(0, 4, size, dtype=np.uint8)
+                bb = np.concatenate([bb[:at], blk, bb[at:]]); pp = np.concatenate([pp[:at], np.full(size, 2, np.uint8), pp[at:]])
+                ii = np.concatenate([ii[:at], np.full(size, 5, np.uint8), ii[at:]])
+        bases.append(bb); pw.append(pp); ipd.append(ii); off.append(off[-1] + len(bb))
+    return base, api.Batch(base.zmw_id, base.snr, base.read_off, np.array(off, np.int64), np.concatenate(bases), np.concatenate(pw),
+                           np.concatenate(ipd), base.flags, base.tpl_off, base.tpl)
+
+
+def test_several_large_insertions_in_one_pass(built):
+    """docs/how-does-ccs-work.md:74-78 speaks of large insertionS.  TWO blocks the band cannot follow: the band finds the path again
+    after each block (it moves two rows per column), the ordinary split takes out the costlier one, the z-score gate drops the
+    windows the pass got wrong — the pass stays a pass and serves most windows.  THREE blocks: no single split column reaches 1.0
+    per base; SPEC "double split" (v4) keeps the stretch before the first block (forward alignment) and after the last (reverse
+    alignment) and no window in between.  The consensus is the clean one either way, the other ZMWs do not notice."""
+    base, batch = _two_block_batch()
+    O.counts_reset()
+    clean, res = _run(base), _run(batch)
+    c = O.counts()
+    assert c["split"] == 2 and c["split2"] == 0
+    assert res.status[1] == 0 and res.np_[1] == 8 and res.ec[1] > 7.0
+    assert _edit_errors(batch, res) <= _edit_errors(base, clean) + 3                # (the stretch the band needs to find the path again is misaligned)
+    for z in (0, 2):
+        assert np.array_equal(res.sequence(z), clean.sequence(z))
+    base, batch = _two_block_batch(sizes=(250, 250, 250), fr=(0.2, 0.5, 0.8))
+    O.counts_reset()
+    res = _run(batch)
+    c = O.counts()
+    assert c["split2"] == 2 and c["split"] == 0
+    assert res.status[1] == 0 and 6 <= res.np_[1] <= 8 and 6.3 < res.ec[1] < 7.7   # both passes serve the windows outside their blocks
+    assert _edit_errors(batch, res) <= _edit_errors(base, clean) + 6                # (between the blocks the ZMW is a six-pass ZMW)
+    for z in (0, 2):
+        assert np.array_equal(res.sequence(z), clean.sequence(z))
+    never = _run(batch, max_insertion_size=-1)
+    assert never.status[1] == 0 and abs(never.ec[1] - res.ec[1]) < 0.2             # (nothing to trim: the blocks' windows do not see the pass)
