@@ -967,31 +967,75 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     int Ld = 0, nw = 0, stat = -1;
     if (ok && n > 0) {
         int kbest = -1, sb = NEGV, best_prev = 0;
+        // Forward pass, 64 columns at a time.  Most columns continue a chain (one in-edge, from the position before): along a chain the
+        // heaviest-path weight is a prefix sum of the columns' own weights.  So a block needs ONE wave scan of the weights, a serial
+        // (wave-uniform) resolution of its chain HEADS only — columns with no / several in-edges or an in-edge from elsewhere —
+        // and two ds_bpermute to hand every column its head's value.  Integer arithmetic: the same numbers as the column-by-column walk.
         for (int kb = 0; kb < n; kb += LANES) {
             const int kkL = kb + lane;
             int4 cL = make_int4(0, -1, -1, -1);
             if (kkL < n) cL = g.crec[kkL];
             const int nblk = (n - kb) < LANES ? (n - kb) : LANES;
-            int myBest = 0, myBp = -1;
-            for (int j = 0; j < nblk; ++j) {
+            const int npL = (cL.x >> 8) & 15;
+            const int wL = kkL < n ? 2 * ((cL.x >> CREC_NREADS_SHIFT) & 127) - nadded : 0;
+            const int Pw = wave_scan_add_i32(wL);                                  // inclusive prefix sum of the block's weights
+            const bool headL = kkL < n && (lane == 0 || npL != 1 || cL.y != kkL - 1);
+            unsigned long long heads = __ballot(headL);
+            const unsigned long long headmask = heads;
+            int hb = 0, bpv = kkL - 1;                                             // lane h: value / back pointer of head h (chain columns: the position before)
+            while (heads) {
+                const int j = (int)__ffsll((long long)heads) - 1;
+                heads &= heads - 1;
                 const int k = kb + j;
-                const int cx = rl(cL.x, j);
-                const int np = (cx >> 8) & 15, nr = (cx >> CREC_NREADS_SHIFT) & 127;
+                const int np = rl(npL, j);
                 int b = 0, p = -1;
                 for (int q = 0; q < np; ++q) {
                     int pu;
                     if (q < 3) pu = q == 0 ? rl(cL.y, j) : (q == 1 ? rl(cL.z, j) : rl(cL.w, j));
                     else { const int v = rfl(order[k]); pu = rfl(g.rank[g.predx[v * 5 + (q - 3)]]); }
                     CHK(pu >= 0 && pu < k, 108);
-                    const int bu = pu == k - 1 ? best_prev : ((pu >= kb) ? rl(myBest, pu - kb) : rfl(g.bestK[pu]));
+                    int bu;
+                    if (pu >= kb) {                                                // inside the block: its head's value + the weights since
+                        const int pj = pu - kb;
+                        const int hd = 63 - __clzll((long long)(headmask & ((2ull << pj) - 1ull)));
+                        bu = rl(hb, hd) + rl(Pw, pj) - rl(Pw, hd);
+                    } else bu = pu == kb - 1 ? best_prev : rfl(g.bestK[pu]);
                     if (bu > b) { b = bu; p = pu; }
                 }
-                const int bv = b + 2 * nr - nadded;
-                if (lane == j) { myBest = bv; myBp = p; }
-                if (bv > sb) { sb = bv; kbest = k; }
-                best_prev = bv;
+                const int bv = b + rl(wL, j);
+                if (lane == j) { hb = bv; bpv = p; }
             }
-            if (kkL < n) { g.bestK[kkL] = myBest; g.bpK[kkL] = myBp; }
+            const int hdL = 63 - __clzll((long long)(headmask & ((2ull << lane) - 1ull)));   // (lanes past the block: any head)
+            int myBest = __shfl(hb, hdL) + Pw - __shfl(Pw, hdL);
+            // a path never continues from a non-positive value (it starts anew: "b = max(0, ...)"), which breaks the prefix sum of a
+            // chain: only where a graph begins or is junk.  Such a block is walked column by column.
+            const unsigned long long nonpos = __ballot(kkL < n && myBest <= 0);
+            if ((nonpos << 1) & ~headmask & (nblk == 64 ? ~0ull : (1ull << nblk) - 1ull)) {
+                int myBp = -1; myBest = 0;
+                int bprev = best_prev;
+                for (int j = 0; j < nblk; ++j) {
+                    const int k = kb + j;
+                    const int np = rl(npL, j);
+                    int b = 0, p = -1;
+                    for (int q = 0; q < np; ++q) {
+                        int pu;
+                        if (q < 3) pu = q == 0 ? rl(cL.y, j) : (q == 1 ? rl(cL.z, j) : rl(cL.w, j));
+                        else { const int v = rfl(order[k]); pu = rfl(g.rank[g.predx[v * 5 + (q - 3)]]); }
+                        const int bu = pu == k - 1 ? bprev : ((pu >= kb) ? rl(myBest, pu - kb) : rfl(g.bestK[pu]));
+                        if (bu > b) { b = bu; p = pu; }
+                    }
+                    const int bv = b + rl(wL, j);
+                    if (lane == j) { myBest = bv; myBp = p; }
+                    bprev = bv;
+                }
+                bpv = myBp;
+            }
+            if (kkL < n) { g.bestK[kkL] = myBest; g.bpK[kkL] = bpv; }
+            // the block's maximum, first position on ties (the walk's "bv > sb" in position order)
+            const int key = wave_max_i32(kkL < n ? myBest * 64 + (63 - lane) : INT32_MIN);
+            const int bmax = key >> 6;
+            if (bmax > sb) { sb = bmax; kbest = kb + 63 - (key & 63); }
+            best_prev = rl(myBest, nblk - 1);
             __threadfence_block();
         }
         // backtrack (uniform), bases collected in reverse into scratch
