@@ -363,20 +363,35 @@ __device__ __forceinline__ void poa_column_records(const PoaSlot &g, const int32
 {
     for (int q = lane; q < n; q += LANES) g.needK[q] = 0;
     __threadfence_block();
-    for (int kb = 0; kb < n; kb += LANES) {
-        const int kk = kb + lane;
-        if (kk < n) {
-            const int v = order[kk];
-            const int4 rec = g.vrec[v];
-            const int np = (rec.x >> 8) & 255;
-            int4 c = make_int4((rec.x & 255) | (np << 8) | ((int)g.nrV[v] << CREC_NREADS_SHIFT), -1, -1, -1);
-            for (int q = 0; q < np; ++q) {
-                const int pu = g.rank[poa_pred(g, rec, v, q)];
-                if (kk - pu > PRING) { g.needK[pu] = 1; if (q == 0) c.x |= CREC_FAR0; }
-                if (q == 0) c.y = pu; else if (q == 1) c.z = pu; else if (q == 2) c.w = pu;
-            }
-            g.crec[kk] = c;
+    // two blocks of 64 columns per iteration: the chain order -> vertex record -> rank of the in-edges is three dependent gathers deep,
+    // so the loads of both blocks are issued level by level before anything is stored (one wave per graph: latency is all it costs)
+    for (int kb = 0; kb < n; kb += 2 * LANES) {
+        const int kA = kb + lane, kB = kb + LANES + lane;
+        const bool inA = kA < n, inB = kB < n;
+        const int vA = inA ? order[kA] : 0, vB = inB ? order[kB] : 0;
+        const int4 rA = inA ? g.vrec[vA] : make_int4(0, -1, -1, -1), rB = inB ? g.vrec[vB] : make_int4(0, -1, -1, -1);
+        const int nrA = inA ? (int)g.nrV[vA] : 0, nrB = inB ? (int)g.nrV[vB] : 0;
+        const int npA = (rA.x >> 8) & 255, npB = (rB.x >> 8) & 255;
+        // in-edges 0..2 of both blocks (nearly every column has at most two)
+        int pA0 = -1, pA1 = -1, pA2 = -1, pB0 = -1, pB1 = -1, pB2 = -1;
+        if (npA > 0) pA0 = g.rank[rA.y];
+        if (npB > 0) pB0 = g.rank[rB.y];
+        if (npA > 1) pA1 = g.rank[rA.z];
+        if (npB > 1) pB1 = g.rank[rB.z];
+        if (npA > 2) pA2 = g.rank[rA.w];
+        if (npB > 2) pB2 = g.rank[rB.w];
+#define CCSX_CREC_OUT(KK, IN, V, REC, NP, NR, P0, P1, P2)                                                                  \
+        if (IN) {                                                                                                          \
+            int4 c = make_int4(((REC).x & 255) | ((NP) << 8) | ((NR) << CREC_NREADS_SHIFT), P0, P1, P2);                   \
+            if ((NP) > 0 && (KK) - (P0) > PRING) { g.needK[P0] = 1; c.x |= CREC_FAR0; }                                    \
+            if ((NP) > 1 && (KK) - (P1) > PRING) g.needK[P1] = 1;                                                          \
+            if ((NP) > 2 && (KK) - (P2) > PRING) g.needK[P2] = 1;                                                          \
+            for (int q = 3; q < (NP); ++q) { const int pu = g.rank[poa_pred(g, REC, V, q)]; if ((KK) - pu > PRING) g.needK[pu] = 1; }   \
+            g.crec[KK] = c;                                                                                                \
         }
+        CCSX_CREC_OUT(kA, inA, vA, rA, npA, nrA, pA0, pA1, pA2)
+        CCSX_CREC_OUT(kB, inB, vB, rB, npB, nrB, pB0, pB1, pB2)
+#undef CCSX_CREC_OUT
     }
     __threadfence_block();
 }
@@ -935,11 +950,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         lastEx = li > lastEx ? li : lastEx;
     }
     __threadfence_block();
-    for (int q = lane; q < n0; q += LANES) {                       // existing vertices shift right
-        const int v = order[q];
-        const int np2 = q + cnt[q];
-        CHK(np2 >= 0 && np2 < n0 + nnew && v >= 0 && v < n0, 105);
-        order_nx[np2] = v; g.rank[v] = np2;
+    for (int q0 = 0; q0 < n0; q0 += 4 * LANES) {                   // existing vertices shift right (four blocks of loads in flight)
+        int v[4], np2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = q0 + u * LANES + lane; v[u] = q < n0 ? order[q] : -1; np2[u] = q < n0 ? q + cnt[q] : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (v[u] >= 0) {
+            CHK(np2[u] >= 0 && np2[u] < n0 + nnew && v[u] < n0, 105);
+            order_nx[np2[u]] = v[u]; g.rank[v[u]] = np2[u];
+        }
     }
     __threadfence_block();
     const int n = n0 + nnew;
