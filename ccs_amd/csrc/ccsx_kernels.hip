@@ -1649,8 +1649,8 @@ __global__ void k_post(KParams P, int pass)
 // waves, serial over read rows exactly as the SPEC orders the operations; per-read gains are summed in 2^-16 fixed point with LDS
 // integer atomics, so the sum does not depend on which wave scored which read.
 #ifndef PW_THREADS
-#define PW_THREADS 256                // 4 waves.  Measured on the 10 x 10 kb workload (ms per 2048 ZMWs): 256 threads x 3 workgroups/CU 95,
-#endif                                //   512 x 2 (all ten reads in one LDS chunk) 101-103, 256 x 2 141, 320 x 2 208: resident waves per CU decide
+#define PW_THREADS 256                // 4 waves.  Round 2 (ms per 2048 ZMWs, 10 x 10 kb): 256 threads x 3 workgroups/CU 95, 512 x 2 (all ten reads in one
+#endif                                //   LDS chunk) 101-103, 256 x 2 141, 320 x 2 208.  Round 3 (ms per 8192): 256 x 4 155, 384 x 3 225, 384 x 2 234-255, 512 x 2 229-260
 #ifndef PW_MINWAVES
 #define PW_MINWAVES 4
 #endif
