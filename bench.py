@@ -72,9 +72,17 @@ def host_memory_budget() -> int:
 
 
 def git_head() -> str | None:
+    """the commit this tree is at: from git where there is a repository, else the stamp __graft_entry__.build() left beside the objects
+    (the GPU box gets a snapshot without .git)"""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        if h:
+            return h
     except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "ccs_amd", "build", "HEAD")).read().strip() or None
+    except OSError:
         return None
 
 
