@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCSX_LIB", os.path.join(_HERE, "libccsx.so"))
 
-BAND, MAXPRED, WIN_CORE, WIN_OVERHANG, JMAX, IMAX, MAX_ITER, NCTX, NOBS = 64, 8, 22, 2, 31, 63, 8, 16, 12
+BAND, MAXPRED, WIN_CORE, WIN_OVERHANG, JMAX, IMAX, MAX_ITER, NCTX, NOBS = 64, 7, 22, 2, 31, 63, 8, 16, 12   # include/ccsx.h (tests/test_abi.py compares)
 
 STATUS_NAMES = {
     0: "SUCCESS", 1: "TOO_FEW_PASSES", 2: "DRAFT_FAILURE", 3: "TOO_MANY_UNUSABLE", 4: "NON_CONVERGENT",

@@ -340,6 +340,12 @@ void finish_zmw(ZmwIn &z, const Options &o)
         // where they reach (docs/faq/accuracy-vs-passes.md:26-29: ec ~ np + 1); they are shorter by nature: no lower length bound
         const bool partial = !full && r.cx >= 0 && (r.cx & 3) != 0 && l >= 50.0 && l <= 2.0 * med && !o.no_partial;
         if (partial && !r.has_n) {
+            // a subread inside [0.5, 2] x median is not a "Median length filter" case whatever its adapters (docs/faq/reports-aux-files.md:26-27:
+            // that category means ALL subreads are outside); a ZMW with one-adapter subreads only ends as "Lacking full passes" 
+            if (l >= 0.5 * med) any_len_ok = true;
+            // the engine's subread limit and the --max-length margin hold for partial passes too: an over-long one is dropped, it never
+            // fails the ZMW or the batch (a > 65535-base partial pass used to make ccsx_submit refuse the whole batch)
+            if (r.size() > 65535 || l > 1.3 * (double)o.o.max_length + 1000.0) continue;
             r.partial = (uint8_t)((r.cx & 3) == 2 ? 6 : 2);      // cx ADAPTER_AFTER only: the adapter is at the pass's end
             part.push_back(std::move(r));
             continue;

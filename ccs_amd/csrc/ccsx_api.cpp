@@ -134,7 +134,9 @@ std::mutex g_scratch_mutex;
 struct ccsx_handle_s {
     int device = 0;
     hipStream_t s_in = nullptr, s_draft = nullptr, s_comp = nullptr, s_out = nullptr;   // s_comp: polish stage (and the synchronous calls' copies)
-    hipEvent_t ev_epoch = nullptr;    // recorded at creation: origin of ccsx_timings.start_ms / end_ms
+    hipEvent_t ev_epoch = nullptr, ev_epoch_nx = nullptr;   // origin of ccsx_timings.start_ms / end_ms: recorded at creation and moved forward every few
+    double epoch_ms = 0.0;            // minutes (epoch_ms = its distance from the creation), so that the float milliseconds HIP reports stay well below
+                                      // 2^23 ms and keep their sub-microsecond resolution in long runs
     bool poisoned = false;            // a submit failed after work was enqueued: the handle refuses further batches
     ccsx_model model;
     ccsx_opts opts;
@@ -155,6 +157,7 @@ static void destroy_handle(ccsx_handle h)
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
     for (auto &s : h->slot) s.release();
     if (h->ev_epoch) (void)hipEventDestroy(h->ev_epoch);
+    if (h->ev_epoch_nx) (void)hipEventDestroy(h->ev_epoch_nx);
     h->d_model.release(); h->d_poa.release(); h->d_align.release();
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_draft && h->s_draft != h->s_comp) (void)hipStreamDestroy(h->s_draft);
@@ -200,7 +203,8 @@ static int create_impl(ccsx_handle h)
     else HIPTRY(hipStreamCreateWithFlags(&h->s_draft, hipStreamNonBlocking));
     HIPTRY(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
     HIPTRY(hipEventCreate(&h->ev_epoch));
-    HIPTRY(hipEventRecord(h->ev_epoch, h->s_comp));
+    HIPTRY(hipEventCreate(&h->ev_epoch_nx));
+    HIPTRY(hipEventRecord(h->ev_epoch, h->s_draft));         // the stream the tickets' first events are recorded on
     for (auto &s : h->slot) {
         for (auto &ev : s.ev) HIPTRY(hipEventCreate(&ev));
         HIPTRY(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
@@ -601,7 +605,15 @@ static int slot_timings(ccsx_handle h, Slot &S, ccsx_timings *t)
     float a = 0.0f, b = 0.0f;
     HIPTRY(hipEventElapsedTime(&a, h->ev_epoch, S.ev[0]));
     HIPTRY(hipEventElapsedTime(&b, h->ev_epoch, S.ev[5]));
-    t->start_ms = a; t->end_ms = b;
+    t->start_ms = h->epoch_ms + (double)a; t->end_ms = h->epoch_ms + (double)b;
+    if (b > 300000.0f) {              // move the origin forward (every 5 minutes of handle lifetime, on the idle download stream)
+        float d = 0.0f;
+        HIPTRY(hipEventRecord(h->ev_epoch_nx, h->s_out));
+        HIPTRY(hipEventSynchronize(h->ev_epoch_nx));
+        HIPTRY(hipEventElapsedTime(&d, h->ev_epoch, h->ev_epoch_nx));
+        h->epoch_ms += (double)d;
+        std::swap(h->ev_epoch, h->ev_epoch_nx);
+    }
     return 0;
 }
 

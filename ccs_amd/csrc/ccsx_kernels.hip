@@ -1,12 +1,18 @@
 // ccsx_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the CCS per-ZMW consensus hot path.
 //
-//   k_setup   A0    per-ZMW Arrow parameter tables           (docs/how-does-ccs-work.md:90-94)
-//   k_poa     D2/D3 sparse-POA draft: one wave per ZMW       (docs/how-does-ccs-work.md:34-51)
-//   k_align   step3 subread -> draft banded alignment        (docs/how-does-ccs-work.md:53-55)
-//   k_post    A7    per-ZMW usable-read accounting           (docs/faq/accuracy-vs-passes.md:37-39)
-//   k_polish  A1-A6 Arrow alpha/beta fill, mutation scoring, polish loop, QVs; one workgroup per window
-//                                                            (docs/how-does-ccs-work.md:57-61,87-106)
-//   k_stitch  step10 concatenate window cores, rq/np/ec      (docs/how-does-ccs-work.md:108-112)
+//   k_setup       A0    per-ZMW Arrow parameter tables + z-score parameters              (docs/how-does-ccs-work.md:90-94)
+//   k_poa_init    D3    pass selection, backbone chain (cascade pass 2: the draft itself)   (docs/how-does-ccs-work.md:34-51,
+//   k_poa_dp      D1/D2 banded POA DP of one pass, FOUR graphs per wave64 (16-lane DPP rows)   docs/faq/accuracy-vs-passes.md:41-46)
+//   k_poa_thread  D3    gate, traceback, threading of the pass, column records of the next DP
+//   k_poa_finish  D3    heaviest path, draft, window bounds (step 4)
+//   k_align16     step3 subread -> draft, 16-row band, FOUR passes per wave; band-saturation trigger (SPEC v5)
+//   k_align       step3 the 64-row retry of the alignment cascade                            (docs/how-does-ccs-work.md:53-55)
+//   k_rescue      step3/6 split / double-split alignment, partial passes                     (docs/how-does-ccs-work.md:74-78)
+//   k_post        A7    per-ZMW usable-pass accounting, draft-cascade marks                  (docs/faq/accuracy-vs-passes.md:37-39)
+//   k_polish      A1-A6 Arrow alpha/beta fill, candidate filter, mutation scoring, polish loop, QVs; one workgroup per window
+//                                                                                            (docs/how-does-ccs-work.md:57-61,80-106)
+//   k_kinetics    N4    HiFi kinetics of the converged windows                               (docs/faq/kinetics.md:8-18)
+//   k_stitch      step10 concatenate window cores, rq / np / ec, status                      (docs/how-does-ccs-work.md:108-112)
 //
 // The arithmetic follows DESIGN.md §SPEC operation by operation (compiled with -ffp-contract=off, no
 // fast-math) so that sequences are bit-identical to the CPU restatement.  No MFMA: the recurrences are
@@ -334,7 +340,7 @@ __device__ __forceinline__ int poa_pred(const PoaSlot &g, const int4 &rec, int v
     return q == 0 ? rec.y : (q == 1 ? rec.z : (q == 2 ? rec.w : g.predx[v * 5 + (q - 3)]));
 }
 
-// append edge from -> to (to's record in registers); SPEC: duplicates ignored, in-edge cap 8
+// append edge from -> to (to's record in registers); SPEC: duplicates ignored, in-edge cap CCSX_MAXPRED = 7
 __device__ __forceinline__ bool poa_add_edge(const PoaSlot &g, int4 &rec, int to, int from)
 {
     const int np = (rec.x >> 8) & 255;
@@ -1216,6 +1222,8 @@ __device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t 
 // from there to the split alignment.  Same cell recurrence, origin / dirty tracking and edge saves as align_pass.
 #define AB16 16
 #define AB16_ABOVE 6
+#define AB16_SAT_ROWS 1               // SPEC v5 "band saturation": best row within the last AB16_SAT_ROWS rows of a band that can still move down
+#define AB16_SAT_GAIN 1               //   ... or a window's worth of columns (edge k-2 -> edge k) without this much gain of the column maximum
 __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
 {
     const int lane = threadIdx.x, h = lane >> 4, l = lane & 15, rowb = lane & 48;
@@ -1235,6 +1243,10 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const int nused = rfl(P.nreads_used[z]);
     if (rfirst - r0 >= nused) return;
     const bool use = live && (r - r0 < nused);
+    if (P.opts.disable_heuristics) {                    // SPEC v5: --disable-heuristics aligns every pass with the 64-row band at once
+        if (l == 0 && use) { const int idx = atomicAdd(&P.align_retry[0], 1); P.align_retry[16 + idx] = r; }
+        return;
+    }
     const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
     const uint8_t *d = P.draft + P.seq_off[z];
     const int32_t *wb = P.wbounds + P.wb_off[z];
@@ -1264,6 +1276,10 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     int lo = 0, br = 0;                                  // per lane, uniform inside a row
     const int hiI = I - (AB16 - 1) > 0 ? I - (AB16 - 1) : 0;
     const int Iclamp = I > 0 ? I - 1 : 0;
+    // SPEC v5 "band saturation": the narrow band's answer is not trusted (-> 64-row retry) when the best row reaches the band's last row
+    // before the band has reached the read's end, or when the column maximum gains less than AB16_SAT_GAIN between two window-edge
+    // columns one window apart (cmE0 / cmE1: the maxima at the last even / odd edge; edge 0 is column 0 with maximum 0)
+    int satf = 0, cmE0 = 0, cmE1 = 0;
     for (int jb = 0; jb < Ld; jb += LANES) {
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
         asm volatile("" :: "v"(dL));
@@ -1340,9 +1356,13 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int cm = __shfl(row_scan_max_i32(best), lane | 15);
             const unsigned long long bal = __ballot(best == cm);
             const unsigned m16 = (unsigned)(bal >> rowb) & 0xffffu;
-            br = lo + (__ffs((int)m16) - 1);
+            const int brl = __ffs((int)m16) - 1;
+            br = lo + brl;
+            satf |= (brl >= AB16 - AB16_SAT_ROWS && lo < hiI) ? 1 : 0;
             Mprev = best; Oprev = org; Kprev = kd;
             if (need) {
+                if (kk & 1) { if (kk >= 2 && cm - cmE1 < AB16_SAT_GAIN) satf = 1; cmE1 = cm; }
+                else { if (cm - cmE0 < AB16_SAT_GAIN) satf = 1; cmE0 = cm; }
                 ++kk;
                 if (kk - kkb >= LANES) { kkb = kk; needv = need_col(wb, nw, Ld, (kkb + lane < nneed) ? kkb + lane : nneed - 1); }
                 next_need = (kk >= nneed) ? -1 : rl(needv, kk - kkb);
@@ -1355,7 +1375,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const int scv = __shfl(Mprev, srcl), eLv = __shfl(Oprev, srcl);
     const unsigned kLv = (unsigned)__shfl((int)Kprev, srcl);
     const int sc = inr ? scv : NEGV;
-    const int valid = (sc > NEGV / 2 && sc >= Ld) ? 1 : 0;
+    const int valid = (sc > NEGV / 2 && sc >= Ld && !satf) ? 1 : 0;
     __threadfence_block();
     if (l == 0 && use) {
         P.ascore[r] = sc; P.avalid[r] = (uint8_t)valid;

@@ -53,7 +53,14 @@ struct JParser {
             if (*p == '\\') {
                 if (++p >= end) return fail("bad escape");
                 switch (*p) { case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break; case 'b': out += '\b'; break;
-                              case 'f': out += '\f'; break; case 'u': return fail("\\u escapes are not supported"); default: out += *p; }
+                              case 'f': out += '\f'; break;
+                              case 'u': {                  // \u00XX (what ccsx_model_to_json writes for control characters); no surrogates / non-ASCII
+                                  unsigned v = 0;
+                                  if (end - p < 5) return fail("bad \\u escape");
+                                  for (int k = 1; k <= 4; ++k) { const int c = std::tolower((unsigned char)p[k]); if (!std::isxdigit(c)) return fail("bad \\u escape"); v = v * 16 + (unsigned)(c <= '9' ? c - '0' : c - 'a' + 10); }
+                                  if (v == 0 || v > 0x7f) return fail("\\u escapes above U+007F are not supported");
+                                  out += (char)v; p += 4; break; }
+                              default: out += *p; }
                 ++p;
             } else out += *p++;
         }

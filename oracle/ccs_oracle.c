@@ -36,7 +36,7 @@
 #endif
 
 /* ---------------- specification constants (same values as include/ccsx.h) -------------- */
-#define ORC_SPEC_VERSION 4  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
+#define ORC_SPEC_VERSION 5  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
 int orc_spec_version(void) { return ORC_SPEC_VERSION; }
 #define BAND      64
 #define ALIGN_BAND1 16      /* rows of the FIRST attempt of the subread -> draft alignment (step 3); BAND rows on failure */
@@ -48,6 +48,9 @@ static __thread int g_bw = BAND;   /* rows of the band in use (alignment retry /
 /* test hooks: the build-defined approximations of the SPEC as variables, so that tools/acc_eval.py can measure what each of them costs on
  * off-model and low-complexity data (profiles/r03_spec_studies.txt).  The product implements the SPEC values only. */
 static int g_poa_band = POA_BAND, g_align_band1 = 16, g_score_band = 5, g_skip_margin = 6;
+static int g_sat_rows = 1, g_sat_gain = 1;                    /* SPEC v5 "band saturation" (see orc_align_ev_w); 0 / very negative = off */
+void orc_set_sat_rows(int n) { g_sat_rows = n; }
+void orc_set_sat_gain(int g) { g_sat_gain = g; }
 void orc_set_poa_band(int bw) { g_poa_band = bw; }
 void orc_set_align_band1(int bw) { g_align_band1 = bw; }      /* 64: no narrow first attempt */
 void orc_set_score_band(int w) { g_score_band = w; }          /* >= 64: the full sum over alignments */
@@ -55,7 +58,7 @@ void orc_set_skip_margin(int m) { g_skip_margin = m; }
 /* ---- path / work counters of the tests and of bench.py's counted-work figure (SURVEY.md §8d "algorithmic work per ZMW: counted on an
  * instrumented CPU path, not estimated"); per-thread tallies are flushed into the global sums once per ZMW ---- */
 enum { CNT_TRIM, CNT_SPLIT, CNT_SPLIT_S0, CNT_SPLIT_SLD, CNT_FALLBACK, CNT_RETRY64, CNT_ZDROP, CNT_NONCONV_WIN, CNT_POA_WIDE, CNT_THIRD_DRAFT,
-       CNT_PARTIAL_USED, CNT_CELLS_POA, CNT_CELLS_ALIGN, CNT_CELLS_FILL, CNT_CELLS_SCORE, CNT_ZMWS, CNT_SPLIT2, CNT_N };
+       CNT_PARTIAL_USED, CNT_CELLS_POA, CNT_CELLS_ALIGN, CNT_CELLS_FILL, CNT_CELLS_SCORE, CNT_ZMWS, CNT_SPLIT2, CNT_SATURATED, CNT_N };
 static int64_t orc_cnt_global[CNT_N];
 static __thread int64_t orc_cnt[CNT_N];
 static __thread int g_cells_kind = CNT_CELLS_ALIGN;         /* which tally dp_column feeds */
@@ -503,33 +506,71 @@ int orc_poa_draft(int nreads, const int64_t *base_off, const uint8_t *bases, con
  * dirty (optional, [Ld]): the pile-up evidence of the candidate filter (docs/how-does-ccs-work.md:80-83) —
  * dirty[p] = 1 iff the optimal path does not pass draft position p by a plain matching DIAG step: a mismatch or a
  * deletion marks p; a read base inserted between positions p-1 and p marks both neighbours.                        */
-static int align_ev_band(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty);
+static int align_ev_band(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty,
+                         const int32_t *need, int nneed, int *sat_out);
 /* SPEC "alignment cascade": the banded global alignment is first tried with ALIGN_BAND1 rows (the band follows the best row, so
  * this finds the same path as the wide band unless an indel run of more than ~ALIGN_BAND1/2 rows occurs); a pass that is not valid
  * in the narrow band is aligned again with BAND rows (and, failing that, by the split alignment).                             */
+int orc_windows(const uint8_t *d, int Ld, int32_t *b, int cap);
+/* SPEC v5 "band saturation": a pass whose narrow-band alignment is valid is STILL aligned again with BAND rows when the narrow band
+ * shows that it could not hold the path — (a) in some column the best row sits in the band's last SAT_ROWS rows while the band has
+ * not reached the read's end (the path wants to leave downwards: an insertion run the band cannot take in one step), or (b) between
+ * two window-edge columns of the same kind (need[k-2] -> need[k], one window apart) the column maximum did not grow by SAT_GAIN
+ * (a window's worth of columns without net score: the band sits on the wrong phase of a repeat).  On low-complexity templates the
+ * narrow band otherwise locks onto a wrong repeat phase and still passes the 1.0-per-base gate (profiles/r04_lowcx_band.txt);
+ * wide = 1 (opts.disable_heuristics) skips the narrow attempt altogether.  need[0] = 0 < ... < need[nneed-1] = Ld.               */
+int orc_align_ev_w(const uint8_t *r, int I, const uint8_t *d, int Ld, const int32_t *need, int nneed, int wide,
+                   int32_t *rstart, int32_t *score_out, uint8_t *dirty)
+{
+    if (!wide && g_align_band1 < BAND) {
+        int sat = 0;
+        g_bw = g_align_band1;
+        int v = align_ev_band(r, I, d, Ld, rstart, score_out, dirty, need, nneed, &sat);
+        g_bw = BAND;
+        if (v && !sat) return 1;
+        orc_cnt[CNT_RETRY64] += 1;
+        if (v) orc_cnt[CNT_SATURATED] += 1;
+    }
+    g_bw = BAND;
+    return align_ev_band(r, I, d, Ld, rstart, score_out, dirty, NULL, 0, NULL);
+}
+/* the same with the window-edge columns derived from the draft (step 4 depends on the draft only) */
 int orc_align_ev(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty)
 {
-    g_bw = g_align_band1;
-    int v = align_ev_band(r, I, d, Ld, rstart, score_out, dirty);
-    g_bw = BAND;
-    if (v) return 1;
-    orc_cnt[CNT_RETRY64] += 1;
-    return align_ev_band(r, I, d, Ld, rstart, score_out, dirty);
+    int wcap0 = Ld / (WIN_CORE - 3) + 4, nneed = 0;
+    int32_t *wb0 = (int32_t *)malloc(sizeof(int32_t) * wcap0), *need = (int32_t *)malloc(sizeof(int32_t) * 2 * wcap0);
+    int nw0 = orc_windows(d, Ld, wb0, wcap0);
+    need[nneed++] = 0;
+    for (int w = 1; w < nw0; ++w) { need[nneed++] = wb0[w] - WIN_OVH; need[nneed++] = wb0[w] + WIN_OVH; }
+    need[nneed++] = Ld;
+    int v = orc_align_ev_w(r, I, d, Ld, need, nneed, 0, rstart, score_out, dirty);
+    free(wb0); free(need);
+    return v;
 }
-static int align_ev_band(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty)
+static int align_ev_band(const uint8_t *r, int I, const uint8_t *d, int Ld, int32_t *rstart, int32_t *score_out, uint8_t *dirty,
+                         const int32_t *need, int nneed, int *sat_out)
 {
     int32_t *lo = (int32_t *)malloc(sizeof(int32_t) * (Ld + 1));
     uint8_t *mv = (uint8_t *)malloc((size_t)(Ld + 1) * BAND);
     int32_t A[BAND], B[BAND], *prevM = A, *curM = B;
     start_column(I, prevM);
     lo[0] = 0; int32_t cm = 0, br = 0; int plo = 0;
+    int sat = 0, kn = 1; int32_t cmE[2] = { 0, 0 };        /* column maxima at the last two window-edge columns (edge 0 = column 0: 0) */
     for (int j = 1; j <= Ld; ++j) {
         int l0 = band_lo(plo, br, I);
         int32_t plos[1] = { plo }; const int32_t *pMs[1] = { prevM };
         dp_column(d[j - 1], r, I, l0, 1, plos, pMs, curM, mv + (size_t)j * BAND, &cm, &br);
         lo[j] = l0; plo = l0;
+        if (sat_out) {                                      /* SPEC v5 "band saturation" (narrow band only) */
+            if (br - l0 >= g_bw - g_sat_rows && l0 + g_bw - 1 < I) sat = 1;
+            if (kn < nneed && j == need[kn]) {
+                if (kn >= 2 && cm - cmE[kn & 1] < g_sat_gain) sat = 1;
+                cmE[kn & 1] = cm; ++kn;
+            }
+        }
         int32_t *t = prevM; prevM = curM; curM = t;
     }
+    if (sat_out) *sat_out = sat;
     int o = I - lo[Ld];
     int valid = (o >= 0 && o < g_bw && prevM[o] > NEG / 2);
     int32_t sc = valid ? prevM[o] : NEG;
@@ -1284,7 +1325,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                     avalid[r] = (uint8_t)(nneed >= 2 ? orc_align_partial(ob, L, draft, Ld, need, nneed, from_end, rstart[r], &sc, dirty[r]) : 0);
                     continue;                               /* not a pass: np / fn / rn count full-length passes */
                 }
-                avalid[r] = (uint8_t)orc_align_ev(ob, L, draft, Ld, rstart[r], &sc, dirty[r]);
+                avalid[r] = (uint8_t)orc_align_ev_w(ob, L, draft, Ld, need, nneed, opts->disable_heuristics != 0, rstart[r], &sc, dirty[r]);
                 /* a pass much longer than the draft that failed: look for ONE large insertion (SPEC "split alignment") */
                 if (!avalid[r] && L - Ld > RESCUE_MIN_EXCESS && nneed >= 3)
                     avalid[r] = (uint8_t)orc_align_rescue(ob, L, draft, Ld, need, nneed, rstart[r], &sc, dirty[r]);

@@ -27,6 +27,15 @@ def test_header_and_exports_agree(built):
     assert L.ccsx_spec_version() >= 2
 
 
+def test_constants_match_header(built):
+    """the ctypes mirror's copies of the SPEC constants equal include/ccsx.h (api.MAXPRED had drifted to 8)"""
+    src = open(os.path.join(ROOT, "include", "ccsx.h")).read()
+    d = {k: int(v) for k, v in re.findall(r"#define\s+CCSX_([A-Z_]+)\s+(\d+)", src)}
+    got = dict(BAND=api.BAND, MAXPRED=api.MAXPRED, WIN_CORE=api.WIN_CORE, WIN_OVERHANG=api.WIN_OVERHANG, JMAX=api.JMAX, IMAX=api.IMAX,
+               MAX_ITER=api.MAX_ITER, NCTX=api.NCTX, NOBS=api.NOBS)
+    assert {k: d[k] for k in got} == got
+
+
 def test_struct_layouts_match_header(built):
     # sizes implied by include/ccsx.h
     assert C.sizeof(api.Model) == 32 + 8 + 16 * 3 * 4 * 4 + 16 * 12 * 4 + 16 * 3 * 4 * 2

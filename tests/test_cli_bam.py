@@ -494,6 +494,27 @@ def test_cli_chunks_and_output_index(built, tmp_path):
         assert np.array_equal(a["seq"], b["seq"]) and np.array_equal(a["qual"], b["qual"]) and a["tags"]["rq"] == b["tags"]["rq"]
 
 
+def test_partial_pass_filters_without_gpu(built, tmp_path):
+    """(a) a ZMW whose in-range subreads all carry one adapter only is "Lacking full passes" (102), not "Median length
+    filter" (101: docs/faq/reports-aux-files.md:26-27 — ALL subreads outside 50 % .. 200 % of the median), with and without
+    --no-partial-passes; (b) a one-adapter subread beyond the engine's 65535-base limit is dropped — it must never reach the engine,
+    where it would make ccsx_submit refuse the whole batch"""
+    rng = np.random.default_rng(11)
+    hdr = "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:x\tPL:PACBIO\tDS:READTYPE=SUBREAD\tPU:m1\n"
+
+    def rec(zm, k, n, cx):
+        seq = "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+        return bam_util.record(f"m1/{zm}/{k * 100000}_{k * 100000 + n}", seq, [("zm", "i", zm), ("sn", "Bf", [9.0, 15.0, 8.0, 12.0]), ("cx", "i", cx)])
+    recs = [rec(5, 0, 300, 2), rec(5, 1, 310, 1)]                                   # only one-adapter subreads
+    recs += [rec(6, 0, 70000, 2), rec(6, 1, 40000, 3), rec(6, 2, 40100, 3), rec(6, 3, 39900, 3), rec(6, 4, 30000, 1)]   # median 40 kb: the 70 kb partial pass passes "<= 2 x median"
+    p = tmp_path / "p.bam"
+    bam_util.write_bam(p, hdr, recs)
+    for extra in ([], ["--no-partial-passes"]):
+        lines = [l.split("\t") for l in _run("--dump-zmws", "--max-length", 50000, *extra, p).stdout.strip().split("\n")]
+        assert lines[0][:2] == ["5", "102"], lines
+        assert lines[1][:3] == ["6", "0", "3" if extra else "4"], lines              # three full passes (+ the 30 kb partial pass; never the 70 kb one)
+
+
 @pytest.mark.gpu
 def test_cli_partial_passes(built, tmp_path):
     """docs/faq/accuracy-vs-passes.md:26-29: the first and last subread of a ZMW carry one adapter only (cx 2 / 1); they are not

@@ -58,6 +58,13 @@ def test_model_json_is_validated_and_escaped(built):
     assert d["ChemistryName"] == 'we"ird\\name' and d["Chemistries"][0]["BindingKit"] == 'kit"1'
     back = api.model_from_json(text)
     assert bytes(back) == bytes(m)
+    # control characters are written as \\u00XX and the bundled parser reads them back (file -> blob -> file stays the identity)
+    api.set_model_name(m, "tab\there\x01")
+    text2 = api.model_to_json(m, ("k\n1", "s", "5.0"))
+    assert json.loads(text2)["ChemistryName"] == "tab\there\x01" and "\\u0009" in text2
+    assert bytes(api.model_from_json(text2)) == bytes(m)
+    with pytest.raises(RuntimeError, match="model json"):
+        api.model_from_json(text2.replace("\\u0009", "\\u00e9"))
     for key, bad in (("EmissionStick", -0.25), ("EmissionBranch", float("inf")), ("EmissionMatch", 0.0), ("TransitionPolynomials", float("nan"))):
         d2 = json.loads(text)
         row = d2[key][3]

@@ -25,7 +25,7 @@ def evaluate(batch, opts, model=None, nthreads=8, label=""):
     c = O.counts()
     st = {api.STATUS_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(res.status, return_counts=True))}
     print(f"{label:28s} errors {err:5d} / {nb} b ({1e6 * err / max(1, nb):7.1f} ppm)  rq {res.rq[ok].mean():.6f}  rounds/win {res.iters.sum() / max(1, res.n_windows.sum()):.3f} "
-          f" status {st}  paths {{trim {c['trim']} split {c['split']} fallback {c['fallback']} retry64 {c['retry64']} zdrop {c['zdrop']} poa_wide {c['poa_wide']}}} "
+          f" status {st}  paths {{trim {c['trim']} split {c['split']} fallback {c['fallback']} retry64 {c['retry64']} sat {c['saturated']} zdrop {c['zdrop']} poa_wide {c['poa_wide']}}} "
           f" cells/ZMW poa {c['cells_poa'] // max(1, c['zmws'])} align {c['cells_align'] // max(1, c['zmws'])} fill {c['cells_fill'] // max(1, c['zmws'])} score {c['cells_score'] // max(1, c['zmws'])}  {dt:.1f}s", flush=True)
     return res, err, c
 
@@ -37,7 +37,7 @@ if __name__ == "__main__":
     for kv in sys.argv[5:]:
         k, v = kv.split("=", 1)
         if k.startswith("env:"): os.environ[k[4:]] = v
-        elif k in ("poa_band", "align_band1", "score_band", "skip_margin"): getattr(O.lib(), "orc_set_" + k)(int(v))   # SPEC approximation knobs
+        elif k in ("poa_band", "align_band1", "score_band", "skip_margin", "sat_rows", "sat_gain"): getattr(O.lib(), "orc_set_" + k)(int(v))   # SPEC approximation knobs
         elif k == "channel": channel = float(v)
         elif k == "tpl": tpl = v
         elif k == "hp_boost": hp_boost = float(v)
