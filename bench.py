@@ -37,7 +37,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-TRAFFIC_FILE = "r03_traffic.json"       # this round's committed PMC passes (tools/prof_round.sh -> tools/mk_traffic.py)
+TRAFFIC_FILE = "r04_traffic.json"       # this round's committed PMC passes (tools/prof_round.sh -> tools/mk_traffic.py)
+QVCAL_FILE = "r04_qv_calibration.json"  # predicted vs empirical accuracy per rq bin (tools/qv_calibration.py, CPU restatement)
+VALU_PEAK_LANE_OPS = 78.6e12            # non-packed VALU issue of one MI355X: 1024 SIMDs x 32 lanes per cycle (v_add / v_mul_f32 issue a wave64
+                                        # in 2 cycles, profiles/r02_valu_peak.txt) x 2.4 GHz; packed fp32 (157 TFLOP/s with FMA) is not what a DP cell can use
+NOMINAL_OPS_PER_CELL = 8                # "8 flop/cell nominal"
+
+
+def gpu_clocks(device: int) -> dict:
+    """sclk / mclk / power of the device as rocm-smi reports them right now (GPU boxes of the pool differ by up to
+    35 % on the VALU-bound kernels; the bench line carries what the box ran at so that a spread can be attributed)"""
+    out = {}
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance level")):
+                out[k] = v
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"[:120]
+    return out
+
+
+def kernels_changed_since(rev: str | None) -> bool | None:
+    """True / False when git can tell whether ccs_amd/csrc differs between `rev` and the working tree, None without a repository"""
+    if not rev:
+        return None
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", rev.split("+")[0], "--", "ccs_amd/csrc"], capture_output=True, timeout=20)
+        return None if r.returncode not in (0, 1) else bool(r.returncode)
+    except Exception:
+        return None
 
 
 def effective_cores() -> int:
@@ -179,10 +211,12 @@ def kernels_span_ms(kt):
     return max(t.end_ms for t in kt) - min(t.start_ms for t in kt)
 
 
-def reference_concordance(api, np, ccs_bin, sample, cores, seconds):
+def reference_concordance(api, np, ccs_bin, sample, cores, seconds, seed=0xC0FFEE):
     """the reference tool, when the box has it (bioconda pbccs), is RUN on the same synthetic subreads — written as
-    a PacBio subreads.bam by this repo's driver — and timed; its HiFi reads are compared with the truth templates and with this
-    library's reads.  Nothing here is exercised without `ccs` on PATH; it is the one code path that can pin parity."""
+    a PacBio subreads.bam by this repo's driver — and timed; its HiFi reads are compared with this library's reads.  It is the one code
+    path that can pin parity; tests/test_gpu_parity.py::test_reference_concordance_harness exercises it with a stand-in `ccs` (a copy of
+    this repo's driver under another path), and every way the reference can fail here — no --version, a chemistry triple it does not
+    know, a crash, a time-out — ends in an `error` / `rc` field, never in an exception."""
     out = {"found": True, "path": ccs_bin}
     try:
         import bam_util
@@ -191,21 +225,34 @@ def reference_concordance(api, np, ccs_bin, sample, cores, seconds):
         with tempfile.TemporaryDirectory() as td:
             sub, ref_out, our_out = os.path.join(td, "s.subreads.bam"), os.path.join(td, "ref.bam"), os.path.join(td, "ours.bam")
             passes = int(np.diff(sample.read_off)[0]); length = int(np.diff(sample.tpl_off)[0])
-            subprocess.run([ours, "--write-synthetic", f"{n},{passes},{length},{0xC0FFEE}", sub], check=True, timeout=600)
-            out["version"] = subprocess.run([ccs_bin, "--version"], capture_output=True, text=True, timeout=60).stdout.strip()[:80]
+            subprocess.run([ours, "--write-synthetic", f"{n},{passes},{length},{seed}", sub], check=True, timeout=600)
+            try:                                             # informational only: a reference without --version is still a reference
+                v = subprocess.run([ccs_bin, "--version"], capture_output=True, text=True, timeout=60)
+                out["version"] = (v.stdout.strip() or v.stderr.strip())[:80] if v.returncode == 0 else f"(--version: rc {v.returncode})"
+            except Exception as e:
+                out["version"] = f"(--version failed: {type(e).__name__})"
             t0 = time.perf_counter()
-            r = subprocess.run([ccs_bin, sub, ref_out, "-j", str(cores), "--min-rq", "0.99"], capture_output=True, text=True, timeout=max(600, 40 * seconds))
+            try:
+                r = subprocess.run([ccs_bin, sub, ref_out, "-j", str(cores), "--min-rq", "0.99"], capture_output=True, text=True, timeout=max(600, 40 * seconds))
+            except subprocess.TimeoutExpired:
+                out.update({"rc": None, "error": "reference ccs timed out"})
+                return out
             dt = time.perf_counter() - t0
             out.update({"rc": r.returncode, "wall_s": round(dt, 2), "zmws": n, "zmws_per_s": round(n / dt, 3), "cores": cores,
                         "stderr_tail": r.stderr[-300:]})
-            if r.returncode == 0:
-                subprocess.run([ours, sub, our_out], check=True, timeout=600)
-                ref_reads = {x["tags"]["zm"]: x["seq"] for x in bam_util.read_bam(ref_out)[1]}
-                our_reads = {x["tags"]["zm"]: x["seq"] for x in bam_util.read_bam(our_out)[1]}
-                both = sorted(set(ref_reads) & set(our_reads))
-                same = sum(1 for z in both if len(ref_reads[z]) == len(our_reads[z]) and np.array_equal(ref_reads[z], our_reads[z]))
-                out.update({"hifi_reads_reference": len(ref_reads), "hifi_reads_ours": len(our_reads), "zmws_in_both": len(both),
-                            "identical_sequences": same})
+            if r.returncode != 0:
+                # typical: "Unsupported chemistries found" — the synthetic BAM's (BindingKit, SequencingKit, BasecallerVersion) triple is the
+                # recalled Sequel II one, a real ccs may not carry it; reported, the timing above is then meaningless
+                out["error"] = "reference ccs failed on the synthetic subreads (see stderr_tail" + ("; chemistry triple not supported" if "hemistr" in r.stderr else "") + ")"
+                out.pop("zmws_per_s", None)
+                return out
+            subprocess.run([ours, sub, our_out], check=True, timeout=600)
+            ref_reads = {x["tags"]["zm"]: x["seq"] for x in bam_util.read_bam(ref_out)[1]}
+            our_reads = {x["tags"]["zm"]: x["seq"] for x in bam_util.read_bam(our_out)[1]}
+            both = sorted(set(ref_reads) & set(our_reads))
+            same = sum(1 for z in both if len(ref_reads[z]) == len(our_reads[z]) and np.array_equal(ref_reads[z], our_reads[z]))
+            out.update({"hifi_reads_reference": len(ref_reads), "hifi_reads_ours": len(our_reads), "zmws_in_both": len(both),
+                        "identical_sequences": same})
     except Exception as e:                                   # the concordance leg must never take the benchmark down
         out["error"] = f"{type(e).__name__}: {e}"[:300]
     return out
@@ -289,6 +336,7 @@ def main():
     barrier()
     elapsed, kt, (ok, rqsum, rqn, checks) = job.run(args.steps, True)
     barrier()
+    clocks_after = gpu_clocks(local_rank) if rank == 0 else None     # right after the last timed kernel: the clocks the run settled at
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -314,11 +362,12 @@ def main():
         # HBM traffic / VALU issue / counted work of that kernel from this round's committed rocprofv3 PMC passes of the SAME command
         # (`bench.py --pmc`; (2*FETCH_SIZE + WRITE_SIZE)*1024 with the calibrated FETCH_SIZE = bytes/2, per ZMW); the file names
         # the commit it was measured at
-        traffic, valu, traffic_head = None, None, None
+        traffic, valu, traffic_head, traffic_zmws = None, None, None, None
+        head = git_head()
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
             kz = tj["kernels"][names[dom]]
-            traffic_head = tj.get("head")
+            traffic_head, traffic_zmws = tj.get("head"), tj.get("zmws")
             if args.passes == 10 and args.length == 10000 and not args.hifi_kinetics and not args.disable_heuristics:
                 traffic = int(kz["hbm_bytes_per_zmw"] * args.zmws)
                 valu = {k: kz[k] for k in ("valu_wave_instr_per_zmw", "valu_issue_frac_if_2cyc", "valu_issue_frac_if_4cyc", "lanes_active_frac",
@@ -328,7 +377,11 @@ def main():
             traffic, valu = None, None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic else None,
-                    "traffic_source": f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of `bench.py --pmc`, measured at commit {traffic_head})" if traffic else None,
+                    "traffic_source": f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of `bench.py --pmc --zmws {traffic_zmws}`, measured at commit {traffic_head})" if traffic else None,
+                    # a counter file from another commit is flagged, not trusted blindly: same commit, or — where git can
+                    # tell — no change under ccs_amd/csrc since
+                    "traffic_head": traffic_head, "traffic_is_this_build": (bool(head) and bool(traffic_head) and head.split("+")[0] == str(traffic_head).split("+")[0]) if traffic else None,
+                    "kernels_changed_since_traffic": kernels_changed_since(traffic_head) if traffic else None,
                     "avg_launch_ms": round(stage_ms[dom], 3), "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                     "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d); "
                             "the kernel is bound by VALU issue and dependent-chain latency (DESIGN.md 4)"}
@@ -358,7 +411,8 @@ def main():
                      "bam_pipeline_note": "this bench feeds the engine from memory; the `ccs` driver's BAM side costs 0.85-0.94 CPU-s per 1000 ZMWs "
                                           "(BGZF inflate 0.57), i.e. ~28 host cores per MI355X at the engine's rate: 17.0-18.8k ZMWs/s BAM->BAM and 24-28k for "
                                           "the host side alone on this box's 16 usable threads (profiles/r03_cli_host_pipeline.txt, DESIGN.md 7)"},
-            "head": git_head(),
+            "head": head,
+            "gpu_clocks": {"after_timed_region": clocks_after, "source": "rocm-smi --showclocks --showpower --showmaxpower --showperflevel"},
         }
         cores = effective_cores()
         # the reference tool, if the box has it (expected absent; bioconda pbccs): probed, and run when found
@@ -395,6 +449,7 @@ def main():
                                              f"{'found at ' + ccs_bin if ccs_bin else 'not on PATH (probed)'}",
                                    "gpu_matches_cpu_sequences": bool(same), "max_abs_qv_diff": qv_max,
                                    "core_seconds_per_zmw": round(core_s, 4),
+                                   "gpu_equivalent_cores": round(value * core_s, 1),     # host cores of THIS port one MI355X replaces (value x core-s per ZMW)
                                    "context": f"this SPEC's port costs {core_s:.3f} core-s per ZMW here; docs/img/runtime.png shows ~1 core-s for ccs 4.2 at "
                                               "10 kb x 7 passes, i.e. the port does far less CPU work per ZMW than ccs, so the GPU/CPU ratio is not a "
                                               "statement about ccs (PacBio's own GPU claim: 10x over 128 cores, docs/faq/revio.md:23-25)"}
@@ -416,6 +471,11 @@ def main():
             except Exception:
                 pass
             out["roofline"]["work"] = work
+            # the interpretable roofline: counted cell updates x the nominal 8 operations per cell against the non-packed
+            # VALU issue peak of the chip — what share of the machine's lane-operations is the recurrence itself
+            out["roofline"]["valu_algorithmic_frac"] = round(tot * NOMINAL_OPS_PER_CELL * value / VALU_PEAK_LANE_OPS, 4)
+            out["roofline"]["valu_algorithmic_note"] = (f"{int(tot)} counted cell updates per ZMW x {NOMINAL_OPS_PER_CELL} nominal ops x {value:.0f} ZMWs/s / "
+                                                        f"{VALU_PEAK_LANE_OPS:.3g} lane-ops/s (1024 SIMDs x 32 lanes/cycle x 2.4 GHz)")
         job.close()
         # ---- the other BASELINE shapes through the same pipeline (N=1 only; a few steps each)
         if world == 1 and args.extra:
@@ -439,6 +499,11 @@ def main():
                     del j2
                 except Exception as e:
                     extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:                                          # predicted vs empirical accuracy (tools/qv_calibration.py; CPU restatement, committed)
+                qc = json.load(open(os.path.join(ROOT, "profiles", QVCAL_FILE)))
+                extra["qv_calibration"] = {"source": f"profiles/{QVCAL_FILE}", "spec_version": qc.get("spec_version"), "datasets": qc.get("headline")}
+            except Exception:
+                pass
             out["extra"] = extra
         print(json.dumps(out), flush=True)
     else:

@@ -188,6 +188,7 @@ bool parse(int argc, char **argv, Options &o)
         std::string a = argv[i];
         auto need = [&](const char *n) -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", n); std::exit(2); } return argv[++i]; };
         if (a == "-h" || a == "--help") { usage(); std::exit(0); }
+        else if (a == "--version") { std::printf("ccs (ccs_amd, MI355X-native consensus path) abi %d spec %d\n", ccsx_abi_version(), ccsx_spec_version()); std::exit(0); }
         else if (a == "-j" || a == "--num-threads") o.threads = std::atoi(need("-j").c_str());
         else if (a == "--min-passes") o.o.min_passes = std::atoi(need(a.c_str()).c_str());
         else if (a == "--top-passes") o.o.top_passes = std::atoi(need(a.c_str()).c_str());

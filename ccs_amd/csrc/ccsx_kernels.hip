@@ -2128,7 +2128,10 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             const int nrest = ntask % PW_WAVES, nsplit = (nrest > 0 && 2 * nrest <= PW_WAVES) ? nrest : 0;
             const int ntfull = ntask - nsplit, nunit_f = ntfull + 2 * nsplit;
 #endif
-            for (int fu = wave; fu < nunit_f; fu += PW_WAVES) {
+#ifndef PW_FILL_WAVES
+#define PW_FILL_WAVES PW_WAVES        // experiment (profiles/r04_fill_waves.txt): the fill's units on fewer waves — same instructions, longer critical path
+#endif
+            for (int fu = wave; fu < nunit_f && wave < PW_FILL_WAVES; fu += PW_FILL_WAVES) {
                 const int tk = fu < ntfull ? fu : ntfull + ((fu - ntfull) >> 1);
                 const int mode = fu < ntfull ? 0 : 1 + ((fu - ntfull) & 1);      // 0: alpha and beta, 1: alpha only, 2: beta only
                 const short2 task = sTask[tk];
@@ -2365,7 +2368,12 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                         ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, S) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, S) + La.q); ca.bq = *ca.be; ca.be += S;
                         ca.op = (lds_cu16)(&sObs[ra][0] + i0a);
                         asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(tAa), "+v"(tBa), "+v"(ca.op));
-                        for (int ia = 0; ia < nrA; ++ia) score_step(ca, La, tAa, tBa, S);
+                        {   // two rows per iteration: the chain's carried values (previous table pairs, beta, a, b) then rotate between two
+                            // register sets instead of being copied at every row (3 v_mov + a loop counter per row before)
+                            int ia = 0;
+                            for (; ia + 2 <= nrA; ia += 2) { score_step(ca, La, tAa, tBa, S); score_step(ca, La, tAa, tBa, S); }
+                            if (ia < nrA) score_step(ca, La, tAa, tBa, S);
+                        }
                         const float res = La.fin ? ca.b : ca.acc;
                         dq = dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k0)));
                     } else {
@@ -2395,7 +2403,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(cb.g), "+v"(cb.be), "+v"(tAa), "+v"(tBa), "+v"(tAb), "+v"(tBb), "+v"(ca.op), "+v"(cb.op));
                     const int nmin = nrA < nrB ? nrA : nrB;
                     int i = 0;
-                    for (; i < nmin; ++i) {                                    // both chains
+                    for (; i + 2 <= nmin; i += 2) {                            // both chains, two rows per iteration (no register copies between rows)
+                        score_step(ca, La, tAa, tBa, S);
+                        score_step(cb, Lb, tAb, tBb, S);
                         score_step(ca, La, tAa, tBa, S);
                         score_step(cb, Lb, tAb, tBb, S);
                     }

@@ -1196,6 +1196,47 @@ int orc_edit_distance(const uint8_t *a, int la, const uint8_t *b, int lb, int ba
     return r;
 }
 
+/* Test / evaluation aid (tools/qv_calibration.py: predicted vs empirical QV): the same banded edit-distance alignment with a traceback that
+ * marks the positions of `a` (a consensus) that take part in an error against `b` (the truth): a mismatch or an extra base marks that base,
+ * a missing base marks the base of `a` that follows the gap (the last base when the gap is at the end).  Returns the edit distance, -1 when
+ * the band cannot hold the alignment.  err[la] is written.                                                                              */
+int orc_error_positions(const uint8_t *a, int la, const uint8_t *b, int lb, int band, uint8_t *err)
+{
+    memset(err, 0, la > 0 ? la : 0);
+    if (abs(la - lb) > band || la <= 0) return -1;
+    int W = 2 * band + 1, INF = 1 << 29;
+    int *D = (int *)malloc(sizeof(int) * (size_t)(la + 1) * W);
+    for (int k = 0; k < W; ++k) { int j = k - band; D[k] = (j >= 0 && j <= lb) ? j : INF; }
+    for (int i = 1; i <= la; ++i) {
+        int *prev = D + (size_t)(i - 1) * W, *cur = D + (size_t)i * W;
+        for (int k = 0; k < W; ++k) {
+            int j = i + k - band, v = INF;
+            if (j >= 0 && j <= lb) {
+                if (j == 0) v = i;
+                else {
+                    int dg = prev[k] + (a[i - 1] != b[j - 1]);
+                    int up = (k + 1 < W) ? prev[k + 1] + 1 : INF;
+                    int lf = (k > 0) ? cur[k - 1] + 1 : INF;
+                    v = dg < up ? dg : up; if (lf < v) v = lf;
+                }
+            }
+            cur[k] = v;
+        }
+    }
+    int i = la, j = lb, k = lb - la + band;
+    int dist = (k >= 0 && k < W) ? D[(size_t)la * W + k] : INF;
+    if (dist >= INF) { free(D); return -1; }
+    while (i > 0 || j > 0) {
+        k = j - i + band;
+        int v = D[(size_t)i * W + k];
+        if (i > 0 && j > 0 && D[(size_t)(i - 1) * W + k] + (a[i - 1] != b[j - 1]) == v) { if (a[i - 1] != b[j - 1]) err[i - 1] = 1; --i; --j; }
+        else if (i > 0 && k + 1 < W && D[(size_t)(i - 1) * W + k + 1] + 1 == v) { err[i - 1] = 1; --i; }      /* extra base in a */
+        else { err[i < la ? i : la - 1] = 1; --j; }                                                               /* base of b missing in a */
+    }
+    free(D);
+    return dist;
+}
+
 /* ---------------- first-principles helpers for tests/test_oracle_hmm.py ---------------------------------- */
 /* full refill likelihood of an explicit template: returns alpha(I,J) (scaled by 4^I), and beta(0,0) */
 void orc_window_likelihood(const float *ME, const float *INS, const float *DL, const uint8_t *t, int J, int lf,

@@ -19,3 +19,12 @@ def built():
     import __graft_entry__ as g
     g.build()
     return True
+
+
+def free_port() -> int:
+    """a rendezvous port the kernel just handed out (the torchrun tests used fixed ports 29517 / 29533, a flake on a
+    shared box); bound to 127.0.0.1 and released right before torch.distributed.run takes it"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])

@@ -3,6 +3,8 @@
 Bar (BASELINE.json north_star): HiFi sequences bit-identical, per-base QVs within 1e-4.  The oracle is
 "parity unpinned" (docs-only reference) — these tests pin the HIP kernels to the specification.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -449,8 +451,9 @@ def test_bench_two_ranks_on_one_device(built, tmp_path):
     GPU 0 through the CCSX_BENCH_DEVICE hook, the timing collectives run over gloo."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from conftest import free_port
     env = dict(os.environ, CCSX_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--zmws", "48", "--length", "2000", "--backend", "gloo",
            "--distinct", "2", "--no-cpu-baseline"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
@@ -826,3 +829,33 @@ def test_double_split_matches_oracle(handle):
             assert np.array_equal(res.kinetics(z), ref.kinetics(z))
     finally:
         hk.close()
+
+
+def test_reference_concordance_harness(built, tmp_path, monkeypatch):
+    """bench.py's `reference_concordance` — the only code that can ever pin parity against a real `ccs` — must work on
+    the day a box has one.  A stand-in reference (this repo's driver copied to another directory, so that its realpath differs from the
+    product's) goes on PATH: the harness writes the synthetic subreads, times the stand-in, runs the product and compares the HiFi reads.
+    A reference that fails (unknown chemistry triple, no --version) is reported in the result, it never raises."""
+    import shutil, stat, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    bindir = tmp_path / "refbin"
+    bindir.mkdir()
+    shutil.copy(os.path.join(root, "ccs_amd", "bin", "ccs"), bindir / "ccs")
+    monkeypatch.setenv("LD_LIBRARY_PATH", os.path.join(root, "ccs_amd") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))   # (the copy's $ORIGIN/.. rpath is gone)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    ref = shutil.which("ccs")
+    assert ref and os.path.realpath(ref) != os.path.realpath(os.path.join(root, "ccs_amd", "bin", "ccs"))
+    sample = api.synth(24, 6, 1500, seed=0xC0FFEE)
+    out = bench.reference_concordance(api, np, ref, sample, 4, 5.0)
+    assert out.get("error") is None and out["rc"] == 0, out
+    assert out["zmws_in_both"] > 0 and out["identical_sequences"] == out["zmws_in_both"] == out["hifi_reads_ours"], out
+    assert out["zmws_per_s"] > 0 and "spec" in out["version"]
+    # a reference that rejects the input (here: a script that complains about the chemistry and exits 1, and knows no --version)
+    bad = tmp_path / "badbin"
+    bad.mkdir()
+    (bad / "ccs").write_text("#!/bin/sh\necho 'Unsupported chemistries found: (101-789-500/101-826-100/5.0)' >&2\nexit 1\n")
+    os.chmod(bad / "ccs", os.stat(bad / "ccs").st_mode | stat.S_IEXEC)
+    out = bench.reference_concordance(api, np, str(bad / "ccs"), sample, 4, 5.0)
+    assert out["rc"] == 1 and "chemistry" in out["error"] and "zmws_per_s" not in out and "rc 1" in out["version"]

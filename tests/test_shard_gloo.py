@@ -46,12 +46,13 @@ def test_shard_bounds_balanced(built):
 def test_two_rank_gloo_matches_single_process(built, tmp_path):
     import pickle
     import oracle_lib as O
+    from conftest import free_port
     out = tmp_path / "gathered.pkl"
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", str(script), ROOT, str(out)]
+           "--master-port", str(free_port()), str(script), ROOT, str(out)]
     subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
     got = pickle.load(open(out, "rb"))
     batch = api.synth(7, (3, 9), (200, 1200), seed=77)
