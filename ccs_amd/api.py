@@ -230,6 +230,18 @@ class Batch:
                      self.ipd[b0:b1].copy(), self.flags[r0:r1].copy(), **kw)
 
 
+def concat(parts) -> "Batch":
+    """the ZMWs of several batches as one batch, in order (ZMW ids are renumbered 0..n-1)"""
+    read_off, base_off, tpl_off = [np.zeros(1, np.int32)], [np.zeros(1, np.int64)], [np.zeros(1, np.int64)]
+    for b in parts:
+        read_off.append(b.read_off[1:] + read_off[-1][-1]); base_off.append(b.base_off[1:] + base_off[-1][-1])
+        tpl_off.append(b.tpl_off[1:] + tpl_off[-1][-1])
+    cat = lambda k: np.ascontiguousarray(np.concatenate([getattr(b, k) for b in parts]))
+    n = sum(b.n_zmw for b in parts)
+    return Batch(np.arange(n, dtype=np.int32), cat("snr"), np.concatenate(read_off).astype(np.int32), np.concatenate(base_off).astype(np.int64),
+                 cat("bases"), cat("pw"), cat("ipd"), cat("flags"), np.concatenate(tpl_off).astype(np.int64), cat("tpl"))
+
+
 def synth(n_zmw: int, passes, length, seed: int = 1, first_zmw_id: int = 0) -> Batch:
     """Deterministic synthetic subreads (ccsx_synth_generate).  passes/length: int or (lo, hi)."""
     plo, phi = (passes, passes) if isinstance(passes, int) else passes

@@ -42,6 +42,7 @@ struct Options {
     int threads = 0;
     double min_snr = 2.5;
     int batch = 2048;
+    long long batch_bases = 0;     // cost budget of a batch in subread bases (0 = 400 kb x --batch-size): SURVEY.md 8e "batches of ~ constant cost"
     int chunk_i = 1, chunk_n = 1;
     int workers_per_gpu = 3;      // packing threads per device (one engine handle per device keeps three batches in flight)
     std::string model_file;       // --model-file: Arrow parameter json (else: chemistry of the BAM header -> bundle dir / built-in)
@@ -169,7 +170,9 @@ void usage()
                  "      --metrics-json F      per-ZMW metrics [<OUT prefix>.zmw_metrics.json.gz]\n"
                  "      --suppress-reports    do not write ccs_report.txt / zmw_metrics.json.gz\n"
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
-                 "      --batch-size N        ZMWs per GPU batch [2048]\n"
+                 "      --batch-size N        ZMWs per GPU batch, at most [2048]\n"
+                 "      --batch-bases N       ... and at most N subread bases (estimated cost, SURVEY.md 8e: batches of about constant cost for mixed\n"
+                 "                            pass counts / insert lengths) [400000 x batch-size]\n"
                  "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"
                  "      --workers-per-gpu N   packing threads per device [3] (one engine handle per device, three batches in flight)\n"
                  "      --report-file F       ccs_report.txt path [<OUT prefix>.ccs_report.txt]\n"
@@ -199,6 +202,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--maxPoaCoverage") o.o.max_poa_cov = std::atoi(need(a.c_str()).c_str());
         else if (a == "--max-insertion-size") { const int v = std::atoi(need(a.c_str()).c_str()); o.o.max_insertion_size = v > 0 ? v : -1; }
         else if (a == "--batch-size") o.batch = std::atoi(need(a.c_str()).c_str());
+        else if (a == "--batch-bases") o.batch_bases = std::atoll(need(a.c_str()).c_str());
         else if (a == "--report-file") o.report = need(a.c_str());
         else if (a == "--workers-per-gpu") o.workers_per_gpu = std::max(1, std::atoi(need(a.c_str()).c_str()));
         else if (a == "--chunk") { if (std::sscanf(need(a.c_str()).c_str(), "%d/%d", &o.chunk_i, &o.chunk_n) != 2 || o.chunk_i < 1 || o.chunk_i > o.chunk_n) { std::fprintf(stderr, "bad --chunk\n"); return false; } }
@@ -218,12 +222,14 @@ bool parse(int argc, char **argv, Options &o)
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
         else pos.push_back(a);
     }
-    if (o.o.top_passes <= 0 || o.o.top_passes > 64) {
-        std::fprintf(stderr, "ccs: warning: --top-passes %d: this engine uses at most 64 passes per ZMW (the 64 closest to the median length)\n", o.o.top_passes);
-        o.o.top_passes = 64;
+    // --top-passes 0 = unlimited (docs/faq/accuracy-vs-passes.md:49-52); the engine takes up to CCSX_MAX_PASSES = 255 per ZMW (SPEC v5)
+    if (o.o.top_passes <= 0) o.o.top_passes = CCSX_MAX_PASSES;
+    if (o.o.top_passes > CCSX_MAX_PASSES) {
+        std::fprintf(stderr, "ccs: warning: --top-passes %d: this engine uses at most %d passes per ZMW (those closest to the median length)\n", o.o.top_passes, CCSX_MAX_PASSES);
+        o.o.top_passes = CCSX_MAX_PASSES;
     }
     if (!o.write_synth.empty()) { if (pos.size() != 1) return false; o.out = pos[0]; return true; }
-    if (o.dump || o.host_only) { if (pos.size() != 1) return false; o.in = pos[0]; if (o.batch < 1) o.batch = 1; return true; }
+    if (o.dump || o.host_only) { if (pos.size() != 1) return false; o.in = pos[0]; if (o.batch < 1) o.batch = 1; if (o.batch_bases <= 0) o.batch_bases = 400000ll * o.batch; return true; }
     if (pos.size() != 2) return false;
     o.in = pos[0]; o.out = pos[1];
     {
@@ -232,6 +238,7 @@ bool parse(int argc, char **argv, Options &o)
         if (o.metrics.empty()) o.metrics = p + ".zmw_metrics.json.gz";
     }
     if (o.batch < 1) o.batch = 1;
+    if (o.batch_bases <= 0) o.batch_bases = 400000ll * o.batch;
     return true;
 }
 
@@ -267,11 +274,22 @@ std::string movie_of(const std::string &qname) { const size_t p = qname.find('/'
 // ---- synthetic subreads.bam (test helper) ----------------------------------------------------------
 int write_synthetic(const Options &o, ThreadPool &pool)
 {
-    int n = 0, P = 0, L = 0, partial = 0; unsigned long long seed = 1;   // n,passes,length[,seed[,1]]: a fifth field 1 = the first and the last
-    // subread of every ZMW are PARTIAL passes (one adapter only, truncated at the polymerase read's start / end)
-    if (std::sscanf(o.write_synth.c_str(), "%d,%d,%d,%llu,%d", &n, &P, &L, &seed, &partial) < 3) { std::fprintf(stderr, "bad --write-synthetic\n"); return 2; }
+    int n = 0, P = 0, P2 = 0, L = 0, L2 = 0, partial = 0; unsigned long long seed = 1;   // n,passes,length[,seed[,1]]: a fifth field 1 = the first and the last
+    // subread of every ZMW are PARTIAL passes (one adapter only, truncated at the polymerase read's start / end); passes and length may be
+    // ranges LO-HI (uniform / log-uniform: the BASELINE configs[4] mix is 3-50,1000-25000)
+    {
+        std::vector<std::string> f;
+        size_t a = 0;
+        for (;;) { const size_t c = o.write_synth.find(',', a); f.push_back(o.write_synth.substr(a, c == std::string::npos ? c : c - a)); if (c == std::string::npos) break; a = c + 1; }
+        auto span = [](const std::string &t, int &lo, int &hi) { const size_t d = t.find('-'); lo = std::atoi(t.c_str()); hi = d == std::string::npos ? lo : std::atoi(t.c_str() + d + 1); };
+        if (f.size() < 3) { std::fprintf(stderr, "bad --write-synthetic\n"); return 2; }
+        n = std::atoi(f[0].c_str()); span(f[1], P, P2); span(f[2], L, L2);
+        if (f.size() > 3) seed = std::strtoull(f[3].c_str(), nullptr, 10);
+        if (f.size() > 4) partial = std::atoi(f[4].c_str());
+        if (n < 1 || P < 1 || P2 < P || L < 1 || L2 < L) { std::fprintf(stderr, "bad --write-synthetic\n"); return 2; }
+    }
     ccsx_synth *s = nullptr;
-    if (ccsx_synth_generate(n, 1000, P, P, L, L, seed, &s)) { std::fprintf(stderr, "%s\n", ccsx_last_error()); return 1; }
+    if (ccsx_synth_generate(n, 1000, P, P2, L, L2, seed, &s)) { std::fprintf(stderr, "%s\n", ccsx_last_error()); return 1; }
     BgzfWriter out(o.out, pool);
     const std::string movie = "m64000_synth";
     write_header(out, "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n@RG\tID:synth001\tPL:PACBIO\tDS:READTYPE=SUBREAD;Ipd:CodecV1=ip;PulseWidth:CodecV1=pw;"
@@ -375,8 +393,8 @@ void finish_zmw(ZmwIn &z, const Options &o)
         for (size_t i : idx) sel.push_back(std::move(z.reads[i]));
         z.reads.swap(sel);
     }
-    // the engine wants a ZMW's partial passes behind its full-length passes; it uses at most 64 passes in all
-    for (auto &r : part) if (z.reads.size() < 64) z.reads.push_back(std::move(r));
+    // the engine wants a ZMW's partial passes behind its full-length passes; it uses at most CCSX_MAX_PASSES in all
+    for (auto &r : part) if (z.reads.size() < (size_t)CCSX_MAX_PASSES) z.reads.push_back(std::move(r));
 }
 
 struct ArenaPool {                          // free list of page-locked arenas: a batch holds its staging until its results are written
@@ -608,6 +626,7 @@ int main(int argc, char **argv)
             ZmwIn cur; bool have = false;
             int64_t nz = 0, nb = 0;
             auto batch = std::make_shared<Batch>();
+            long long batch_cost = 0;                        // subread bases of the ZMWs in `batch` that will reach the engine
             auto emit_zmw = [&](ZmwIn &zin) {
                 finish_zmw(zin, opt);
                 if (opt.dump) {
@@ -622,8 +641,15 @@ int main(int argc, char **argv)
                                 zin.reads.size(), zin.snr[0], zin.snr[1], zin.snr[2], zin.snr[3], hsh);
                 }
                 else {
+                    // cost-binned batches: the engine's work grows with passes x length (= the subread bases), which spreads over
+                    // ~400x in a Sequel-II-like mix; a batch closes at --batch-size ZMWs or --batch-bases bases, whichever comes first, so every
+                    // ticket the GPU workers draw from the shared queue costs about the same (and its staging stays bounded)
+                    long long cost = 0;
+                    if (zin.host_status == HS_OK) for (const Subread &r : zin.reads) cost += (long long)r.size();
+                    if (!batch->zmws.empty() && batch_cost + cost > opt.batch_bases) { batch->index = nb++; to_pack.push(batch); batch = std::make_shared<Batch>(); batch_cost = 0; }
                     batch->zmws.push_back(std::move(zin));
-                    if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_pack.push(batch); batch = std::make_shared<Batch>(); }
+                    batch_cost += cost;
+                    if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_pack.push(batch); batch = std::make_shared<Batch>(); batch_cost = 0; }
                 }
             };
             auto flush_zmw = [&] {
@@ -757,10 +783,10 @@ int main(int argc, char **argv)
         });
 
         if (opt.host_only) {                                  // no engine: count what arrives, hand the staging back
-            int64_t nz = 0, nzok = 0, nbases = 0;
+            int64_t nz = 0, nzok = 0, nbases = 0, nbatches = 0;
             std::thread sink([&] {
                 std::shared_ptr<Batch> b;
-                while (to_gpu.pop(b)) { nz += (int64_t)b->zmws.size(); if (b->n > 0) { nzok += b->n; nbases += b->n_bases; } in_pool.put(std::move(b->in_arena)); }
+                while (to_gpu.pop(b)) { ++nbatches; nz += (int64_t)b->zmws.size(); if (b->n > 0) { nzok += b->n; nbases += b->n_bases; } in_pool.put(std::move(b->in_arena)); }
             });
             reader.join();
             for (auto &w : packers) w.join();
@@ -768,8 +794,8 @@ int main(int argc, char **argv)
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             std::fprintf(stderr, "ccs: reader thread: framing/inflate %.2f s, waiting for record decode %.2f s, grouping+filters+queue %.2f s; packing (sum over %zu threads) %.2f s\n",
                          rd_us[0] * 1e-6, rd_us[1] * 1e-6, rd_us[2] * 1e-6, n_packers, us_pack.load() * 1e-6);
-            std::printf("host-only: %" PRId64 " ZMWs read, %" PRId64 " packed (%" PRId64 " bases) in %.2f s = %.1f ZMWs/s on %d host threads + %zu pack threads\n", nz, nzok, nbases, el,
-                        nz / el, nthreads, n_packers);
+            std::printf("host-only: %" PRId64 " ZMWs read, %" PRId64 " packed (%" PRId64 " bases) in %.2f s = %.1f ZMWs/s on %d host threads + %zu pack threads; %" PRId64 " batches\n", nz, nzok, nbases, el,
+                        nz / el, nthreads, n_packers, nbatches);
             if (failed) std::fprintf(stderr, "ccs: %s\n", err_msg.c_str());
             return failed ? 1 : 0;
         }

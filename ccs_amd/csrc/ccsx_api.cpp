@@ -290,7 +290,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     for (int z = 0; z < n; ++z) {
         int64_t maxL = 0;
         int nr = b->read_off[z + 1] - b->read_off[z];
-        { const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > 64) ? 64 : h->opts.top_passes; if (nr > top) nr = top; }
+        { const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > CCSX_MAX_PASSES) ? CCSX_MAX_PASSES : h->opts.top_passes; if (nr > top) nr = top; }
         nr_max = std::max(nr_max, nr);
         for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) {
             S.read_zmw[r] = z;
@@ -323,7 +323,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         if (R > 0) order_by(S.rperm, (size_t)R, [&](size_t r) { return b->base_off[r + 1] - b->base_off[r]; });
         // k_align16's work items: up to four consecutive passes of one ZMW (of the passes the engine uses), longest first
         std::vector<int32_t> qpack; std::vector<int64_t> qlen;
-        const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > 64) ? 64 : h->opts.top_passes;
+        const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > CCSX_MAX_PASSES) ? CCSX_MAX_PASSES : h->opts.top_passes;
         for (int z = 0; z < n; ++z) {
             const int r0 = b->read_off[z];
             int nr = std::min(b->read_off[z + 1] - r0, top);

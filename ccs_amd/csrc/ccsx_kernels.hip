@@ -28,7 +28,7 @@
 #include "wave_ops.h"
 
 #define LANES 64
-#define PW_MAXREADS_SPEC 64
+#define PW_MAXREADS_SPEC CCSX_MAX_PASSES      // passes of a ZMW the engine uses (k_polish / k_kinetics take them in groups of PW_MAXREADS = 64)
 #ifdef CCSX_PROFILE_PHASES
 #define PHASE_T0() unsigned long long ph_t = __builtin_readcyclecounter(); (void)ph_t
 #define PHASE(idx) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd((unsigned long long *)P.phase + (idx), n_ - ph_t); ph_t = n_; } } while (0)
@@ -355,7 +355,7 @@ __device__ __forceinline__ bool poa_add_edge(const PoaSlot &g, int4 &rec, int to
 extern __shared__ uint32_t dyn_lds[];
 #define TB_BLOCK 64                   // positions cached per traceback block (64 move rows of 32 bytes)
 
-// zref[z]: bits 0-5 = backbone pass of the current draft, plus the state of the draft cascade (SPEC "fallback draft", "last resort")
+// zref[z]: bits 0-7 = backbone pass of the current draft, plus the state of the draft cascade (SPEC "fallback draft", "last resort")
 #define ZREF_RETRY 256                  // k_post: this ZMW's first draft failed or most passes do not map to it
 #define ZREF_DONE 512                   // the fallback draft (pass 1) has been made
 #define ZREF_RETRY2 1024                // k_post: the fallback draft failed as well (bits 0-5: its backbone)
@@ -455,13 +455,17 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
     __threadfence_block();
     const int r0 = rfl(P.read_off[z]);
     int nreads = rfl(P.read_off[z + 1]) - r0;
-    {   // SPEC: at most 64 passes are used (the polish kernel keeps per-read state for 64 reads)
+    {   // SPEC v5: at most CCSX_MAX_PASSES = 255 passes are used (--top-passes 0 = all of them)
         const int top = (P.opts.top_passes <= 0 || P.opts.top_passes > PW_MAXREADS_SPEC) ? PW_MAXREADS_SPEC : P.opts.top_passes;
         if (nreads > top) nreads = top;
     }
     // SPEC "partial passes" (flag bit 1; they follow the ZMW's full-length passes): not in the draft, not counted as passes
     const int nall = nreads;
-    nreads = rfl(__popcll(__ballot(lane < nall && !(P.flags[r0 + (lane < nall ? lane : 0)] & 2))));
+    {
+        int nf = 0;
+        for (int b0 = 0; b0 < nall; b0 += LANES) nf += __popcll(__ballot(b0 + lane < nall && !(P.flags[r0 + (b0 + lane < nall ? b0 + lane : 0)] & 2)));
+        nreads = rfl(nf);
+    }
     // SPEC "fallback draft" (docs/faq/accuracy-vs-passes.md:41-46: a cascade from fast to robust draft generators): pass 1
     // (only for ZMWs k_post marked) takes the pass whose length is closest to the median as backbone and threads twice as
     // many passes, starting at the backbone and wrapping around
@@ -471,20 +475,33 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
     if (pass >= 1) {
         const int zr = rfl(P.zref[z]);
         if (!(zr & (pass == 1 ? ZREF_RETRY : ZREF_RETRY2))) return;
-        const int bb1 = pass == 2 ? (zr & 63) : -1;
-        const int len = lane < nreads ? (int)(P.base_off[r0 + lane + 1] - P.base_off[r0 + lane]) : 0x7fffffff;
-        int rank = 0;                                   // position of my length in the sorted order (ties by index)
-        for (int q = 0; q < nreads; ++q) { const int lq = __shfl(len, q); rank += (lq < len || (lq == len && q < lane)) ? 1 : 0; }
-        const int med = rfl(__shfl(len, __ffsll((long long)__ballot(lane < nreads && rank == nreads / 2)) - 1));
-        int dist = len - med; dist = dist < 0 ? -dist : dist;
-        const bool cand = lane < nreads && !(pass == 2 && ((lane == bb1 && nreads > 1) || (lane == 0 && nreads > 2)));   // not a backbone that failed
-        const int key = cand ? ((dist > 0xffffff ? 0xffffff : dist) << 6) | lane : 0x7fffffff;
-        bb = rfl(wave_min_i32(key)) & 63;
+        const int bb1 = pass == 2 ? (zr & 255) : -1;
+        // up to CCSX_MAX_PASSES = 255 full-length passes: their lengths go to LDS, a lane ranks the passes lane, lane + 64, ...
+        int32_t *slen = (int32_t *)sread;
+        for (int q = lane; q < nreads; q += LANES) slen[q] = (int)(P.base_off[r0 + q + 1] - P.base_off[r0 + q]);
+        __syncthreads();
+        int medl = 0x7fffffff;                          // the length whose rank (ties by index) is nreads / 2
+        for (int i = lane; i < nreads; i += LANES) {
+            const int len = slen[i];
+            int rank = 0;
+            for (int q = 0; q < nreads; ++q) { const int lq = slen[q]; rank += (lq < len || (lq == len && q < i)) ? 1 : 0; }
+            if (rank == nreads / 2) medl = len;
+        }
+        const int med = rfl(wave_min_i32(medl));
+        int key = 0x7fffffff;
+        for (int i = lane; i < nreads; i += LANES) {
+            int dist = slen[i] - med; dist = dist < 0 ? -dist : dist;
+            const bool cand = !(pass == 2 && ((i == bb1 && nreads > 1) || (i == 0 && nreads > 2)));   // not a backbone that failed
+            const int k = ((dist > 0x3fffff ? 0x3fffff : dist) << 8) | i;
+            if (cand && k < key) key = k;
+        }
+        bb = rfl(wave_min_i32(key)) & 255;
+        __syncthreads();                                // (sread is loaded with the backbone below)
     }
     if (lane == 0) { P.nreads_used[z] = nall; P.nfull[z] = nreads; P.draft_len[z] = 0; P.nwin[z] = 0; P.zref[z] = bb | (pass ? ZREF_PASSBIT(pass) : 0); }
     // a new draft invalidates the partial passes' alignments of the previous generator (k_align16 resets the full-length passes it
     // realigns; the partial ones are aligned by k_rescue, which only looks at passes that are not valid)
-    if (lane >= nreads && lane < nall) { P.avalid[r0 + lane] = 0; P.ascore[r0 + lane] = NEGV; }
+    for (int q = nreads + lane; q < nall; q += LANES) { P.avalid[r0 + q] = 0; P.ascore[r0 + q] = NEGV; }
     const bool enough = !(nreads < P.opts.min_passes || nreads < 1);
     if (!enough) { if (lane == 0) P.zstat[z] = CCSX_TOO_FEW_PASSES; return; }
     const int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
@@ -1251,7 +1268,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const uint8_t *d = P.draft + P.seq_off[z];
     const int32_t *wb = P.wbounds + P.wb_off[z];
     const int wstride = CH16 / 16 + 2;                  // LDS words per pass: one chunk of the pass at a time
-    const int fl0 = rfl(P.flags[r0 + (zr & 63)] & 1);
+    const int fl0 = rfl(P.flags[r0 + (zr & 255)] & 1);
     for (int hh = 0; hh < nq; ++hh) {
         const int rr = rfirst + hh;
         const int Ih = rfl((int)(P.base_off[rr + 1] - P.base_off[rr]));
@@ -1422,7 +1439,7 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int pass)
     const uint8_t *d = P.draft + P.seq_off[z];
     const int32_t *wb = P.wbounds + P.wb_off[z];
     const int I = rfl((int)(P.base_off[r + 1] - P.base_off[r]));
-    const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0 + (zr & 63)] & 1)) ? 1 : 0);
+    const int rev = rfl(((P.flags[r] & 1) != (P.flags[r0 + (zr & 255)] & 1)) ? 1 : 0);
     load_read_packed(sread, P.bases + P.base_off[r], I, rev, lane);
     __syncthreads();
     const AlignEnd ae = align_pass<0>(P, sread, I, d, Ld, wb, nw, Osave, lane);
@@ -1493,7 +1510,7 @@ __global__ __launch_bounds__(64) void k_rescue(KParams P, int pass)
         const uint8_t *d = P.draft + P.seq_off[z];
         const int32_t *wb = P.wbounds + P.wb_off[z];
         const int fl = rfl((int)P.flags[r]);
-        const int rev = rfl(((fl & 1) != (P.flags[r0 + (zr & 63)] & 1)) ? 1 : 0);
+        const int rev = rfl(((fl & 1) != (P.flags[r0 + (zr & 255)] & 1)) ? 1 : 0);
         if (fl & 2) {
             // SPEC "partial passes": anchored at one end of the draft (flag bit 2 = the adapter is at the pass's end; in draft orientation
             // that is the draft's end iff the pass is on the draft's strand).  The column loop runs from the anchored end; the pass covers
@@ -1635,14 +1652,14 @@ __global__ void k_post(KParams P, int pass)
     // the draft cascade: a failed draft, or one most passes do not map to, is retried — pass 0 -> the fallback draft (pass 1), pass 1 ->
     // the last resort (pass 2); the last attempt's outcome is final
     const bool may_retry = !P.opts.no_fallback_draft && pass < 2;
-    const int retry = pass == 0 ? ZREF_RETRY : ((zr & 63) | ZREF_RETRY2);
+    const int retry = pass == 0 ? ZREF_RETRY : ((zr & 255) | ZREF_RETRY2);
     if (P.zstat[z] != CCSX_SUCCESS) {
         P.np[z] = 0; P.out_fn[z] = 0; P.out_rn[z] = 0;
         if (may_retry && P.zstat[z] == CCSX_DRAFT_FAILURE) P.zref[z] = retry;
         return;
     }
     int r0 = P.read_off[z], nr = P.nfull[z], np = 0, rn = 0;     // full-length passes only: partial passes are not passes
-    const int f0 = P.flags[r0 + (zr & 63)];
+    const int f0 = P.flags[r0 + (zr & 255)];
     for (int r = 0; r < nr; ++r) {
         const int v = P.avalid[r0 + r];
         np += v;
@@ -1805,6 +1822,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     // lane can form before its first / after its last column exists and holds (1.0, the zero entry), so no look-up needs a guard
     __shared__ int2 sEA[2][FE_A], sEB[2][FE_B];
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
+    __shared__ uint8_t sTd[32];                              // the draft's window as it was (the large-insertion trim of a reloaded group compares with it)
     // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
     // A code is stored as obs * 264 = the byte offset of its row in sCTX (OBS_CODE), so the scoring loop adds it to a per-lane base.
     uint16_t (*sObs)[68] = (uint16_t (*)[68])dyn_lds;
@@ -1813,7 +1831,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
-    __shared__ uint8_t sZdrop[PW_MAXREADS];                  // z-score gate: decided on the draft window (round 0), then kept
+    __shared__ uint8_t sZdrop[CCSX_MAX_PASSES + 1];          // z-score gate, by PASS (all groups): decided on the draft window (round 0), then kept
     __shared__ float sBase[PW_MAXREADS], sB00[PW_MAXREADS];   // alpha(I,J) / beta(0,0) of the chunk's reads (the fill's two halves meet here)
     __shared__ short2 sTask[PW_MAXREADS];                    // fill tasks: (read A, read B or -1)
     __shared__ int sDeltaI[256];                             // fixed-point sums of the per-read gains; converted in place to float
@@ -1843,7 +1861,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     const uint8_t *draft = P.draft + so;
     const int wb0 = wb[w], wb1 = wb[w + 1];
     const int64_t bo_r0 = P.base_off[r0];
-    const int fl0 = P.flags[r0 + (P.zref[z] & 63)] & 1;    // orientation of the draft = that of its backbone pass
+    const int fl0 = P.flags[r0 + (P.zref[z] & 255)] & 1;    // orientation of the draft = that of its backbone pass
     int ws = wb0 - CCSX_WIN_OVERHANG; if (ws < 0) ws = 0;
     int we = wb1 + CCSX_WIN_OVERHANG; if (we > Ld) we = Ld;
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
@@ -1851,7 +1869,6 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     const int lf = ws > 0 ? lfv : 4, rf = we < Ld ? rfv : 4;
     // the (at most three) alignment intervals this window spans: start columns relative to ws and lengths
     const int c1 = need_col(wb, nw, Ld, idx_ws + 1), c2 = (idx_ws + 2 <= idx_we) ? need_col(wb, nw, Ld, idx_ws + 2) : we;
-    int trimflag = 0;
     const int maxins = P.opts.max_insertion_size == 0 ? 30 : P.opts.max_insertion_size;
     {
         // level 2: everything that needs only z / r0 / the window bounds
@@ -1863,8 +1880,24 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         const float zp = P.tabZ[(size_t)z * 32 + (tid & 31)];
         const int tcl = tid < we - ws ? tid : we - ws - 1;
         const uint8_t dr = draft[ws + tcl];
-        const int rcl = tid < nreads ? tid : nreads - 1;
-        const int rr = r0 + rcl;
+        if (tid < CCSX_NOBS * 32) sCTX[(e0 >> 5) * CTXS + (e0 & 31)] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
+        if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[(e1 >> 5) * CTXS + (e1 & 31)] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
+        if (tid < CTXS) sCTX[CCSX_NOBS * CTXS + tid] = make_float2(0.0f, 0.0f);
+        if (CTXS > 32 && tid < CCSX_NOBS) sCTX[tid * CTXS + 32] = make_float2(0.0f, 0.0f);     // (the padding entry of every row)
+        if (tid < 16) sDL[tid] = dl;
+        if (tid < 32) sZP[tid] = zp;
+        if (tid < we - ws) { sT[0][tid] = dr; sTd[tid] = dr; }
+        if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb0 - ws; sCtl[2] = wb1 - ws; }
+    }
+    // SPEC v5: a ZMW's passes (up to CCSX_MAX_PASSES = 255) are taken in GROUPS of PW_MAXREADS = 64: the per-read arrays below, the observation
+    // codes and the chunk plan always describe one group (local read index = pass - g0).  A ZMW of at most 64 passes — nearly all — loads
+    // its one group here and never again; larger ones reload group after group in every round (rare, so the reload is not optimised).
+    const int ngroups = (nreads + PW_MAXREADS - 1) / PW_MAXREADS;
+    // levels 2 + 3 of the prologue for the reads g0 .. g0 + ng - 1: metadata, entry rows of the window's two edge columns, dirty masks
+    auto load_meta = [&](int g0, int ng) -> int {
+        int trimflag = 0;
+        const int rcl = tid < ng ? tid : ng - 1;
+        const int rr = r0 + g0 + rcl;
         const int64_t bo0 = P.base_off[rr], bo1 = P.base_off[rr + 1], eo = P.ent_off[rr];
         const int flr = P.flags[rr] & 1, av = P.avalid[rr];
         // level 3: entry rows of the window's two edge columns (in bounds for every read; ignored unless the read mapped)
@@ -1872,15 +1905,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         const unsigned m1 = P.dmask[eo + idx_ws + 1];
         const unsigned m2 = (idx_ws + 2 <= idx_we) ? P.dmask[eo + idx_ws + 2] : 0u;
         const unsigned m3 = (idx_ws + 3 <= idx_we) ? P.dmask[eo + idx_ws + 3] : 0u;
-        if (tid < CCSX_NOBS * 32) sCTX[(e0 >> 5) * CTXS + (e0 & 31)] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
-        if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[(e1 >> 5) * CTXS + (e1 & 31)] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
-        if (tid < CTXS) sCTX[CCSX_NOBS * CTXS + tid] = make_float2(0.0f, 0.0f);
-        if (CTXS > 32 && tid < CCSX_NOBS) sCTX[tid * CTXS + 32] = make_float2(0.0f, 0.0f);     // (the padding entry of every row)
-        if (tid < 16) sDL[tid] = dl;
-        if (tid < 32) sZP[tid] = zp;
-        if (tid < we - ws) sT[0][tid] = dr;
-        if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb0 - ws; sCtl[2] = wb1 - ws; }
-        if (tid < nreads) {
+        if (tid < ng) {
             const int L = (int)(bo1 - bo0);
             const int st = flr != fl0 ? 1 : 0;
             int n = -1, na = 0;
@@ -1893,27 +1918,32 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 else { sBoff[tid] = 0; if (n < 0 || n > CCSX_IMAX) n = -1; }
                 na = st ? L - b : a;
             } else sBoff[tid] = 0;
-            sI[tid] = n; sStrand[tid] = (uint8_t)st; sZdrop[tid] = 0;
+            sI[tid] = n; sStrand[tid] = (uint8_t)st;
             sGoff[tid] = (int)(bo0 - bo_r0) + na;            // segment start relative to the ZMW's first base (sGoff is re-planned later)
             // interval k covers draft positions col(k-1) .. col(k)-1: bit (p - col(k-1))
             sDirty[tid] = av ? (m1 | (m2 << (c1 - ws)) | (m3 << (c2 - ws))) : 0u;
         }
-    }
-    const int anytrim = __syncthreads_or(trimflag);
-    // level 4: the read segments (native orientation), four reads per wave in flight
-    for (int rb = 0; rb < nreads; rb += 4 * PW_WAVES) {
+        return trimflag;
+    };
+    const int ng0 = nreads < PW_MAXREADS ? nreads : PW_MAXREADS;
+    const int trimflag = load_meta(0, ng0);
+    for (int q = tid; q <= CCSX_MAX_PASSES; q += PW_THREADS) sZdrop[q] = 0;
+    // level 4 for the group's ng reads: the read segments (native orientation), four reads per wave in flight; then the rare trim
+    auto load_obs = [&](int ng, int tflag) {
+    const int anytrim = __syncthreads_or(tflag);
+    for (int rb = 0; rb < ng; rb += 4 * PW_WAVES) {
         uint8_t bq[4], pq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = rb + PW_WAVES * q + wave;
-            const int n = r < nreads ? sI[r] : -1;
+            const int n = r < ng ? sI[r] : -1;
             const int64_t p = bo_r0 + ((lane < n) ? sGoff[r] + lane : 0);
             bq[q] = P.bases[p]; pq[q] = P.pw[p];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = rb + PW_WAVES * q + wave;
-            if (r < nreads) {
+            if (r < ng) {
                 const int n = sI[r];
                 sObs[r][lane] = (lane < n) ? (uint16_t)OBS_CODE(obs_of(bq[q], pq[q])) : (uint16_t)(lane == n ? OBS_CODE(CCSX_NOBS) : 0);   // row n: "no base"
                 if (lane < 4) sObs[r][64 + lane] = 0;
@@ -1925,7 +1955,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         // matches of prefix and suffix against the window in read orientation (ties: the smallest s).  The main loop above has
         // already stored the first J codes; the same wave owns the read here.
         const int J0 = we - ws;
-        for (int r = wave; r < nreads; r += PW_WAVES) {
+        for (int r = wave; r < ng; r += PW_WAVES) {
             const int nfull = rfl(sBoff[r]);
             if (nfull == 0) continue;
             const int st = rfl((int)sStrand[r]);
@@ -1933,29 +1963,45 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             const bool in = lane < J0;
             const int bp = in ? P.bases[p0 + lane] : 0;
             const int bs = in ? P.bases[p0 + nfull - J0 + lane] : 0, ps = in ? P.pw[p0 + nfull - J0 + lane] : 0;
-            const int T = in ? (st ? 3 - (int)sT[0][J0 - 1 - lane] : (int)sT[0][lane]) : 9;
+            const int T = in ? (st ? 3 - (int)sTd[J0 - 1 - lane] : (int)sTd[lane]) : 9;
             const unsigned long long mp = __ballot(in && (bp & 3) == T), ms = __ballot(in && (bs & 3) == T);
             const int tot = (lane <= J0) ? __popcll(mp & ((1ull << lane) - 1ull)) + __popcll(ms >> lane) : -1;
             const int sb = 63 - (rfl(wave_max_i32((tot << 6) | (63 - lane))) & 63);
             if (in && lane >= sb) sObs[r][lane] = (uint16_t)OBS_CODE(obs_of(bs, ps));
         }
     }
-    // ---- step 7, candidate filter: pile-up margin of every window position over the reads with a usable segment
-    if (wave == 0) {
-        const int J0 = we - ws;
-        int nuse = 0, nd = 0;
-        const int vIr = lane < nreads ? sI[lane] : -1;                      // lane = read: one load each, then v_readlane per read
-        const unsigned vDr = lane < nreads ? sDirty[lane] : 0u;
-        for (int r = 0; r < nreads; ++r) if (rl(vIr, r) >= 0) { ++nuse; nd += (int)(((unsigned)rl((int)vDr, r) >> (lane & 31)) & 1u); }
-        const int margin = nuse - 2 * nd;
-        const bool inw = lane < J0;
-        const unsigned neg = (unsigned)__ballot(inw && margin < 0);
-        // positions within SKIP_SPREAD of a dirty majority are polished too
-        const unsigned nearneg = neg | (neg << 1) | (neg << 2) | (neg << 3) | (neg >> 1) | (neg >> 2) | (neg >> 3);
-        const bool ok = inw && !P.opts.disable_heuristics && margin >= SKIP_MARGIN && !((nearneg >> lane) & 1u);
-        const unsigned ev = (unsigned)__ballot(ok);
-        if (lane == 0) sCtl[7] = (int)ev;
-        if (lane < 36) sPskip[lane] = inw ? skip_perr(margin) : 0.0f;
+    };
+    load_obs(ng0, trimflag);
+    // ---- step 7, candidate filter: pile-up margin of every window position over the reads with a usable segment (of every group: a ZMW
+    // of more than 64 passes walks its groups from the last to the first here, so that group 0 is the one loaded when the rounds begin)
+    {
+        int nuse = 0, nd = 0;                                 // (wave 0)
+        for (int g0 = (ngroups - 1) * PW_MAXREADS; g0 >= 0; g0 -= PW_MAXREADS) {
+            const int ng = nreads - g0 < PW_MAXREADS ? nreads - g0 : PW_MAXREADS;
+            if (ngroups > 1) {
+                __syncthreads();
+                const int tf = load_meta(g0, ng);
+                load_obs(ng, tf);
+                __syncthreads();
+            }
+            if (wave == 0) {
+                const int vIr = lane < ng ? sI[lane] : -1;                      // lane = read: one load each, then v_readlane per read
+                const unsigned vDr = lane < ng ? sDirty[lane] : 0u;
+                for (int r = 0; r < ng; ++r) if (rl(vIr, r) >= 0) { ++nuse; nd += (int)(((unsigned)rl((int)vDr, r) >> (lane & 31)) & 1u); }
+            }
+        }
+        if (wave == 0) {
+            const int J0 = we - ws;
+            const int margin = nuse - 2 * nd;
+            const bool inw = lane < J0;
+            const unsigned neg = (unsigned)__ballot(inw && margin < 0);
+            // positions within SKIP_SPREAD of a dirty majority are polished too
+            const unsigned nearneg = neg | (neg << 1) | (neg << 2) | (neg << 3) | (neg >> 1) | (neg >> 2) | (neg >> 3);
+            const bool ok = inw && !P.opts.disable_heuristics && margin >= SKIP_MARGIN && !((nearneg >> lane) & 1u);
+            const unsigned ev = (unsigned)__ballot(ok);
+            if (lane == 0) sCtl[7] = (int)ev;
+            if (lane < 36) sPskip[lane] = inw ? skip_perr(margin) : 0.0f;
+        }
     }
     const int half = lane >> 5, hrow = lane & 31;          // fill: which read of the pair, row within it
     PHASE(0);
@@ -1972,7 +2018,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __syncthreads();
     if (tid < 32) sT[0][tid] = (uint8_t)xr_t;
     if (tid < 36) sPskip[tid] = xr_p;
-    if (tid < PW_MAXREADS) sZdrop[tid] = 0;
+    for (int q = tid; q <= CCSX_MAX_PASSES; q += PW_THREADS) sZdrop[q] = 0;
     if (tid == 0) { sCtl[0] = xr_c0; sCtl[1] = xr_c1; sCtl[2] = xr_c2; sCtl[7] = xr_c7; }
     __syncthreads();
 #endif
@@ -2077,15 +2123,22 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         int curblk = -1;                                     // the block whose lane constants this wave holds (they survive the chunks of a round)
         LaneMut LF, LR;
         int myM = 0; bool mval = false;
-        // ---- chunks of reads whose gamma/beta fit the LDS budget
+        // ---- groups of PW_MAXREADS passes (one group for nearly every ZMW), and in a group: chunks of reads whose gamma/beta fit the LDS budget
+        for (int g0 = 0; g0 < nreads; g0 += PW_MAXREADS) {
+        const int ng = nreads - g0 < PW_MAXREADS ? nreads - g0 : PW_MAXREADS;
+        if (ngroups > 1) {                                   // (the per-read arrays and observation codes of the group; group 0 of round 0 is loaded already)
+            __syncthreads();
+            const int tf = load_meta(g0, ng);
+            load_obs(ng, tf);
+        }
         int rbeg = 0;
-        while (rbeg < nreads) {
+        while (rbeg < ng) {
             __syncthreads();
             int rend, ntask;
             {   // lane = read: the greedy plan by prefix sum and ballots.  EVERY wave computes it (identical values, benign identical
                 // LDS writes): a wave then reads only what it wrote itself, so no barrier is needed before the fill
                 const int r = lane;
-                const int n = (r >= rbeg && r < nreads) ? sI[r] : -1;
+                const int n = (r >= rbeg && r < ng) ? sI[r] : -1;
                 const bool cand = n >= 0;
                 const int need = cand ? (2 * n + 3) * S : 0;
                 const int incl = wave_scan_add_i32(need);
@@ -2095,7 +2148,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
 #else
                 const unsigned long long over = __ballot(cand && incl > GB_FLOATS);
 #endif
-                const int rend_ = over ? (int)__ffsll((long long)over) - 1 : nreads;         // the first read that does not fit any more
+                const int rend_ = over ? (int)__ffsll((long long)over) - 1 : ng;             // the first read that does not fit any more
                 if (r >= rbeg && r < rend_) {
                     if (!cand) { sGoff[r] = -1; sValid[r] = 0; }
                     else { const int off = incl - need; sGoff[r] = off; sBoff[r] = off + (n + 1) * S; }
@@ -2291,11 +2344,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     vLa = det_log2f(aIJ); const float lb = det_log2f(b00);
                     float df = vLa - lb; if (df < 0.0f) df = -df;
                     vOk = !(df > AB_TOL);
-                    if (sZdrop[lane]) vOk = 0;
+                    if (sZdrop[g0 + lane]) vOk = 0;
                     else if (vOk && it == 0 && P.opts.min_zscore != 0.0f) {   // A7 z-score gate, round 0 only (x4 per emitted base = 2 bits per read base)
                         const float zd = (vLa - (float)(2 * I)) - sZS[2 * sd];
                         const float zm = P.opts.min_zscore;
-                        if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) { vOk = 0; sZdrop[lane] = 1; }   // (every wave writes the same 1)
+                        if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) { vOk = 0; sZdrop[g0 + lane] = 1; }   // (every wave writes the same 1)
                     }
                 }
             }
@@ -2306,7 +2359,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const bool v = vOk != 0;
                 const unsigned long long bv = __ballot(v), lower = (1ull << lane) - 1ull;
                 nv_chunk = rfl(__popcll(bv));
-                nvfull += __popcll(bv & (nfull >= 64 ? ~0ull : (1ull << nfull) - 1ull));   // (partial passes sit behind the full ones)
+                nvfull += __popcll(bv & (nfull - g0 >= 64 ? ~0ull : (nfull - g0 <= 0 ? 0ull : (1ull << (nfull - g0)) - 1ull)));   // (partial passes sit behind the full ones)
                 const int dest = v ? __popcll(bv & lower) : nv_chunk + __popcll(~bv & lower);
                 vRlist = __builtin_amdgcn_ds_permute(dest << 2, lane);
             }
@@ -2425,6 +2478,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             }
             rbeg = rend;
             PHASE(4);
+        }
         }
         ++iters;
         nvalid_last = nvalid; nvfull_last = nvfull;
@@ -2624,10 +2678,14 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
     if (tid < J) { const uint8_t b = P.wtpl[wi * 32 + tid]; sT[0][tid] = b; sT[1][J - 1 - tid] = (uint8_t)(3 - b); }
     if (tid < 192) (&sK[0][0][0])[tid] = 0u;
-    if (tid < nreads) {                                      // one lane per read: segment of the read inside this window
-        const int rr = r0 + tid;
+    // SPEC v5: up to CCSX_MAX_PASSES passes, taken in groups of PW_MAXREADS = 64 (the sums in sK run over all groups)
+    for (int g0 = 0; g0 < nreads; g0 += PW_MAXREADS) {
+    const int ng = nreads - g0 < PW_MAXREADS ? nreads - g0 : PW_MAXREADS;
+    __syncthreads();
+    if (tid < ng) {                                          // one lane per read: segment of the read inside this window
+        const int rr = r0 + g0 + tid;
         int n = -1, off = 0;
-        const int st = ((P.flags[rr] ^ P.flags[r0 + (P.zref[z] & 63)]) & 1) ? 1 : 0;
+        const int st = ((P.flags[rr] ^ P.flags[r0 + (P.zref[z] & 255)]) & 1) ? 1 : 0;
         if (P.avalid[rr]) {
             const int32_t *ent = P.ent + P.ent_off[rr];
             const int a = ent[idx_ws], b = ent[idx_we];
@@ -2640,7 +2698,7 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
     __syncthreads();
     if (tid == 0) {                                          // tasks: two short segments share a wave (32 lanes each)
         int nt = 0, pend = -1;
-        for (int r = 0; r < nreads; ++r) {
+        for (int r = 0; r < ng; ++r) {
             const int n = sN[r];
             if (n < 0) continue;
             if (n > 31) sTask[nt++] = make_short2((short)r, (short)-1);
@@ -2664,7 +2722,7 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
         const int base = half * 32, row = lane - base;
         const int myr = half ? task.y : task.x;
         const int n = sN[myr], st = sSt[myr];
-        const int64_t p0 = P.base_off[r0 + myr] + sOff[myr];
+        const int64_t p0 = P.base_off[r0 + g0 + myr] + sOff[myr];
         const int rbv = (row >= 1 && row <= n) ? (P.bases[p0 + row - 1] & 3) : 0;   // lane of row i holds read base i-1
         const uint8_t *t = sT[st];
         // bit c of mt: read base of this row == template column c (the two bit planes of the template come as ballots)
@@ -2708,6 +2766,7 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
             }
         }
     }
+    }
     __syncthreads();
     if (tid < ce - cs) {
         const int c = cs + tid;
@@ -2723,20 +2782,20 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
 __global__ __launch_bounds__(64) void k_stitch(KParams P)
 {
     __shared__ double sSum;
-    __shared__ int sHist[65];                               // windows by number of passes used
+    __shared__ int sHist[256];                              // windows by number of passes used (0 .. CCSX_MAX_PASSES)
     const int z = blockIdx.x, lane = threadIdx.x;
     int stat = P.zstat[z];
     const int nw = (stat == CCSX_SUCCESS) ? P.nwin[z] : 0;
     const size_t w0 = (size_t)(P.wb_off[z] - z);
     const int64_t so = P.seq_off[z], cap = P.seq_off[z + 1] - so;
     int run = 0, nvs = 0, its = 0, ncv = 0;
-    if (lane == 0) { sSum = 0.0; sHist[64] = 0; }
-    sHist[lane] = 0;
+    if (lane == 0) sSum = 0.0;
+    for (int q = lane; q < 256; q += LANES) sHist[q] = 0;
     __syncthreads();
     for (int wbase = 0; wbase < nw; wbase += LANES) {
         const int w = wbase + lane;
         int4 mt = make_int4(0, 0, 0, 0);
-        if (w < nw) { mt = P.wmeta[w0 + w]; if ((unsigned)(mt.y >> 8) <= 64u) atomicAdd(&sHist[mt.y >> 8], 1); mt.y &= 255; }   // np: full-length passes; ec: all
+        if (w < nw) { mt = P.wmeta[w0 + w]; if ((unsigned)(mt.y >> 8) <= (unsigned)CCSX_MAX_PASSES) atomicAdd(&sHist[mt.y >> 8], 1); mt.y &= 255; }   // np: full-length passes; ec: all
         int pre = mt.x;                                     // inclusive scan of lengths
 #pragma unroll
         for (int s = 1; s < LANES; s <<= 1) { int o = __shfl_up(pre, s); if (lane >= s) pre += o; }
@@ -2768,9 +2827,9 @@ __global__ __launch_bounds__(64) void k_stitch(KParams P)
     // np = mode over windows of the passes used for polishing (docs/faq/accuracy-vs-passes.md:18-24); ties: the smaller count
     int npmode;
     {
-        int key = (sHist[lane] << 7) | (127 - lane);
-        if (lane == 0) { const int k64 = (sHist[64] << 7) | (127 - 64); key = k64 > key ? k64 : key; }
-        npmode = 127 - (wave_max_i32(key) & 127);
+        int key = 0;                                         // (windows << 8) | (255 - passes): the most windows, then the smaller count
+        for (int v = lane; v < 256; v += LANES) { const int k = (sHist[v] << 8) | (255 - v); key = k > key ? k : key; }
+        npmode = 255 - (wave_max_i32(key) & 255);
     }
     if (lane == 0) {
         if (stat == CCSX_SUCCESS) P.np[z] = npmode;
@@ -2836,7 +2895,7 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
     }
     trace_sync(st, "k_setup");
     if (ev) (void)hipEventRecord(ev[1], st);
-    const size_t lds_read = (((size_t)P.maxL_max + 15) / 16) * 4 + 64;
+    const size_t lds_read = (((size_t)P.maxL_max + 15) / 16) * 4 + 64 + 4 * (CCSX_MAX_PASSES + 1);   // the packed read; k_poa_init: the lengths of up to 255 passes
     // pass 0 = the draft; pass 1 = the fallback draft of the ZMWs k_post marked (their waves run, all others leave at once:
     // the second round of launches costs microseconds unless something failed)
     for (int pass = 0; pass < (P.opts.no_fallback_draft ? 1 : 3); ++pass) {

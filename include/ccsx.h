@@ -35,6 +35,7 @@ extern "C" {
 /* ---- fixed constants of the algorithm specification ---- */
 #define CCSX_BAND          64   /* DP band rows of the wide alignment (retry of the cascade, split alignment: one wave64) */
 #define CCSX_POA_BAND      32   /* DP band rows of the POA (four graphs per wave64, two rows per lane)                    */
+#define CCSX_MAX_PASSES    255  /* passes of a ZMW the engine uses (SPEC v5; k_polish works through them in groups of 64)               */
 #define CCSX_MAXPRED       7    /* POA in-edge cap per vertex (a move is a nibble: slot * 2 + [deletion], 15 = insertion) */
 #define CCSX_WIN_CORE      22   /* target window core size, docs/how-does-ccs-work.md:57-59      */
 #define CCSX_WIN_OVERHANG  2    /* +-2 bp overlap, same citation                                 */
@@ -76,7 +77,7 @@ typedef struct ccsx_model {
 typedef struct ccsx_opts {
     int32_t max_poa_cov;     /* --maxPoaCoverage (docs/changelog.md:114): subreads threaded into the POA */
     int32_t min_passes;      /* --min-passes                                                    */
-    int32_t top_passes;      /* at most this many of a ZMW's passes are used, the FIRST ones in batch order (0 or > 64 = 64).  The reference's
+    int32_t top_passes;      /* at most this many of a ZMW's passes are used, the FIRST ones in batch order (0 or > CCSX_MAX_PASSES = all, up to CCSX_MAX_PASSES).  The reference's
                                 --top-passes ("closest to the median length", docs/faq/accuracy-vs-passes.md:49-52) is a selection the
                                 caller makes when it builds the batch: the `ccs` driver does (ccs_main.cpp finish_zmw)             */
     int32_t min_length;      /* --min-length                                                    */

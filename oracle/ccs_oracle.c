@@ -75,6 +75,7 @@ static void orc_counts_flush(void)
 }
 static __thread int g_poa_scores[64], g_poa_nscores = 0;   /* test hook: end scores of the passes threaded into the last POA */
 int orc_poa_last_scores(int *out) { for (int i = 0; i < g_poa_nscores; ++i) out[i] = g_poa_scores[i]; return g_poa_nscores; }
+#define MAX_PASSES 255      /* passes of a ZMW that are used (include/ccsx.h CCSX_MAX_PASSES) */
 #define MAXPRED   7         /* in-edge cap of a POA vertex (SPEC v3; the device stores a move in a nibble) */
 #define WIN_CORE  22
 #define WIN_OVH   2
@@ -1303,8 +1304,8 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
 {
     memset(out, 0, sizeof(*out));
     int nreads = nreads_in;
-    {   /* SPEC: at most 64 passes are used (--top-passes 0 = "all" means the first 64) */
-        int top = (opts->top_passes <= 0 || opts->top_passes > 64) ? 64 : opts->top_passes;
+    {   /* SPEC v5: at most MAX_PASSES = 255 passes are used (--top-passes 0 = "all"; SPEC v4 stopped at 64) */
+        int top = (opts->top_passes <= 0 || opts->top_passes > MAX_PASSES) ? MAX_PASSES : opts->top_passes;
         if (nreads > top) nreads = top;
     }
     /* SPEC "partial passes": flag bit 1; a ZMW's partial passes follow its full-length passes (the batch is validated for that) */
@@ -1411,7 +1412,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         const uint8_t **obs = (const uint8_t **)malloc(sizeof(uint8_t *) * nreads);
         int32_t *Iw = (int32_t *)malloc(sizeof(int32_t) * nreads), *Ikin = (int32_t *)malloc(sizeof(int32_t) * nreads);
         int64_t len = 0; double perr_sum = 0.0; int64_t nvalid_sum = 0; int nonconv_any = 0, overflow = 0;
-        int32_t nv_hist[65]; memset(nv_hist, 0, sizeof(nv_hist));
+        int32_t nv_hist[MAX_PASSES + 1]; memset(nv_hist, 0, sizeof(nv_hist));
         for (int w = 0; w < nw; ++w) {
             int ws = wb[w] - WIN_OVH; if (ws < 0) ws = 0;
             int we = wb[w + 1] + WIN_OVH; if (we > Ld) we = Ld;
@@ -1475,7 +1476,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                                         orc_dbg.calib ? 0u : ev0, skp, MU, VAR, opts->min_zscore, wseq, wperr, wqv, &wlen, &wnv, &wnc, NULL, &wf, &nsc);
             out->iters += it; nvalid_sum += wnv; nonconv_any |= wnc;
             pw_nfull = 1 << 30;
-            if (pw_nvalid_full >= 0 && pw_nvalid_full <= 64) nv_hist[pw_nvalid_full] += 1;
+            if (pw_nvalid_full >= 0 && pw_nvalid_full <= MAX_PASSES) nv_hist[pw_nvalid_full] += 1;
             if (orc_dbg.stats == 2) {
                 fprintf(stderr, "WIN %d ws %d we %d cs %d ce %d it %d nv %d ev %08x draft ", w, ws, we, cs, ce, it, wnv, ev0);
                 for (int q = 0; q < J; ++q) fputc("ACGT"[draft[ws + q]], stderr);
@@ -1543,7 +1544,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
         out->ec = nw > 0 ? (float)((double)nvalid_sum / (double)nw) : 0.0f;
         {   /* np = mode over windows of the passes used for polishing (docs/faq/accuracy-vs-passes.md:18-24); ties: the smaller count */
             int best = 0;
-            for (int v = 1; v <= 64; ++v) if (nv_hist[v] > nv_hist[best]) best = v;
+            for (int v = 1; v <= MAX_PASSES; ++v) if (nv_hist[v] > nv_hist[best]) best = v;
             out->np = best;
         }
         if (overflow) out->status = ST_CAPACITY;

@@ -173,17 +173,33 @@ def test_empty_and_tiny_reads(handle):
     _compare(res, _oracle(handle, batch), batch)
 
 
-def test_more_than_64_passes_are_capped(built):
-    """SPEC: at most 64 passes are used (--top-passes 0 / >64 = 64); 70 passes must not overrun anything"""
-    o = api.default_opts(); o.top_passes = 0
+@pytest.mark.parametrize("kin", [0, 1])
+def test_more_than_64_passes(built, kin):
+    """SPEC v5 (docs/faq/accuracy-vs-passes.md:49-52: `--top-passes 0` = unlimited): up to CCSX_MAX_PASSES = 255 passes
+    of a ZMW are used — k_polish and k_kinetics take them in groups of 64, the draft cascade ranks all of them.  100- and 150-pass ZMWs next
+    to ordinary ones, partial passes behind 70 full ones, a junk first pass (fallback backbone among > 64 passes): bit-exact against the
+    oracle, np reports more than 64; a 300-pass ZMW is capped at 255"""
+    o = api.default_opts(); o.top_passes = 0; o.hifi_kinetics = kin
+    parts = [api.synth(1, 100, 400, seed=35), api.synth(2, 9, 700, seed=36), api.synth(1, 150, 300, seed=37), api.synth(1, 65, 500, seed=38),
+             api.synth(1, 300, 200, seed=39)]
+    batch = api.concat(parts)
+    rng = np.random.default_rng(5)
+    a, b = int(batch.base_off[0]), int(batch.base_off[1])
+    batch.bases[a:b] = rng.integers(0, 4, b - a, dtype=np.uint8)        # ZMW 0: pass 0 is junk -> the fallback draft picks among 100 passes
     h = api.Handle(0, opts=o)
-    batch = api.synth(1, 70, 300, seed=35)
-    res = h.consensus(batch)
-    ref = api.Results.allocate(batch)
-    O.consensus_batch(h.model, o, batch, ref)
-    _compare(res, ref, batch)
-    assert res.np_[0] == 64
-    h.close()
+    try:
+        res = h.consensus(batch)
+        ref = api.Results.allocate(batch, kinetics=bool(kin))
+        O.consensus_batch(h.model, o, batch, ref, nthreads=8)
+        _compare(res, ref, batch)
+        assert np.array_equal(res.np_, ref.np_) and np.array_equal(res.fn, ref.fn) and np.array_equal(res.rn, ref.rn)
+        assert np.allclose(res.ec, ref.ec, atol=1e-6)
+        if kin:
+            for z in range(batch.n_zmw):
+                assert np.array_equal(res.kinetics(z), ref.kinetics(z))
+        assert res.np_[0] > 64 and res.np_[3] > 100 and res.np_[5] > 200 and res.np_[4] >= 64
+    finally:
+        h.close()
 
 
 def test_api_misuse_is_reported_not_fatal(built):

@@ -250,3 +250,22 @@ def test_partial_passes_serve_the_polish_but_are_not_passes(built):
     assert res.rq.mean() > ref.rq.mean()                          # more evidence, higher predicted accuracy
     err = lambda r, b: sum(O.edit_distance(r.sequence(z), b.tpl[b.tpl_off[z]:b.tpl_off[z + 1]]) for z in range(6))
     assert err(res, batch) <= err(ref, fo) + 1
+
+
+def test_more_than_64_passes_are_used(built):
+    """SPEC v5 (docs/faq/accuracy-vs-passes.md:49-52, `--top-passes 0` = unlimited): up to 255 passes of a ZMW are used; np is the mode over
+    windows of the passes used, so it reports more than 64; accuracy does not get worse with the extra passes; 300 passes are capped at 255"""
+    o = api.default_opts(); o.top_passes = 0
+    m = api.default_model()
+    b = api.synth(1, 100, 600, seed=71)
+    r = api.Results.allocate(b)
+    O.consensus_batch(m, o, b, r)
+    assert r.status[0] == 0 and 90 <= r.np_[0] <= 100
+    o64 = api.default_opts(); o64.top_passes = 64
+    r64 = api.Results.allocate(b)
+    O.consensus_batch(m, o64, b, r64)
+    assert r64.np_[0] <= 64 and r.rq[0] >= r64.rq[0] - 1e-6
+    big = api.synth(1, 300, 200, seed=72)
+    rb = api.Results.allocate(big)
+    O.consensus_batch(m, o, big, rb)
+    assert rb.np_[0] == 255
