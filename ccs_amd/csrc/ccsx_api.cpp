@@ -286,12 +286,12 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     if (S.read_zmw.resize(R > 0 ? R : 1) || S.vcap.resize(n) || S.dcap.resize(n) || S.seq_off.assign(n + 1, 0) || S.wb_off.assign(n + 1, 0) ||
         S.ent_off.assign(R + 1, 0) || S.read_off.resize(n + 1) || S.base_off.resize(R + 1) || S.zperm.resize(n) || S.rperm.resize(R > 0 ? R : 1))
         return -2;
-    int64_t maxL_max = 1, vcap_max = 1; int need_max = 2, nr_max = 1, n_quads = 0;
+    int64_t maxL_max = 1, vcap_max = 1; int need_max = 2, nr_max = 1, nr_min = 1 << 30, n_quads = 0;
     for (int z = 0; z < n; ++z) {
         int64_t maxL = 0;
         int nr = b->read_off[z + 1] - b->read_off[z];
         { const int top = (h->opts.top_passes <= 0 || h->opts.top_passes > CCSX_MAX_PASSES) ? CCSX_MAX_PASSES : h->opts.top_passes; if (nr > top) nr = top; }
-        nr_max = std::max(nr_max, nr);
+        nr_max = std::max(nr_max, nr); nr_min = std::min(nr_min, nr);
         for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) {
             S.read_zmw[r] = z;
             const int64_t L = b->base_off[r + 1] - b->base_off[r];
@@ -425,7 +425,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
 
     KParams &P = S.P;
     std::memset(&P, 0, sizeof(P));
-    P.n_zmw = n; P.n_reads = R; P.maxL_max = (int32_t)maxL_max; P.vcap_max = (int32_t)vcap_max; P.need_max = need_max; P.max_reads = nr_max;
+    P.n_zmw = n; P.n_reads = R; P.maxL_max = (int32_t)maxL_max; P.vcap_max = (int32_t)vcap_max; P.need_max = need_max; P.max_reads = nr_max; P.min_reads = n > 0 ? nr_min : 0;
     P.opts = h->opts;
     P.model = (const ccsx_model *)h->d_model.p;
     P.snr = (const float *)S.d_snr.p; P.read_off = (const int32_t *)S.d_read_off.p; P.base_off = (const int64_t *)S.d_base_off.p;
@@ -444,7 +444,12 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.align_scratch = (int32_t *)h->d_align.p; P.align_slot_i32 = S.align_slot_i32; P.align_slots = align_slots;
     P.avalid = (uint8_t *)S.d_avalid.p; P.ascore = (int32_t *)S.d_ascore.p; P.ent = (int32_t *)S.d_ent.p; P.dmask = (uint32_t *)S.d_dmask.p;
     P.total_wslots = total_wslots;
-    if (ccsx_polish_lds(nr_max, &P.pw_obs_bytes, &P.pw_gb_floats)) { ccsx_set_error("ccsx_upload: cannot size the polish kernel's LDS"); return -2; }
+    {   // the narrow instantiation of k_polish sees ZMWs of fewer than ccsx_polish_wide_min_reads() passes only: its observation codes are sized for those
+        const int wmin = ccsx_polish_wide_min_reads();
+        if (ccsx_polish_lds(std::min(nr_max, wmin - 1), 0, &P.pw_obs_bytes[0], &P.pw_gb_floats[0]) || ccsx_polish_lds(nr_max, 1, &P.pw_obs_bytes[1], &P.pw_gb_floats[1])) {
+            ccsx_set_error("ccsx_upload: cannot size the polish kernel's LDS"); return -2;
+        }
+    }
     P.wseq = (uint8_t *)S.d_wseq.p; P.wqv = (float *)S.d_wqv.p; P.wsum = (float *)S.d_wsum.p; P.wmeta = (int4 *)S.d_wmeta.p;
     P.out_seq = (uint8_t *)S.d_out_seq.p; P.out_qual = (uint8_t *)S.d_out_qual.p; P.out_raw = (float *)S.d_out_raw.p;
     int32_t *oi = (int32_t *)S.d_out_i32.p;

@@ -1809,7 +1809,14 @@ __device__ __forceinline__ float skip_perr(int g)
 }
 
 
-__global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
+// Two instantiations: PWT threads, PWMIN workgroups' worth of waves per SIMD, PWCH reads per gamma/beta chunk.
+//   narrow  256 threads x 4 workgroups per CU (40 KB each), 4 reads per chunk   — ZMWs of up to PW_WIDE_MIN_READS - 1 passes (c2: 10 passes = 4 + 4 + 2)
+//   wide    512 threads x 2 workgroups per CU (80 KB each), 8 reads per chunk   — ZMWs of more passes (c4: 30 passes = 8 + 8 + 8 + 6; the narrow
+//           shape holds only three 30-pass reads per chunk next to their observation codes: 844 -> 356 ms per 8192 ZMWs, profiles/r04_c4_shapes.txt)
+// Both are launched over all window slots; a workgroup whose ZMW belongs to the other class leaves at once (the host skips a class no ZMW of the
+// batch is in).
+template <int PWT, int PWMIN, int PWCH>
+__global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int obs_bytes, int gb_floats, int nr_lo, int nr_hi)
 {
     // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0); row 12 = zeros ("no base").  Row stride CTXS = 33 entries: with the banded link every
     // lane looks up its OWN observation row, and with 32 entries per row all lanes of one context hit the same bank pair whatever
@@ -1826,8 +1833,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
     // A code is stored as obs * 264 = the byte offset of its row in sCTX (OBS_CODE), so the scoring loop adds it to a per-lane base.
     uint16_t (*sObs)[68] = (uint16_t (*)[68])dyn_lds;
-    float *sGB = (float *)((uint8_t *)dyn_lds + P.pw_obs_bytes);
-    const int GB_FLOATS = P.pw_gb_floats;
+    float *sGB = (float *)((uint8_t *)dyn_lds + obs_bytes);
+    const int GB_FLOATS = gb_floats;
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
@@ -1837,11 +1844,10 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __shared__ int sDeltaI[256];                             // fixed-point sums of the per-read gains; converted in place to float
     float *sDelta = (float *)sDeltaI;                        // (each thread converts its own entry after the scoring barrier)
     __shared__ uint8_t sMvalid[256];
-    __shared__ int sAcc[32];
     __shared__ int sCtl[12];                                 // 0:J 1:cs 2:ce 3:nacc 7:ev bits
     __shared__ float sZS[4];                                 // z-score sums: M fwd, V fwd, M rev, V rev
     __shared__ float sPskip[36];                             // error probability of a position if it is skipped (travels with the base)
-    __shared__ int sCnt[PW_WAVES];
+    __shared__ int sCnt[(PWT / 64)];
     __shared__ short sList[256];                             // compacted valid mutation lanes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);      // wave-uniform values are made scalar explicitly (rfl):
@@ -1856,7 +1862,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     const int r0 = P.read_off[z], nreads = P.nreads_used[z];
     const int64_t so = P.seq_off[z];
     const int w = bid - (wbo - z);
-    if (w >= nw) return;
+    if (w >= nw || nreads < nr_lo || nreads > nr_hi) return;     // (nr_lo .. nr_hi: the pass counts this instantiation serves)
     const int32_t *wb = P.wbounds + wbo;
     const uint8_t *draft = P.draft + so;
     const int wb0 = wb[w], wb1 = wb[w + 1];
@@ -1872,7 +1878,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     const int maxins = P.opts.max_insertion_size == 0 ? 30 : P.opts.max_insertion_size;
     {
         // level 2: everything that needs only z / r0 / the window bounds
-        const int e0 = tid < CCSX_NOBS * 32 ? tid : 0, e1 = tid + PW_THREADS < CCSX_NOBS * 32 ? tid + PW_THREADS : e0;
+        const int e0 = tid < CCSX_NOBS * 32 ? tid : 0, e1 = tid + PWT < CCSX_NOBS * 32 ? tid + PWT : e0;
         const size_t tz = (size_t)z * 192;
         const int i0 = (e0 & 15) * CCSX_NOBS + (e0 >> 5), i1 = (e1 & 15) * CCSX_NOBS + (e1 >> 5);
         const float me0 = P.tabME[tz + i0], in0 = P.tabINS[tz + i0], me1 = P.tabME[tz + i1], in1 = P.tabINS[tz + i1];
@@ -1881,7 +1887,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         const int tcl = tid < we - ws ? tid : we - ws - 1;
         const uint8_t dr = draft[ws + tcl];
         if (tid < CCSX_NOBS * 32) sCTX[(e0 >> 5) * CTXS + (e0 & 31)] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
-        if (tid + PW_THREADS < CCSX_NOBS * 32) sCTX[(e1 >> 5) * CTXS + (e1 & 31)] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
+        if (tid + PWT < CCSX_NOBS * 32) sCTX[(e1 >> 5) * CTXS + (e1 & 31)] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
         if (tid < CTXS) sCTX[CCSX_NOBS * CTXS + tid] = make_float2(0.0f, 0.0f);
         if (CTXS > 32 && tid < CCSX_NOBS) sCTX[tid * CTXS + 32] = make_float2(0.0f, 0.0f);     // (the padding entry of every row)
         if (tid < 16) sDL[tid] = dl;
@@ -1927,22 +1933,22 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     };
     const int ng0 = nreads < PW_MAXREADS ? nreads : PW_MAXREADS;
     const int trimflag = load_meta(0, ng0);
-    for (int q = tid; q <= CCSX_MAX_PASSES; q += PW_THREADS) sZdrop[q] = 0;
+    for (int q = tid; q <= CCSX_MAX_PASSES; q += PWT) sZdrop[q] = 0;
     // level 4 for the group's ng reads: the read segments (native orientation), four reads per wave in flight; then the rare trim
     auto load_obs = [&](int ng, int tflag) {
     const int anytrim = __syncthreads_or(tflag);
-    for (int rb = 0; rb < ng; rb += 4 * PW_WAVES) {
+    for (int rb = 0; rb < ng; rb += 4 * (PWT / 64)) {
         uint8_t bq[4], pq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = rb + PW_WAVES * q + wave;
+            const int r = rb + (PWT / 64) * q + wave;
             const int n = r < ng ? sI[r] : -1;
             const int64_t p = bo_r0 + ((lane < n) ? sGoff[r] + lane : 0);
             bq[q] = P.bases[p]; pq[q] = P.pw[p];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = rb + PW_WAVES * q + wave;
+            const int r = rb + (PWT / 64) * q + wave;
             if (r < ng) {
                 const int n = sI[r];
                 sObs[r][lane] = (lane < n) ? (uint16_t)OBS_CODE(obs_of(bq[q], pq[q])) : (uint16_t)(lane == n ? OBS_CODE(CCSX_NOBS) : 0);   // row n: "no base"
@@ -1955,7 +1961,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         // matches of prefix and suffix against the window in read orientation (ties: the smallest s).  The main loop above has
         // already stored the first J codes; the same wave owns the read here.
         const int J0 = we - ws;
-        for (int r = wave; r < ng; r += PW_WAVES) {
+        for (int r = wave; r < ng; r += (PWT / 64)) {
             const int nfull = rfl(sBoff[r]);
             if (nfull == 0) continue;
             const int st = rfl((int)sStrand[r]);
@@ -2018,7 +2024,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     __syncthreads();
     if (tid < 32) sT[0][tid] = (uint8_t)xr_t;
     if (tid < 36) sPskip[tid] = xr_p;
-    for (int q = tid; q <= CCSX_MAX_PASSES; q += PW_THREADS) sZdrop[q] = 0;
+    for (int q = tid; q <= CCSX_MAX_PASSES; q += PWT) sZdrop[q] = 0;
     if (tid == 0) { sCtl[0] = xr_c0; sCtl[1] = xr_c1; sCtl[2] = xr_c2; sCtl[7] = xr_c7; }
     __syncthreads();
 #endif
@@ -2104,7 +2110,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             if (v0) sList[basew + __popcll(bal & ((1ull << lane) - 1ull))] = (short)tid;
             __syncthreads();
         }
-        for (int e = tid; e < 2 * (FE_A + FE_B); e += PW_THREADS) {          // (sColJ is complete: two barriers since)
+        for (int e = tid; e < 2 * (FE_A + FE_B); e += PWT) {          // (sColJ is complete: two barriers since)
             const bool isa = e < 2 * FE_A;
             const int e2 = isa ? e : e - 2 * FE_A, len = isa ? FE_A : FE_B;
             const int sd = e2 >= len ? 1 : 0, idx = e2 - sd * len;
@@ -2116,7 +2122,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
         }
         int nvm = 0;
 #pragma unroll
-        for (int q = 0; q < PW_WAVES; ++q) nvm += rfl(sCnt[q]);
+        for (int q = 0; q < (PWT / 64); ++q) nvm += rfl(sCnt[q]);
         const int nblk = (nvm + 63) >> 6;
         PHASE(1);
         int nvalid = 0, nvfull = 0;
@@ -2142,12 +2148,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 const bool cand = n >= 0;
                 const int need = cand ? (2 * n + 3) * S : 0;
                 const int incl = wave_scan_add_i32(need);
-#if PW_CHUNK_READS > 0
                 const unsigned long long bcand = __ballot(cand);
-                const unsigned long long over = __ballot(cand && (incl > GB_FLOATS || __popcll(bcand & ((1ull << lane) - 1ull)) >= PW_CHUNK_READS));
-#else
-                const unsigned long long over = __ballot(cand && incl > GB_FLOATS);
-#endif
+                const unsigned long long over = __ballot(cand && (incl > GB_FLOATS || (PWCH > 0 && __popcll(bcand & ((1ull << lane) - 1ull)) >= PWCH)));
                 const int rend_ = over ? (int)__ffsll((long long)over) - 1 : ng;             // the first read that does not fit any more
                 if (r >= rbeg && r < rend_) {
                     if (!cand) { sGoff[r] = -1; sValid[r] = 0; }
@@ -2178,13 +2180,12 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
 #ifdef CCSX_EXP_NO_FILL
             const int nsplit = 0, ntfull = 0, nunit_f = 0;
 #else
-            const int nrest = ntask % PW_WAVES, nsplit = (nrest > 0 && 2 * nrest <= PW_WAVES) ? nrest : 0;
+            const int nrest = ntask % (PWT / 64), nsplit = (nrest > 0 && 2 * nrest <= (PWT / 64)) ? nrest : 0;
             const int ntfull = ntask - nsplit, nunit_f = ntfull + 2 * nsplit;
 #endif
-#ifndef PW_FILL_WAVES
-#define PW_FILL_WAVES PW_WAVES        // experiment (profiles/r04_fill_waves.txt): the fill's units on fewer waves — same instructions, longer critical path
-#endif
-            for (int fu = wave; fu < nunit_f && wave < PW_FILL_WAVES; fu += PW_FILL_WAVES) {
+            // (experiment, profiles/r04_fill_waves.txt: the same units on 2 / 1 of the 4 waves — same instructions, longer critical path — cost
+            // +32 / +117 ms of 157: a workgroup's critical path counts, not only its instruction total)
+            for (int fu = wave; fu < nunit_f; fu += (PWT / 64)) {
                 const int tk = fu < ntfull ? fu : ntfull + ((fu - ntfull) >> 1);
                 const int mode = fu < ntfull ? 0 : 1 + ((fu - ntfull) & 1);      // 0: alpha and beta, 1: alpha only, 2: beta only
                 const short2 task = sTask[tk];
@@ -2384,8 +2385,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                     vR = lane < nv ? vRlist : rl(vRlist, 0);
                     vI = sI[vR]; vSt = (int)sStrand[vR]; vG = sGoff[vR]; vB = sBoff[vR]; vBase = __shfl(vLa, vR);
                 }
-                const int u_end = ((wave + 1) * nunits) / PW_WAVES;
-                for (int u = (wave * nunits) / PW_WAVES; u < u_end;) {
+                const int u_end = ((wave + 1) * nunits) / (PWT / 64);
+                for (int u = (wave * nunits) / (PWT / 64); u < u_end;) {
                     const int blk = u / nv, k0 = u - blk * nv;
                     const bool two = (u + 1 < u_end) && (k0 + 1 < nv);       // the next unit is mine and in the same block
                     u += two ? 2 : 1;
@@ -2494,6 +2495,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             int candmask = 0;
             for (int k = 0; k < 4; ++k) { int m = lane + 64 * k; if (sMvalid[m] && sDelta[m] > MUT_EPS) candmask |= 1 << k; }
             int Jn = J, nacc = 0;
+            unsigned accpos = 0;                             // positions of the accepted mutations (at most one per position: they are >= MUT_SEP apart)
+            int accm = 0;                                    // lane c (< 32): the mutation accepted at position c
             for (;;) {
                 float bd = -1.0f; int bm = 1 << 20;
                 for (int k = 0; k < 4; ++k) if (candmask & (1 << k)) { int m = lane + 64 * k; float dv = sDelta[m]; if (dv > bd) { bd = dv; bm = m; } }
@@ -2505,43 +2508,51 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
                 if (sl >= 4 && Jn >= CCSX_JMAX) continue;
                 if (sl == 3 && Jn <= JMIN_DEL + 1) continue;
                 if (sl >= 4) ++Jn; else if (sl == 3) --Jn;
-                if (lane == 0) sAcc[nacc] = msel;
+                if (lane == c) accm = msel;
+                accpos |= 1u << c;
                 ++nacc;
                 if (it >= MULTI_ROUNDS) break;
                 int dc = (lane & 31) - c; if (dc < 0) dc = -dc;
                 if (dc < MUT_SEP) candmask = 0;
             }
-            if (lane == 0) {
-                // apply in descending position order
-                for (int a = 0; a < nacc; ++a) for (int b2 = a + 1; b2 < nacc; ++b2)
-                    if ((sAcc[b2] & 31) > (sAcc[a] & 31)) { int tt = sAcc[a]; sAcc[a] = sAcc[b2]; sAcc[b2] = tt; }
+            {
+                // apply in descending position order.  lane = column: the template base and the skip probability of every column sit in a register
+                // and an insertion / deletion is one lane shift (round 3 walked both arrays in LDS on lane 0, a dependent load -> store per column)
                 int Jc = J, cs = sCtl[1], ce = sCtl[2];
                 unsigned ev = (unsigned)sCtl[7];
-                uint8_t *t = sT[0];
-                for (int a = 0; a < nacc; ++a) {
-                    const int m = sAcc[a], sl = m >> 5, c = m & 31;
-                    if (sl < 3) t[c] = (uint8_t)((t[c] + 1 + sl) & 3);
+                int tb = lane < 32 ? (int)sT[0][lane] : 0;
+                float ps = lane < 36 ? sPskip[lane] : 0.0f;
+                while (accpos) {
+                    const int c = 31 - __clz((int)accpos);
+                    accpos &= ~(1u << c);
+                    const int m = rl(accm, c), sl = m >> 5;
+                    if (sl < 3) { if (lane == c) tb = (tb + 1 + sl) & 3; }
                     else if (sl >= 4) {
-                        for (int k = Jc; k > c; --k) t[k] = t[k - 1];
-                        t[c] = (uint8_t)(sl - 4); ++Jc;
+                        const int tu = __shfl_up(tb, 1);
+                        const float pu = __shfl_up(ps, 1);
+                        tb = lane < c ? tb : (lane == c ? sl - 4 : tu);
+                        if (lane < 32) ps = lane < c ? ps : (lane == c ? 0.0f : pu);      // (entries 32 .. 35 stay, as in the column-by-column walk)
+                        ++Jc;
                         if (c < cs) { ++cs; ++ce; } else if (c < ce) ++ce;
                         // the evidence bit and the skip probability travel with their base; an inserted base is a candidate
                         const unsigned lowm = (1u << c) - 1u;
                         ev = (ev & lowm) | ((ev & ~lowm) << 1);
-                        for (int k = CCSX_JMAX; k > c; --k) sPskip[k] = sPskip[k - 1];
-                        sPskip[c] = 0.0f;
                     } else {
-                        for (int k = c; k + 1 < Jc; ++k) t[k] = t[k + 1];
+                        const int td = __shfl_down(tb, 1);
+                        const float pd = __shfl_down(ps, 1);
+                        if (lane >= c) tb = td;
+                        if (lane >= c && lane < 31) ps = pd;
                         --Jc;
                         if (c < cs) { --cs; --ce; } else if (c < ce) --ce;
                         const unsigned lowm = (1u << c) - 1u;
                         ev = (ev & lowm) | ((ev >> 1) & ~lowm);
-                        for (int k = c; k < CCSX_JMAX; ++k) sPskip[k] = sPskip[k + 1];
                     }
                     // re-open the neighbourhood of the applied mutation for the following rounds
                     for (int q = c - SKIP_SPREAD; q <= c + SKIP_SPREAD; ++q) if (q >= 0 && q < 32) ev &= ~(1u << q);
                 }
-                sCtl[0] = Jc; sCtl[1] = cs; sCtl[2] = ce; sCtl[3] = nacc; sCtl[7] = (int)ev;
+                if (lane < 32) sT[0][lane] = (uint8_t)tb;
+                if (lane < 36) sPskip[lane] = ps;
+                if (lane == 0) { sCtl[0] = Jc; sCtl[1] = cs; sCtl[2] = ce; sCtl[3] = nacc; sCtl[7] = (int)ev; }
             }
         }
         __syncthreads();
@@ -2552,6 +2563,10 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
     // ---- A6: QVs of the core positions from the last scoring round
     const int J = sCtl[0], cs = sCtl[1], ce = sCtl[2];
     const size_t wi = (size_t)(P.wb_off[z] - z) + w;
+    // every mutation lane's term exp2(min(delta, 20)) is computed by the lane's own thread (all waves at once; the core threads below used to
+    // evaluate their 8 - 12 exponentials one after the other while three waves waited), then summed per position in the SPEC's order
+    if (tid < 256 && sMvalid[tid]) { float dv = sDelta[tid]; if (dv > 20.0f) dv = 20.0f; sDelta[tid] = det_exp2f(dv); }
+    __syncthreads();
     float pl = 0.0f;                                        // this position's error probability
     if (tid < ce - cs) {
         const int c = cs + tid;
@@ -2561,11 +2576,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MINWAVES) void k_polish(KParams P)
             float s = (((unsigned)sCtl[7] >> c) & 1u) ? sPskip[c] : 0.0f;   // quiet homopolymer position: its untested mutations
             for (int sl = 0; sl < 8; ++sl) {
                 int m = sl * 32 + c;
-                if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }
+                if (sMvalid[m]) s = s + sDelta[m];
             }
             if (c == J - 1) for (int sl = 4; sl < 8; ++sl) {
                 int m = sl * 32 + J;
-                if (sMvalid[m]) { float dv = sDelta[m]; if (dv > 20.0f) dv = 20.0f; s = s + det_exp2f(dv); }
+                if (sMvalid[m]) s = s + sDelta[m];
             }
             p = __fdiv_rn(s, 1.0f + s);
         }
@@ -2862,16 +2877,25 @@ static void trace_sync(hipStream_t st, const char *what)
 
 // dynamic LDS of k_polish: [reads][68] observation codes for the largest ZMW of the batch, the rest of the workgroup's
 // budget holds gamma/beta of one chunk of reads
-int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
+#ifndef PW_WIDE_MIN_READS
+#define PW_WIDE_MIN_READS 14          // ZMWs of at least this many passes take the wide instantiation (profiles/r04_c4_shapes.txt)
+#endif
+#define PW_WIDE_THREADS 512
+#define PW_WIDE_LDS_BYTES 81920       // two wide workgroups per CU
+#define PW_WIDE_CHUNK_READS 8         // eight reads = four pairs = eight alpha-only / beta-only units = one sweep on each of the eight waves
+int ccsx_polish_wide_min_reads(void) { return PW_WIDE_MIN_READS; }
+int ccsx_polish_lds(int max_reads, int wide, int *obs_bytes, int *gb_floats)
 {
     hipFuncAttributes fa;                                  // per call: the attribute is per device, handles live on several
-    if (hipFuncGetAttributes(&fa, (const void *)k_polish) != hipSuccess) return -1;
+    const void *fn = wide ? (const void *)k_polish_t<PW_WIDE_THREADS, 2, PW_WIDE_CHUNK_READS> : (const void *)k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>;
+    const int budget = wide ? PW_WIDE_LDS_BYTES : PW_LDS_BYTES;
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return -1;
     const int static_bytes = (int)fa.sharedSizeBytes;
-    if (hipFuncSetAttribute((const void *)k_polish, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES - static_bytes) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, budget - static_bytes) != hipSuccess) return -1;
     if (max_reads > PW_MAXREADS) max_reads = PW_MAXREADS;
     if (max_reads < 1) max_reads = 1;
     *obs_bytes = ((max_reads * 68 * 2) + 15) & ~15;
-    *gb_floats = (PW_LDS_BYTES - static_bytes - *obs_bytes) / 4;
+    *gb_floats = (budget - static_bytes - *obs_bytes) / 4;
     return 0;
 }
 
@@ -2950,8 +2974,17 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
     } else if (st_polish != st && !failed) failed = "two streams need events";
     st = st_polish;
     if (P.total_wslots > 0) {
-        hipLaunchKernelGGL(k_polish, dim3((unsigned)P.total_wslots), dim3(PW_THREADS), (size_t)P.pw_obs_bytes + (size_t)P.pw_gb_floats * 4, st, P);
-        LAUNCH_CHECK("k_polish");
+        // narrow instantiation: ZMWs of fewer than PW_WIDE_MIN_READS passes; wide: the others.  A class without ZMWs in this batch is not launched.
+        if (P.min_reads < PW_WIDE_MIN_READS) {
+            hipLaunchKernelGGL((k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>), dim3((unsigned)P.total_wslots), dim3(PW_THREADS),
+                               (size_t)P.pw_obs_bytes[0] + (size_t)P.pw_gb_floats[0] * 4, st, P, P.pw_obs_bytes[0], P.pw_gb_floats[0], 0, PW_WIDE_MIN_READS - 1);
+            LAUNCH_CHECK("k_polish");
+        }
+        if (P.max_reads >= PW_WIDE_MIN_READS) {
+            hipLaunchKernelGGL((k_polish_t<PW_WIDE_THREADS, 2, PW_WIDE_CHUNK_READS>), dim3((unsigned)P.total_wslots), dim3(PW_WIDE_THREADS),
+                               (size_t)P.pw_obs_bytes[1] + (size_t)P.pw_gb_floats[1] * 4, st, P, P.pw_obs_bytes[1], P.pw_gb_floats[1], PW_WIDE_MIN_READS, 1 << 30);
+            LAUNCH_CHECK("k_polish(wide)");
+        }
     }
     trace_sync(st, "k_polish");
     if (P.opts.hifi_kinetics && P.total_wslots > 0) {

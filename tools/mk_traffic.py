@@ -5,12 +5,19 @@ taken from the number of k_polish dispatches (one per pass)."""
 import glob, json, os, sqlite3, sys
 root, n = sys.argv[1], int(sys.argv[2])
 head = sys.argv[3] if len(sys.argv) > 3 else None
+def kname(n):
+    """kernel name without return type, template arguments and parameters: 'void k_polish_t<512, 2, 8>(KParams, ...)' -> 'k_polish'"""
+    n = n.split("(")[0].split("<")[0].strip()
+    n = n[5:] if n.startswith("void ") else n
+    return "k_polish" if n == "k_polish_t" else n
+
+
 val, cnt = {}, {}
 for db in glob.glob(os.path.join(root, "pmc_*", "pmc_results.db")):
     c = sqlite3.connect(db)
     for kn, cn, v, k in c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"):
-        val.setdefault(kn.split("(")[0], {})[cn] = v
-        cnt.setdefault(kn.split("(")[0], {})[cn] = k
+        d_ = val.setdefault(kname(kn), {}); d_[cn] = d_.get(cn, 0) + v       # (the two instantiations of k_polish_t add up)
+        c_ = cnt.setdefault(kname(kn), {}); c_[cn] = max(c_.get(cn, 0), k)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ_* (separate passes), python bench.py "
                  f"--pmc --zmws {n} --steps 1 --warmup 1 --distinct 1, tools/prof_round.sh",
        "head": head,

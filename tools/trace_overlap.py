@@ -5,10 +5,14 @@ the union-busy time of the two stages and the wall span.  usage: trace_overlap.p
 import glob, os, sqlite3, sys
 db = glob.glob(os.path.join(sys.argv[1], "**", "*results.db"), recursive=True)[0]
 c = sqlite3.connect(db)
-rows = [(n.split("(")[0], s, e, q) for n, s, e, q in c.execute("select name, start, end, queue_id from kernels order by start")]
+def kname(n):                                   # 'void k_polish_t<512, 2, 8>(KParams, ...)' -> 'k_polish'
+    n = n.split("(")[0].split("<")[0].strip()
+    n = n[5:] if n.startswith("void ") else n
+    return "k_polish" if n == "k_polish_t" else n
+rows = [(kname(n), s, e, q) for n, s, e, q in c.execute("select name, start, end, queue_id from kernels order by start")]
 t0 = min(r[1] for r in rows)
 pol = [(s, e) for n, s, e, q in rows if n in ("k_polish", "k_stitch", "k_kinetics")]
-dra = [(n, s, e) for n, s, e, q in rows if n in ("k_poa", "k_align16", "k_align", "k_rescue", "k_post", "k_setup")]
+dra = [(n, s, e) for n, s, e, q in rows if n in ("k_poa_init", "k_poa_dp", "k_poa_thread", "k_poa_finish", "k_align16", "k_align", "k_rescue", "k_post", "k_setup")]
 def union(iv):
     iv = sorted(iv); out = []
     for s, e in iv:
