@@ -344,6 +344,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         }
     }
     const int64_t total_wslots = (int64_t)S.wb_off[n] - n;
+    if (total_wslots > 0x7fff0000ll) { ccsx_set_error("ccsx_upload: batch too large (more than 2^31 window slots): split it"); return -1; }
     if (S.wslot.resize(total_wslots > 0 ? total_wslots : 1)) return -2;
     for (int z = 0; z < n; ++z) std::fill(S.wslot.p + (S.wb_off[z] - z), S.wslot.p + (S.wb_off[z + 1] - (z + 1)), z);
 
@@ -444,12 +445,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.align_scratch = (int32_t *)h->d_align.p; P.align_slot_i32 = S.align_slot_i32; P.align_slots = align_slots;
     P.avalid = (uint8_t *)S.d_avalid.p; P.ascore = (int32_t *)S.d_ascore.p; P.ent = (int32_t *)S.d_ent.p; P.dmask = (uint32_t *)S.d_dmask.p;
     P.total_wslots = total_wslots;
-    {   // the narrow instantiation of k_polish sees ZMWs of fewer than ccsx_polish_wide_min_reads() passes only: its observation codes are sized for those
-        const int wmin = ccsx_polish_wide_min_reads();
-        if (ccsx_polish_lds(std::min(nr_max, wmin - 1), 0, &P.pw_obs_bytes[0], &P.pw_gb_floats[0]) || ccsx_polish_lds(nr_max, 1, &P.pw_obs_bytes[1], &P.pw_gb_floats[1])) {
-            ccsx_set_error("ccsx_upload: cannot size the polish kernel's LDS"); return -2;
-        }
-    }
+    if (ccsx_polish_lds(nr_max, &P.pw_obs_bytes, &P.pw_gb_floats)) { ccsx_set_error("ccsx_upload: cannot size the polish kernel's LDS"); return -2; }
     P.wseq = (uint8_t *)S.d_wseq.p; P.wqv = (float *)S.d_wqv.p; P.wsum = (float *)S.d_wsum.p; P.wmeta = (int4 *)S.d_wmeta.p;
     P.out_seq = (uint8_t *)S.d_out_seq.p; P.out_qual = (uint8_t *)S.d_out_qual.p; P.out_raw = (float *)S.d_out_raw.p;
     int32_t *oi = (int32_t *)S.d_out_i32.p;

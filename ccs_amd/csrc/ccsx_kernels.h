@@ -51,7 +51,7 @@ struct KParams {
     uint32_t *dmask;           // same indexing: pile-up dirty bits of the draft positions between two window-edge columns
     // ---- per-window polish outputs
     long long total_wslots;
-    int32_t pw_obs_bytes[2], pw_gb_floats[2];   // k_polish dynamic LDS of the narrow [0] / wide [1] instantiation: observation codes, gamma/beta floats
+    int32_t pw_obs_bytes, pw_gb_floats;   // k_polish dynamic LDS: observation codes, gamma/beta floats
     uint8_t *wseq;             // [wslots][32]
     float *wqv;                // [wslots][32]
     float *wsum;               // [wslots] sum of p_err over the core
@@ -78,5 +78,4 @@ struct KParams {
 };
 
 const char *ccsx_launch_all(const KParams &P, hipStream_t st_draft, hipStream_t st_polish, hipEvent_t *ev /* [7] */);   // NULL, or the name of the launch that failed
-int ccsx_polish_lds(int max_reads, int wide, int *obs_bytes, int *gb_floats);
-int ccsx_polish_wide_min_reads(void);
+int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats);

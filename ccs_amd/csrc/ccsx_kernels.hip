@@ -1699,7 +1699,9 @@ __global__ void k_post(KParams P, int pass)
                                       // adds a task and turns the units into full alpha+beta sweeps on three waves.  Eight-wave workgroups with 8 / 10
                                       // reads per chunk (2 per CU, 80 KB each) ran 260 / 229 ms: profiles/r03_polish_fill_variants.txt
 #endif
-#define PW_MAXREADS 64
+#ifndef PW_MAXREADS
+#define PW_MAXREADS 64                // passes per GROUP: the per-read arrays, observation codes and chunk plan of k_polish / k_kinetics describe one group
+#endif
 #ifndef PW_LDS_BYTES
 #define PW_LDS_BYTES 40960            // static + dynamic LDS of one workgroup: FOUR workgroups per CU fill its 160 KB exactly.  Round 3 sweep (ms of
                                       // k_polish per 8192 ZMWs 10 x 10 kb, alone / under the draft stage of the next batch): 52992 (3 per CU) 217.9 / 305.3,
@@ -1809,14 +1811,11 @@ __device__ __forceinline__ float skip_perr(int g)
 }
 
 
-// Two instantiations: PWT threads, PWMIN workgroups' worth of waves per SIMD, PWCH reads per gamma/beta chunk.
-//   narrow  256 threads x 4 workgroups per CU (40 KB each), 4 reads per chunk   — ZMWs of up to PW_WIDE_MIN_READS - 1 passes (c2: 10 passes = 4 + 4 + 2)
-//   wide    512 threads x 2 workgroups per CU (80 KB each), 8 reads per chunk   — ZMWs of more passes (c4: 30 passes = 8 + 8 + 8 + 6; the narrow
-//           shape holds only three 30-pass reads per chunk next to their observation codes: 844 -> 356 ms per 8192 ZMWs, profiles/r04_c4_shapes.txt)
-// Both are launched over all window slots; a workgroup whose ZMW belongs to the other class leaves at once (the host skips a class no ZMW of the
-// batch is in).
+// PWT threads, PWMIN workgroups' worth of waves per SIMD, PWCH reads per gamma/beta chunk: ONE instantiation is shipped, 256 x 4 x 4.  Round 4 measured
+// the 512-thread shape (2 workgroups of 80 KB per CU, 8 reads per chunk) at 14 / 18 / 24 passes and on the configs[4] mix: 2.2 / 2.3 / 1.8 / 1.7 times
+// SLOWER than this one (profiles/r04_c4_shapes.txt; its apparent 2.4x win at 30 passes x 20 kb came from a grid of more than 2^32 threads that covered 23 % of the windows).
 template <int PWT, int PWMIN, int PWCH>
-__global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int obs_bytes, int gb_floats, int nr_lo, int nr_hi)
+__global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 {
     // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0); row 12 = zeros ("no base").  Row stride CTXS = 33 entries: with the banded link every
     // lane looks up its OWN observation row, and with 32 entries per row all lanes of one context hit the same bank pair whatever
@@ -1833,8 +1832,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int obs_byte
     // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
     // A code is stored as obs * 264 = the byte offset of its row in sCTX (OBS_CODE), so the scoring loop adds it to a per-lane base.
     uint16_t (*sObs)[68] = (uint16_t (*)[68])dyn_lds;
-    float *sGB = (float *)((uint8_t *)dyn_lds + obs_bytes);
-    const int GB_FLOATS = gb_floats;
+    float *sGB = (float *)((uint8_t *)dyn_lds + P.pw_obs_bytes);
+    const int GB_FLOATS = P.pw_gb_floats;
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
@@ -1856,13 +1855,13 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int obs_byte
     // ---- locate (zmw, window).  The prologue is a chain of dependent global loads; every level issues all of its
     // loads before the first use (clamped indices instead of branches), so the chain is 4 round trips deep
     // (z-level scalars -> window bounds + per-read metadata + tables -> entry rows -> segments), not one per array.
-    const int bid = blockIdx.x;
+    const int bid = slot0 + (int)blockIdx.x;               // (slot0: a batch of more than 2^23 window slots is launched in pieces, see ccsx_launch_all)
     const int z = P.wslot_zmw[bid];                         // host-built map: no dependent search
     const int wbo = P.wb_off[z], nw = P.nwin[z], Ld = P.draft_len[z];
     const int r0 = P.read_off[z], nreads = P.nreads_used[z];
     const int64_t so = P.seq_off[z];
     const int w = bid - (wbo - z);
-    if (w >= nw || nreads < nr_lo || nreads > nr_hi) return;     // (nr_lo .. nr_hi: the pass counts this instantiation serves)
+    if (w >= nw) return;
     const int32_t *wb = P.wbounds + wbo;
     const uint8_t *draft = P.draft + so;
     const int wb0 = wb[w], wb1 = wb[w + 1];
@@ -2672,7 +2671,7 @@ __device__ __forceinline__ int kin_traceback_runs(int upm, unsigned long long nd
     return myrow;
 }
 
-__global__ __launch_bounds__(256) void k_kinetics(KParams P)
+__global__ __launch_bounds__(256) void k_kinetics(KParams P, int slot0)
 {
     __shared__ uint8_t sT[2][32];
     __shared__ unsigned sK[2][3][32];                       // [strand][ipd, pw, count][forward column]
@@ -2681,7 +2680,7 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P)
     __shared__ short2 sTask[PW_MAXREADS];
     __shared__ int sNT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = blockIdx.x;
+    const int bid = slot0 + (int)blockIdx.x;
     const int z = P.wslot_zmw[bid];
     const int w = bid - (P.wb_off[z] - z);
     if (w >= P.nwin[z]) return;
@@ -2877,25 +2876,17 @@ static void trace_sync(hipStream_t st, const char *what)
 
 // dynamic LDS of k_polish: [reads][68] observation codes for the largest ZMW of the batch, the rest of the workgroup's
 // budget holds gamma/beta of one chunk of reads
-#ifndef PW_WIDE_MIN_READS
-#define PW_WIDE_MIN_READS 14          // ZMWs of at least this many passes take the wide instantiation (profiles/r04_c4_shapes.txt)
-#endif
-#define PW_WIDE_THREADS 512
-#define PW_WIDE_LDS_BYTES 81920       // two wide workgroups per CU
-#define PW_WIDE_CHUNK_READS 8         // eight reads = four pairs = eight alpha-only / beta-only units = one sweep on each of the eight waves
-int ccsx_polish_wide_min_reads(void) { return PW_WIDE_MIN_READS; }
-int ccsx_polish_lds(int max_reads, int wide, int *obs_bytes, int *gb_floats)
+int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
 {
     hipFuncAttributes fa;                                  // per call: the attribute is per device, handles live on several
-    const void *fn = wide ? (const void *)k_polish_t<PW_WIDE_THREADS, 2, PW_WIDE_CHUNK_READS> : (const void *)k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>;
-    const int budget = wide ? PW_WIDE_LDS_BYTES : PW_LDS_BYTES;
+    const void *fn = (const void *)k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>;
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return -1;
     const int static_bytes = (int)fa.sharedSizeBytes;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, budget - static_bytes) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES - static_bytes) != hipSuccess) return -1;
     if (max_reads > PW_MAXREADS) max_reads = PW_MAXREADS;
     if (max_reads < 1) max_reads = 1;
     *obs_bytes = ((max_reads * 68 * 2) + 15) & ~15;
-    *gb_floats = (budget - static_bytes - *obs_bytes) / 4;
+    *gb_floats = (PW_LDS_BYTES - static_bytes - *obs_bytes) / 4;
     return 0;
 }
 
@@ -2973,23 +2964,23 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
         (void)hipEventRecord(ev[6], st_polish);            // the polish stage starts here (after the queue between the stages)
     } else if (st_polish != st && !failed) failed = "two streams need events";
     st = st_polish;
-    if (P.total_wslots > 0) {
-        // narrow instantiation: ZMWs of fewer than PW_WIDE_MIN_READS passes; wide: the others.  A class without ZMWs in this batch is not launched.
-        if (P.min_reads < PW_WIDE_MIN_READS) {
-            hipLaunchKernelGGL((k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>), dim3((unsigned)P.total_wslots), dim3(PW_THREADS),
-                               (size_t)P.pw_obs_bytes[0] + (size_t)P.pw_gb_floats[0] * 4, st, P, P.pw_obs_bytes[0], P.pw_gb_floats[0], 0, PW_WIDE_MIN_READS - 1);
-            LAUNCH_CHECK("k_polish");
-        }
-        if (P.max_reads >= PW_WIDE_MIN_READS) {
-            hipLaunchKernelGGL((k_polish_t<PW_WIDE_THREADS, 2, PW_WIDE_CHUNK_READS>), dim3((unsigned)P.total_wslots), dim3(PW_WIDE_THREADS),
-                               (size_t)P.pw_obs_bytes[1] + (size_t)P.pw_gb_floats[1] * 4, st, P, P.pw_obs_bytes[1], P.pw_gb_floats[1], PW_WIDE_MIN_READS, 1 << 30);
-            LAUNCH_CHECK("k_polish(wide)");
-        }
+    // One workgroup per window slot.  A grid may not exceed 2^32 threads in all: 256 threads x 16.7 M slots — 8192 ZMWs of 30 passes x 20 kb have 10.8 M, and a
+    // larger batch would silently lose its tail (round 4 met exactly this with a 512-thread experiment: 75 % of the ZMWs "failed").  The slots are therefore
+    // launched in pieces of at most 2^23 workgroups (CCSX_POLISH_MAX_BLOCKS: a test hook that forces small pieces).
+    static const long long max_blocks = [] { const char *e = getenv("CCSX_POLISH_MAX_BLOCKS"); long long v = e ? atoll(e) : 0; return v > 0 ? v : (1ll << 23); }();
+    for (long long s0 = 0; s0 < P.total_wslots; s0 += max_blocks) {
+        const unsigned nb = (unsigned)((P.total_wslots - s0) < max_blocks ? (P.total_wslots - s0) : max_blocks);
+        hipLaunchKernelGGL((k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>), dim3(nb), dim3(PW_THREADS),
+                           (size_t)P.pw_obs_bytes + (size_t)P.pw_gb_floats * 4, st, P, (int)s0);
+        LAUNCH_CHECK("k_polish");
     }
     trace_sync(st, "k_polish");
-    if (P.opts.hifi_kinetics && P.total_wslots > 0) {
-        hipLaunchKernelGGL(k_kinetics, dim3((unsigned)P.total_wslots), dim3(256), 0, st, P);
-        LAUNCH_CHECK("k_kinetics");
+    if (P.opts.hifi_kinetics) {
+        for (long long s0 = 0; s0 < P.total_wslots; s0 += max_blocks) {
+            const unsigned nb = (unsigned)((P.total_wslots - s0) < max_blocks ? (P.total_wslots - s0) : max_blocks);
+            hipLaunchKernelGGL(k_kinetics, dim3(nb), dim3(256), 0, st, P, (int)s0);
+            LAUNCH_CHECK("k_kinetics");
+        }
         trace_sync(st, "k_kinetics");
     }
     if (ev) (void)hipEventRecord(ev[4], st);

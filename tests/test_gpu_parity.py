@@ -875,3 +875,32 @@ def test_reference_concordance_harness(built, tmp_path, monkeypatch):
     os.chmod(bad / "ccs", os.stat(bad / "ccs").st_mode | stat.S_IEXEC)
     out = bench.reference_concordance(api, np, str(bad / "ccs"), sample, 4, 5.0)
     assert out["rc"] == 1 and "chemistry" in out["error"] and "zmws_per_s" not in out and "rc 1" in out["version"]
+
+
+def test_polish_grid_is_launched_in_pieces(built, tmp_path):
+    """a grid may not exceed 2^32 threads: k_polish / k_kinetics run one 256-thread workgroup per window slot, so a batch of more than 16.7 M
+    slots (16 k ZMWs of 25 kb) would silently lose its tail — the slots are launched in pieces of 2^23 workgroups.  CCSX_POLISH_MAX_BLOCKS forces
+    pieces of 37 here (in a fresh process: the hook is read once): same results as the oracle, with and without kinetics"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from ccs_amd import api
+import oracle_lib as O
+for kin in (0, 1):
+    o = api.default_opts(); o.hifi_kinetics = kin
+    b = api.synth(9, (4, 12), (600, 2500), seed=91)
+    h = api.Handle(0, opts=o)
+    r = h.consensus(b)
+    ref = api.Results.allocate(b, kinetics=bool(kin))
+    O.consensus_batch(h.model, o, b, ref, nthreads=4)
+    assert int(r.n_windows.sum()) > 300
+    for z in range(b.n_zmw):
+        assert r.status[z] == ref.status[z] and np.array_equal(r.sequence(z), ref.sequence(z)) and np.array_equal(r.raw(z), ref.raw(z)), z
+        if kin: assert np.array_equal(r.kinetics(z), ref.kinetics(z))
+    h.close()
+print("pieces ok")
+""" % (root, os.path.join(root, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CCSX_POLISH_MAX_BLOCKS="37"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "pieces ok" in p.stdout, p.stderr[-2000:]

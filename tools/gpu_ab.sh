@@ -3,6 +3,7 @@
 #   VARIANTS="name:-DFLAG=1,-DOTHER=2 name2:"      compile-time variants of the working tree (CCSX_EXTRA_FLAGS); "name:" = no flags
 #   OLD=tools/_old_kernels.hip                     additionally: the kernel file of an earlier commit (git show REV:ccs_amd/csrc/ccsx_kernels.hip > tools/_old_kernels.hip)
 #   BENCH_ARGS="--workload c4"                     extra bench.py arguments;  PARITY=0 skips the parity subset
+#   every result line is also appended to gpurun_out/ab_all.txt (survives several invocations in one gpurun call)
 #   usage: gpurun --timeout 1500 -- 'VARIANTS="head: lds48:-DPW_LDS_BYTES=49152" bash tools/gpu_ab.sh'
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/ab; rm -rf $O; mkdir -p $O
@@ -31,11 +32,11 @@ for v in $VARIANTS; do
   name=${v%%:*}; flags=${v#*:}; flags=${flags//,/ }
   CCSX_EXTRA_FLAGS="$flags" python -c "import __graft_entry__ as g; g.build(force=True)" > $O/build_$name.log 2>&1 || { echo "build $name failed"; tail -5 $O/build_$name.log; continue; }
   run $name
-done 2>&1 | tee -a $O/ab.txt
+done 2>&1 | tee -a $O/ab.txt gpurun_out/ab_all.txt
 if [ -n "$OLD" ] && [ -f "$OLD" ]; then
   cp ccs_amd/csrc/ccsx_kernels.hip $O/new.hip
   cp $OLD ccs_amd/csrc/ccsx_kernels.hip
-  { python -c "import __graft_entry__ as g; g.build(force=True)" > $O/build_old.log 2>&1 && PARITY=0 run old || tail -5 $O/build_old.log; } 2>&1 | tee -a $O/ab.txt
+  { python -c "import __graft_entry__ as g; g.build(force=True)" > $O/build_old.log 2>&1 && PARITY=0 run old || tail -5 $O/build_old.log; } 2>&1 | tee -a $O/ab.txt gpurun_out/ab_all.txt
   cp $O/new.hip ccs_amd/csrc/ccsx_kernels.hip; rm $O/new.hip
 fi
 python -c "import __graft_entry__ as g; g.build(force=True)" > /dev/null 2>&1

@@ -19,7 +19,7 @@ for db in glob.glob(os.path.join(root, "pmc_*", "pmc_results.db")):
         d_ = val.setdefault(kname(kn), {}); d_[cn] = d_.get(cn, 0) + v       # (the two instantiations of k_polish_t add up)
         c_ = cnt.setdefault(kname(kn), {}); c_[cn] = max(c_.get(cn, 0), k)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ_* (separate passes), python bench.py "
-                 f"--pmc --zmws {n} --steps 1 --warmup 1 --distinct 1, tools/prof_round.sh",
+                 f"--pmc --zmws {n} --steps 1 --warmup 1 --distinct 1 (the headline step: two-stage queue on), tools/prof_round.sh",
        "head": head,
        "note": "hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on this gfx950 stack FETCH_SIZE reports exactly half of the bytes of a "
                "coalesced streaming read at 1, 4 and 16 bytes per lane and WRITE_SIZE is exact (profiles/r01_counter_calibration.txt, "

@@ -4,8 +4,9 @@
 # command the bench line comes from; <head> (the commit, passed in from the build container: the box has no .git) is stored in it.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-T=${1:-r03}
+T=${1:-r04}
 H=${2:-unknown}
+Z=${Z:-8192}
 D=$R/gpurun_out/prof_$T
 rm -rf $D; mkdir -p $D
 timeout 900 python $R/bench.py > $D/bench_default.json 2> $D/bench_default.err
@@ -13,9 +14,10 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $D/trace -o trace -- python $R/b
 python $R/tools/trace_overlap.py $D/trace > $D/overlap.txt 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout 400 rocprofv3 --kernel-trace --pmc $set -d $D/pmc_$tag -o pmc -- python $R/bench.py --pmc --zmws 2048 --steps 1 --warmup 1 --distinct 1 > $D/bench_$tag.json 2> $D/bench_$tag.err
+  # the HEADLINE step: 8192 ZMWs per batch, two-stage queue on (round 3 counted a 2048-ZMW step, where k_poa_dp has 0.5 waves per SIMD)
+  timeout 600 rocprofv3 --kernel-trace --pmc $set -d $D/pmc_$tag -o pmc -- python $R/bench.py --pmc --zmws $Z --steps 1 --warmup 1 --distinct 1 > $D/bench_$tag.json 2> $D/bench_$tag.err
 done
 python $R/tools/profsum.py $D > $D/summary.txt
-python $R/tools/mk_traffic.py $D 2048 $H > $D/traffic.json
+python $R/tools/mk_traffic.py $D $Z $H > $D/traffic.json
 rm -rf $D/pmc_* $D/trace
 ls -la $D; cat $D/traffic.json
