@@ -100,7 +100,7 @@ struct Slot {
     DevBuf d_out_seq, d_out_qual, d_out_raw, d_out_i32 /* 6 x n */, d_out_f32 /* 2 x n */;
     DevBuf d_wtpl, d_wtmeta, d_wkin, d_out_kin;   // HiFi kinetics only
     // host copies of the layout (page-locked: sources of the asynchronous uploads)
-    PinVec<int32_t> read_zmw, vcap, dcap, wslot, zperm, rperm, wb_off, read_off, quads, qperm;
+    PinVec<int32_t> read_zmw, vcap, dcap, zperm, rperm, wb_off, read_off, quads, qperm;
     PinVec<int64_t> seq_off, ent_off, base_off;
     KParams P;
     hipEvent_t ev[7] = {}, ev_up = nullptr, ev_done = nullptr;   // ev[0..5]: stage boundaries, ev[6]: start of the polish stage
@@ -117,7 +117,7 @@ struct Slot {
                           &d_zmw_i32, &d_wbounds, &d_ticket, &d_avalid, &d_ascore, &d_ent, &d_wseq, &d_wqv, &d_wsum, &d_wmeta, &d_out_seq,
                           &d_out_qual, &d_out_raw, &d_out_i32, &d_out_f32, &d_wtpl, &d_wtmeta, &d_wkin, &d_out_kin};
         for (auto *b : bufs) b->release();
-        read_zmw.release(); vcap.release(); dcap.release(); wslot.release(); zperm.release(); rperm.release(); quads.release(); qperm.release(); wb_off.release();
+        read_zmw.release(); vcap.release(); dcap.release(); zperm.release(); rperm.release(); quads.release(); qperm.release(); wb_off.release();
         read_off.release(); seq_off.release(); ent_off.release(); base_off.release();
         for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_up) { (void)hipEventDestroy(ev_up); ev_up = nullptr; }
@@ -345,8 +345,6 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     }
     const int64_t total_wslots = (int64_t)S.wb_off[n] - n;
     if (total_wslots > 0x7fff0000ll) { ccsx_set_error("ccsx_upload: batch too large (more than 2^31 window slots): split it"); return -1; }
-    if (S.wslot.resize(total_wslots > 0 ? total_wslots : 1)) return -2;
-    for (int z = 0; z < n; ++z) std::fill(S.wslot.p + (S.wb_off[z] - z), S.wslot.p + (S.wb_off[z + 1] - (z + 1)), z);
 
 #define UP(buf, src, bytes)                                                                                    \
     do {                                                                                                       \
@@ -366,7 +364,6 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     UP(S.d_seq_off, S.seq_off.p, (size_t)(n + 1) * 8);
     UP(S.d_wb_off, S.wb_off.p, (size_t)(n + 1) * 4);
     UP(S.d_ent_off, S.ent_off.p, (size_t)(R + 1) * 8);
-    UP(S.d_wslot, S.wslot.p, S.wslot.size() * 4);
     UP(S.d_zperm, S.zperm.p, S.zperm.size() * 4);
     UP(S.d_rperm, S.rperm.p, S.rperm.size() * 4);
     UP(S.d_quads, S.quads.p, S.quads.size() * 4);
@@ -378,6 +375,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     RES(S.d_draft, (size_t)cap_total);
     RES(S.d_zmw_i32, (size_t)n * 4 * 7);   // draft_len, nwin, zstat, nreads_used, np, zref, nfull
     RES(S.d_wbounds, (size_t)S.wb_off[n] * 4);
+    RES(S.d_wslot, (size_t)(total_wslots + 1) * 4 + ((size_t)n + 2) * 4);      // compact window map + first index per ZMW, built by k_wmap
     RES(S.d_ticket, 256);
     RES(S.d_avalid, (size_t)(R > 0 ? R : 1)); RES(S.d_ascore, (size_t)(R > 0 ? R : 1) * 4);
     RES(S.d_retry, ((size_t)(R > 0 ? R : 1) + 16) * 4);
@@ -432,7 +430,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.snr = (const float *)S.d_snr.p; P.read_off = (const int32_t *)S.d_read_off.p; P.base_off = (const int64_t *)S.d_base_off.p;
     P.bases = (const uint8_t *)S.d_bases.p; P.pw = (const uint8_t *)S.d_pw.p; P.flags = (const uint8_t *)S.d_flags.p;
     P.read_zmw = (const int32_t *)S.d_read_zmw.p; P.vcap = (const int32_t *)S.d_vcap.p; P.dcap = (const int32_t *)S.d_dcap.p;
-    P.seq_off = (const int64_t *)S.d_seq_off.p; P.wb_off = (const int32_t *)S.d_wb_off.p; P.ent_off = (const int64_t *)S.d_ent_off.p; P.wslot_zmw = (const int32_t *)S.d_wslot.p;
+    P.seq_off = (const int64_t *)S.d_seq_off.p; P.wb_off = (const int32_t *)S.d_wb_off.p; P.ent_off = (const int64_t *)S.d_ent_off.p; P.wslot_zmw = (int32_t *)S.d_wslot.p; P.wstart = P.wslot_zmw + (total_wslots + 1);
     P.zmw_perm = (const int32_t *)S.d_zperm.p; P.read_perm = (const int32_t *)S.d_rperm.p;
     P.quads = (const int32_t *)S.d_quads.p; P.n_quads = n_quads; P.align_retry = (int32_t *)S.d_retry.p;
     P.tabME = (float *)S.d_tabME.p; P.tabINS = (float *)S.d_tabINS.p; P.tabDL = (float *)S.d_tabDL.p; P.tabZ = (float *)S.d_tabZ.p;
@@ -662,10 +660,10 @@ int ccsx_sync(ccsx_handle h)
     if (S.staged && S.ran) {
         unsigned long long ph[16];
         HIPTRY(hipMemcpy(ph, S.P.phase, sizeof(ph), hipMemcpyDeviceToHost));
-        static const char *nm[7] = {"prologue", "tables+lanes", "chunk plan", "fill", "score", "select/apply", "qv+store"};
+        static const char *nm[8] = {"prologue", "tables+lanes", "chunk plan", "fill", "score", "select/apply", "qv+store", "validity+list"};
         unsigned long long tot = 0;
-        for (int i = 0; i < 7; ++i) tot += ph[i];
-        for (int i = 0; i < 7; ++i) std::fprintf(stderr, "[ccsx phase] %-14s %6.2f %%  (%llu cycles)\n", nm[i], tot ? 100.0 * ph[i] / tot : 0.0, ph[i]);
+        for (int i = 0; i < 8; ++i) tot += ph[i];
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, "[ccsx phase] %-14s %6.2f %%  (%llu cycles)\n", nm[i], tot ? 100.0 * ph[i] / tot : 0.0, ph[i]);
         static const char *pn[6] = {"thr setup+read", "thr traceback", "thr ids+zero", "thr records", "thr order", "thr col records"};
         unsigned long long pt = 0;
         for (int i = 8; i < 14; ++i) pt += ph[i];

@@ -26,7 +26,8 @@ struct KParams {
     const int64_t *seq_off;    // [n+1] offsets of draft and outputs (capacity layout)
     const int32_t *wb_off;     // [n+1] offsets into wbounds; window slots of z = wb_off[z+1]-wb_off[z]-1
     const int64_t *ent_off;    // [R] offsets into ent
-    const int32_t *wslot_zmw;  // [total window slots] owning ZMW of every polish workgroup slot
+    int32_t *wslot_zmw;        // [total window slots] compact map built on the device after the draft stage (k_wmap): owning ZMW of the i-th WINDOW
+    int32_t *wstart;           // [n_zmw + 1] first compact index of every ZMW's windows; [n_zmw] = windows of the batch
     // ---- per-ZMW state
     float *tabME, *tabINS, *tabDL;
     float *tabZ;               // [n][32] z-score parameters per context: MU[16], VAR[16]

@@ -9,6 +9,7 @@
 //   k_align       step3 the 64-row retry of the alignment cascade                            (docs/how-does-ccs-work.md:53-55)
 //   k_rescue      step3/6 split / double-split alignment, partial passes                     (docs/how-does-ccs-work.md:74-78)
 //   k_post        A7    per-ZMW usable-pass accounting, draft-cascade marks                  (docs/faq/accuracy-vs-passes.md:37-39)
+//   k_wmap(_fill) step4 the batch's windows in compact order (grid map of the polish stage)
 //   k_polish      A1-A6 Arrow alpha/beta fill, candidate filter, mutation scoring, polish loop, QVs; one workgroup per window
 //                                                                                            (docs/how-does-ccs-work.md:57-61,80-106)
 //   k_kinetics    N4    HiFi kinetics of the converged windows                               (docs/faq/kinetics.md:8-18)
@@ -28,7 +29,7 @@
 #include "wave_ops.h"
 
 #define LANES 64
-#define PW_MAXREADS_SPEC CCSX_MAX_PASSES      // passes of a ZMW the engine uses (k_polish / k_kinetics take them in groups of PW_MAXREADS = 64)
+#define PW_MAXREADS_SPEC CCSX_MAX_PASSES      // passes of a ZMW the engine uses (k_polish / k_kinetics take them in groups of PW_MAXREADS)
 #ifdef CCSX_PROFILE_PHASES
 #define PHASE_T0() unsigned long long ph_t = __builtin_readcyclecounter(); (void)ph_t
 #define PHASE(idx) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd((unsigned long long *)P.phase + (idx), n_ - ph_t); ph_t = n_; } } while (0)
@@ -1672,6 +1673,38 @@ __global__ void k_post(KParams P, int pass)
     }
 }
 
+// The windows of the batch in compact order (after the last k_post: nwin[z] is final).  The polish / kinetics grids used to cover every window SLOT
+// (capacity: 1.25 x the longest pass / 19 + 4 per ZMW, a host-built map) — 31 % of the workgroups found no window and left, each after holding a workgroup's
+// LDS for two dependent loads.  One workgroup: exclusive scan of nwin over the ZMWs, then the map (window index -> ZMW).
+__global__ __launch_bounds__(1024) void k_wmap(KParams P)
+{
+    __shared__ int sTot[16], sCarry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) sCarry = 0;
+    __syncthreads();
+    for (int z0 = 0; z0 < P.n_zmw; z0 += 1024) {
+        const int z = z0 + tid;
+        const int v = z < P.n_zmw ? P.nwin[z] : 0;
+        const int incl = wave_scan_add_i32(v);
+        if (lane == 63) sTot[wv] = incl;
+        __syncthreads();
+        int base = sCarry;
+        for (int q = 0; q < wv; ++q) base += sTot[q];
+        if (z < P.n_zmw) P.wstart[z] = base + incl - v;
+        __syncthreads();
+        if (tid == 1023) sCarry = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) P.wstart[P.n_zmw] = sCarry;
+}
+__global__ __launch_bounds__(256) void k_wmap_fill(KParams P)     // one wave per ZMW: the map entries of its windows
+{
+    const int z = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (z >= P.n_zmw) return;
+    const int a = P.wstart[z], nw = P.nwin[z];
+    for (int w = lane; w < nw; w += LANES) P.wslot_zmw[a + w] = z;
+}
+
 // ------------------------------------------------------------------------------------------------
 // A1-A7 + step 7: Arrow polish of one window per workgroup (PW_THREADS = 4 waves).
 //
@@ -1700,7 +1733,9 @@ __global__ void k_post(KParams P, int pass)
                                       // reads per chunk (2 per CU, 80 KB each) ran 260 / 229 ms: profiles/r03_polish_fill_variants.txt
 #endif
 #ifndef PW_MAXREADS
-#define PW_MAXREADS 64                // passes per GROUP: the per-read arrays, observation codes and chunk plan of k_polish / k_kinetics describe one group
+#define PW_MAXREADS 32                // passes per GROUP: the per-read arrays, observations and chunk plan of k_polish / k_kinetics describe one group.  Round 4
+                                      // (profiles/r04_group_size.txt, ms of k_polish at 10 passes / the configs[4] mix / 30 passes x 20 kb): 64 157 / 311 / 861 with 16-bit
+                                      // observation codes; one byte per observation: 32 156 / 254 / 705, 16 156 / 258 / 755, 12 155 / 260 / 763
 #endif
 #ifndef PW_LDS_BYTES
 #define PW_LDS_BYTES 40960            // static + dynamic LDS of one workgroup: FOUR workgroups per CU fill its 160 KB exactly.  Round 3 sweep (ms of
@@ -1714,8 +1749,7 @@ __global__ void k_post(KParams P, int pass)
 #define FE_A 105
 #define FE_BLO 69
 #define FE_B 136
-#define OBS_CODE(o) ((o) * (CTXS * 8))        // an observation code as stored in sObs: the byte offset of its row in sCTX
-#define OBS_OF_CODE(c) ((unsigned)(c) / (unsigned)(CTXS * 8))   // ... and back (a multiply + shift)
+#define OBS_CODE(o) ((o) * (CTXS * 8))        // the byte offset of observation o's row in sCTX (sObs holds the 8-bit observation itself)
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
     int c, q, kA, kB, isdel, fin;    // kA / kB index sCTX; +16 selects the copy whose INS component is zero
@@ -1749,12 +1783,12 @@ __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_
 typedef const float __attribute__((address_space(3))) *lds_cf;
 typedef const char __attribute__((address_space(3))) *lds_cc;
 
-typedef const uint16_t __attribute__((address_space(3))) *lds_cu16;
+typedef const uint8_t __attribute__((address_space(3))) *lds_cu8;
 struct ScoreChain {                  // running state of one (lane, read) mutation evaluation
     float ap, bp, acc, b, bq;
     float2 pA, pB;
     lds_cf g, be;                    // gamma(i, c) and beta(i+1, q) of the row about to be processed: both advance by S per row
-    lds_cu16 op;                     // observation code of that row (as the byte offset of its sCTX row)
+    lds_cu8 op;                      // observation of that row (0..11, 12 = none)
 };
 
 // one row of the extend+link recursion.  tA / tB = the lane's columns of sCTX (context kA / kB).  Every lane walks
@@ -1764,7 +1798,7 @@ __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_
 {
     typedef const unsigned long long __attribute__((address_space(3))) *lds_cu64;
     const float gmm = *s.g;
-    const int o256 = (int)*s.op;
+    const int o256 = __mul24((int)*s.op, CTXS * 8);   // byte offset of the observation's row in sCTX
     const unsigned long long va = *(lds_cu64)(tA + o256), vb = *(lds_cu64)(tB + o256);   // one ds_read_b64 each
     const float2 nA = make_float2(__uint_as_float((unsigned)va), __uint_as_float((unsigned)(va >> 32)));
     const float2 nB = make_float2(__uint_as_float((unsigned)vb), __uint_as_float((unsigned)(vb >> 32)));
@@ -1830,8 +1864,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
     __shared__ uint8_t sTd[32];                              // the draft's window as it was (the large-insertion trim of a reloaded group compares with it)
     // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
-    // A code is stored as obs * 264 = the byte offset of its row in sCTX (OBS_CODE), so the scoring loop adds it to a per-lane base.
-    uint16_t (*sObs)[68] = (uint16_t (*)[68])dyn_lds;
+    // One BYTE per read row (round 3 stored the 16-bit byte offset of the observation's sCTX row: at 30 passes those 4 KB left room for only three
+    // reads per gamma/beta chunk; the scoring rows are bound by their LDS round trips, the extra multiply per row is not measurable).
+    uint8_t (*sObs)[68] = (uint8_t (*)[68])dyn_lds;
     float *sGB = (float *)((uint8_t *)dyn_lds + P.pw_obs_bytes);
     const int GB_FLOATS = P.pw_gb_floats;
     __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
@@ -1856,12 +1891,12 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     // loads before the first use (clamped indices instead of branches), so the chain is 4 round trips deep
     // (z-level scalars -> window bounds + per-read metadata + tables -> entry rows -> segments), not one per array.
     const int bid = slot0 + (int)blockIdx.x;               // (slot0: a batch of more than 2^23 window slots is launched in pieces, see ccsx_launch_all)
-    const int z = P.wslot_zmw[bid];                         // host-built map: no dependent search
+    if (bid >= P.wstart[P.n_zmw]) return;                  // (the grid covers the slot capacity, the map only the windows there are)
+    const int z = P.wslot_zmw[bid];                         // device-built compact map (k_wmap): no dependent search
     const int wbo = P.wb_off[z], nw = P.nwin[z], Ld = P.draft_len[z];
     const int r0 = P.read_off[z], nreads = P.nreads_used[z];
     const int64_t so = P.seq_off[z];
-    const int w = bid - (wbo - z);
-    if (w >= nw) return;
+    const int w = bid - P.wstart[z];
     const int32_t *wb = P.wbounds + wbo;
     const uint8_t *draft = P.draft + so;
     const int wb0 = wb[w], wb1 = wb[w + 1];
@@ -1894,8 +1929,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         if (tid < we - ws) { sT[0][tid] = dr; sTd[tid] = dr; }
         if (tid == 0) { sCtl[0] = we - ws; sCtl[1] = wb0 - ws; sCtl[2] = wb1 - ws; }
     }
-    // SPEC v5: a ZMW's passes (up to CCSX_MAX_PASSES = 255) are taken in GROUPS of PW_MAXREADS = 64: the per-read arrays below, the observation
-    // codes and the chunk plan always describe one group (local read index = pass - g0).  A ZMW of at most 64 passes — nearly all — loads
+    // SPEC v5: a ZMW's passes (up to CCSX_MAX_PASSES = 255) are taken in GROUPS of PW_MAXREADS = 32: the per-read arrays below, the observation
+    // codes and the chunk plan always describe one group (local read index = pass - g0).  A ZMW of at most 32 passes — most — loads
     // its one group here and never again; larger ones reload group after group in every round (rare, so the reload is not optimised).
     const int ngroups = (nreads + PW_MAXREADS - 1) / PW_MAXREADS;
     // levels 2 + 3 of the prologue for the reads g0 .. g0 + ng - 1: metadata, entry rows of the window's two edge columns, dirty masks
@@ -1950,7 +1985,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             const int r = rb + (PWT / 64) * q + wave;
             if (r < ng) {
                 const int n = sI[r];
-                sObs[r][lane] = (lane < n) ? (uint16_t)OBS_CODE(obs_of(bq[q], pq[q])) : (uint16_t)(lane == n ? OBS_CODE(CCSX_NOBS) : 0);   // row n: "no base"
+                sObs[r][lane] = (lane < n) ? (uint8_t)obs_of(bq[q], pq[q]) : (uint8_t)(lane == n ? CCSX_NOBS : 0);   // row n: "no base"
                 if (lane < 4) sObs[r][64 + lane] = 0;
             }
         }
@@ -1972,7 +2007,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             const unsigned long long mp = __ballot(in && (bp & 3) == T), ms = __ballot(in && (bs & 3) == T);
             const int tot = (lane <= J0) ? __popcll(mp & ((1ull << lane) - 1ull)) + __popcll(ms >> lane) : -1;
             const int sb = 63 - (rfl(wave_max_i32((tot << 6) | (63 - lane))) & 63);
-            if (in && lane >= sb) sObs[r][lane] = (uint16_t)OBS_CODE(obs_of(bs, ps));
+            if (in && lane >= sb) sObs[r][lane] = (uint8_t)obs_of(bs, ps);
         }
     }
     };
@@ -2198,8 +2233,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int2 *CJ = sColJ[sd];
                 const bool rowok = row <= I;
                 // the lane's rows of sCTX, as byte offsets (sObs holds them in that form)
-                const int op = (row >= 1 && rowok) ? (int)sObs[myr][row - 1] : OBS_CODE(12);   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
-                const int oc = (row < I) ? (int)sObs[myr][row] : OBS_CODE(12);                  // o_i;     12 = no base: row I emits nothing more
+                const int op = OBS_CODE((row >= 1 && rowok) ? (int)sObs[myr][row - 1] : 12);   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                const int oc = OBS_CODE((row < I) ? (int)sObs[myr][row] : 12);                  // o_i;     12 = no base: row I emits nothing more
                 const char *rowA = (const char *)sCTX + op, *rowB = (const char *)sCTX + oc;
                 // activity windows: alpha computes column j = t - row for t in [row, row+J]; beta computes column
                 // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step, so the steps of
@@ -2335,6 +2370,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 }
             }
             __syncthreads();
+            PHASE(3);
             // read validity (lane = read; every wave computes the same values): alpha/beta agreement, the z-score gate of round 0
             int vOk = 0; float vLa = 0.0f;
             if (lane >= rbeg && lane < rend && sGoff[lane] >= 0) {
@@ -2363,7 +2399,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int dest = v ? __popcll(bv & lower) : nv_chunk + __popcll(~bv & lower);
                 vRlist = __builtin_amdgcn_ds_permute(dest << 2, lane);
             }
-            PHASE(3);
+            PHASE(7);
             // ---- A3/A4: work pool.  A unit = (block of 64 compacted mutation lanes) x (one usable read), numbered block-major; every
             // wave takes an equal contiguous share and walks it two reads at a time (two independent chains per lane) while the
             // block stays the same — 2 blocks x 5 reads are 3+3+2+2 units, not 2+2+1+1 pair tasks.  Gains are added to sDeltaI in
@@ -2419,7 +2455,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         ScoreChain ca;
                         ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
                         ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, S) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, S) + La.q); ca.bq = *ca.be; ca.be += S;
-                        ca.op = (lds_cu16)(&sObs[ra][0] + i0a);
+                        ca.op = (lds_cu8)(&sObs[ra][0] + i0a);
                         asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(tAa), "+v"(tBa), "+v"(ca.op));
                         {   // two rows per iteration: the chain's carried values (previous table pairs, beta, a, b) then rotate between two
                             // register sets instead of being copied at every row (3 v_mov + a loop counter per row before)
@@ -2450,7 +2486,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f);
                     ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, S) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, S) + La.q); ca.bq = *ca.be; ca.be += S;
                     cb.g = (lds_cf)(sGB + gB_ + __mul24(i0b, S) + Lb.c); cb.be = (lds_cf)(sGB + bB_ + __mul24(i0b, S) + Lb.q); cb.bq = *cb.be; cb.be += S;
-                    ca.op = (lds_cu16)(&sObs[ra][0] + i0a); cb.op = (lds_cu16)(&sObs[rb][0] + i0b);
+                    ca.op = (lds_cu8)(&sObs[ra][0] + i0a); cb.op = (lds_cu8)(&sObs[rb][0] + i0b);
                     // opaque to the optimiser from here: the running pointers hold complete LDS addresses (otherwise the
                     // dynamic-LDS base is re-added at every use)
                     asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(cb.g), "+v"(cb.be), "+v"(tAa), "+v"(tBa), "+v"(tAb), "+v"(tBb), "+v"(ca.op), "+v"(cb.op));
@@ -2681,9 +2717,9 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P, int slot0)
     __shared__ int sNT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = slot0 + (int)blockIdx.x;
+    if (bid >= P.wstart[P.n_zmw]) return;
     const int z = P.wslot_zmw[bid];
-    const int w = bid - (P.wb_off[z] - z);
-    if (w >= P.nwin[z]) return;
+    const int w = bid - P.wstart[z];
     const int nw = P.nwin[z];
     const size_t wi = (size_t)(P.wb_off[z] - z) + w;
     const short2 tm = P.wtmeta[wi];
@@ -2692,7 +2728,7 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P, int slot0)
     const int idx_ws = (w == 0) ? 0 : 2 * w - 1, idx_we = (w == nw - 1) ? 2 * nw - 1 : 2 * (w + 1);
     if (tid < J) { const uint8_t b = P.wtpl[wi * 32 + tid]; sT[0][tid] = b; sT[1][J - 1 - tid] = (uint8_t)(3 - b); }
     if (tid < 192) (&sK[0][0][0])[tid] = 0u;
-    // SPEC v5: up to CCSX_MAX_PASSES passes, taken in groups of PW_MAXREADS = 64 (the sums in sK run over all groups)
+    // SPEC v5: up to CCSX_MAX_PASSES passes, taken in groups of PW_MAXREADS (the sums in sK run over all groups)
     for (int g0 = 0; g0 < nreads; g0 += PW_MAXREADS) {
     const int ng = nreads - g0 < PW_MAXREADS ? nreads - g0 : PW_MAXREADS;
     __syncthreads();
@@ -2874,7 +2910,7 @@ static void trace_sync(hipStream_t st, const char *what)
     fprintf(stderr, "[ccsx] %s done: %s\n", what, hipGetErrorString(e));
 }
 
-// dynamic LDS of k_polish: [reads][68] observation codes for the largest ZMW of the batch, the rest of the workgroup's
+// dynamic LDS of k_polish: [reads][68] observations (a byte each) for the largest ZMW of the batch (at most one group of PW_MAXREADS), the rest of the workgroup's
 // budget holds gamma/beta of one chunk of reads
 int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
 {
@@ -2885,7 +2921,7 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES - static_bytes) != hipSuccess) return -1;
     if (max_reads > PW_MAXREADS) max_reads = PW_MAXREADS;
     if (max_reads < 1) max_reads = 1;
-    *obs_bytes = ((max_reads * 68 * 2) + 15) & ~15;
+    *obs_bytes = ((max_reads * 68) + 15) & ~15;
     *gb_floats = (PW_LDS_BYTES - static_bytes - *obs_bytes) / 4;
     return 0;
 }
@@ -2958,6 +2994,10 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
         hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P, pass);
         LAUNCH_CHECK("k_post");
     }
+    hipLaunchKernelGGL(k_wmap, dim3(1), dim3(1024), 0, st, P);     // the batch's windows in compact order: the polish stage's grid map
+    LAUNCH_CHECK("k_wmap");
+    hipLaunchKernelGGL(k_wmap_fill, dim3((P.n_zmw + 3) / 4), dim3(256), 0, st, P);
+    LAUNCH_CHECK("k_wmap_fill");
     if (ev) {
         if (hipEventRecord(ev[3], st) != hipSuccess && !failed) failed = "hipEventRecord";
         if (st_polish != st && hipStreamWaitEvent(st_polish, ev[3], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
