@@ -2377,7 +2377,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const float aIJ = sBase[lane], b00 = sB00[lane];
                 const int I = sI[lane], sd = sStrand[lane];
                 if (aIJ > TINY_P && b00 > TINY_P) {
+#ifdef CCSX_EXP_CHEAP_VALIDITY                              // experiment (timing only, wrong results): what the two logarithms of the validity step cost
+                    vLa = aIJ; const float lb = b00 - (b00 - aIJ);
+#else
                     vLa = det_log2f(aIJ); const float lb = det_log2f(b00);
+#endif
                     float df = vLa - lb; if (df < 0.0f) df = -df;
                     vOk = !(df > AB_TOL);
                     if (sZdrop[g0 + lane]) vOk = 0;
@@ -2600,7 +2604,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     const size_t wi = (size_t)(P.wb_off[z] - z) + w;
     // every mutation lane's term exp2(min(delta, 20)) is computed by the lane's own thread (all waves at once; the core threads below used to
     // evaluate their 8 - 12 exponentials one after the other while three waves waited), then summed per position in the SPEC's order
+#ifndef CCSX_EXP_NO_QV_EXP                                  // (experiment, timing only: the QV exponentials compiled out)
     if (tid < 256 && sMvalid[tid]) { float dv = sDelta[tid]; if (dv > 20.0f) dv = 20.0f; sDelta[tid] = det_exp2f(dv); }
+#endif
     __syncthreads();
     float pl = 0.0f;                                        // this position's error probability
     if (tid < ce - cs) {

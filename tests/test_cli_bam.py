@@ -498,6 +498,21 @@ def test_cli_chunks_and_output_index(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_top_passes_zero_is_unlimited(built, tmp_path):
+    """docs/faq/accuracy-vs-passes.md:49-52: `--top-passes 0` = all passes (SPEC v5: up to 255; round 3 announced a cap of 64).  80-pass ZMWs: the
+    default keeps the 60 passes closest to the median length, 0 keeps all 80 (np is the mode over windows of the passes used)"""
+    bam = tmp_path / "deep.subreads.bam"
+    _run("--write-synthetic", "4,80,600,7", bam)
+    d, a = tmp_path / "d.bam", tmp_path / "a.bam"
+    _run(bam, d, "--suppress-reports")
+    r = _run(bam, a, "--top-passes", 0, "--suppress-reports")
+    assert "at most" not in r.stderr
+    nd = [x["tags"]["np"] for x in bam_util.read_bam(d)[1]]
+    na = [x["tags"]["np"] for x in bam_util.read_bam(a)[1]]
+    assert len(nd) == len(na) == 4 and max(nd) <= 60 and min(nd) >= 55 and min(na) > 70 and max(na) <= 80
+
+
+@pytest.mark.gpu
 def test_cli_mixed_workload_is_independent_of_worker_count(built, tmp_path):
     """VERDICT r03 item 8a / SURVEY.md 8e: a Sequel-II-like mix (BASELINE configs[4] shape, scaled down: 3-50 passes x 1-6 kb, --min-rq
     0.99) through cost-binned batches (--batch-bases) drawn from the shared queue by one, two and FOUR engine handles on device 0

@@ -20,6 +20,9 @@ def make_batch(k, seed0):
         import lowcx
         base = lowcx.make(n, (int(rng.integers(3, 6)), int(rng.integers(6, 24))), (max(60, lmax // 4), lmax), seed0 + 31 * k,
                           channel=float(rng.choice([0.6, 1.0, 1.5])), tpl=("lowcx" if rng.random() < 0.6 else None), hp_boost=float(rng.choice([1.0, 2.5])))
+    elif rng.random() < 0.12:                               # round 4: many passes (SPEC v5: up to 255 are used, k_polish takes them in groups of 32)
+        n, lmax = int(rng.integers(4, 12)), int(rng.choice([300, 1500]))
+        base = api.synth(n, (int(rng.integers(20, 60)), int(rng.integers(60, 300))), (max(40, lmax // 4), lmax), seed=seed0 + 31 * k)
     else:
         base = api.synth(n, (int(rng.integers(1, 6)), int(rng.integers(6, 24))), (max(40, lmax // 4), lmax), seed=seed0 + 31 * k)
     base.ipd = rng.integers(0, 256, len(base.bases)).astype(np.uint8)
@@ -66,6 +69,7 @@ def make_batch(k, seed0):
     o.max_insertion_size = int(rng.choice([0, 30, 10, 5, -1])); o.no_fallback_draft = int(rng.random() < 0.25)
     o.disable_heuristics = int(rng.random() < 0.2); o.hifi_kinetics = int(rng.random() < 0.4); o.max_poa_cov = int(rng.choice([3, 5, 7]))
     o.min_rq = float(rng.choice([0.99, 0.9, 0.0]))
+    o.top_passes = int(rng.choice([0, 60, 60, 100, 33]))
     return batch, o, n, lmax, ncorr, int(base.read_off[-1])
 
 
