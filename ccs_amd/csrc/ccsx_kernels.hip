@@ -2453,7 +2453,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         const LaneMut La = rl(vSt, k0) ? LR : LF;
                         const int gA_ = rl(vG, k0), bA_ = rl(vB, k0);
                         const int dA = Ia > J ? Ia - J : J - Ia, WrA = SCORE_BAND + (dA > 2 ? dA - 2 : 0);
+#ifdef CCSX_EXP_NO_ROWS                                     // experiment (timing only): a unit without its rows
+                        const int nrA = 0;
+#else
                         const int nrA = (Ia < 2 * WrA ? Ia : 2 * WrA) + 1;
+#endif
                         const int i0a = band_row0(La.c, Ia, 2 * J, invJ2, J, WrA, nrA);
                         lds_cc tAa = (lds_cc)(sCTX + La.kA), tBa = (lds_cc)(sCTX + La.kB);
                         ScoreChain ca;
@@ -2468,7 +2472,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                             if (ia < nrA) score_step(ca, La, tAa, tBa, S);
                         }
                         const float res = La.fin ? ca.b : ca.acc;
+#ifdef CCSX_EXP_NO_SCORE_LOG                                // experiment (timing only): a unit without its logarithm and fixed-point conversion
+                        dq = __float_as_int(res) >> 20;
+#else
                         dq = dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k0)));
+#endif
                     } else {
                     const int k1 = k0 + 1;
                     const int ra = rl(vR, k0), rb = rl(vR, k1);
@@ -2527,6 +2535,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         if (tid < 256) { delta = (float)sDeltaI[tid] * (1.0f / DQ_SCALE); sDelta[tid] = delta; }   // same slot, same thread
         const int fav = (tid < 256 && sMvalid[tid] && delta > MUT_EPS) ? 1 : 0;
         const int anyfav = __syncthreads_or(fav);
+#ifdef CCSX_EXP_ONE_ROUND                                   // experiment (timing only): exactly one round per window whatever the gains say, so that variants which
+        break;                                              // corrupt the gains (rows / logarithm compiled out) do not change the control flow they are compared under
+#endif
         if (!anyfav) break;
         if (it == CCSX_MAX_ITER - 1) { nonconv = 1; break; }
         // ---- A5: greedy selection (wave 0; lane l owns m = l, l+64, l+128, l+192 which share position l&31)
