@@ -2067,6 +2067,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     int nvalid_last = 0, nvfull_last = 0;                    // usable reads of the last round: all / full-length passes only
     const int nfull = P.nfull[z];
     for (int it = 0; it < CCSX_MAX_ITER; ++it) {
+        // (round 4 measured the round without three of its barriers — this one in later rounds, the one after sT[1], the second one of the lane compaction:
+        // 155.6 -> 156.1 ms, no gain; the barriers stay where they make the hazards obvious)
         __syncthreads();
         const int J = rfl(sCtl[0]);
         const float invJ2 = 1.0f / (float)(2 * J);           // band_row0's reciprocal
@@ -2074,6 +2076,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                                                              // lane-to-lane address stride is S - 1, which must be odd to be bank-conflict free
         if (tid < J) sT[1][tid] = (uint8_t)(3 - sT[0][J - 1 - tid]);
         __syncthreads();
+        auto tbase = [&](int sd, int j) -> int { return (int)sT[sd][j]; };   // base j of the window template on strand sd
         const int lfr = (rf < 4) ? 3 - rf : 4;
         // per-column table of the fill: column j's deletion weight and WHERE its context sits in a row of sCTX — the fill's lane
         // (= read row, fixed observation) looks (ME, INS) up in its own sCTX row.  Round 3: a per-column copy of the tables
@@ -2087,8 +2090,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             if (j <= J) {
                 int k = 32; float dlv = 1.0f;
                 if (j < J) {
-                    const int prev = j > 0 ? sT[sd][j - 1] : (sd ? lfr : lf);
-                    k = ctx_of(prev, sT[sd][j]);
+                    const int prev = j > 0 ? tbase(sd, j - 1) : (sd ? lfr : lf);
+                    k = ctx_of(prev, tbase(sd, j));
                     dlv = sDL[k];
                 }
                 sColJ[sd][j] = make_int2(__float_as_int(dlv), k * 8);
@@ -2097,10 +2100,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         // z-score expectation of the window template on each strand, summed in column order (SPEC); the gate is decided in round 0
         // only.  Lane j fetches column j's terms, the ordered sum takes them with v_readlane (no chain of dependent LDS loads).
         if (it == 0 && wave < 2 && P.opts.min_zscore != 0.0f) {
-            const uint8_t *t = sT[wave];
             const int j = lane < J ? lane : 0;
-            const int prev = j > 0 ? t[j - 1] : (wave ? lfr : lf);
-            const int k = ctx_of(prev, t[j]);
+            const int prev = j > 0 ? tbase(wave, j - 1) : (wave ? lfr : lf);
+            const int k = ctx_of(prev, tbase(wave, j));
             const float mu = sZP[k], va = sZP[16 + k];
             float M = 0.0f, V = 0.0f;
             for (int q = 0; q < J; ++q) {
@@ -2426,7 +2428,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 }
                 const int u_end = ((wave + 1) * nunits) / (PWT / 64);
                 for (int u = (wave * nunits) / (PWT / 64); u < u_end;) {
-                    const int blk = u / nv, k0 = u - blk * nv;
+                    int blk = 0, k0 = u;                                     // u = blk * nv + k0 (a window has one or two blocks of lanes: no integer division)
+                    while (k0 >= nv) { k0 -= nv; ++blk; }
                     const bool two = (u + 1 < u_end) && (k0 + 1 < nv);       // the next unit is mine and in the same block
                     u += two ? 2 : 1;
                     if (blk != curblk) {
