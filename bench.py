@@ -61,6 +61,20 @@ def gpu_clocks(device: int) -> dict:
     return out
 
 
+def csrc_sha16() -> str | None:
+    """hash of the kernel / library sources (ccs_amd/csrc/*, include/ccsx.h): what ties a counter file to a build where there is no git (the GPU box)"""
+    import hashlib
+    try:
+        h = hashlib.sha256()
+        d = os.path.join(ROOT, "ccs_amd", "csrc")
+        for f in sorted(os.listdir(d)) + ["../../include/ccsx.h"]:
+            if f.endswith((".hip", ".cpp", ".h")):
+                h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+        return h.hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def kernels_changed_since(rev: str | None) -> bool | None:
     """True / False when git can tell whether ccs_amd/csrc differs between `rev` and the working tree, None without a repository"""
     if not rev:
@@ -362,12 +376,12 @@ def main():
         # HBM traffic / VALU issue / counted work of that kernel from this round's committed rocprofv3 PMC passes of the SAME command
         # (`bench.py --pmc`; (2*FETCH_SIZE + WRITE_SIZE)*1024 with the calibrated FETCH_SIZE = bytes/2, per ZMW); the file names
         # the commit it was measured at
-        traffic, valu, traffic_head, traffic_zmws = None, None, None, None
+        traffic, valu, traffic_head, traffic_zmws, traffic_src = None, None, None, None, None
         head = git_head()
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
             kz = tj["kernels"][names[dom]]
-            traffic_head, traffic_zmws = tj.get("head"), tj.get("zmws")
+            traffic_head, traffic_zmws, traffic_src = tj.get("head"), tj.get("zmws"), tj.get("csrc_sha16")
             if args.passes == 10 and args.length == 10000 and not args.hifi_kinetics and not args.disable_heuristics:
                 traffic = int(kz["hbm_bytes_per_zmw"] * args.zmws)
                 valu = {k: kz[k] for k in ("valu_wave_instr_per_zmw", "valu_issue_frac_if_2cyc", "valu_issue_frac_if_4cyc", "lanes_active_frac",
@@ -382,6 +396,7 @@ def main():
                     # tell — no change under ccs_amd/csrc since
                     "traffic_head": traffic_head, "traffic_is_this_build": (bool(head) and bool(traffic_head) and head.split("+")[0] == str(traffic_head).split("+")[0]) if traffic else None,
                     "kernels_changed_since_traffic": kernels_changed_since(traffic_head) if traffic else None,
+                    "traffic_matches_these_sources": (traffic_src == csrc_sha16()) if (traffic and traffic_src) else None,   # sha256 over ccs_amd/csrc + include/ccsx.h
                     "avg_launch_ms": round(stage_ms[dom], 3), "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                     "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d); "
                             "the kernel is bound by VALU issue and dependent-chain latency (DESIGN.md 4)"}

@@ -3,6 +3,7 @@
 Counters are summed over every dispatch of a kernel in the run; one bench run = (warmup + steps + 1) passes over the batch,
 taken from the number of k_polish dispatches (one per pass)."""
 import glob, json, os, sqlite3, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root, n = sys.argv[1], int(sys.argv[2])
 head = sys.argv[3] if len(sys.argv) > 3 else None
 def kname(n):
@@ -20,7 +21,7 @@ for db in glob.glob(os.path.join(root, "pmc_*", "pmc_results.db")):
         c_ = cnt.setdefault(kname(kn), {}); c_[cn] = max(c_.get(cn, 0), k)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ_* (separate passes), python bench.py "
                  f"--pmc --zmws {n} --steps 1 --warmup 1 --distinct 1 (the headline step: two-stage queue on), tools/prof_round.sh",
-       "head": head,
+       "head": head, "csrc_sha16": __import__("bench").csrc_sha16() if os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")) else None,
        "note": "hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on this gfx950 stack FETCH_SIZE reports exactly half of the bytes of a "
                "coalesced streaming read at 1, 4 and 16 bytes per lane and WRITE_SIZE is exact (profiles/r01_counter_calibration.txt, "
                "tools/calib; MI355X_MICROARCH.md HBM section)",
