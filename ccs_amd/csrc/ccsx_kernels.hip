@@ -1158,7 +1158,8 @@ __device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t 
         cursor_load(bcur, sread, nwords, lo + 61, lane);  // the next 64 columns fetch their band-top bases from this window
         asm volatile("" :: "v"(dL), "v"(bcur.vw));       // wait for the block loads here, not inside the column loop
         const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
-        for (int jj = 0; jj < nblk; ++jj) {
+        // two columns per loop iteration (round 4, as in k_align16): the carried cells rotate between two register sets
+        auto column = [&](const int jj) {
             const int j = jb + jj + 1;
             const int plo = lo;
             lo = rfl(band_lo_s(plo, br, hiI));           // scalar unit; the readfirstlane tells the compiler the result is wave-uniform
@@ -1225,7 +1226,8 @@ __device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t 
                 ++kk;
                 next_need = (kk >= nneed) ? -1 : rfl(need_at(kk));
             }
-        }
+        };
+        { int jj = 0; for (; jj + 2 <= nblk; jj += 2) { column(jj); column(jj + 1); } if (jj < nblk) column(jj); }
     }
     AlignEnd out; out.M = Mprev; out.O = Oprev; out.K = Kprev; out.lo = lo;
     return out;
@@ -1302,7 +1304,9 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
         asm volatile("" :: "v"(dL));
         const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
-        for (int jj = 0; jj < nblk; ++jj) {
+        // two columns per loop iteration (round 4): the column body is a lambda called twice, so that the carried cells (score, origin, dirty bits) rotate
+        // between two register sets instead of being copied at the end of every column
+        auto column = [&](const int jj) {
             const int j = jb + jj + 1;
             const int plo = lo;
             {   // band_lo with 16 rows, per row
@@ -1385,7 +1389,8 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
                 if (kk - kkb >= LANES) { kkb = kk; needv = need_col(wb, nw, Ld, (kkb + lane < nneed) ? kkb + lane : nneed - 1); }
                 next_need = (kk >= nneed) ? -1 : rl(needv, kk - kkb);
             }
-        }
+        };
+        { int jj = 0; for (; jj + 2 <= nblk; jj += 2) { column(jj); column(jj + 1); } if (jj < nblk) column(jj); }
     }
     const int oe = I - lo;
     const bool inr = oe >= 0 && oe < AB16;

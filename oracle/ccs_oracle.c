@@ -374,9 +374,13 @@ static void start_column(int I, int32_t *M)
 }
 
 /* Thread one read (draft orientation) into the graph.  Returns 1 if added, 0 if skipped, -1 on capacity overflow. */
-static int poa_add_read(poa_t *g, const uint8_t *r, int I, int32_t *pathv /* scratch [I] */)
+static int poa_add_read(poa_t *g, const uint8_t *r, int I, int32_t *pathv /* scratch [I] */, int first)
 {
-    if (g->n == 0) {                                     /* SPEC: the first read becomes the backbone chain */
+    /* SPEC: the FIRST read (the backbone pass of the draft generator) becomes the chain, whatever its length.  An empty backbone leaves an empty
+     * graph to which nothing can be threaded: the generator ends in DRAFT_FAILURE and the cascade moves on (round 4: the restatement used to take
+     * the first NON-empty read as backbone, the kernels never did — found by tools/corruption_fuzz.py with a zero-length pass 0) */
+    if (!first && g->n == 0) return 0;
+    if (first) {
         int prev = -1;
         for (int i = 0; i < I; ++i) {
             int v = poa_new_vertex(g, r[i], prev);
@@ -489,7 +493,7 @@ int orc_poa_draft_bb(int nreads, const int64_t *base_off, const uint8_t *bases, 
         int L = (int)(base_off[r + 1] - base_off[r]);
         orient(bases + base_off[r], NULL, L, (flags[r] & 1) != rev0, ob, NULL);
         g_bw = g_poa_band; g_cells_kind = CNT_CELLS_POA;            /* SPEC: the POA runs in a POA_BAND-row band */
-        if (poa_add_read(g, ob, L, pathv) < 0) ok = 0;
+        if (poa_add_read(g, ob, L, pathv, rr == 0) < 0) ok = 0;
         g_bw = BAND; g_cells_kind = CNT_CELLS_ALIGN;
     }
     int len = ok ? poa_consensus(g, draft, draft_cap) : 0;

@@ -904,3 +904,27 @@ print("pieces ok")
 """ % (root, os.path.join(root, "tests"))
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CCSX_POLISH_MAX_BLOCKS="37"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "pieces ok" in p.stdout, p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("nofb", [0, 1])
+def test_empty_backbone_pass(built, nofb):
+    """found by tools/corruption_fuzz.py in round 4 (batch 47 of seed 11000): pass 0 of a ZMW has no bases.  SPEC: the backbone pass becomes the chain
+    whatever its length; an empty backbone leaves a graph nothing can be threaded into -> DRAFT_FAILURE, and the draft cascade takes the median-length pass
+    (the restatement used to take the first non-empty pass as backbone, the kernels never did).  Few and many (70) passes, with and without the cascade."""
+    parts = [api.synth(1, 8, 600, seed=41), api.synth(1, 70, 300, seed=42), api.synth(1, 6, 500, seed=43)]
+    batch = api.concat(parts)
+    bo = batch.base_off.copy()
+    for z in (0, 1):                                                   # pass 0 of ZMWs 0 and 1 loses its bases to pass 1
+        r0 = int(batch.read_off[z]); bo[r0 + 1] = bo[r0]
+    batch.base_off = bo
+    o = api.default_opts(); o.no_fallback_draft = nofb; o.top_passes = 0; o.min_rq = 0.9
+    h = api.Handle(0, opts=o)
+    try:
+        res = h.consensus(batch)
+        ref = api.Results.allocate(batch)
+        O.consensus_batch(h.model, o, batch, ref, nthreads=4)
+        _compare(res, ref, batch)
+        assert np.array_equal(res.np_, ref.np_)
+        assert res.status[2] == 0 and (res.status[:2] == (2 if nofb else 0)).all()      # DRAFT_FAILURE without the cascade, rescued with it
+    finally:
+        h.close()

@@ -1,16 +1,18 @@
-# end-of-round numbers besides the default bench: the other BASELINE shapes and the ccs BAM -> BAM path.  usage: bash tools/final_numbers.sh <tag>
+# end-of-round numbers besides the default bench (whose `extra` carries the other BASELINE shapes): the `ccs` driver BAM -> BAM, incl. a configs[4]-like mix through
+# cost-binned batches.  usage (through gpurun): bash tools/final_numbers.sh <tag>   -> gpurun_out/<tag>/cli.txt
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; T=${1:-final}; O=$R/gpurun_out/$T; rm -rf $O; mkdir -p $O
-for w in c1 c4 c5; do timeout 500 python $R/bench.py --workload $w --steps 4 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err; done
-timeout 300 $R/ccs_amd/bin/ccs --write-synthetic 32768,10,10000,5 /tmp/big.subreads.bam
-ls -la /tmp/big.subreads.bam* > $O/cli.txt
-( time timeout 600 $R/ccs_amd/bin/ccs /tmp/big.subreads.bam /tmp/big.hifi.bam --batch-size 4096 --log-level INFO ) > $O/cli.log 2>&1
-tail -8 $O/cli.log >> $O/cli.txt; ls -la /tmp/big.hifi.bam* >> $O/cli.txt
-( time timeout 600 $R/ccs_amd/bin/ccs /tmp/big.subreads.bam /tmp/big2.hifi.bam --chunk 2/4 --batch-size 4096 ) >> $O/cli.txt 2>&1
-python - <<PY
-import json
-for w in ("c1","c4","c5"):
-    d=json.loads(open("$O/bench_%s.json"%w).read().strip().splitlines()[-1])
-    print(w, d["value"], d["resident_zmws_per_s"], d["config"]["zmws_per_gpu"], d["stage_ms"]["total_ms"], d["cpu_baseline"]["value"], d["cpu_baseline"].get("gpu_matches_cpu_sequences"), d.get("success_frac"))
-PY
+R=$GRAFT_REPO_ROOT; T=${1:-final}; O=$R/gpurun_out/$T; mkdir -p $O
+CCS=$R/ccs_amd/bin/ccs
+{
+echo "== 32768 ZMWs x 10 passes x 10 kb (4.5 GB BAM)"
+timeout 300 $CCS --write-synthetic 32768,10,10000,5 /tmp/big.subreads.bam; ls -la /tmp/big.subreads.bam | awk '{print $5, $9}'
+timeout 300 $CCS --host-only /tmp/big.subreads.bam 2>&1 | tail -1
+( time timeout 600 $CCS /tmp/big.subreads.bam /tmp/big.hifi.bam --batch-size 4096 --log-level INFO ) 2>&1 | tail -6
+echo "== 8192 ZMWs, 3-50 passes x 1-25 kb (configs[4] shape), --min-rq 0.99, cost-binned batches"
+timeout 300 $CCS --write-synthetic 8192,3-50,1000-25000,9 /tmp/mix.subreads.bam; ls -la /tmp/mix.subreads.bam | awk '{print $5, $9}'
+timeout 300 $CCS --host-only --batch-size 4096 /tmp/mix.subreads.bam 2>&1 | tail -1
+( time timeout 600 $CCS /tmp/mix.subreads.bam /tmp/mix.hifi.bam --batch-size 4096 --min-rq 0.99 --log-level INFO ) 2>&1 | tail -6
+( time timeout 600 $CCS /tmp/mix.subreads.bam /tmp/mix2.hifi.bam --batch-size 4096 --batch-bases 200000000 --min-rq 0.99 ) 2>&1 | tail -4
+cmp /tmp/mix.hifi.bam /tmp/mix2.hifi.bam && echo "hifi.bam identical for both batch cuts"
+} > $O/cli.txt 2>&1
 cat $O/cli.txt
