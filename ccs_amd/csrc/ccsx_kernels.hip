@@ -1241,6 +1241,7 @@ __device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t 
 // (bit-identical consensus on the test sets); a pass that is not valid here goes on a list for the 64-row retry (k_align), and
 // from there to the split alignment.  Same cell recurrence, origin / dirty tracking and edge saves as align_pass.
 #define AB16 16
+#define NEG16 (-(1 << 23))           // k_align16's internal "minus infinity" (see the kernel)
 #define AB16_ABOVE 6
 #define AB16_SAT_ROWS 1               // SPEC v5 "band saturation": best row within the last AB16_SAT_ROWS rows of a band that can still move down
 #define AB16_SAT_GAIN 1               //   ... or a window's worth of columns (edge k-2 -> edge k) without this much gain of the column maximum
@@ -1289,17 +1290,21 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     int kkb = 1;
     int needv = need_col(wb, nw, Ld, (kkb + lane < nneed) ? kkb + lane : nneed - 1);
     int next_need = rl(needv, 0);
-    int Mprev = (l <= I) ? l * SC_INS : NEGV;
+    // (round 4) inside this kernel an invalid cell is NEG16 = -2^23 instead of NEGV = -2^28: still below every cell of a valid path (> -2^19) and below the
+    // -2^22 threshold that resets a cell, but small enough that (cell + 4 * lane) << 6 cannot overflow — the insertion chain's packed key needs no clamp
+    int Mprev = (l <= I) ? l * SC_INS : NEG16;
     int Oprev = 0;
     unsigned Kprev = (l >= 1) ? 1u : 0u;
     int ecol = 0;
     int lo = 0, br = 0;                                  // per lane, uniform inside a row
     const int hiI = I - (AB16 - 1) > 0 ? I - (AB16 - 1) : 0;
     const int Iclamp = I > 0 ? I - 1 : 0;
+    const int lane257 = 257 * lane;                      // ((4 * lane) << 6) | lane
     // SPEC v5 "band saturation": the narrow band's answer is not trusted (-> 64-row retry) when the best row reaches the band's last row
     // before the band has reached the read's end, or when the column maximum gains less than AB16_SAT_GAIN between two window-edge
     // columns one window apart (cmE0 / cmE1: the maxima at the last even / odd edge; edge 0 is column 0 with maximum 0)
     int satf = 0, cmE0 = 0, cmE1 = 0;
+    unsigned long long satm = 0ull;
     for (int jb = 0; jb < Ld; jb += LANES) {
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
         asm volatile("" :: "v"(dL));
@@ -1309,20 +1314,21 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
         auto column = [&](const int jj) {
             const int j = jb + jj + 1;
             const int plo = lo;
-            {   // band_lo with 16 rows, per row
+            {   // band_lo with 16 rows, per row (the SPEC's final max(., 0) cannot bind: plo >= 0 and hiI >= plo)
                 int t = br + 1 - AB16_ABOVE;              // 6 rows above the best row, 9 below: insertion bursts push the path down
                 t = t > plo ? t : plo;
                 t = t < plo + 2 ? t : plo + 2;
-                t = t < hiI ? t : hiI;
-                lo = t > 0 ? t : 0;
+                lo = t < hiI ? t : hiI;
             }
             const int sh = lo - plo;                    // 0..2, per row
             const int i = lo + l;
             const int vb = rl(dL, jj);
-            if (__any(lo + AB16 + 2 > c0 + CH16)) {           // (every ~2000 columns per pass) the band reaches the end of a chunk: next chunk
+            // (every ~2000 columns per pass) the band reaches the end of a chunk: next chunk.  Looked at every 8th column only — the band moves at most two rows
+            // per column, so 16 rows of margin cover the columns in between (the chunk holds CH16 + 32 bases)
+            if ((jj & 7) == 0 && __any(lo + AB16 + 2 + 16 > c0 + CH16)) {
                 for (int hh = 0; hh < nq; ++hh) {
                     const int src = hh << 4;
-                    if (rl(lo, src) + AB16 + 2 > rl(c0, src) + CH16) {
+                    if (rl(lo, src) + AB16 + 2 + 16 > rl(c0, src) + CH16) {
                         const int rr = rfirst + hh;
                         const int Ih = rfl((int)(P.base_off[rr + 1] - P.base_off[rr]));
                         const int nc0 = rl(lo, src) - 16 > 0 ? rl(lo, src) - 16 : 0;
@@ -1337,12 +1343,12 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int bi = (i - 1 < 0 ? 0 : (i - 1 > Iclamp ? Iclamp : i - 1)) - c0;
             const uint32_t bw = myread[bi >> 4];
             // rows of the previous column in the new band position: the three possible shifts, selected per row
-            const int m1 = row_shl1_i32(Mprev, NEGV), o1 = row_shl1_i32_z(Oprev), k1 = row_shl1_i32_z((int)Kprev);
+            const int m1 = row_shl1_i32(Mprev, NEG16), o1 = row_shl1_i32_z(Oprev), k1 = row_shl1_i32_z((int)Kprev);
             int x, y, ox, oy; unsigned kx, ky;
             if (__all(sh == 1)) {                         // every band moves down by one row (the common column): no selects
                 x = Mprev; y = m1; ox = Oprev; oy = o1; kx = Kprev; ky = (unsigned)k1;
             } else {
-                const int mR = row_shr1_i32(Mprev, NEGV), m2 = row_shl2_i32(Mprev, NEGV);
+                const int mR = row_shr1_i32(Mprev, NEG16), m2 = row_shl2_i32(Mprev, NEG16);
                 const int oR = row_shr1_i32_z(Oprev), o2 = row_shl2_i32_z(Oprev);
                 const int kR = row_shr1_i32_z((int)Kprev), k2 = row_shl2_i32_z((int)Kprev);
                 const bool s0 = sh == 0, s1 = sh == 1;
@@ -1351,7 +1357,9 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
                 kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1)); ky = (unsigned)(s0 ? (int)Kprev : (s1 ? k1 : k2));
             }
             const unsigned bitj = 1u << (j - ecol - 1);
-            const int rbv = (i >= 1 && i <= I) ? (int)((bw >> (2 * (bi & 15))) & 3u) : 4;
+            // (no "no base" code for rows 0 and > I: row 0 has no diagonal source — its x is the shift's fill — and a row beyond the read is reset below, so
+            // whatever base the clamped index fetches there cannot reach a valid cell)
+            const int rbv = (int)((bw >> (2 * (bi & 15))) & 3u);
             const bool match = (vb == rbv);
             int best = x + (match ? SC_MATCH : SC_MISMATCH), org = ox;
             unsigned kd = match ? kx : (kx | bitj);
@@ -1365,22 +1373,20 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
                 kd = 0u; insbits = 0x80000001u; ecol = j;
             }
             // insertion chain inside the row: one packed max-scan (value << 6 | lane), origin / dirty bits of the winner by bpermute
-            const int d0 = best + 4 * lane;
-            const int dc = d0 > -(1 << 24) ? d0 : -(1 << 24);
-            const int key = row_scan_max_i32((dc << 6) | lane);
+            const int key = row_scan_max_i32((best << 6) + lane257);             // ((best + 4 * lane) << 6) | lane
             const int xi = (key >> 6) - 4 * lane;
             const int ksl = key & 63;
             const int osrc = __shfl(org, ksl);
             const unsigned ksrc = (unsigned)__shfl((int)kd, ksl);
             if (xi > best) { best = xi; org = osrc; kd = ksrc | insbits; }
-            if (i > I || best < -(1 << 22)) best = NEGV;
+            if (i > I || best < -(1 << 22)) best = NEG16;
             // column maximum of the row and its lowest row
             const int cm = __shfl(row_scan_max_i32(best), lane | 15);
             const unsigned long long bal = __ballot(best == cm);
             const unsigned m16 = (unsigned)(bal >> rowb) & 0xffffu;
             const int brl = __ffs((int)m16) - 1;
             br = lo + brl;
-            satf |= (brl >= AB16 - AB16_SAT_ROWS && lo < hiI) ? 1 : 0;
+            satm |= __builtin_amdgcn_sicmp(brl, AB16 - AB16_SAT_ROWS, 39 /* >= */) & __builtin_amdgcn_sicmp(lo, hiI, 40 /* < */);   // (wave masks: two compares, the rest scalar)
             Mprev = best; Oprev = org; Kprev = kd;
             if (need) {
                 if (kk & 1) { if (kk >= 2 && cm - cmE1 < AB16_SAT_GAIN) satf = 1; cmE1 = cm; }
@@ -1397,7 +1403,8 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const int srcl = rowb + (inr ? oe : 0);
     const int scv = __shfl(Mprev, srcl), eLv = __shfl(Oprev, srcl);
     const unsigned kLv = (unsigned)__shfl((int)Kprev, srcl);
-    const int sc = inr ? scv : NEGV;
+    satf |= (int)((satm >> lane) & 1ull);
+    const int sc = (inr && scv > -(1 << 22)) ? scv : NEGV;     // (an invalid end cell is reported as the SPEC's NEG)
     const int valid = (sc > NEGV / 2 && sc >= Ld && !satf) ? 1 : 0;
     __threadfence_block();
     if (l == 0 && use) {
