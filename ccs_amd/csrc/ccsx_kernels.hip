@@ -1271,17 +1271,20 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const int Ld = rfl(P.draft_len[z]), nw = rfl(P.nwin[z]);
     const uint8_t *d = P.draft + P.seq_off[z];
     const int32_t *wb = P.wbounds + P.wb_off[z];
-    const int wstride = CH16 / 16 + 2;                  // LDS words per pass: one chunk of the pass at a time
+    const int wstride = CH16 / 16 + 3;                  // LDS words per pass: one guard word (the base "before" the chunk: row 0 of a band at 0 looks there),
+                                                        // then one chunk of the pass at a time
     const int fl0 = rfl(P.flags[r0 + (zr & 255)] & 1);
     for (int hh = 0; hh < nq; ++hh) {
         const int rr = rfirst + hh;
         const int Ih = rfl((int)(P.base_off[rr + 1] - P.base_off[rr]));
-        load_read_chunk(sread + hh * wstride, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), 0, lane);
+        load_read_chunk(sread + hh * wstride + 1, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), 0, lane);
     }
+    if (lane < 4) sread[lane * wstride] = 0u;           // the guard words
     __syncthreads();
     int c0 = 0;                                         // first base of the row's chunk in LDS (per lane, uniform inside a row)
+    int bi = l - 1;                                     // chunk index of the base of row i - 1 (the band starts at row 0)
     const int I = use ? (int)(P.base_off[r + 1] - P.base_off[r]) : 0;
-    const uint32_t *myread = sread + h * wstride;
+    const uint32_t *myread = sread + h * wstride + 1;
     const int nneed = 2 * nw;
     int2 *OMsave = (int2 *)Osave;
     int32_t *lo_need = Osave + (size_t)P.need_max * 128;        // [need][4]
@@ -1298,7 +1301,6 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     int ecol = 0;
     int lo = 0, br = 0;                                  // per lane, uniform inside a row
     const int hiI = I - (AB16 - 1) > 0 ? I - (AB16 - 1) : 0;
-    const int Iclamp = I > 0 ? I - 1 : 0;
     const int lane257 = 257 * lane;                      // ((4 * lane) << 6) | lane
     // SPEC v5 "band saturation": the narrow band's answer is not trusted (-> 64-row retry) when the best row reaches the band's last row
     // before the band has reached the read's end, or when the column maximum gains less than AB16_SAT_GAIN between two window-edge
@@ -1322,6 +1324,8 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             }
             const int sh = lo - plo;                    // 0..2, per row
             const int i = lo + l;
+            bi += sh;                                   // index of base i - 1 in the row's chunk (no clamps: index -1 is the guard word, indices beyond the read
+                                                        // hold zero bits; neither can reach a valid cell)
             const int vb = rl(dL, jj);
             // (every ~2000 columns per pass) the band reaches the end of a chunk: next chunk.  Looked at every 8th column only — the band moves at most two rows
             // per column, so 16 rows of margin cover the columns in between (the chunk holds CH16 + 32 bases)
@@ -1333,28 +1337,32 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
                         const int Ih = rfl((int)(P.base_off[rr + 1] - P.base_off[rr]));
                         const int nc0 = rl(lo, src) - 16 > 0 ? rl(lo, src) - 16 : 0;
                         __syncthreads();
-                        load_read_chunk(sread + hh * wstride, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), nc0, lane);
+                        load_read_chunk(sread + hh * wstride + 1, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), nc0, lane);
                         __syncthreads();
-                        if (h == hh) c0 = nc0;
+                        if (h == hh) { c0 = nc0; bi = i - 1 - nc0; }
                     }
                 }
             }
             // the read base of row i-1: an unconditional (clamped) LDS read issued here, consumed after the shifts below
-            const int bi = (i - 1 < 0 ? 0 : (i - 1 > Iclamp ? Iclamp : i - 1)) - c0;
             const uint32_t bw = myread[bi >> 4];
-            // rows of the previous column in the new band position: the three possible shifts, selected per row
-            const int m1 = row_shl1_i32(Mprev, NEG16), o1 = row_shl1_i32_z(Oprev), k1 = row_shl1_i32_z((int)Kprev);
+            // rows of the previous column in the new band position.  x = cell (i - 1) of the previous column is the previous column shifted by sh - 1 lanes (one
+            // of three variants, selected per row — none at all when all four bands move down by one row, the common column); y = cell i is x shifted up by one
+            // more lane, except for a band that did not move (its last lane keeps its own cell): one shift of the selected x and one select instead of a
+            // second three-way selection (round 4)
             int x, y, ox, oy; unsigned kx, ky;
-            if (__all(sh == 1)) {                         // every band moves down by one row (the common column): no selects
-                x = Mprev; y = m1; ox = Oprev; oy = o1; kx = Kprev; ky = (unsigned)k1;
+            if (__all(sh == 1)) {                         // every band moves down by one row: no selects
+                x = Mprev; ox = Oprev; kx = Kprev;
+                y = row_shl1_i32(Mprev, NEG16); oy = row_shl1_i32_z(Oprev); ky = (unsigned)row_shl1_i32_z((int)Kprev);
             } else {
-                const int mR = row_shr1_i32(Mprev, NEG16), m2 = row_shl2_i32(Mprev, NEG16);
-                const int oR = row_shr1_i32_z(Oprev), o2 = row_shl2_i32_z(Oprev);
-                const int kR = row_shr1_i32_z((int)Kprev), k2 = row_shl2_i32_z((int)Kprev);
+                const int mR = row_shr1_i32(Mprev, NEG16), m1 = row_shl1_i32(Mprev, NEG16);
+                const int oR = row_shr1_i32_z(Oprev), o1 = row_shl1_i32_z(Oprev);
+                const int kR = row_shr1_i32_z((int)Kprev), k1 = row_shl1_i32_z((int)Kprev);
                 const bool s0 = sh == 0, s1 = sh == 1;
-                x = s0 ? mR : (s1 ? Mprev : m1); y = s0 ? Mprev : (s1 ? m1 : m2);
-                ox = s0 ? oR : (s1 ? Oprev : o1); oy = s0 ? Oprev : (s1 ? o1 : o2);
-                kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1)); ky = (unsigned)(s0 ? (int)Kprev : (s1 ? k1 : k2));
+                x = s0 ? mR : (s1 ? Mprev : m1);
+                ox = s0 ? oR : (s1 ? Oprev : o1);
+                kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1));
+                const int yu = row_shl1_i32(x, NEG16), oyu = row_shl1_i32_z(ox), kyu = row_shl1_i32_z((int)kx);
+                y = s0 ? Mprev : yu; oy = s0 ? Oprev : oyu; ky = (unsigned)(s0 ? (int)Kprev : kyu);
             }
             const unsigned bitj = 1u << (j - ecol - 1);
             // (no "no base" code for rows 0 and > I: row 0 has no diagonal source — its x is the shift's fill — and a row beyond the read is reset below, so
@@ -3005,7 +3013,7 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
         // alignment cascade: four passes per wave in 16-row bands, then the 64-row retry of the few that failed there
         if (hipMemsetAsync(P.align_retry, 0, 64, st) != hipSuccess && !failed) failed = "hipMemsetAsync";
         {
-            const size_t lds16 = 4 * (CH16 / 16 + 2) * sizeof(uint32_t);
+            const size_t lds16 = 4 * (CH16 / 16 + 3) * sizeof(uint32_t);
             for (int qb = 0; qb < P.n_quads; qb += P.align_slots) {
                 const int nb = (P.n_quads - qb) < P.align_slots ? (P.n_quads - qb) : P.align_slots;
                 hipLaunchKernelGGL(k_align16, dim3(nb), dim3(64), lds16, st, P, qb, pass);
