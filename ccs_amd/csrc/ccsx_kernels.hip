@@ -1310,6 +1310,9 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     for (int jb = 0; jb < Ld; jb += LANES) {
         const int dL = (jb + lane < Ld) ? d[jb + lane] : 0;
         asm volatile("" :: "v"(dL));
+        // the 64 draft bases of the block as two wave masks: a column takes its base with scalar shifts (round 4: a v_readlane per column before — 6 cycles of the
+        // VALU this kernel saturates)
+        const unsigned long long dB0 = __ballot(dL & 1), dB1 = __ballot(dL & 2);
         const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
         // two columns per loop iteration (round 4): the column body is a lambda called twice, so that the carried cells (score, origin, dirty bits) rotate
         // between two register sets instead of being copied at the end of every column
@@ -1326,7 +1329,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int i = lo + l;
             bi += sh;                                   // index of base i - 1 in the row's chunk (no clamps: index -1 is the guard word, indices beyond the read
                                                         // hold zero bits; neither can reach a valid cell)
-            const int vb = rl(dL, jj);
+            const int vb = (int)((dB0 >> jj) & 1ull) | ((int)((dB1 >> jj) & 1ull) << 1);
             // (every ~2000 columns per pass) the band reaches the end of a chunk: next chunk.  Looked at every 8th column only — the band moves at most two rows
             // per column, so 16 rows of margin cover the columns in between (the chunk holds CH16 + 32 bases)
             if ((jj & 7) == 0 && __any(lo + AB16 + 2 + 16 > c0 + CH16)) {
@@ -1387,7 +1390,8 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int osrc = __shfl(org, ksl);
             const unsigned ksrc = (unsigned)__shfl((int)kd, ksl);
             if (xi > best) { best = xi; org = osrc; kd = ksrc | insbits; }
-            if (i > I || best < -(1 << 22)) best = NEG16;
+            if (i > I) best = NEG16;                     // (a row beyond the read must not take part in the column maximum; an invalid cell inside the read may keep
+                                                         // whatever it has below -2^22: it loses every comparison and cannot drift far in 65 k columns)
             // column maximum of the row and its lowest row
             const int cm = __shfl(row_scan_max_i32(best), lane | 15);
             const unsigned long long bal = __ballot(best == cm);
