@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const int lane257 = 257 * lane;                      // ((4 * lane) << 6) | lane
     // SPEC v5 "band saturation": the narrow band's answer is not trusted (-> 64-row retry) when the best row reaches the band's last row
     // before the band has reached the read's end, or when the column maximum gains less than AB16_SAT_GAIN between two window-edge
-    // columns one window apart (cmE0 / cmE1: the maxima at the last even / odd edge; edge 0 is column 0 with maximum 0)
+    // columns one window apart (cmE0 / cmE1: the maxima two edges / one edge back; edge 0 is column 0 with maximum 0)
     int satf = 0, cmE0 = 0, cmE1 = 0;
     unsigned long long satm = 0ull;
     for (int jb = 0; jb < Ld; jb += LANES) {
@@ -1352,29 +1352,33 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             // of three variants, selected per row — none at all when all four bands move down by one row, the common column); y = cell i is x shifted up by one
             // more lane, except for a band that did not move (its last lane keeps its own cell): one shift of the selected x and one select instead of a
             // second three-way selection (round 4)
-            int x, y, ox, oy; unsigned kx, ky;
-            if (__all(sh == 1)) {                         // every band moves down by one row: no selects
-                x = Mprev; ox = Oprev; kx = Kprev;
-                y = row_shl1_i32(Mprev, NEG16); oy = row_shl1_i32_z(Oprev); ky = (unsigned)row_shl1_i32_z((int)Kprev);
-            } else {
-                const int mR = row_shr1_i32(Mprev, NEG16), m1 = row_shl1_i32(Mprev, NEG16);
-                const int oR = row_shr1_i32_z(Oprev), o1 = row_shl1_i32_z(Oprev);
-                const int kR = row_shr1_i32_z((int)Kprev), k1 = row_shl1_i32_z((int)Kprev);
-                const bool s0 = sh == 0, s1 = sh == 1;
-                x = s0 ? mR : (s1 ? Mprev : m1);
-                ox = s0 ? oR : (s1 ? Oprev : o1);
-                kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1));
-                const int yu = row_shl1_i32(x, NEG16), oyu = row_shl1_i32_z(ox), kyu = row_shl1_i32_z((int)kx);
-                y = s0 ? Mprev : yu; oy = s0 ? Oprev : oyu; ky = (unsigned)(s0 ? (int)Kprev : kyu);
-            }
             const unsigned bitj = 1u << (j - ecol - 1);
             // (no "no base" code for rows 0 and > I: row 0 has no diagonal source — its x is the shift's fill — and a row beyond the read is reset below, so
             // whatever base the clamped index fetches there cannot reach a valid cell)
             const int rbv = (int)((bw >> (2 * (bi & 15))) & 3u);
             const bool match = (vb == rbv);
-            int best = x + (match ? SC_MATCH : SC_MISMATCH), org = ox;
-            unsigned kd = match ? kx : (kx | bitj);
-            { const int c = y + SC_DEL; if (c > best) { best = c; org = oy; kd = ky | bitj; } }
+            int best, org; unsigned kd;
+            // diagonal / deletion step of the cell.  Called in BOTH variants below rather than after them: merged x / ox / kx values would cost the common
+            // variant three register copies (x = Mprev there, and Mprev is still read after x is formed in the other one)
+            auto cell = [&](const int x, const int ox, const unsigned kx, const int y, const int oy, const unsigned ky) {
+                best = x + (match ? SC_MATCH : SC_MISMATCH); org = ox;
+                kd = match ? kx : (kx | bitj);
+                const int c = y + SC_DEL;
+                if (c > best) { best = c; org = oy; kd = ky | bitj; }
+            };
+            if (__all(sh == 1)) {                         // every band moves down by one row: no selects
+                cell(Mprev, Oprev, Kprev, row_shl1_i32(Mprev, NEG16), row_shl1_i32_z(Oprev), (unsigned)row_shl1_i32_z((int)Kprev));
+            } else {
+                const int mR = row_shr1_i32(Mprev, NEG16), m1 = row_shl1_i32(Mprev, NEG16);
+                const int oR = row_shr1_i32_z(Oprev), o1 = row_shl1_i32_z(Oprev);
+                const int kR = row_shr1_i32_z((int)Kprev), k1 = row_shl1_i32_z((int)Kprev);
+                const bool s0 = sh == 0, s1 = sh == 1;
+                const int x = s0 ? mR : (s1 ? Mprev : m1);
+                const int ox = s0 ? oR : (s1 ? Oprev : o1);
+                const unsigned kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1));
+                const int yu = row_shl1_i32(x, NEG16), oyu = row_shl1_i32_z(ox), kyu = row_shl1_i32_z((int)kx);
+                cell(x, ox, kx, s0 ? Mprev : yu, s0 ? Oprev : oyu, (unsigned)(s0 ? (int)Kprev : kyu));
+            }
             const bool need = (j == next_need);
             unsigned insbits = bitj | (bitj << 1);
             if (need) {
@@ -1401,8 +1405,8 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             satm |= __builtin_amdgcn_sicmp(brl, AB16 - AB16_SAT_ROWS, 39 /* >= */) & __builtin_amdgcn_sicmp(lo, hiI, 40 /* < */);   // (wave masks: two compares, the rest scalar)
             Mprev = best; Oprev = org; Kprev = kd;
             if (need) {
-                if (kk & 1) { if (kk >= 2 && cm - cmE1 < AB16_SAT_GAIN) satf = 1; cmE1 = cm; }
-                else { if (cm - cmE0 < AB16_SAT_GAIN) satf = 1; cmE0 = cm; }
+                if (kk >= 2 && cm - cmE0 < AB16_SAT_GAIN) satf = 1;       // cmE0 = the maximum two edges back, cmE1 = one edge back (a rotation: an
+                cmE0 = cmE1; cmE1 = cm;                                   // index kk & 1 made the compiler put the pair into scratch memory)
                 ++kk;
                 if (kk - kkb >= LANES) { kkb = kk; needv = need_col(wb, nw, Ld, (kkb + lane < nneed) ? kkb + lane : nneed - 1); }
                 next_need = (kk >= nneed) ? -1 : rl(needv, kk - kkb);
