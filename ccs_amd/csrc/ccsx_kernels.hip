@@ -2333,26 +2333,48 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     // has four steps to arrive and nothing is copied between registers.  The only state a step changes under its
                     // activity mask is the running cell: ME of the previous column is simply the previous slot's pair (the column
                     // before column 0 is the zero entry with DL = 1, as the boundary cells want it).
+                    // (experiments, timing only, under CCSX_EXP_ONE_ROUND — profiles/r04_fill_lds.txt: the (ME, INS) look-up at ONE address (no bank conflicts),
+                    // the sweep without its per-step column entry, without its gamma / beta store)
+#ifdef CCSX_EXP_FILL_FIXED_PAIR
+#define LDPR(ROWP, OFF) (*(const float2 *)((const char *)sCTX + (((OFF) >> 20) << 3)))
+#else
 #define LDPR(ROWP, OFF) (*(const float2 *)((ROWP) + (OFF)))
+#endif
+#ifdef CCSX_EXP_FILL_NO_ENTRY
+#define LDEN(PTR, IDX) (PTR##0x)
+#else
+#define LDEN(PTR, IDX) ((PTR)[(IDX)])
+#endif
+#ifdef CCSX_EXP_FILL_NO_MASK                                 // (the steps without their activity test: what the two VALU + exec bookkeeping per step cost)
+#define FILL_ACTIVE(C) true
+#else
+#define FILL_ACTIVE(C) (C)
+#endif
+#ifdef CCSX_EXP_FILL_NO_STORE
+#define STGB(LV, V) ((void)(V))
+#else
+#define STGB(LV, V) ((LV) = (V))
+#endif
                     if (mode != 2) {
                         const int2 *eA = sEA[sd] + (FE_ALO - row);                       // eA[x] = the entry of column x - row
 #define CCSX_A_INIT(K) const int2 ea##K = eA[K], fa##K = eA[(K) - 4]; float dl##K = __int_as_float(ea##K.x); int cx##K = ea##K.y; float2 p##K = LDPR(rowA, fa##K.y);
                         CCSX_A_INIT(0) CCSX_A_INIT(1) CCSX_A_INIT(2) CCSX_A_INIT(3)
+                        const int2 eA0x = ea0; (void)eA0x;
 #undef CCSX_A_INIT
                         int cnt = -tA0;
 #define CCSX_A_STEP(K)                                                                                                     \
                         {                                                                                                  \
                             const float up = wave_shr1_f32_z(acur);                                                        \
-                            if ((unsigned)(cnt + (K)) <= uJ) {       /* alpha, column j = t + K - row */                   \
+                            if (FILL_ACTIVE((unsigned)(cnt + (K)) <= uJ)) { /* alpha, column j = t + K - row */            \
                                 const float m = updiag * mePrev, dl = acur * dl##K;                                        \
                                 const float gmm = m + dl;                                                                  \
                                 const float st = up * p##K.y;        /* row 0 and column J read zero entries: +0 */        \
-                                gA[(K)] = gmm;                                                                             \
+                                STGB(gA[(K)], gmm);                                                                        \
                                 acur = gmm + st;                                                                           \
                             }                                                                                              \
                             updiag = up; mePrev = p##K.x;                                                                  \
                             p##K = LDPR(rowA, cx##K);                                                                      \
-                            const int2 en = eA[(K) + 4];                                                                   \
+                            const int2 en = LDEN(eA, (K) + 4);                                                             \
                             dl##K = __int_as_float(en.x); cx##K = en.y;                                                    \
                         }
                         for (int t = 0; t <= Tmax; t += 4, eA += 4, gA += 4, cnt += 4) { CCSX_A_STEP(0) CCSX_A_STEP(1) CCSX_A_STEP(2) CCSX_A_STEP(3) }
@@ -2363,27 +2385,31 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         float *bE = sGB + sBoff[myr] + row * S + (J + I - row);          // bE[-x] = beta(row, J + I - row - x)
 #define CCSX_B_INIT(K) const int2 eb##K = eB[-(K)], fb##K = eB[4 - (K)]; float dk##K = __int_as_float(eb##K.x); int cy##K = eb##K.y; float2 q##K = LDPR(rowB, fb##K.y);
                         CCSX_B_INIT(0) CCSX_B_INIT(1) CCSX_B_INIT(2) CCSX_B_INIT(3)
+                        const int2 eB0x = eb0; (void)eB0x;
 #undef CCSX_B_INIT
                         int cnt = -tB0;
 #define CCSX_B_STEP(K)                                                                                                     \
                         {                                                                                                  \
                             const float dn = wave_shl1_f32_z(bcur);                                                        \
-                            if ((unsigned)(cnt + (K)) <= uJ) {       /* beta, column jb = J + I - row - (t + K) */         \
+                            if (FILL_ACTIVE((unsigned)(cnt + (K)) <= uJ)) { /* beta, column jb = J + I - row - (t + K) */  \
                                 const float t1 = q##K.x * dndiag, t2 = q##K.y * dn;                                        \
                                 const float t3 = dk##K * bcur;                                                             \
                                 const float bv = (t1 + t2) + t3;                                                           \
-                                bE[-(K)] = bv;                                                                             \
+                                STGB(bE[-(K)], bv);                                                                        \
                                 bcur = bv;                                                                                 \
                             }                                                                                              \
                             dndiag = dn;                                                                                   \
                             q##K = LDPR(rowB, cy##K);                                                                      \
-                            const int2 en = eB[-(K) - 4];                                                                  \
+                            const int2 en = LDEN(eB, -(K) - 4);                                                            \
                             dk##K = __int_as_float(en.x); cy##K = en.y;                                                    \
                         }
                         for (int t = 0; t <= Tmax; t += 4, eB -= 4, bE -= 4, cnt += 4) { CCSX_B_STEP(0) CCSX_B_STEP(1) CCSX_B_STEP(2) CCSX_B_STEP(3) }
 #undef CCSX_B_STEP
                     }
 #undef LDPR
+#undef LDEN
+#undef STGB
+#undef FILL_ACTIVE
                 }
 #undef CCSX_FILL_LOOP
 #undef CCSX_FILL_STEP
@@ -2422,6 +2448,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     }
                 }
             }
+#ifdef CCSX_EXP_ALL_VALID                                   // experiment (timing only): every read with a segment counts as usable, whatever the fill produced
+            vOk = (lane >= rbeg && lane < rend && sGoff[lane] >= 0) ? 1 : 0;
+#endif
             // usable reads of the chunk, in read order: every wave builds the list in a register (lane k = the k-th usable read) with one
             // ds_permute (valid lane r sends r to lane rank(r), the others fill the remaining lanes): no LDS list, no second barrier
             int vRlist, nv_chunk;

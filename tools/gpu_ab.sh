@@ -2,7 +2,7 @@
 # the serial-stage and the two-stage bench.  Replaces round 3's one-off r03_oldnew* / r03_variant* / r03_ab scripts.
 #   VARIANTS="name:-DFLAG=1,-DOTHER=2 name2:"      compile-time variants of the working tree (CCSX_EXTRA_FLAGS); "name:" = no flags
 #   OLD=tools/_old_kernels.hip                     additionally: the kernel file of an earlier commit (git show REV:ccs_amd/csrc/ccsx_kernels.hip > tools/_old_kernels.hip)
-#   BENCH_ARGS="--workload c4"                     extra bench.py arguments;  PARITY=0 skips the parity subset
+#   BENCH_ARGS="--workload c4"                     extra bench.py arguments;  PARITY=0 skips the parity subset;  MODES=--serial-stages REPS=1: one serial-stage line only
 #   every result line is also appended to gpurun_out/ab_all.txt (survives several invocations in one gpurun call)
 #   usage: gpurun --timeout 1500 -- 'VARIANTS="head: lds48:-DPW_LDS_BYTES=49152" bash tools/gpu_ab.sh'
 cd $GRAFT_REPO_ROOT
@@ -14,8 +14,8 @@ run() {
     tail -1 $O/pytest_$name.txt
     if ! grep -q " passed" $O/pytest_$name.txt || grep -q " failed" $O/pytest_$name.txt; then echo "parity $name FAILED"; grep -m3 "Error\|error\|FAILED" $O/pytest_$name.txt; return; fi
   fi
-  for mode in "--serial-stages" ""; do
-    for rep in 1 2; do
+  for mode in ${MODES:-"--serial-stages" ""}; do
+    for rep in $(seq ${REPS:-2}); do
       timeout 400 python bench.py --no-cpu-baseline --extra '' --steps ${STEPS:-8} --warmup 3 $mode $BENCH_ARGS > $O/b.json 2> $O/b.err
       python - <<PY
 import json
