@@ -55,8 +55,13 @@ struct Options {
     bool by_strand = false;       // --by-strand: one consensus per strand (docs/faq/mode-by-strand.md:8-23)
     bool no_partial = false;      // --no-partial-passes: drop the subreads that are not flanked by adapters on both sides (as round 2 did)
     bool qv_binning = false;      // --qv-binning: 7-bin per-base QVs after rq is computed (docs/faq/qv-binning.md:19-31)
-    bool suppress_reports = false;
+    bool suppress_reports = false; // --suppress-reports: no report / metrics files "per default" — a file that is NAMED is still written (docs/faq/sqiie.md:36-46)
+    bool report_named = false, metrics_named = false;
     std::string metrics;          // --metrics-json (default <prefix>.zmw_metrics.json.gz)
+    std::string report_json;      // --report-json: the ccs_report counts as JSON (docs/changelog.md:72, docs/faq/sqiie.md:42); written only when named
+    std::string hifi_summary;     // --hifi-summary-json: the HiFi statistics block as JSON (docs/faq/sqiie.md:45); written only when named
+    std::string log_file;         // --log-file: log lines go there instead of stderr (docs/faq/sqiie.md:40)
+    double refresh_rate = 5.0;    // --refresh-rate: seconds between progress lines at --log-level INFO (docs/faq/reports-aux-files.md:176-177)
     int log_level = 1;
 };
 
@@ -152,8 +157,8 @@ void usage()
                  "usage: ccs [options] IN.subreads.bam OUT.{bam,fastq.gz}\n"
                  "  -j, --num-threads N       host threads for BAM (de)compression [all usable: affinity / cgroup quota]\n"
                  "      --min-passes N        minimum full-length passes [3]\n"
-                 "      --top-passes N        use at most the N passes closest to the median length [60]; the engine holds 64 passes\n"
-                 "                            per ZMW, so 0 (unlimited in the reference) and values above 64 mean 64 here\n"
+                 "      --top-passes N        use at most the N passes closest to the median length [60]; 0 = unlimited (the engine takes up\n"
+                 "                            to 255 passes per ZMW)\n"
                  "      --model-file F        Arrow model parameters (json); default: chosen by the chemistry in the BAM header from\n"
                  "                            $SMRT_CHEMISTRY_BUNDLE_DIR/arrow/*.json, then the built-in set\n"
                  "      --disable-heuristics  polish every position (no candidate filter)\n"
@@ -168,7 +173,7 @@ void usage()
                  "      --qv-binning          write 7-bin per-base QVs (Q3 Q10 Q17 Q22 Q27 Q35 Q40)\n"
                  "      --hifi-kinetics       averaged per-strand kinetics: tags fi fp fn ri rp rn (ip pw with --by-strand)\n"
                  "      --metrics-json F      per-ZMW metrics [<OUT prefix>.zmw_metrics.json.gz]\n"
-                 "      --suppress-reports    do not write ccs_report.txt / zmw_metrics.json.gz\n"
+                 "      --suppress-reports    do not write the default ccs_report.txt / zmw_metrics.json.gz (files named explicitly are still written)\n"
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
                  "      --batch-size N        ZMWs per GPU batch, at most [2048]\n"
                  "      --batch-bases N       ... and at most N subread bases (estimated cost, SURVEY.md 8e: batches of about constant cost for mixed\n"
@@ -176,7 +181,11 @@ void usage()
                  "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"
                  "      --workers-per-gpu N   packing threads per device [3] (one engine handle per device, three batches in flight)\n"
                  "      --report-file F       ccs_report.txt path [<OUT prefix>.ccs_report.txt]\n"
+                 "      --report-json F       the same counts as JSON (only when named)\n"
+                 "      --hifi-summary-json F HiFi yield / length / quality statistics as JSON (only when named)\n"
                  "      --log-level L         ERROR|WARN|INFO [WARN]\n"
+                 "      --log-file F          write log lines to F instead of stderr\n"
+                 "      --refresh-rate S      seconds between progress lines at --log-level INFO [5]\n"
                  "  test helpers (not in the reference):\n"
                  "      --write-synthetic N,P,L[,seed]  write a synthetic subreads.bam to OUT (no IN)\n"
                  "      --dump-zmws                     list ZMWs after the step-1 filters (no GPU, no OUT)\n"
@@ -203,7 +212,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--max-insertion-size") { const int v = std::atoi(need(a.c_str()).c_str()); o.o.max_insertion_size = v > 0 ? v : -1; }
         else if (a == "--batch-size") o.batch = std::atoi(need(a.c_str()).c_str());
         else if (a == "--batch-bases") o.batch_bases = std::atoll(need(a.c_str()).c_str());
-        else if (a == "--report-file") o.report = need(a.c_str());
+        else if (a == "--report-file") { o.report = need(a.c_str()); o.report_named = true; }
         else if (a == "--workers-per-gpu") o.workers_per_gpu = std::max(1, std::atoi(need(a.c_str()).c_str()));
         else if (a == "--chunk") { if (std::sscanf(need(a.c_str()).c_str(), "%d/%d", &o.chunk_i, &o.chunk_n) != 2 || o.chunk_i < 1 || o.chunk_i > o.chunk_n) { std::fprintf(stderr, "bad --chunk\n"); return false; } }
         else if (a == "--gpus") { std::string v = need(a.c_str()); if (v == "all") o.all_gpus = true; else { size_t p = 0; while (p < v.size()) { o.gpus.push_back(std::atoi(v.c_str() + p)); p = v.find(',', p); if (p == std::string::npos) break; ++p; } } }
@@ -218,7 +227,16 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--suppress-reports") o.suppress_reports = true;
         else if (a == "--model-file") o.model_file = need(a.c_str());
         else if (a == "--disable-heuristics") o.o.disable_heuristics = 1;
-        else if (a == "--metrics-json") o.metrics = need(a.c_str());
+        else if (a == "--metrics-json") { o.metrics = need(a.c_str()); o.metrics_named = true; }
+        else if (a == "--report-json") o.report_json = need(a.c_str());
+        else if (a == "--hifi-summary-json") o.hifi_summary = need(a.c_str());
+        else if (a == "--log-file") o.log_file = need(a.c_str());
+        else if (a == "--refresh-rate") { o.refresh_rate = std::atof(need(a.c_str()).c_str()); if (!(o.refresh_rate >= 0.0)) o.refresh_rate = 0.0; }
+        else if (a == "--all" || a == "--all-kinetics" || a == "--subread-fallback" || a == "--split-heteroduplexes" || a == "--hd-finder" || a == "--streamed") {
+            // modes of the reference outside this path (OUT OF SCOPE rows): refused by name rather than as a typo
+            std::fprintf(stderr, "ccs: %s is not supported by this build (the MI355X consensus path covers the default HiFi mode, --by-strand and --hifi-kinetics)\n", a.c_str());
+            std::exit(2);
+        }
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
         else pos.push_back(a);
     }
@@ -442,7 +460,8 @@ void pack(Batch &b, Arena &arena)
 struct Report {
     int64_t input = 0, pass = 0;
     std::map<std::string, int64_t> fail;
-    std::vector<int32_t> lens; std::vector<float> rqs; int64_t np_sum = 0;
+    std::vector<int32_t> lens; std::vector<float> rqs; std::vector<int32_t> nps;   // one entry per written read
+    int64_t bases_q30 = 0;        // written bases with a phred QV >= 30 ("Base quality >=Q30 (bp)", docs/faq/reports-aux-files.md:66)
 };
 
 const char *fail_label(int st)
@@ -482,37 +501,123 @@ const char *status_name(int st)
     }
 }
 
+// the rows of "Exclusive failed counts" this path can produce, in the order of docs/faq/reports-aux-files.md:24-46 (the rows of the subsystems
+// outside this path — heteroduplex, coverage drops, adapter / control classes — cannot occur and are not listed)
+const char *const kFailOrder[] = {"Below SNR threshold", "Median length filter", "Lacking full passes", "Draft generation error",
+                                  "Draft above --max-length", "Draft below --min-length", "Reads failed polishing", "Empty coverage windows",
+                                  "CCS did not converge", "CCS below minimum RQ", "Consensus outgrew its buffer", "Unknown error"};
+
+// statistics of one class of written reads (docs/faq/reports-aux-files.md:52-64: HiFi = predicted accuracy >= Q20, "<Q20", ">=Q30")
+struct ReadClass {
+    int64_t reads = 0, yield = 0, len_mean = 0, len_median = 0, n50 = 0, np_mean = 0;
+    int qual_median = 0;
+};
+
+int rq_to_q(float rq) { return rq >= 1.0f ? 60 : (int)std::floor(-10.0 * std::log10(1.0 - (double)rq) + 1e-9); }
+
+ReadClass classify(const Report &r, float rq_lo, float rq_hi)
+{
+    ReadClass c;
+    std::vector<int32_t> len; std::vector<float> rq; int64_t nps = 0;
+    for (size_t i = 0; i < r.lens.size(); ++i)
+        if (r.rqs[i] >= rq_lo && r.rqs[i] < rq_hi) { len.push_back(r.lens[i]); rq.push_back(r.rqs[i]); nps += r.nps[i]; c.yield += r.lens[i]; }
+    c.reads = (int64_t)len.size();
+    if (len.empty()) return c;
+    std::sort(len.begin(), len.end()); std::sort(rq.begin(), rq.end());
+    c.len_mean = c.yield / c.reads;
+    c.len_median = len[len.size() / 2];
+    c.qual_median = rq_to_q(rq[rq.size() / 2]);
+    c.np_mean = nps / c.reads;
+    int64_t acc = 0;                                            // N50: the length L such that reads of length >= L hold half of the yield
+    for (size_t i = len.size(); i-- > 0;) { acc += len[i]; if (2 * acc >= c.yield) { c.n50 = len[i]; break; } }
+    return c;
+}
+
+std::string with_commas(int64_t v)                              // 63881 -> "63,881", as the reference prints its yield / length rows
+{
+    std::string d = std::to_string(v < 0 ? -v : v), o;
+    for (size_t i = 0; i < d.size(); ++i) { if (i && (d.size() - i) % 3 == 0) o += ','; o += d[i]; }
+    return v < 0 ? "-" + o : o;
+}
+
 void write_report(const Options &o, const Report &r)
 {
-    FILE *f = std::fopen(o.report.c_str(), "w");
-    if (!f) return;
     const int64_t failed = r.input - r.pass;
     auto pct = [](int64_t a, int64_t b) { return b ? 100.0 * (double)a / (double)b : 0.0; };
-    std::fprintf(f, "ZMWs input                    : %" PRId64 "\n\n", r.input);
-    std::fprintf(f, "ZMWs pass filters             : %" PRId64 " (%.2f%%)\n", r.pass, pct(r.pass, r.input));
-    std::fprintf(f, "ZMWs fail filters             : %" PRId64 " (%.2f%%)\n", failed, pct(failed, r.input));
-    std::fprintf(f, "ZMWs shortcut filters         : 0 (0.00%%)\n\n");
-    std::fprintf(f, "Exclusive failed counts\n");
-    static const char *order[] = {"Below SNR threshold", "Median length filter", "Lacking full passes", "Draft generation error",
-                                  "Draft above --max-length", "Draft below --min-length", "Reads failed polishing", "Empty coverage windows",
-                                  "CCS did not converge", "CCS below minimum RQ", "Unknown error"};
-    for (const char *k : order) {
-        auto it = r.fail.find(k);
-        const int64_t c = it == r.fail.end() ? 0 : it->second;
-        std::fprintf(f, "%-30s: %" PRId64 " (%.2f%%)\n", k, c, pct(c, failed));
+    const ReadClass hifi = classify(r, 0.99f, 2.0f), lowq = classify(r, -1.0f, 0.99f), q30 = classify(r, 0.999f, 2.0f);
+    int64_t all_bases = 0;
+    for (int32_t l : r.lens) all_bases += l;
+    if (FILE *f = std::fopen(o.report.c_str(), "w")) {
+        std::fprintf(f, "ZMWs input                    : %" PRId64 "\n\n", r.input);
+        std::fprintf(f, "ZMWs pass filters             : %" PRId64 " (%.2f%%)\n", r.pass, pct(r.pass, r.input));
+        std::fprintf(f, "ZMWs fail filters             : %" PRId64 " (%.2f%%)\n", failed, pct(failed, r.input));
+        std::fprintf(f, "ZMWs shortcut filters         : 0 (0.00%%)\n\n");
+        std::fprintf(f, "Exclusive failed counts\n");
+        for (const char *k : kFailOrder) {
+            auto it = r.fail.find(k);
+            const int64_t c = it == r.fail.end() ? 0 : it->second;
+            if (c == 0 && std::string(k) == "Consensus outgrew its buffer") continue;      // (not a row of the reference: shown only when it happened)
+            std::fprintf(f, "%-30s: %" PRId64 " (%.2f%%)\n", k, c, pct(c, failed));
+        }
+        std::fprintf(f, "\n- - - - - - - - - - - - - - - : - - - - -\n\n");
+        std::fprintf(f, "HiFi Reads                    : %s\n", with_commas(hifi.reads).c_str());
+        std::fprintf(f, "HiFi Yield (bp)               : %s\n", with_commas(hifi.yield).c_str());
+        std::fprintf(f, "HiFi Read Length (mean, bp)   : %s\n", with_commas(hifi.len_mean).c_str());
+        std::fprintf(f, "HiFi Read Length (median, bp) : %s\n", with_commas(hifi.len_median).c_str());
+        std::fprintf(f, "HiFi Read Length N50 (bp)     : %s\n", with_commas(hifi.n50).c_str());
+        std::fprintf(f, "HiFi Read Quality (median)    : %d\n", hifi.qual_median);
+        std::fprintf(f, "HiFi Number of Passes (mean)  : %" PRId64 "\n", hifi.np_mean);
+        if (lowq.reads > 0) {                                    // reads below Q20 are written only under --min-rq < 0.99
+            std::fprintf(f, "\n<Q20 Reads                    : %s\n", with_commas(lowq.reads).c_str());
+            std::fprintf(f, "<Q20 Yield (bp)               : %s\n", with_commas(lowq.yield).c_str());
+            std::fprintf(f, "<Q20 Read Length (mean, bp)   : %s\n", with_commas(lowq.len_mean).c_str());
+            std::fprintf(f, "<Q20 Read Length (median, bp) : %s\n", with_commas(lowq.len_median).c_str());
+            std::fprintf(f, "<Q20 Read Quality (median)    : %d\n", lowq.qual_median);
+        }
+        std::fprintf(f, "\n>=Q30 Reads                   : %s\n", with_commas(q30.reads).c_str());
+        std::fprintf(f, ">=Q30 Yield (bp)              : %s\n", with_commas(q30.yield).c_str());
+        std::fprintf(f, ">=Q30 Read Length (mean, bp)  : %s\n", with_commas(q30.len_mean).c_str());
+        std::fprintf(f, ">=Q30 Read Length (median, bp): %s\n", with_commas(q30.len_median).c_str());
+        std::fprintf(f, ">=Q30 Read Quality (median)   : %d\n", q30.qual_median);
+        std::fprintf(f, "\nBase quality >=Q30 (bp)       : %s (%.1f%%)\n", with_commas(r.bases_q30).c_str(), pct(r.bases_q30, all_bases));
+        std::fclose(f);
     }
-    std::fprintf(f, "\n- - - - - - - - - - - - - - - : - - - - -\n\n");
-    int64_t yield = 0;
-    for (int32_t l : r.lens) yield += l;
-    std::vector<int32_t> s = r.lens; std::sort(s.begin(), s.end());
-    std::vector<float> q = r.rqs; std::sort(q.begin(), q.end());
-    auto qv = [](float rq) { return rq >= 1.0f ? 60 : (int)std::floor(-10.0 * std::log10(1.0 - (double)rq)); };
-    std::fprintf(f, "HiFi Reads                    : %zu\n", r.lens.size());
-    std::fprintf(f, "HiFi Yield (bp)               : %" PRId64 "\n", yield);
-    std::fprintf(f, "HiFi Read Length (mean, bp)   : %" PRId64 "\n", r.lens.empty() ? 0 : yield / (int64_t)r.lens.size());
-    std::fprintf(f, "HiFi Read Length (median, bp) : %d\n", s.empty() ? 0 : s[s.size() / 2]);
-    std::fprintf(f, "HiFi Read Quality (median)    : %d\n", q.empty() ? 0 : qv(q[q.size() / 2]));
-    std::fprintf(f, "HiFi Number of Passes (mean)  : %" PRId64 "\n", r.lens.empty() ? 0 : r.np_sum / (int64_t)r.lens.size());
+}
+
+// --report-json (docs/changelog.md:72 "JSON output of ccs_reports"; docs/faq/sqiie.md:42): the counts of ccs_report.txt, keyed by the row labels
+void write_report_json(const Options &o, const Report &r)
+{
+    FILE *f = std::fopen(o.report_json.c_str(), "w");
+    if (!f) { std::fprintf(stderr, "ccs: cannot write %s\n", o.report_json.c_str()); return; }
+    std::fprintf(f, "{\n  \"zmws_input\": %" PRId64 ",\n  \"zmws_pass_filters\": %" PRId64 ",\n  \"zmws_fail_filters\": %" PRId64 ",\n  \"zmws_shortcut_filters\": 0,\n  \"exclusive_failed_counts\": {",
+                 r.input, r.pass, r.input - r.pass);
+    bool first = true;
+    for (const char *k : kFailOrder) {
+        auto it = r.fail.find(k);
+        std::fprintf(f, "%s\n    \"%s\": %" PRId64, first ? "" : ",", k, it == r.fail.end() ? (int64_t)0 : it->second);
+        first = false;
+    }
+    std::fprintf(f, "\n  }\n}\n");
+    std::fclose(f);
+}
+
+// --hifi-summary-json (docs/faq/sqiie.md:45 "summary JSON file for hifi statistics"): the statistics block of ccs_report.txt
+void write_hifi_summary(const Options &o, const Report &r)
+{
+    FILE *f = std::fopen(o.hifi_summary.c_str(), "w");
+    if (!f) { std::fprintf(stderr, "ccs: cannot write %s\n", o.hifi_summary.c_str()); return; }
+    int64_t all_bases = 0;
+    for (int32_t l : r.lens) all_bases += l;
+    auto cls = [&](const char *name, const ReadClass &c, bool last) {
+        std::fprintf(f, "  \"%s\": {\"reads\": %" PRId64 ", \"yield_bp\": %" PRId64 ", \"read_length_mean\": %" PRId64 ", \"read_length_median\": %" PRId64
+                        ", \"read_length_n50\": %" PRId64 ", \"read_quality_median\": %d, \"number_of_passes_mean\": %" PRId64 "}%s\n",
+                     name, c.reads, c.yield, c.len_mean, c.len_median, c.n50, c.qual_median, c.np_mean, last ? "" : ",");
+    };
+    std::fprintf(f, "{\n");
+    cls("hifi", classify(r, 0.99f, 2.0f), false);
+    cls("below_q20", classify(r, -1.0f, 0.99f), false);
+    cls("q30_and_above", classify(r, 0.999f, 2.0f), false);
+    std::fprintf(f, "  \"bases\": %" PRId64 ",\n  \"bases_q30_and_above\": %" PRId64 "\n}\n", all_bases, r.bases_q30);
     std::fclose(f);
 }
 
@@ -522,6 +627,10 @@ int main(int argc, char **argv)
 {
     Options opt;
     if (!parse(argc, argv, opt)) { usage(); return 2; }
+    if (!opt.log_file.empty() && !std::freopen(opt.log_file.c_str(), "w", stderr)) {      // --log-file (docs/faq/sqiie.md:40): every log line goes there
+        std::printf("ccs: cannot write %s\n", opt.log_file.c_str());
+        return 1;
+    }
     int nthreads = opt.threads > 0 ? opt.threads : effective_cores();
     if (nthreads < 1) nthreads = 1;
     try {
@@ -861,9 +970,11 @@ int main(int argc, char **argv)
             PbiIndex pbi; std::vector<uint64_t> marks;             // OUT.bam.pbi: one entry per HiFi record
             std::vector<uint8_t> kin_rev;
             std::shared_ptr<Batch> b;
+            double last_progress = -1e30;
             std::string metrics = "{\n  \"zmws\": [\n";
             bool first_metric = true;
-            gzFile gzm = opt.suppress_reports ? nullptr : gzopen(opt.metrics.c_str(), "wb");
+            const bool want_metrics = !opt.suppress_reports || opt.metrics_named;
+            gzFile gzm = want_metrics ? gzopen(opt.metrics.c_str(), "wb") : nullptr;
             auto flush_metrics = [&](bool force) {
                 if (gzm && (force || metrics.size() > (1u << 20))) { gzwrite(gzm, metrics.data(), (unsigned)metrics.size()); metrics.clear(); }
             };
@@ -883,7 +994,7 @@ int main(int argc, char **argv)
                     int st = z.host_status;
                     const int s = bt.slot[i];
                     if (st == HS_OK) st = bt.have_results ? bt.status[s] : -1;      // -1: EXCEPTION_THROWN / "Unknown error" (engine failure)
-                    if (!opt.suppress_reports) {
+                    if (want_metrics) {
                         const bool have = (s >= 0 && bt.have_results);
                         const int32_t isz = (have && bt.seq_len[s] > 0) ? bt.seq_len[s] : z.median_len;
                         char line[512];
@@ -899,6 +1010,7 @@ int main(int argc, char **argv)
                     ++rep.pass;
                     const int64_t o = bt.seq_off[s]; const int32_t len = bt.seq_len[s];
                     if (opt.qv_binning) for (int32_t q = 0; q < len; ++q) { uint8_t &v = bt.qual[o + q]; v = qvbin[v > 93 ? 93 : v]; }   // after rq (qv-binning.md:19-21)
+                    for (int32_t q = 0; q < len; ++q) rep.bases_q30 += bt.qual[o + q] >= 30 ? 1 : 0;
                     const std::string qname = movie + "/" + std::to_string(z.zm) + "/ccs" + (z.strand_tag == 1 ? "/fwd" : (z.strand_tag == 2 ? "/rev" : ""));
                     if (fastq) {
                         fq.clear(); fq += '@'; fq += qname; fq += '\n';
@@ -907,7 +1019,7 @@ int main(int argc, char **argv)
                         for (int32_t q = 0; q < len; ++q) fq += (char)(33 + (bt.qual[o + q] > 93 ? 93 : bt.qual[o + q]));
                         fq += '\n';
                         if (gzwrite(gzq, fq.data(), (unsigned)fq.size()) != (int)fq.size()) throw std::runtime_error("short write (fastq.gz)");
-                        rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.np_sum += bt.np[s];
+                        rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.nps.push_back(bt.np[s]);
                         continue;
                     }
                     rb.begin(qname, bt.seq + o, bt.qual + o, (uint32_t)len);
@@ -935,7 +1047,7 @@ int main(int argc, char **argv)
                     pbi.rg_id.push_back(0); pbi.q_start.push_back(0); pbi.q_end.push_back(len); pbi.hole.push_back(z.zm);
                     pbi.read_qual.push_back(bt.rq[s]); pbi.ctxt.push_back(0);
                     rb.finish(*outp);
-                    rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.np_sum += bt.np[s];
+                    rep.lens.push_back(len); rep.rqs.push_back(bt.rq[s]); rep.nps.push_back(bt.np[s]);
                 }
             };
             while (to_writer.pop(b)) {
@@ -945,8 +1057,9 @@ int main(int argc, char **argv)
                     out_pool.put(std::move(hold.begin()->second->out_arena));
                     hold.erase(hold.begin()); ++next;
                 }
-                if (opt.log_level >= 2) {
-                    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                if (opt.log_level >= 2 && el - last_progress >= opt.refresh_rate) {     // --refresh-rate (docs/faq/reports-aux-files.md:176-177)
+                    last_progress = el;
                     if (total_zmws > 0 && rep.input > 0)               // with an index the number of ZMWs ahead is known: ETA (reports-aux-files.md:183-192)
                         std::fprintf(stderr, "%" PRId64 "/%.1f %" PRId64 "/%.1f ETA %.0f s\n", rep.input, rep.input / el * 60, rep.pass, rep.pass / el * 60,
                                      el * (double)(total_zmws - rep.input) / (double)rep.input);
@@ -976,7 +1089,9 @@ int main(int argc, char **argv)
         to_writer.close();
         writer.join();
         for (ccsx_handle h : handles) ccsx_destroy(h);
-        if (!opt.suppress_reports) write_report(opt, rep);
+        if (!opt.suppress_reports || opt.report_named) write_report(opt, rep);
+        if (!opt.report_json.empty()) write_report_json(opt, rep);            // named files are written even under --suppress-reports (docs/faq/sqiie.md:36-46
+        if (!opt.hifi_summary.empty()) write_hifi_summary(opt, rep);          //  combines --suppress-reports with explicit report names)
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         if (opt.log_level >= 2)
             std::fprintf(stderr, "ccs: reader thread: framing/inflate %.2f s, waiting for record decode %.2f s, grouping+filters+queue %.2f s\n",

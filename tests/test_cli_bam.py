@@ -145,6 +145,70 @@ def test_cli_reports_and_qv_binning(built, tmp_path):
         assert m["polymerase_length"] > 8 * 500 and abs(m["effective_coverage"] - r["tags"]["ec"]) < 0.01
 
 
+def test_cli_names_the_modes_it_does_not_cover(built, tmp_path):
+    """--all / --all-kinetics / --subread-fallback / heteroduplex modes (out of scope for this path) are refused by name
+    before any input is opened; an unknown option is a usage error."""
+    for opt in ("--all", "--all-kinetics", "--subread-fallback", "--split-heteroduplexes", "--hd-finder", "--streamed"):
+        q = _run(opt, tmp_path / "missing.bam", tmp_path / "o.bam", check=False)
+        assert q.returncode == 2 and f"{opt} is not supported" in q.stderr, opt
+    q = _run("--no-such-option", tmp_path / "missing.bam", tmp_path / "o.bam", check=False)
+    assert q.returncode == 2 and "unknown option" in q.stderr
+
+
+@pytest.mark.gpu
+def test_cli_report_files_and_log(built, tmp_path):
+    """The instrument-style invocation of docs/faq/sqiie.md:34-46: --suppress-reports with explicitly NAMED report files (those are still
+    written), --report-json, --hifi-summary-json, --log-file; the statistics block of ccs_report.txt (docs/faq/reports-aux-files.md:52-66:
+    HiFi = rq >= Q20, the "<Q20" and ">=Q30" classes, N50, bases >= Q30) recomputed from the written records."""
+    import json
+    bam, out = tmp_path / "s.subreads.bam", tmp_path / "o.hifi.bam"
+    _run("--write-synthetic", "24,4-9,400-900,31", bam)
+    rep, rj, hs, lg, mj = (tmp_path / n for n in ("named_report.txt", "rep.json", "hifi.json", "run.log", "named_metrics.json.gz"))
+    p = _run(bam, out, "--min-rq", "0.9", "--suppress-reports", "--report-file", rep, "--report-json", rj, "--hifi-summary-json", hs,
+             "--log-file", lg, "--metrics-json", mj, "--log-level", "INFO", "--refresh-rate", "0", "--batch-size", 8)
+    assert p.stderr == "" and "ZMWs in," in open(lg).read() and "consensus model" in open(lg).read()
+    assert rep.exists() and mj.exists() and not (tmp_path / "o.hifi.ccs_report.txt").exists() and not (tmp_path / "o.hifi.zmw_metrics.json.gz").exists()
+    _, recs = bam_util.read_bam(out)
+    assert len(recs) > 4
+    rq = np.array([r["tags"]["rq"] for r in recs], np.float32); ln = np.array([len(r["seq"]) for r in recs])
+    npass = np.array([r["tags"]["np"] for r in recs])
+    q30b = sum(int((r["qual"] >= 30).sum()) for r in recs)
+
+    def cls(sel):
+        l = np.sort(ln[sel])
+        if len(l) == 0:
+            return dict(reads=0, yield_bp=0, read_length_mean=0, read_length_median=0, read_length_n50=0, number_of_passes_mean=0)
+        acc, n50 = 0, 0
+        for v in l[::-1]:
+            acc += int(v)
+            if 2 * acc >= int(l.sum()):
+                n50 = int(v); break
+        return dict(reads=len(l), yield_bp=int(l.sum()), read_length_mean=int(l.sum()) // len(l), read_length_median=int(l[len(l) // 2]), read_length_n50=n50,
+                    number_of_passes_mean=int(npass[sel].sum()) // len(l))
+    h = json.load(open(hs))
+    for name, sel in (("hifi", rq >= np.float32(0.99)), ("below_q20", rq < np.float32(0.99)), ("q30_and_above", rq >= np.float32(0.999))):
+        want = cls(sel)
+        assert {k: h[name][k] for k in want} == want, name
+    assert h["bases"] == int(ln.sum()) and h["bases_q30_and_above"] == q30b
+    assert h["hifi"]["reads"] + h["below_q20"]["reads"] == len(recs)
+    j = json.load(open(rj))
+    assert j["zmws_input"] == 24 and j["zmws_pass_filters"] == len(recs) and j["zmws_fail_filters"] == 24 - len(recs)
+    assert sum(j["exclusive_failed_counts"].values()) == 24 - len(recs)
+    text = open(rep).read()
+    fmt = lambda v: f"{v:,}"
+    assert f"HiFi Reads                    : {fmt(h['hifi']['reads'])}\n" in text and f"HiFi Yield (bp)               : {fmt(h['hifi']['yield_bp'])}\n" in text
+    assert f"HiFi Read Length N50 (bp)     : {fmt(h['hifi']['read_length_n50'])}\n" in text
+    assert f">=Q30 Reads                   : {fmt(h['q30_and_above']['reads'])}\n" in text
+    assert ("<Q20 Reads" in text) == (h["below_q20"]["reads"] > 0)
+    assert f"Base quality >=Q30 (bp)       : {fmt(q30b)} (" in text
+    for k, v in j["exclusive_failed_counts"].items():
+        if k != "Consensus outgrew its buffer":
+            assert f"{k:<30s}: {v} (" in text
+    # a mode of the reference outside this path is refused by name, not as a typo
+    q = _run(bam, out, "--all", check=False)
+    assert q.returncode == 2 and "--all is not supported" in q.stderr
+
+
 @pytest.mark.gpu
 def test_cli_hifi_kinetics(built, tmp_path):
     """--hifi-kinetics: fi fp fn ri rp rn on double-strand records, ip pw on --by-strand records
