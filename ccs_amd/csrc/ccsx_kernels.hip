@@ -28,6 +28,12 @@
 #include "ccsx_kernels.h"
 #include "wave_ops.h"
 
+// gfx950 counts global STORES in vmcnt like loads, and the counter retires in order: a wait for one load drains every store issued before it.  The compiler
+// waits for a load at its first use; when a RARE branch loads a value that is used after the join, that wait sits on the common path and every
+// iteration stalls until the stores of the previous iteration have been acknowledged (k_poa_dp: two such waits per column).  LANDED(x) makes x
+// "used" right where it is written, so the wait stays inside the rare branch and the common path keeps its stores in flight.
+#define LANDED(x) asm volatile("" : "+v"(x))
+
 #define LANES 64
 #define PW_MAXREADS_SPEC CCSX_MAX_PASSES      // passes of a ZMW the engine uses (k_polish / k_kinetics take them in groups of PW_MAXREADS)
 #ifdef CCSX_PROFILE_PHASES
@@ -615,8 +621,10 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
     int4 *kip = kinfo;
     int32_t *lop = G.loK;
     int32_t *Mp = Mcol + 2 * l;
-    int4 recN = make_int4(0, -1, -1, -1);               // the NEXT block of 16 column records (lane l: column kb + 16 + l)
-    if (l < n0) { recN = crec[l]; if (needK[l]) recN.x |= CREC_NEED; }
+    int4 recN = make_int4(0, -1, -1, -1);               // the NEXT block of 16 column records (lane l: column kb + 16 + l) and its
+    int needN = 0;                                      // "a far in-edge reads this column" byte: merged at the hand-off, 16 columns after the loads were issued
+    recN = crec[l < n0 ? l : 0];                        // (unconditional, clamped, masked at the hand-off: a load under a lane mask is copied into the
+    needN = needK[l < n0 ? l : 0];                      //  loop-carried register at once, i.e. waited for)
 #define LDS_I32(addr) (*(lds_i32)(uintptr_t)(addr))
     // wave masks of per-lane conditions straight from the compare (a bool that goes through ballot costs two extra VALU ops)
 #define M_NE0(a) __builtin_amdgcn_uicmp((unsigned)(a), 0u, 33)
@@ -627,9 +635,8 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
     const unsigned long long livem = M_NE0(live ? 1 : 0);
     for (int k = 0; k < nmax; ++k, mvp += POA_MV_BYTES, ++kip, ++lop, Mp += PB) {
         if ((k & 15) == 0) {                            // hand the prefetched block to LDS, start fetching the one after it
-            sCrec[gq][l] = recN;
-            recN = make_int4(0, -1, -1, -1);
-            if (k + 16 + l < n0) { recN = crec[k + 16 + l]; if (needK[k + 16 + l]) recN.x |= CREC_NEED; }
+            { int4 r = recN; if (needN) r.x |= CREC_NEED; sCrec[gq][l] = (k + l < n0) ? r : make_int4(0, -1, -1, -1); }
+            { const int kn = k + 16 + l < n0 ? k + 16 + l : 0; recN = crec[kn]; needN = needK[kn]; }
             __syncthreads();
         }
         const unsigned long long actm = livem & M_SLT(k, n0);
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
         const uint32_t slot0 = p0 < 0 ? PRING : (uint32_t)(p0 & (PRING - 1));
         int k0x, k0y, k0z;
         { const uint32_t ka = kinBase + slot0 * 16; k0x = LDS_I32(ka); k0y = LDS_I32(ka + 4); k0z = LDS_I32(ka + 8); }
-        if (far0m) { if (rec.x & CREC_FAR0) { const int4 t = kinfo[p0]; k0x = t.x; k0y = t.y; k0z = t.z; } }
+        if (far0m) { if (rec.x & CREC_FAR0) { const int4 t = kinfo[p0]; k0x = t.x; k0y = t.y; k0z = t.z; } LANDED(k0x); LANDED(k0y); LANDED(k0z); }
         int ulo = k0x, ubr = k0z;
         int plo1 = 0, plo2 = 0;
         if (multim) {
@@ -652,15 +659,18 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
             for (int q = 1; q < CCSX_MAXPRED; ++q) {
                 if ((actm & M_SGT(np, q)) == 0ull) break;
                 int pq = q == 1 ? rec.z : rec.w;
-                if (q >= 3 && act && np > q) {          // in-edges 3..7 (rare): through the vertex id
-                    const int32_t *order = st[ST_PAR] ? G.order1 : G.order0;
-                    pq = G.rank[G.predx[order[k] * 5 + (q - 3)]];
+                if (q >= 3) {                           // in-edges 3..7 (rare): through the vertex id
+                    if (act && np > q) {
+                        const int32_t *order = st[ST_PAR] ? G.order1 : G.order0;
+                        pq = G.rank[G.predx[order[k] * 5 + (q - 3)]];
+                    }
+                    LANDED(pq);
                 }
                 const bool on = act && np > q;
                 const bool farq = on && k - pq > PRING;
                 const uint32_t ka = kinBase + (on ? (uint32_t)(pq & (PRING - 1)) : (uint32_t)PRING) * 16;
                 int qx = LDS_I32(ka), qy = LDS_I32(ka + 4), qz = LDS_I32(ka + 8);
-                if (M_NE0(farq ? 1 : 0)) { if (farq) { const int4 t = kinfo[pq]; qx = t.x; qy = t.y; qz = t.z; } }
+                if (M_NE0(farq ? 1 : 0)) { if (farq) { const int4 t = kinfo[pq]; qx = t.x; qy = t.y; qz = t.z; } LANDED(qx); LANDED(qy); LANDED(qz); }
                 if (q == 1) plo1 = qx; else if (q == 2) plo2 = qx;
                 if (on && qy > bestcm) { bestcm = qy; ulo = qx; ubr = qz; }
             }
@@ -701,6 +711,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                     y0 = (unsigned)(o + 1) < (unsigned)PB ? Mu[o + 1] : NEGV;
                     y1 = (unsigned)(o + 2) < (unsigned)PB ? Mu[o + 2] : NEGV;
                 }
+                LANDED(x0); LANDED(y0); LANDED(y1);
             }
             const int d0 = x0 + s0, e0 = y0 + SC_DEL, d1 = y0 + s1, e1 = y1 + SC_DEL;
             const bool t0 = e0 > d0, t1 = e1 > d1;              // move codes (a nibble): in-edge slot * 2 + [deletion], 15 = insertion
@@ -714,10 +725,13 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                 if ((actm & M_SGT(np, q)) == 0ull) break;
                 const bool on = act && np > q;
                 int pq = q == 1 ? rec.z : rec.w, plo = q == 1 ? plo1 : plo2;
-                if (q >= 3 && on) {
-                    const int32_t *order = st[ST_PAR] ? G.order1 : G.order0;
-                    pq = G.rank[G.predx[order[k] * 5 + (q - 3)]];
-                    if (k - pq > PRING) plo = kinfo[pq].x; else plo = LDS_I32(kinBase + (uint32_t)(pq & (PRING - 1)) * 16);
+                if (q >= 3) {
+                    if (on) {
+                        const int32_t *order = st[ST_PAR] ? G.order1 : G.order0;
+                        pq = G.rank[G.predx[order[k] * 5 + (q - 3)]];
+                        if (k - pq > PRING) plo = kinfo[pq].x; else plo = LDS_I32(kinBase + (uint32_t)(pq & (PRING - 1)) * 16);
+                    }
+                    LANDED(pq); LANDED(plo);
                 }
                 const bool farq = on && k - pq > PRING;
                 const int off = r0w - plo;
@@ -732,6 +746,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                         y0 = (unsigned)(o + 1) < (unsigned)PB ? Mu[o + 1] : NEGV;
                         y1 = (unsigned)(o + 2) < (unsigned)PB ? Mu[o + 2] : NEGV;
                     }
+                    LANDED(x0); LANDED(y0); LANDED(y1);
                 }
                 const int mq = q << 1;
                 int c;
