@@ -228,19 +228,46 @@ __global__ void k_setup(KParams P)
 // packed 2-bit oriented read in LDS (one wave owns it)
 // mode bit 0: walk the bytes backwards, bit 1: complement.  0 = as stored, 3 = reverse complement (rev), 1 / 2 = those two read
 // from their last base to their first (the reversed half of the split alignment)
+// 16 consecutive bases of a read as one packed word.  A load under `if (i < L)` is waited for on the spot, so the plain form (still used for the words
+// at the two ends of a read) costs sixteen DEPENDENT memory round trips per word (~ 1.5 us each under load: 0.2 ms per 2048-base chunk of k_poa_dp, with
+// the other three graphs of the wave waiting at the barrier).  A word that lies inside the read issues its sixteen byte loads off ONE address
+// (immediate offsets) before the first is used: one round trip.
+// (NB = byte loads in flight at a time: 16, or 8 where the caller's loop is short of registers)
+template <int NB>
+__device__ __forceinline__ uint32_t pack16_bases(const uint8_t *bases, int L, int i0, bool backwards, bool complement)
+{
+    uint32_t v = 0;
+    if (NB > 0 && i0 >= 0 && i0 + 15 < L) {
+#pragma unroll
+        for (int h = 0; h < 16; h += (NB > 0 ? NB : 16)) {
+            uint32_t b[NB > 0 ? NB : 1];
+            if (backwards) {
+                const uint8_t *p = bases + (L - 1 - i0 - h);
+#pragma unroll
+                for (int k = 0; k < NB; ++k) b[k] = (uint32_t)p[-k];
+            } else {
+                const uint8_t *p = bases + i0 + h;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) b[k] = (uint32_t)p[k];
+            }
+            if (NB < 16) asm volatile("" : "+v"(b[NB - 1]));    // (keeps the second batch from being hoisted above the first batch's use)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) v |= (b[k] & 3u) << (2 * (h + k));
+        }
+        if (complement) v = ~v;                                 // 3 - b on every 2-bit field
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = i0 + k;
+            if (i >= 0 && i < L) { uint32_t b = (uint32_t)bases[backwards ? L - 1 - i : i]; if (complement) b = 3u - b; v |= (b & 3u) << (2 * k); }
+        }
+    }
+    return v;
+}
 __device__ __forceinline__ void load_read_packed_mode(uint32_t *sread, const uint8_t *bases, int L, int mode, int lane)
 {
     int nw = (L + 15) >> 4;
-    for (int w = lane; w < nw; w += LANES) {
-        uint32_t v = 0;
-        int i0 = w << 4;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            int i = i0 + k;
-            if (i < L) { uint32_t b = (uint32_t)bases[(mode & 1) ? L - 1 - i : i]; if (mode & 2) b = 3u - b; v |= (b & 3u) << (2 * k); }
-        }
-        sread[w] = v;
-    }
+    for (int w = lane; w < nw; w += LANES) sread[w] = pack16_bases<16>(bases, L, w << 4, (mode & 1) != 0, (mode & 2) != 0);
 }
 __device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t *bases, int L, int rev, int lane)
 {
@@ -251,16 +278,7 @@ __device__ __forceinline__ void load_read_packed(uint32_t *sread, const uint8_t 
 #define CH16 2048
 __device__ __forceinline__ void load_read_chunk(uint32_t *sread, const uint8_t *bases, int L, int rev, int c0, int lane)
 {
-    for (int w = lane; w <= CH16 / 16; w += LANES) {
-        uint32_t v = 0;
-        const int i0 = c0 + (w << 4);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = i0 + k;
-            if (i < L) { uint32_t b = (uint32_t)bases[rev ? L - 1 - i : i]; if (rev) b = 3u - b; v |= (b & 3u) << (2 * k); }
-        }
-        sread[w] = v;
-    }
+    for (int w = lane; w <= CH16 / 16; w += LANES) sread[w] = pack16_bases<0>(bases, L, c0 + (w << 4), rev != 0, rev != 0);   // (plain form: k_align16 needs <= 64 VGPRs for its 8 waves per SIMD, which cover the latency)
 }
 __device__ __forceinline__ int read_base_packed(const uint32_t *sread, int i) { return (int)((sread[i >> 4] >> (2 * (i & 15))) & 3u); }
 // the band's next read base, wave-uniform index: 64 packed words (1024 bases) of the read sit in one VGPR, lane = word, loaded
@@ -554,16 +572,7 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
 // c0 - 1 + 16 w .. (index -1 = a dummy), so that the base of row i - 1 for row i = c0 + x sits at packed position x
 __device__ __forceinline__ void load_read_chunk_m1(uint32_t *sread, const uint8_t *bases, int L, int rev, int c0, int l16)
 {
-    for (int w = l16; w <= CH16 / 16 + 1; w += 16) {
-        uint32_t v = 0;
-        const int i0 = c0 - 1 + (w << 4);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = i0 + k;
-            if (i >= 0 && i < L) { uint32_t b = (uint32_t)bases[rev ? L - 1 - i : i]; if (rev) b = 3u - b; v |= (b & 3u) << (2 * k); }
-        }
-        sread[w] = v;
-    }
+    for (int w = l16; w <= CH16 / 16 + 1; w += 16) sread[w] = pack16_bases<8>(bases, L, c0 - 1 + (w << 4), rev != 0, rev != 0);
 }
 
 // ---- k_poa_dp: the banded DP of pass rr over FOUR graphs per wave (see the header of this section)
