@@ -872,7 +872,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             fetch(kb - TB_BLOCK);                              // in flight while this block is walked
             __syncthreads();
             while (k >= kb) {                                  // uniform walk: every lane follows the same (k, i)
-                const int kl = k - kb;
+                int kl = k - kb;
+                int mknown;                                    // the move of the cell the walk stands on after the run, if a lane has read it already (255: no)
                 {
                     // a run of plain DIAG steps along the chain (in-edge 0 is the previous position): lane s tests
                     // step s of the run, one ballot gives its length, the path entries are stored by the lanes
@@ -891,13 +892,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                             g.pathv[ir] = ((meta_s & 3) == read_base_packed(sread, ir)) ? v_s : -1;
                         }
                         k -= R; i -= R;
-                        continue;
+                        if (R >= 64 || k < kb) continue;
+                        kl = k - kb;
                     }
+                    // the cell that ended the run (or the very first one, R = 0) is lane R's cell: its move is in that lane's register already, so the step
+                    // below needs neither another detection pass (two ds_bpermute + a byte read + a ballot per run before) nor a second LDS read
+                    mknown = rl(m_s, R);
                 }
                 const int lo_k = rl(kiL.x, kl);
                 CHK(i - lo_k >= 0 && i - lo_k < PB && i >= 0, 101);
                 const int mo = i - lo_k;
-                const int m = rfl((sMv[kl * POA_MV_BYTES + (mo >> 1)] >> ((mo & 1) << 2)) & 15);
+                const int m = mknown != 255 ? mknown : rfl((sMv[kl * POA_MV_BYTES + (mo >> 1)] >> ((mo & 1) << 2)) & 15);
                 const int t = m == 15 ? MV_INS : (m & 1), slot = m >> 1;   // (MV_DIAG = 0, MV_DEL = 1)
                 CHK(i >= 1 || t == MV_DEL, 102);
                 if (t == MV_INS) { if (lane == 0) g.pathv[i - 1] = -1; --i; continue; }
