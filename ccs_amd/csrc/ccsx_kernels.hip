@@ -930,13 +930,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // ---- thread the read into the graph (wave-parallel; identical result to the serial list insertion)
     int32_t *cnt = g.bestK;
     int carry = 0;
-    for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 1: vertex ids of the path
-        const int i = c0 + lane;
-        const int pv = i < I ? g.pathv[i] : 0;
-        const int isnew = (i < I && pv < 0) ? 1 : 0;
-        const int incl = wave_scan_add_i32(isnew);
-        if (i < I) g.pathv[i] = isnew ? n0 + carry + incl - 1 : pv;
-        carry += rl(incl, 63);
+    // (second session of round 4: the passes below take TWO / FOUR blocks of 64 path elements per iteration and issue the loads of one dependence level for all
+    // of them before the first is used — one wave per graph, so a pass costs its dependent memory round trips: ~ 1660 per threaded pass before, ~ 700 now)
+    for (int c0 = 0; c0 < I; c0 += 4 * LANES) {                    // pass 1: vertex ids of the path
+        int pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = c0 + u * LANES + lane; pv[u] = g.pathv[i < I ? i : I - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = c0 + u * LANES + lane;
+            const int isnew = (i < I && pv[u] < 0) ? 1 : 0;
+            const int incl = wave_scan_add_i32(isnew);
+            if (i < I && isnew) g.pathv[i] = n0 + carry + incl - 1;        // (an existing vertex keeps its entry)
+            carry += rl(incl, 63);
+        }
     }
     const int nnew = carry;
     if (n0 + nnew > vcap) { if (lane == 0) g.st[ST_OK] = 0; return; }
@@ -944,63 +951,115 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     __threadfence_block();
     TPH(10);
     int lastEx = -1;
-    for (int c0 = 0; c0 < I; c0 += LANES) {                        // pass 2: records, edges, run counts
-        const int i = c0 + lane;
-        const bool valid = i < I;
-        const int w = valid ? g.pathv[i] : 0;
-        const int pw = (valid && i > 0) ? g.pathv[i - 1] : -1;
-        const bool isnew = valid && w >= n0;
-        const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
-        int ex = wave_shr1_i32(incl, -1);
-        ex = ex > lastEx ? ex : lastEx;                            // last existing path element before i
-        if (valid) {
-            int4 rec;
-            bool dirty = isnew;
-            if (!isnew) { rec = g.vrec[w]; g.nrV[w] += 1; }        // (a vertex is on the path once: one writer)
-            else {
-                g.nrV[w] = 1;
-                rec = make_int4(read_base_packed(sread, i), -1, -1, -1);
-                // the last vertex of a run of new vertices records the run length at its anchor (plain store, one writer)
-                const bool lastOfRun = (i + 1 >= I) || (g.pathv[i + 1] < n0);
-                if (lastOfRun) {
-                    const int apos = ex >= 0 ? g.rank[g.pathv[ex]] : -1;
-                    CHK(apos >= -1 && apos < n0, 106);
-                    cnt[apos + 1] = i - ex;
-                }
-            }
-            if (pw >= 0) dirty |= poa_add_edge(g, rec, w, pw);
-            if (dirty) g.vrec[w] = rec;                          // most path vertices match and keep their record
+    for (int c0 = 0; c0 < I; c0 += 2 * LANES) {                    // pass 2: records, edges, run counts
+        int w[2], pw[2], wn[2], ex[2], apos[2];
+        bool valid[2], isnew[2], lastOfRun[2];
+        // level 1: the path entries of the element, its predecessor and its successor
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = c0 + u * LANES + lane;
+            valid[u] = i < I;
+            const int ic = valid[u] ? i : I - 1;
+            w[u] = g.pathv[ic];
+            pw[u] = g.pathv[ic > 0 ? ic - 1 : 0];
+            wn[u] = g.pathv[ic + 1 < I ? ic + 1 : ic];
         }
-        const int li = rl(incl, 63);
-        lastEx = li > lastEx ? li : lastEx;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = c0 + u * LANES + lane;
+            if (!valid[u]) w[u] = 0;
+            if (!(valid[u] && i > 0)) pw[u] = -1;
+            isnew[u] = valid[u] && w[u] >= n0;
+            const int incl = wave_scan_max_i32((valid[u] && !isnew[u]) ? i : -1);
+            int e = wave_shr1_i32(incl, -1);
+            e = e > lastEx ? e : lastEx;                           // last existing path element before i
+            ex[u] = e;
+            const int li = rl(incl, 63);
+            lastEx = li > lastEx ? li : lastEx;
+            // the last vertex of a run of new vertices records the run length at its anchor (plain store, one writer)
+            lastOfRun[u] = isnew[u] && ((i + 1 >= I) || (wn[u] < n0));
+        }
+        // level 2: the vertex records (existing vertices), the anchors' vertex ids (ends of runs of new vertices)
+        int4 rec[2]; int nr[2], av[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int wc = (valid[u] && !isnew[u]) ? w[u] : 0;
+            rec[u] = g.vrec[wc]; nr[u] = (int)g.nrV[wc];
+            av[u] = g.pathv[(lastOfRun[u] && ex[u] >= 0) ? ex[u] : 0];
+        }
+        // level 3: the anchors' positions
+#pragma unroll
+        for (int u = 0; u < 2; ++u) apos[u] = g.rank[(lastOfRun[u] && ex[u] >= 0) ? av[u] : 0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = c0 + u * LANES + lane;
+            if (valid[u]) {
+                bool dirty = isnew[u];
+                if (!isnew[u]) g.nrV[w[u]] = nr[u] + 1;            // (a vertex is on the path once: one writer)
+                else {
+                    g.nrV[w[u]] = 1;
+                    rec[u] = make_int4(read_base_packed(sread, i), -1, -1, -1);
+                    if (lastOfRun[u]) {
+                        const int ap = ex[u] >= 0 ? apos[u] : -1;
+                        CHK(ap >= -1 && ap < n0, 106);
+                        cnt[ap + 1] = i - ex[u];
+                    }
+                }
+                if (pw[u] >= 0) dirty |= poa_add_edge(g, rec[u], w[u], pw[u]);
+                if (dirty) g.vrec[w[u]] = rec[u];                // most path vertices match and keep their record
+            }
+        }
     }
     __threadfence_block();
     TPH(11);
     carry = 0;
-    for (int c0 = 0; c0 <= n0; c0 += LANES) {                      // inclusive prefix sum of run counts
-        const int q = c0 + lane;
-        const int incl = wave_scan_add_i32(q <= n0 ? cnt[q] : 0);
-        if (q <= n0) cnt[q] = carry + incl;
-        carry += rl(incl, 63);
+    for (int c0 = 0; c0 <= n0; c0 += 4 * LANES) {                  // inclusive prefix sum of run counts
+        int cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = c0 + u * LANES + lane; cv[u] = cnt[q <= n0 ? q : n0]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = c0 + u * LANES + lane;
+            const int incl = wave_scan_add_i32(q <= n0 ? cv[u] : 0);
+            if (q <= n0) cnt[q] = carry + incl;
+            carry += rl(incl, 63);
+        }
     }
     __threadfence_block();
     lastEx = -1;
-    for (int c0 = 0; c0 < I; c0 += LANES) {                        // new vertices: position right after their anchor
-        const int i = c0 + lane;
-        const bool valid = i < I;
-        const int w = valid ? g.pathv[i] : 0;
-        const bool isnew = valid && w >= n0;
-        const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
-        int ex = wave_shr1_i32(incl, -1);
-        ex = ex > lastEx ? ex : lastEx;
-        if (isnew) {
-            int pos = i - ex - 1;
-            if (ex >= 0) { const int apos = g.rank[g.pathv[ex]]; pos += apos + cnt[apos] + 1; }
-            CHK(pos >= 0 && pos < n0 + nnew && w < vcap, 104);
-            order_nx[pos] = w; g.rank[w] = pos;
+    for (int c0 = 0; c0 < I; c0 += 2 * LANES) {                    // new vertices: position right after their anchor
+        int w[2], ex[2], av[2], ap[2], ca[2];
+        bool isnew[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = c0 + u * LANES + lane; w[u] = g.pathv[i < I ? i : I - 1]; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = c0 + u * LANES + lane;
+            const bool valid = i < I;
+            isnew[u] = valid && w[u] >= n0;
+            const int incl = wave_scan_max_i32((valid && !isnew[u]) ? i : -1);
+            int e = wave_shr1_i32(incl, -1);
+            e = e > lastEx ? e : lastEx;
+            ex[u] = e;
+            const int li = rl(incl, 63);
+            lastEx = li > lastEx ? li : lastEx;
         }
-        const int li = rl(incl, 63);
-        lastEx = li > lastEx ? li : lastEx;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) av[u] = g.pathv[(isnew[u] && ex[u] >= 0) ? ex[u] : 0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ap[u] = g.rank[(isnew[u] && ex[u] >= 0) ? av[u] : 0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ca[u] = cnt[(isnew[u] && ex[u] >= 0) ? ap[u] : 0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = c0 + u * LANES + lane;
+            if (isnew[u]) {
+                int pos = i - ex[u] - 1;
+                if (ex[u] >= 0) pos += ap[u] + ca[u] + 1;
+                CHK(pos >= 0 && pos < n0 + nnew && w[u] < vcap, 104);
+                order_nx[pos] = w[u]; g.rank[w[u]] = pos;
+            }
+        }
     }
     __threadfence_block();
     for (int q0 = 0; q0 < n0; q0 += 4 * LANES) {                   // existing vertices shift right (four blocks of loads in flight)
