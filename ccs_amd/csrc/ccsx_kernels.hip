@@ -576,6 +576,9 @@ __device__ __forceinline__ void load_read_chunk_m1(uint32_t *sread, const uint8_
 }
 
 // ---- k_poa_dp: the banded DP of pass rr over FOUR graphs per wave (see the header of this section)
+// (branch layout: a taken branch costs the wave ~ 20 cycles of instruction fetch and this kernel runs two waves per SIMD, so the conditions of the rare blocks
+// below carry __builtin_expect(., 0) — the blocks move out of line and the common column falls through.  The "two or more in-edges" blocks (43 % of the
+// wave's columns) carry none: either hint measured slower, profiles/r04_poa_dp_vmcnt.txt)
 __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int rr)
 {
     __shared__ __attribute__((aligned(16))) int32_t sRing[4][PRING + 1][PGS];
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
     const uint32_t kinBase = (uint32_t)(uintptr_t)(lds_i32)(int32_t *)&sKin[gq][0];
     const unsigned long long livem = M_NE0(live ? 1 : 0);
     for (int k = 0; k < nmax; ++k, mvp += POA_MV_BYTES, ++kip, ++lop, Mp += PB) {
-        if ((k & 15) == 0) {                            // hand the prefetched block to LDS, start fetching the one after it
+        if (__builtin_expect((k & 15) == 0, 0)) {       // hand the prefetched block to LDS, start fetching the one after it
             { int4 r = recN; if (needN) r.x |= CREC_NEED; sCrec[gq][l] = (k + l < n0) ? r : make_int4(0, -1, -1, -1); }
             { const int kn = k + 16 + l < n0 ? k + 16 + l : 0; recN = crec[kn]; needN = needK[kn]; }
             __syncthreads();
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
         const uint32_t slot0 = p0 < 0 ? PRING : (uint32_t)(p0 & (PRING - 1));
         int k0x, k0y, k0z;
         { const uint32_t ka = kinBase + slot0 * 16; k0x = LDS_I32(ka); k0y = LDS_I32(ka + 4); k0z = LDS_I32(ka + 8); }
-        if (far0m) { if (rec.x & CREC_FAR0) { const int4 t = kinfo[p0]; k0x = t.x; k0y = t.y; k0z = t.z; } LANDED(k0x); LANDED(k0y); LANDED(k0z); }
+        if (__builtin_expect(far0m != 0ull, 0)) { if (rec.x & CREC_FAR0) { const int4 t = kinfo[p0]; k0x = t.x; k0y = t.y; k0z = t.z; } LANDED(k0x); LANDED(k0y); LANDED(k0z); }
         int ulo = k0x, ubr = k0z;
         int plo1 = 0, plo2 = 0;
         if (multim) {
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                 const bool farq = on && k - pq > PRING;
                 const uint32_t ka = kinBase + (on ? (uint32_t)(pq & (PRING - 1)) : (uint32_t)PRING) * 16;
                 int qx = LDS_I32(ka), qy = LDS_I32(ka + 4), qz = LDS_I32(ka + 8);
-                if (M_NE0(farq ? 1 : 0)) { if (farq) { const int4 t = kinfo[pq]; qx = t.x; qy = t.y; qz = t.z; } LANDED(qx); LANDED(qy); LANDED(qz); }
+                if (__builtin_expect(M_NE0(farq ? 1 : 0) != 0ull, 0)) { if (farq) { const int4 t = kinfo[pq]; qx = t.x; qy = t.y; qz = t.z; } LANDED(qx); LANDED(qy); LANDED(qz); }
                 if (q == 1) plo1 = qx; else if (q == 2) plo2 = qx;
                 if (on && qy > bestcm) { bestcm = qy; ulo = qx; ubr = qz; }
             }
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
         lo = lo < hiI ? lo : hiI;
         lo = lo > 0 ? lo : 0;
         // ---- the read bases of rows r0 - 1 and r0 (r0 = lo + 2l): the chunk follows the band
-        if (actm & M_UGT(lo - c0, CH16 - PB - 2)) {
+        if (__builtin_expect((actm & M_UGT(lo - c0, CH16 - PB - 2)) != 0ull, 0)) {
             __syncthreads();
             if (live && k < n0 && (unsigned)(lo - c0) > (unsigned)(CH16 - PB - 2)) {
                 c0 = lo - 128 > 0 ? lo - 128 : 0;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
             const int w = imed3(r0w - k0x + 3, 1, PGS - 3);   // word of row (r0 - plo) - 1 behind the 4 guard words
             const uint32_t src = ringBase + slot0 * (PGS * 4) + ((uint32_t)w << 2);
             int x0 = LDS_I32(src), y0 = LDS_I32(src + 4), y1 = LDS_I32(src + 8);
-            if (far0m) {
+            if (__builtin_expect(far0m != 0ull, 0)) {
                 if (rec.x & CREC_FAR0) {                // the source column comes from HBM
                     const int32_t *Mu = Mcol + (size_t)p0 * PB;
                     const int o = r0w - k0x - 1;
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                 const int w = imed3(off + 3, 1, PGS - 3);
                 const uint32_t src = ringBase + (on ? (uint32_t)(pq & (PRING - 1)) : (uint32_t)PRING) * (PGS * 4) + ((uint32_t)w << 2);
                 int x0 = LDS_I32(src), y0 = LDS_I32(src + 4), y1 = LDS_I32(src + 8);
-                if (M_NE0(farq ? 1 : 0)) {
+                if (__builtin_expect(M_NE0(farq ? 1 : 0) != 0ull, 0)) {
                     if (farq) {
                         const int32_t *Mu = Mcol + (size_t)pq * PB;
                         const int o = off - 1;
@@ -788,7 +791,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
             cm = key >> 6; br = (lo + 63) - (key & 63);
         }
         // ---- the read's last row: best end cell over all columns (first in topological order)
-        if (actm & M_SGT(lo + PB, I)) {
+        if (__builtin_expect((actm & M_SGT(lo + PB, I)) != 0ull, 0)) {
             const int e = r0w == I ? b0 : (r0w + 1 == I ? b1 : NEGV);
             const int ev = __builtin_amdgcn_ds_bpermute(bcastAddr, row_scan_max_i32(e));
             if (live && k < n0 && ev > NEGV / 2 && ev > bs) { bs = ev; kend = k; }
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                 sKin[gq][k & (PRING - 1)] = make_int4(lo, cm, br, 0);
                 *lop = lo;                                  // all the traceback needs of a column (in-edge 0's position is in its record)
             }
-            if (rec.x & CREC_NEED) {                        // a far in-edge will read this column back: its scores and its record
+            if (__builtin_expect((rec.x & CREC_NEED) != 0, 0)) {   // a far in-edge will read this column back: its scores and its record
                 *(int2 *)Mp = make_int2(b0, b1);
                 if (l == 0) *kip = make_int4(lo, cm, br, p0);
             }
