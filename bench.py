@@ -3,8 +3,9 @@
 
 A "step" = one pass of the whole hot path (tables, POA draft, subread->draft alignment, windowing, candidate filter,
 Arrow polish + QVs, stitch) over one batch of synthetic ZMWs.  Workload at N=1 is BASELINE.json configs[1]: 10 passes x
-10 kb synthetic subreads, 8192 ZMWs per step; successive steps take successive DISTINCT batches (13 distinct batches =
-106 k ZMWs, the configs[1] job; a longer run cycles through them).  ZMWs shard across ranks with no collective on the data
+10 kb synthetic subreads, 16384 ZMWs per step (four k_poa_dp waves per SIMD instead of two: +2 % over 8192-ZMW steps on the same box, 32768 gives no more —
+DESIGN.md 4, round 4); successive steps take successive DISTINCT batches (7 distinct batches = 115 k ZMWs, the configs[1] job; a longer run cycles through
+them).  ZMWs shard across ranks with no collective on the data
 path (weak scaling: per-GPU batch fixed).
 
 Timed region: from the first submit to the last result of K steps through the library's asynchronous
@@ -133,9 +134,10 @@ def git_head() -> str | None:
 
 
 # BASELINE.json configs (SURVEY.md §8 sizes): (passes, template length, ZMWs per GPU per step in the default run).  Every preset keeps
-# 8192 POA graphs resident where memory allows (one wave per graph: fewer leave SIMDs idle in the draft stage);
+# at least 8192 POA graphs resident where memory allows (one wave per graph: fewer leave SIMDs idle in the draft stage); the headline
+# shape takes 16384 per step (k_poa_dp: four waves per SIMD; 34.8 k against 34.0 k ZMWs/s at 8192 on the same box, 32768: 34.7 k).
 # `fit_zmws` halves the batch until its page-locked copies fit the host.
-WORKLOADS = {"c1": (3, 1000, 65536), "c2": (10, 10000, 8192), "c4": (30, 20000, 8192), "c5": ((3, 50), (1000, 25000), 8192)}
+WORKLOADS = {"c1": (3, 1000, 65536), "c2": (10, 10000, 16384), "c4": (30, 20000, 8192), "c5": ((3, 50), (1000, 25000), 8192)}
 
 
 def _span(v):
@@ -275,14 +277,14 @@ def reference_concordance(api, np, ccs_bin, sample, cores, seconds, seed=0xC0FFE
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=13, help="timed steps (one batch each); the default 13 x 8192 ZMWs = the 100k-ZMW job of configs[1]")
+    ap.add_argument("--steps", type=int, default=13, help="timed steps (one batch each); the default 13 x 16384 ZMWs = twice the 100k-ZMW job of configs[1]")
     ap.add_argument("--warmup", type=int, default=3, help="untimed steps; at least one per batch slot (3), so that every hipMalloc of the engine happens before the timed region")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="BASELINE.json config shape: c2 (default, the "
                     "one the metric is quoted on) 10 x 10 kb; c1 3 x 1 kb; c4 30 x 20 kb; c5 3-50 passes x 1-25 kb (log-uniform)")
     ap.add_argument("--zmws", type=int, default=0, help="ZMWs per GPU per step [workload default]")
     ap.add_argument("--passes", type=_span, default=None, help="passes per ZMW, N or LO-HI [workload default]")
     ap.add_argument("--length", type=_span, default=None, help="template length, N or LO-HI (log-uniform) [workload default]")
-    ap.add_argument("--distinct", type=int, default=13, help="distinct synthetic batches the steps cycle through (bounded by host memory)")
+    ap.add_argument("--distinct", type=int, default=7, help="distinct synthetic batches the steps cycle through (bounded by host memory; 7 x 16384 ZMWs = the 100k-ZMW job of configs[1])")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (the engine has three batch slots)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL; gloo for CPU-side tests)")
     ap.add_argument("--hifi-kinetics", action="store_true", help="also run the N4 kinetics kernel (not part of the headline metric)")

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 T=${1:-r04}
 H=${2:-unknown}
-Z=${Z:-8192}
+Z=${Z:-16384}
 D=$R/gpurun_out/prof_$T
 rm -rf $D; mkdir -p $D
 timeout 900 python $R/bench.py > $D/bench_default.json 2> $D/bench_default.err
@@ -14,7 +14,7 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $D/trace -o trace -- python $R/b
 python $R/tools/trace_overlap.py $D/trace > $D/overlap.txt 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  # the HEADLINE step: 8192 ZMWs per batch, two-stage queue on (round 3 counted a 2048-ZMW step, where k_poa_dp has 0.5 waves per SIMD)
+  # the HEADLINE step: 16384 ZMWs per batch (8192 until round 4's second session), two-stage queue on (round 3 counted a 2048-ZMW step, where k_poa_dp has 0.5 waves per SIMD)
   timeout 600 rocprofv3 --kernel-trace --pmc $set -d $D/pmc_$tag -o pmc -- python $R/bench.py --pmc --zmws $Z --steps 1 --warmup 1 --distinct 1 > $D/bench_$tag.json 2> $D/bench_$tag.err
 done
 python $R/tools/profsum.py $D > $D/summary.txt
