@@ -2009,7 +2009,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     // ---- locate (zmw, window).  The prologue is a chain of dependent global loads; every level issues all of its
     // loads before the first use (clamped indices instead of branches), so the chain is 4 round trips deep
     // (z-level scalars -> window bounds + per-read metadata + tables -> entry rows -> segments), not one per array.
-    const int bid = slot0 + (int)blockIdx.x;               // (slot0: a batch of more than 2^23 window slots is launched in pieces, see ccsx_launch_all)
+    const int bid = slot0 + (int)blockIdx.x;               // (slot0: a batch of more than 2^24 - 256 window slots is launched in pieces, see ccsx_launch_all)
     if (bid >= P.wstart[P.n_zmw]) return;                  // (the grid covers the slot capacity, the map only the windows there are)
     const int z = P.wslot_zmw[bid];                         // device-built compact map (k_wmap): no dependent search
     const int wbo = P.wb_off[z], nw = P.nwin[z], Ld = P.draft_len[z];
@@ -3174,8 +3174,9 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
     st = st_polish;
     // One workgroup per window slot.  A grid may not exceed 2^32 threads in all: 256 threads x 16.7 M slots — 8192 ZMWs of 30 passes x 20 kb have 10.8 M, and a
     // larger batch would silently lose its tail (round 4 met exactly this with a 512-thread experiment: 75 % of the ZMWs "failed").  The slots are therefore
-    // launched in pieces of at most 2^23 workgroups (CCSX_POLISH_MAX_BLOCKS: a test hook that forces small pieces).
-    static const long long max_blocks = [] { const char *e = getenv("CCSX_POLISH_MAX_BLOCKS"); long long v = e ? atoll(e) : 0; return v > 0 ? v : (1ll << 23); }();
+    // launched in pieces of at most 2^24 - 256 workgroups (just under the limit, so that a 16384-ZMW batch of 10 kb inserts — 8.5 M slots of capacity — is ONE launch:
+    // the profile's per-launch average and bench.py's per-batch duration then describe the same thing; CCSX_POLISH_MAX_BLOCKS: a test hook that forces small pieces).
+    static const long long max_blocks = [] { const char *e = getenv("CCSX_POLISH_MAX_BLOCKS"); long long v = e ? atoll(e) : 0; return v > 0 ? v : (1ll << 24) - 256; }();
     for (long long s0 = 0; s0 < P.total_wslots; s0 += max_blocks) {
         const unsigned nb = (unsigned)((P.total_wslots - s0) < max_blocks ? (P.total_wslots - s0) : max_blocks);
         hipLaunchKernelGGL((k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>), dim3(nb), dim3(PW_THREADS),

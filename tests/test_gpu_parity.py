@@ -879,7 +879,7 @@ def test_reference_concordance_harness(built, tmp_path, monkeypatch):
 
 def test_polish_grid_is_launched_in_pieces(built, tmp_path):
     """a grid may not exceed 2^32 threads: k_polish / k_kinetics run one 256-thread workgroup per window slot, so a batch of more than 16.7 M
-    slots (16 k ZMWs of 25 kb) would silently lose its tail — the slots are launched in pieces of 2^23 workgroups.  CCSX_POLISH_MAX_BLOCKS forces
+    slots (16 k ZMWs of 25 kb) would silently lose its tail — the slots are launched in pieces of at most 2^24 - 256 workgroups.  CCSX_POLISH_MAX_BLOCKS forces
     pieces of 37 here (in a fresh process: the hook is read once): same results as the oracle, with and without kinetics"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic (FETCH_SIZE + WRITE_SIZE, raw KB) and VALU issue from the PMC passes of tools/prof_round.sh.
 Counters are summed over every dispatch of a kernel in the run; one bench run = (warmup + steps + 1) passes over the batch,
-taken from the number of k_polish dispatches (one per pass)."""
+taken from the number of k_stitch dispatches (one per pass)."""
 import glob, json, os, sqlite3, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root, n = sys.argv[1], int(sys.argv[2])
@@ -34,7 +34,7 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ
 CYC = {"k_polish": 3.2, "k_poa_dp": 4.2, "k_align16": 4.2, "k_align": 4.2, "k_rescue": 4.2, "k_kinetics": 4.2}
 tot_busy = tot_cycles = 0.0
 for k, d in sorted(val.items()):
-    runs = max(1, cnt.get("k_polish", {}).get(next(iter(d)), 1))
+    runs = max(1, cnt.get("k_stitch", cnt.get("k_polish", {})).get(next(iter(d)), 1))   # k_stitch: exactly one dispatch per pass (k_polish: one per piece of the slot grid)
     e = {}
     per = lambda name: d[name] / (runs * n)
     if "FETCH_SIZE" in d: e["fetch_size_kb_per_zmw"] = per("FETCH_SIZE")
