@@ -576,7 +576,7 @@ __device__ __forceinline__ void load_read_chunk_m1(uint32_t *sread, const uint8_
 }
 
 // ---- k_poa_dp: the banded DP of pass rr over FOUR graphs per wave (see the header of this section)
-// (branch layout: a taken branch costs the wave ~ 20 cycles of instruction fetch and this kernel runs two to four waves per SIMD (8192 / 16384 graphs), so the conditions of the rare blocks
+// (branch layout: a taken branch costs the wave ~ 20 cycles of instruction fetch and this kernel runs two waves per SIMD, so the conditions of the rare blocks
 // below carry __builtin_expect(., 0) — the blocks move out of line and the common column falls through.  The "two or more in-edges" blocks (43 % of the
 // wave's columns) carry none: either hint measured slower, profiles/r04_poa_dp_vmcnt.txt)
 __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int rr)
