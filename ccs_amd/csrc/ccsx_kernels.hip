@@ -3001,6 +3001,9 @@ __global__ __launch_bounds__(64) void k_stitch(KParams P)
 {
     __shared__ double sSum;
     __shared__ int sHist[256];                              // windows by number of passes used (0 .. CCSX_MAX_PASSES)
+    __shared__ int sOff[LANES], sLen[LANES];                // a block of 64 windows: offset of each core in the block's output, its length
+    __shared__ float sQ[LANES * 32];                        // ... the block's QVs and bases, compacted
+    __shared__ uint8_t sS[LANES * 32];
     const int z = blockIdx.x, lane = threadIdx.x;
     int stat = P.zstat[z];
     const int nw = (stat == CCSX_SUCCESS) ? P.nwin[z] : 0;
@@ -3018,26 +3021,49 @@ __global__ __launch_bounds__(64) void k_stitch(KParams P)
 #pragma unroll
         for (int s = 1; s < LANES; s <<= 1) { int o = __shfl_up(pre, s); if (lane >= s) pre += o; }
         const int off = run + pre - mt.x;
-        for (int k = 0; k < mt.x; ++k) {
-            if (off + k < cap) {
-                float qv = P.wqv[(w0 + w) * 32 + k];
-                P.out_seq[so + off + k] = P.wseq[(w0 + w) * 32 + k];
-                P.out_raw[so + off + k] = qv;
-                P.out_qual[so + off + k] = (uint8_t)(qv + 0.5f);
-                if (P.out_kin) {
+        // The block's 64 window rows are read row-major (coalesced) and compacted in LDS, then written out position-major (coalesced).  Before, a lane copied its
+        // own window base by base: 4-byte stores 88 bytes apart — the kernel wrote 1.3 MB per ZMW for 60 KB of results (PMC, profiles/r04_traffic.json).
+        sOff[lane] = pre - mt.x; sLen[lane] = mt.x;
+        __syncthreads();
+        const int nrow = (nw - wbase < LANES ? nw - wbase : LANES) * 32;
+        const size_t rowbase = (w0 + (size_t)wbase) * 32;
+        for (int q0 = 0; q0 < nrow; q0 += 4 * LANES) {
+            float fq[4]; uint8_t fs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int q = q0 + u * LANES + lane; const int qc = q < nrow ? q : nrow - 1; fq[u] = P.wqv[rowbase + qc]; fs[u] = P.wseq[rowbase + qc]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u * LANES + lane;
+                if (q < nrow) { const int wl = q >> 5, k = q & 31; if (k < sLen[wl]) { const int d = sOff[wl] + k; sQ[d] = fq[u]; sS[d] = fs[u]; } }
+            }
+        }
+        __syncthreads();
+        const int tot = __shfl(pre, 63);
+        for (int p0 = lane; p0 < tot; p0 += LANES) {
+            if (run + p0 < cap) {
+                const float qv = sQ[p0];
+                P.out_seq[so + run + p0] = sS[p0];
+                P.out_raw[so + run + p0] = qv;
+                P.out_qual[so + run + p0] = (uint8_t)(qv + 0.5f);
+            }
+        }
+        if (P.out_kin) {                                    // (--hifi-kinetics only: the four kinetics planes keep the window-by-window copy)
+            for (int k = 0; k < mt.x; ++k) {
+                if (off + k < cap) {
                     const uchar4 kk = P.wkin[(w0 + w) * 32 + k];
                     uint8_t *o = P.out_kin + so + off + k;
                     o[0] = kk.x; o[P.kin_plane] = kk.y; o[2 * P.kin_plane] = kk.z; o[3 * P.kin_plane] = kk.w;
                 }
             }
         }
-        run += __shfl(pre, 63);
+        run += tot;
         nvs += mt.y; ncv |= mt.z; its += mt.w;
         // fixed-order (window order) double sum of per-window float sums
         for (int k = 0; k < LANES; ++k) {
             float v = __shfl((w < nw) ? P.wsum[w0 + w] : 0.0f, k);
             if (lane == 0 && wbase + k < nw) sSum += (double)v;
         }
+        __syncthreads();                                    // (the next block reuses sOff / sLen / sQ / sS)
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { nvs += __shfl_xor(nvs, s); its += __shfl_xor(its, s); ncv |= __shfl_xor(ncv, s); }
