@@ -1180,12 +1180,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int kk = kb + lane;
             const int bpL = kk < n ? g.bpK[kk] : -1;
             const int bL = kk < n ? (g.crec[kk].x & 255) : 0;
+            // whole runs per step: `chain` marks the positions whose back pointer is the position before; from kl the path takes every position down to the
+            // highest one at or below kl whose bit is clear (t), each lane stores its own base, and the walk continues at t's back pointer (one position per
+            // step and a lane-0 store before: ~ 10 k dependent steps per graph)
+            const unsigned long long chain = __ballot(kk < n && bpL == kk - 1);
             while (k >= kb) {
                 const int kl = k - kb;
-                CHK(len < n, 107);
-                if (lane == 0) tmp[len] = (uint8_t)rl(bL, kl);
-                ++len;
-                k = rl(bpL, kl);
+                const unsigned long long inv = ~chain & ((2ull << kl) - 1ull);
+                const int t = inv ? 63 - __clzll((long long)inv) : 0;
+                CHK(len + kl - t < n, 107);
+                if (lane >= t && lane <= kl) tmp[len + (kl - lane)] = (uint8_t)bL;
+                len += kl - t + 1;
+                k = inv ? rl(bpL, t) : kb - 1;
             }
         }
         __threadfence_block();
