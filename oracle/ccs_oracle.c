@@ -55,6 +55,12 @@ void orc_set_poa_band(int bw) { g_poa_band = bw; }
 void orc_set_align_band1(int bw) { g_align_band1 = bw; }      /* 64: no narrow first attempt */
 void orc_set_score_band(int w) { g_score_band = w; }          /* >= 64: the full sum over alignments */
 void orc_set_skip_margin(int m) { g_skip_margin = m; }
+/* STUDY KNOB, not part of SPEC v5 (default -1 = off: the full matrices).  >= 0: alpha and beta are filled on the diagonals j - i in
+ * [min(0, J - I) - W, max(0, J - I) + W] only, W = fill_band + the scoring half width (SCORE_BAND + max(0, |I - J| - 2)); cells outside are exact zeros
+ * for BOTH matrices (the same set of paths, so alpha(I,J) and beta(0,0) still agree).  The candidate of DESIGN.md 8.8 (a fill on band diagonals:
+ * seven reads per wave sweep on the GPU); tools/acc_eval.py fill_band=2 measures what it changes. */
+static int g_fill_band = -1;
+void orc_set_fill_band(int w) { g_fill_band = w; }
 /* ---- path / work counters of the tests and of bench.py's counted-work figure (SURVEY.md §8d "algorithmic work per ZMW: counted on an
  * instrumented CPU path, not estimated"); per-thread tallies are flushed into the global sums once per ZMW ---- */
 enum { CNT_TRIM, CNT_SPLIT, CNT_SPLIT_S0, CNT_SPLIT_SLD, CNT_FALLBACK, CNT_RETRY64, CNT_ZDROP, CNT_NONCONV_WIN, CNT_POA_WIDE, CNT_THIRD_DRAFT,
@@ -789,9 +795,16 @@ static void fill(const float *ME, const float *INS, const float *DL, const uint8
     orc_cnt[CNT_CELLS_FILL] += 2 * (int64_t)(I + 1) * (J + 1);
     float acol[IMAX + 2], pcol[IMAX + 2];
     memset(pcol, 0, sizeof(pcol));
+    int dlo = -(1 << 20), dhi = 1 << 20;                       /* study knob orc_set_fill_band: the band of diagonals j - i that is filled */
+    if (g_fill_band >= 0) {
+        int dIJ = I > J ? I - J : J - I;
+        int W = g_fill_band + g_score_band + (dIJ > 2 ? dIJ - 2 : 0);
+        dlo = (J - I < 0 ? J - I : 0) - W; dhi = (J - I > 0 ? J - I : 0) + W;
+    }
     for (int j = 0; j <= J; ++j) {
         for (int i = 0; i <= I; ++i) {
             float g;
+            if (j - i < dlo || j - i > dhi) { gam[i * GS + j] = 0.0f; acol[i] = 0.0f; continue; }
             if (j == 0) g = (i == 0) ? 1.0f : 0.0f;
             else {
                 float m = (i > 0) ? pcol[i - 1] * ME[k[j - 1] * NOBS + o[i - 1]] : 0.0f;
@@ -805,10 +818,11 @@ static void fill(const float *ME, const float *INS, const float *DL, const uint8
         memcpy(pcol, acol, sizeof(float) * (I + 1));
     }
     *aIJ = pcol[I];
-    for (int i = 0; i <= I + 1; ++i) bet[i * GS + J] = (i == I) ? 1.0f : 0.0f;
+    for (int i = 0; i <= I + 1; ++i) bet[i * GS + J] = (i == I) ? 1.0f : 0.0f;             /* (cell (I, J) lies on diagonal J - I: inside every band) */
     for (int j = J - 1; j >= 0; --j) {
         bet[(I + 1) * GS + j] = 0.0f;
         for (int i = I; i >= 0; --i) {
+            if (j - i < dlo || j - i > dhi) { bet[i * GS + j] = 0.0f; continue; }
             float t1 = (i < I) ? ME[k[j] * NOBS + o[i]] * bet[(i + 1) * GS + j + 1] : 0.0f;
             float t2 = (i < I) ? INS[k[j] * NOBS + o[i]] * bet[(i + 1) * GS + j] : 0.0f;
             float t3 = DL[k[j]] * bet[i * GS + j + 1];

@@ -37,7 +37,7 @@ if __name__ == "__main__":
     for kv in sys.argv[5:]:
         k, v = kv.split("=", 1)
         if k.startswith("env:"): os.environ[k[4:]] = v
-        elif k in ("poa_band", "align_band1", "score_band", "skip_margin", "sat_rows", "sat_gain"): getattr(O.lib(), "orc_set_" + k)(int(v))   # SPEC approximation knobs
+        elif k in ("poa_band", "align_band1", "score_band", "skip_margin", "sat_rows", "sat_gain", "fill_band"): getattr(O.lib(), "orc_set_" + k)(int(v))   # SPEC approximation knobs
         elif k == "channel": channel = float(v)
         elif k == "tpl": tpl = v
         elif k == "hp_boost": hp_boost = float(v)
