@@ -133,3 +133,24 @@ def test_polish_fixes_a_draft_error_and_reports_low_qv_without_evidence(tabs):
         assert out["qv"].min() > 30
     none = O.polish_window(ME, INS, DL, truth, 2, 24, 4, 4, [None, None], [0, 1])
     assert none["nvalid"] == 0 and none["qv"].max() < 3 and np.array_equal(none["seq"], truth[2:24])
+
+
+def test_diagonal_band_schedule():
+    """Groundwork for the diagonal-band fill of DESIGN.md 8.8 (tools/diag_fill_model.py, a schedule model, not a kernel): filling the band of diagonals in the
+    proposed lane / step order — a lane owns two adjacent diagonals and walks a staircase, one value shifted in from a neighbouring lane per step — gives gamma, alpha
+    and beta bit for bit as the oracle's column order does, alpha(I, J) equals beta(0, 0), and a typical 26 x 26 window needs 8 lanes per read."""
+    import diag_fill_model as M
+    rng = np.random.default_rng(5)
+    F = np.float32
+    for trial in range(12):
+        J = int(rng.integers(6, 32)); I = max(1, J + int(rng.integers(-7, 8)))
+        ME = rng.random((16, 12)).astype(F) * F(0.3); INS = rng.random((16, 12)).astype(F) * F(0.1); DL = rng.random(16).astype(F) * F(0.1)
+        k = rng.integers(0, 16, J + 1); o = rng.integers(0, 12, I + 1)
+        dlo, dhi = M.band(I, J, int(rng.integers(0, 4)))
+        a = M.fill_by_columns(ME, INS, DL, k, o, I, J, dlo, dhi)
+        b = M.fill_by_staircase(ME, INS, DL, k, o, I, J, dlo, dhi)
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (trial, I, J, dlo, dhi)
+        assert a[1][I, J] > 0 and abs(a[1][I, J] - a[2][0, 0]) <= 1e-5 * a[1][I, J]
+    dlo, dhi = M.band(26, 26, 2)
+    assert (dhi - dlo + 2) // 2 == 8
