@@ -61,6 +61,10 @@ void orc_set_skip_margin(int m) { g_skip_margin = m; }
  * seven reads per wave sweep on the GPU); tools/acc_eval.py fill_band=2 measures what it changes. */
 static int g_fill_band = -1;
 void orc_set_fill_band(int w) { g_fill_band = w; }
+/* STUDY KNOB, second form (default -1 = off): the fill stays full, but the mutation scoring reads gamma / beta OUTSIDE the same band of diagonals as zeros — what a kernel
+ * does that stores only the band (eight reads per gamma / beta chunk) and masks the scoring rows' reads. */
+static int g_score_mask_band = -1;
+void orc_set_score_mask_band(int w) { g_score_mask_band = w; }
 /* ---- path / work counters of the tests and of bench.py's counted-work figure (SURVEY.md §8d "algorithmic work per ZMW: counted on an
  * instrumented CPU path, not estimated"); per-thread tallies are flushed into the global sums once per ZMW ---- */
 enum { CNT_TRIM, CNT_SPLIT, CNT_SPLIT_S0, CNT_SPLIT_SLD, CNT_FALLBACK, CNT_RETRY64, CNT_ZDROP, CNT_NONCONV_WIN, CNT_POA_WIDE, CNT_THIRD_DRAFT,
@@ -862,6 +866,9 @@ static float score_mut(const float *ME, const float *INS, const float *DL, const
     int rc = (J > 0) ? (2 * c * I + J) / (2 * J) : 0;
     int i0 = rc - Wr; if (i0 < 0) i0 = 0; if (i0 > I + 1 - nrows) i0 = I + 1 - nrows;
     orc_cnt[CNT_CELLS_SCORE] += (type == MT_DEL ? 1 : 2) * (int64_t)nrows;
+    int mlo = -(1 << 20), mhi = 1 << 20;                       /* study knob orc_set_score_mask_band */
+    if (g_score_mask_band >= 0) { int W = g_score_mask_band + Wr; mlo = (J - I < 0 ? J - I : 0) - W; mhi = (J - I > 0 ? J - I : 0) + W; }
+#define BANDED(mat, ii, jj) (((jj) - (ii) < mlo || (jj) - (ii) > mhi) ? 0.0f : (mat)[(ii) * GS + (jj)])
     for (int i = i0; i < i0 + nrows; ++i) {
         float insA = 0.0f, meA = 0.0f, insB = 0.0f;
         if (i > 0) {
@@ -869,18 +876,19 @@ static float score_mut(const float *ME, const float *INS, const float *DL, const
             meA = ME[kA * NOBS + o[i - 1]];
             if (!fin) insB = INS[kB * NOBS + o[i - 1]];
         }
-        float a = gam[i * GS + c] + ap * insA;
+        float a = BANDED(gam, i, c) + ap * insA;
         float b;
         if (type == MT_DEL) b = a;
         else b = ((ap * meA) + (a * DL[kA])) + bp * insB;
         if (fin) res = b;
         else {
-            float t1 = (i < I) ? ME[kB * NOBS + o[i]] * bet[(i + 1) * GS + q] : 0.0f;
-            float t3 = DL[kB] * bet[i * GS + q];
+            float t1 = (i < I) ? ME[kB * NOBS + o[i]] * BANDED(bet, i + 1, q) : 0.0f;
+            float t3 = DL[kB] * BANDED(bet, i, q);
             acc = acc + b * (t1 + t3);
         }
         ap = a; bp = b;
     }
+#undef BANDED
     return fin ? res : acc;
 }
 
