@@ -75,6 +75,7 @@
 #define SKIP_MARGIN 6
 #define SKIP_SPREAD 3
 #define SCORE_BAND 5                  // SPEC: half width (read rows) of the mutation scoring band around the window diagonal
+#define FILL_MARGIN 2                 // SPEC v6 "banded fill": alpha / beta exist on the diagonals j - i in [min(0, J - I) - (Wr + 2), max(0, J - I) + (Wr + 2)] only
 #define DQ_SCALE 65536.0f
 #define DQ_CLAMP 100.0f
 
@@ -1851,7 +1852,7 @@ __global__ __launch_bounds__(256) void k_wmap_fill(KParams P)     // one wave pe
 #endif
 #define PW_WAVES (PW_THREADS / 64)
 #ifndef PW_CHUNK_READS
-#define PW_CHUNK_READS 4              // reads per gamma/beta chunk (0: as many as fit).  A chunk costs one fill sweep + one scoring pass however many
+#define PW_CHUNK_READS 8              // reads per gamma/beta chunk (0: as many as fit).  A chunk costs one fill sweep + one scoring pass however many
                                       // reads it holds (ms of k_polish per 8192 ZMWs: 2 reads per chunk 234, 4 reads 169.5, as many as fit = 4-5 reads 175.7):
                                       // four reads = two pair tasks = four alpha-only / beta-only units = every wave busy for ONE sweep, a fifth read
                                       // adds a task and turns the units into full alpha+beta sweeps on three waves.  Eight-wave workgroups with 8 / 10
@@ -1912,23 +1913,28 @@ typedef const uint8_t __attribute__((address_space(3))) *lds_cu8;
 struct ScoreChain {                  // running state of one (lane, read) mutation evaluation
     float ap, bp, acc, b, bq;
     float2 pA, pB;
-    lds_cf g, be;                    // gamma(i, c) and beta(i+1, q) of the row about to be processed: both advance by S per row
+    lds_cf g, be;                    // gamma(i, c) and beta(i+1, q) of the row about to be processed: both advance by the read's pitch per row
     lds_cu8 op;                      // observation of that row (0..11, 12 = none)
+    int dg, db;                      // SPEC v6: their diagonals relative to the read's band, c - i - dlo and q - (i + 1) - dlo: outside 0 .. bw-1 the cell is a zero
 };
 
 // one row of the extend+link recursion.  tA / tB = the lane's columns of sCTX (context kA / kB).  Every lane walks
 // its own rows (the SPEC's band around the window diagonal starts at a per-lane row), so the row's observation code comes from LDS;
 // row I of a read carries code 12 = the all-zero row of sCTX ("no base left": the SPEC's i < I cases become exact +0 products).
-__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_cc tA, lds_cc tB, int S)
+// SPEC v6: gamma / beta are stored on the read's band only; a scoring band that is clamped into a corner of the window reads cells outside it, which are zeros
+// (the address of such a cell aliases a neighbouring row's: the value is replaced, never used).
+__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_cc tA, lds_cc tB, int pitch, unsigned bw)
 {
     typedef const unsigned long long __attribute__((address_space(3))) *lds_cu64;
-    const float gmm = *s.g;
+    float gmm = *s.g;
+    if ((unsigned)s.dg >= bw) gmm = 0.0f;
     const int o256 = __mul24((int)*s.op, CTXS * 8);   // byte offset of the observation's row in sCTX
     const unsigned long long va = *(lds_cu64)(tA + o256), vb = *(lds_cu64)(tB + o256);   // one ds_read_b64 each
     const float2 nA = make_float2(__uint_as_float((unsigned)va), __uint_as_float((unsigned)(va >> 32)));
     const float2 nB = make_float2(__uint_as_float((unsigned)vb), __uint_as_float((unsigned)(vb >> 32)));
-    const float bqn = *s.be;
-    s.g += S; s.be += S; s.op += 1;
+    float bqn = *s.be;
+    if ((unsigned)s.db >= bw) bqn = 0.0f;
+    s.g += pitch; s.be += pitch; s.op += 1; s.dg -= 1; s.db -= 1;
     const float insA = s.pA.y, meA = s.pA.x, insB = s.pB.y;
     const float a = gmm + s.ap * insA;
     float b;
@@ -1970,6 +1976,25 @@ __device__ __forceinline__ float skip_perr(int g)
 }
 
 
+// SPEC v6 "banded fill": the diagonals d = j - i on which alpha / beta of a (read, window) pair exist (exact zeros elsewhere), and how gamma / beta are laid out in
+// LDS.  A band narrower than a matrix row is stored BY DIAGONAL: cell (i, j) at i * (BWp - 1) + (j - dlo), BWp = BW | 1 floats per row (odd: the fill's lane stride
+// BWp - 2 and the scoring lanes' ~ BWp are then conflict free) — 15 floats per row instead of 28 at I = J, so a chunk holds twice the reads.  A band that wide or wider
+// (|I - J| >= 5: rare) keeps the row layout i * S + j.  Both are "org + i * pitch + j".
+struct FillBand { int dlo, dhi, bw, pitch, org, rowsz; };
+__device__ __forceinline__ FillBand fill_band_of(int I, int J, int S)
+{
+    FillBand b;
+    const int dIJ = I > J ? I - J : J - I;
+    const int W = SCORE_BAND + FILL_MARGIN + (dIJ > 2 ? dIJ - 2 : 0);
+    const int lo = (J - I < 0 ? J - I : 0) - W, hi = (J - I > 0 ? J - I : 0) + W;
+    b.dlo = lo < -I ? -I : lo; b.dhi = hi > J ? J : hi;
+    b.bw = b.dhi - b.dlo + 1;
+    const int bwp = b.bw | 1;
+    const bool diag = bwp < S;
+    b.rowsz = diag ? bwp : S; b.pitch = diag ? bwp - 1 : S; b.org = diag ? -b.dlo : 0;
+    return b;
+}
+
 // PWT threads, PWMIN workgroups' worth of waves per SIMD, PWCH reads per gamma/beta chunk: ONE instantiation is shipped, 256 x 4 x 4.  Round 4 measured
 // the 512-thread shape (2 workgroups of 80 KB per CU, 8 reads per chunk) at 14 / 18 / 24 passes and on the configs[4] mix: 2.2 / 2.3 / 1.8 / 1.7 times
 // SLOWER than this one (profiles/r04_c4_shapes.txt; its apparent 2.4x win at 30 passes x 20 kb came from a grid of more than 2^32 threads that covered 23 % of the windows).
@@ -1994,7 +2019,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     uint8_t (*sObs)[68] = (uint8_t (*)[68])dyn_lds;
     float *sGB = (float *)((uint8_t *)dyn_lds + P.pw_obs_bytes);
     const int GB_FLOATS = P.pw_gb_floats;
-    __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];
+    __shared__ int sI[PW_MAXREADS], sGoff[PW_MAXREADS], sBoff[PW_MAXREADS];   // segment length; where gamma / beta (i, j) = sGB[off + i * pitch + j] of the chunk's reads start
+    __shared__ int sBand[PW_MAXREADS];                       // the read's band and layout (SPEC v6): pitch | rowsz << 8 | bw << 16 | (dlo + 128) << 24
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
     __shared__ uint8_t sZdrop[CCSX_MAX_PASSES + 1];          // z-score gate, by PASS (all groups): decided on the draft window (round 0), then kept
@@ -2307,14 +2333,19 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int r = lane;
                 const int n = (r >= rbeg && r < ng) ? sI[r] : -1;
                 const bool cand = n >= 0;
-                const int need = cand ? (2 * n + 3) * S : 0;
+                const FillBand fb = fill_band_of(cand ? n : 0, J, S);
+                const int need = cand ? (2 * n + 3) * fb.rowsz : 0;          // gamma rows 0..n, beta rows 0..n+1 (row n+1: zeros)
                 const int incl = wave_scan_add_i32(need);
                 const unsigned long long bcand = __ballot(cand);
                 const unsigned long long over = __ballot(cand && (incl > GB_FLOATS || (PWCH > 0 && __popcll(bcand & ((1ull << lane) - 1ull)) >= PWCH)));
                 const int rend_ = over ? (int)__ffsll((long long)over) - 1 : ng;             // the first read that does not fit any more
                 if (r >= rbeg && r < rend_) {
                     if (!cand) { sGoff[r] = -1; sValid[r] = 0; }
-                    else { const int off = incl - need; sGoff[r] = off; sBoff[r] = off + (n + 1) * S; }
+                    else {
+                        const int off = incl - need;
+                        sGoff[r] = off + fb.org; sBoff[r] = off + (n + 1) * fb.rowsz + fb.org;
+                        sBand[r] = fb.pitch | (fb.rowsz << 8) | (fb.bw << 16) | ((fb.dlo + 128) << 24);
+                    }
                 }
                 const bool inchunk = cand && r < rend_;
                 const bool lng = inchunk && n > 31, sht = inchunk && n <= 31;  // long segment: a wave of its own; short ones pair up in order
@@ -2359,6 +2390,10 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int sd = sStrand[myr];
                 const int2 *CJ = sColJ[sd];
                 const bool rowok = row <= I;
+                // SPEC v6: the columns of this lane's row that lie on the read's band, jlo .. jhi; the cells outside are zeros and are neither computed nor stored
+                const int band = sBand[myr];
+                const int pitch = band & 255, rowsz = (band >> 8) & 255, bdlo = (int)((unsigned)band >> 24) - 128, bdhi = bdlo + ((band >> 16) & 255) - 1;
+                const int jlo = (row + bdlo > 0) ? row + bdlo : 0, jhi = (row + bdhi < J) ? row + bdhi : J;
                 // the lane's rows of sCTX, as byte offsets (sObs holds them in that form)
                 const int op = OBS_CODE((row >= 1 && rowok) ? (int)sObs[myr][row - 1] : 12);   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
                 const int oc = OBS_CODE((row < I) ? (int)sObs[myr][row] : 12);                  // o_i;     12 = no base: row I emits nothing more
@@ -2366,43 +2401,51 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 // activity windows: alpha computes column j = t - row for t in [row, row+J]; beta computes column
                 // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step, so the steps of
                 // an iteration address with immediates.
-                const int tA0 = rowok ? row : (1 << 20), tB0 = rowok ? I - row : (1 << 20);
+                // (alpha reaches column jlo at t = row + jlo; beta starts at column jhi at t = (I - row) + (J - jhi))
+                const int tA0 = rowok ? row + jlo : (1 << 20), tB0 = rowok ? I - row + J - jhi : (1 << 20);
                 const float one0 = (row == 0) ? 1.0f : 0.0f, oneI = (row == I) ? 1.0f : 0.0f;
                 const int2 *cA = CJ - row;
-                float *gA = sGB + sGoff[myr] + row * S - row;
+                float *gA = sGB + sGoff[myr] + row * pitch - row;
                 const int2 *cB = CJ + (J + I - row - 1);                                   // the SECOND step of an iteration; the first is one column up
-                float *bB = sGB + sBoff[myr] + row * S + (J + I - row - 1);
+                float *bB = sGB + sBoff[myr] + row * pitch + (J + I - row - 1);
                 // start values chosen so that the general recurrence yields the boundary cells: gamma(i,0) = 0*x + one0*1,
                 // beta(i,J) = (0 + 0) + 1*oneI (column J of the tables is zero with DL = 1)
                 float acur = one0, updiag = 0.0f, mePrev = 0.0f, dlPrev = 1.0f;
                 float bcur = oneI, dndiag = 0.0f;
-                const unsigned uJ = (unsigned)J;
+                // a lane whose step is not on the band holds a ZERO running cell (SPEC v6: its neighbours read the cell past the band's edge as zero); row 0 / row I
+                // keep their start value until their first step, which is the sweep's first
+                const unsigned uJ = (unsigned)(jhi - jlo);
+                const int tAc = rowok ? row : (1 << 20);             // (the plain loop carries ME / DL of the previous column from column 0 on)
+                const unsigned uJc = (unsigned)J;
 #define CCSX_FILL_STEP(T, AOFF, BOFF, DOA, DOB, CJA, CJB)                                                                  \
                 {                                                                                                          \
                     if (DOA) {                                                                                               \
                         const float up = wave_shr1_f32_z(acur);      /* all rows of the read shift together (full exec) */     \
-                        if ((unsigned)((T) - tA0) <= uJ) {           /* alpha, column j = T - row */                          \
+                        float nv = 0.0f;                                                                                     \
+                        if ((unsigned)((T) - tAc) <= uJc) {          /* alpha, column j = T - row of the window */            \
                             const float2 pr = *(const float2 *)(rowA + (CJA).y);                                             \
                             const float dlc = __int_as_float((CJA).x);                                                       \
                             const float m = updiag * mePrev, dl = acur * dlPrev;                                              \
                             const float gmm = m + dl;                                                                        \
                             const float st = up * pr.y;              /* row 0 and column J read zero entries: +0 */           \
-                            gA[(AOFF)] = gmm;                                                                                \
-                            acur = gmm + st;                                                                                 \
+                            if ((unsigned)((T) - tA0) <= uJ) { gA[(AOFF)] = gmm; nv = gmm + st; }   /* ... and on the band */ \
                             mePrev = pr.x; dlPrev = dlc;                                                                     \
                         }                                                                                                    \
+                        acur = nv;                                                                                           \
                         updiag = up;                                                                                         \
                     }                                                                                                        \
                     if (DOB) {                                                                                               \
                         const float dn = wave_shl1_f32_z(bcur);                                                                \
-                        if ((unsigned)((T) - tB0) <= uJ) {           /* beta, column jb = J - (T - (I - row)) */              \
+                        float nv = 0.0f;                                                                                     \
+                        if ((unsigned)((T) - tB0) <= uJ) {           /* beta, column jb = J - (T - (I - row)), on the band */ \
                             const float2 pr = *(const float2 *)(rowB + (CJB).y);                                             \
                             const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                                   \
                             const float t3 = __int_as_float((CJB).x) * bcur;                                                 \
                             const float bv = (t1 + t2) + t3;                                                                 \
                             bB[(BOFF)] = bv;                                                                                 \
-                            bcur = bv;                                                                                       \
+                            nv = bv;                                                                                         \
                         }                                                                                                    \
+                        bcur = nv;                                                                                           \
                         dndiag = dn;                                                                                         \
                     }                                                                                                        \
                 }
@@ -2462,12 +2505,13 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 #define CCSX_A_STEP(K)                                                                                                     \
                         {                                                                                                  \
                             const float up = wave_shr1_f32_z(acur);                                                        \
-                            if (FILL_ACTIVE((unsigned)(cnt + (K)) <= uJ)) { /* alpha, column j = t + K - row */            \
+                            {                                        /* alpha, column j = t + K - row */                   \
                                 const float m = updiag * mePrev, dl = acur * dl##K;                                        \
                                 const float gmm = m + dl;                                                                  \
                                 const float st = up * p##K.y;        /* row 0 and column J read zero entries: +0 */        \
-                                STGB(gA[(K)], gmm);                                                                        \
-                                acur = gmm + st;                                                                           \
+                                const bool on = FILL_ACTIVE((unsigned)(cnt + (K)) <= uJ);   /* ... if it is on the band */  \
+                                if (on) STGB(gA[(K)], gmm);                                                                \
+                                acur = on ? gmm + st : 0.0f;                                                               \
                             }                                                                                              \
                             updiag = up; mePrev = p##K.x;                                                                  \
                             p##K = LDPR(rowA, cx##K);                                                                      \
@@ -2479,7 +2523,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     }
                     if (mode != 1) {
                         const int2 *eB = sEB[sd] + (FE_BLO + J + I - row);               // eB[-x] = the entry of column J + I - row - x
-                        float *bE = sGB + sBoff[myr] + row * S + (J + I - row);          // bE[-x] = beta(row, J + I - row - x)
+                        float *bE = sGB + sBoff[myr] + row * pitch + (J + I - row);      // bE[-x] = beta(row, J + I - row - x)
 #define CCSX_B_INIT(K) const int2 eb##K = eB[-(K)], fb##K = eB[4 - (K)]; float dk##K = __int_as_float(eb##K.x); int cy##K = eb##K.y; float2 q##K = LDPR(rowB, fb##K.y);
                         CCSX_B_INIT(0) CCSX_B_INIT(1) CCSX_B_INIT(2) CCSX_B_INIT(3)
                         const int2 eB0x = eb0; (void)eB0x;
@@ -2488,12 +2532,13 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 #define CCSX_B_STEP(K)                                                                                                     \
                         {                                                                                                  \
                             const float dn = wave_shl1_f32_z(bcur);                                                        \
-                            if (FILL_ACTIVE((unsigned)(cnt + (K)) <= uJ)) { /* beta, column jb = J + I - row - (t + K) */  \
+                            {                                        /* beta, column jb = J + I - row - (t + K) */         \
                                 const float t1 = q##K.x * dndiag, t2 = q##K.y * dn;                                        \
                                 const float t3 = dk##K * bcur;                                                             \
                                 const float bv = (t1 + t2) + t3;                                                           \
-                                STGB(bE[-(K)], bv);                                                                        \
-                                bcur = bv;                                                                                 \
+                                const bool on = FILL_ACTIVE((unsigned)(cnt + (K)) <= uJ);                                  \
+                                if (on) STGB(bE[-(K)], bv);                                                                \
+                                bcur = on ? bv : 0.0f;                                                                     \
                             }                                                                                              \
                             dndiag = dn;                                                                                   \
                             q##K = LDPR(rowB, cy##K);                                                                      \
@@ -2511,15 +2556,15 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 #undef CCSX_FILL_LOOP
 #undef CCSX_FILL_STEP
                 const int basel = paired ? (half << 5) : 0;
+                // (a lane's running cell is zero once its row has left the band, so alpha(I,J) = gamma(I,J) — no stay in the final column — and beta(0,0) are read back
+                // from the cells the wave has just stored)
                 if (mode != 1) {                                     // zero row I+1 of beta; beta(0,0)
-                    if (row < S && (paired || lane < 32) ) sGB[sBoff[myr] + (I + 1) * S + row] = 0.0f;
-                    if (!paired && lane >= 32 && lane < S) sGB[sBoff[myr] + (I + 1) * S + lane] = 0.0f;   // S can reach 33
-                    const float b00 = __shfl(bcur, basel);
-                    if (row == 0 && (paired || lane == 0)) sB00[myr] = b00;
+                    const int org_ = pitch == S ? 0 : -bdlo;      // (row layout: no origin shift)
+                    if (row < rowsz) sGB[sBoff[myr] - org_ + (I + 1) * rowsz + row] = 0.0f;   // (rowsz <= 32 = the lanes of a pair's half)
+                    if (row == 0 && (paired || lane == 0)) sB00[myr] = sGB[sBoff[myr]];
                 }
                 if (mode != 2) {
-                    const float aIJ = __shfl(acur, basel + I);
-                    if (row == 0 && (paired || lane == 0)) sBase[myr] = aIJ;   // (alpha(I,J) itself; its log2 is taken after the barrier)
+                    if (row == 0 && (paired || lane == 0)) sBase[myr] = sGB[sGoff[myr] + I * pitch + J];   // (alpha(I,J) itself; its log2 is taken after the barrier)
                 }
             }
             __syncthreads();
@@ -2575,10 +2620,10 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 nvalid += nv;
                 // per-read scalars of the chunk's usable reads, one read per lane: a unit takes them with v_readlane (no chain of
                 // dependent LDS loads at the start of every unit)
-                int vR, vI, vSt, vG, vB; float vBase;
+                int vR, vI, vSt, vG, vB, vBd; float vBase;
                 {
                     vR = lane < nv ? vRlist : rl(vRlist, 0);
-                    vI = sI[vR]; vSt = (int)sStrand[vR]; vG = sGoff[vR]; vB = sBoff[vR]; vBase = __shfl(vLa, vR);
+                    vI = sI[vR]; vSt = (int)sStrand[vR]; vG = sGoff[vR]; vB = sBoff[vR]; vBd = sBand[vR]; vBase = __shfl(vLa, vR);
                 }
                 const int u_end = ((wave + 1) * nunits) / (PWT / 64);
                 for (int u = (wave * nunits) / (PWT / 64); u < u_end;) {
@@ -2608,7 +2653,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         // second chain's set-up
                         const int ra = rl(vR, k0), Ia = rl(vI, k0);
                         const LaneMut La = rl(vSt, k0) ? LR : LF;
-                        const int gA_ = rl(vG, k0), bA_ = rl(vB, k0);
+                        const int gA_ = rl(vG, k0), bA_ = rl(vB, k0), bdA = rl(vBd, k0);
+                        const int pA = bdA & 255, dloA = (int)((unsigned)bdA >> 24) - 128; const unsigned bwA = (unsigned)(bdA >> 16) & 255u;
                         const int dA = Ia > J ? Ia - J : J - Ia, WrA = SCORE_BAND + (dA > 2 ? dA - 2 : 0);
 #ifdef CCSX_EXP_NO_ROWS                                     // experiment (timing only): a unit without its rows
                         const int nrA = 0;
@@ -2619,14 +2665,17 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         lds_cc tAa = (lds_cc)(sCTX + La.kA), tBa = (lds_cc)(sCTX + La.kB);
                         ScoreChain ca;
                         ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
-                        ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, S) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, S) + La.q); ca.bq = *ca.be; ca.be += S;
+                        ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, pA) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, pA) + La.q);
+                        ca.dg = La.c - i0a - dloA; ca.db = La.q - i0a - dloA;
+                        ca.bq = *ca.be; if ((unsigned)ca.db >= bwA) ca.bq = 0.0f;
+                        ca.be += pA; ca.db -= 1;
                         ca.op = (lds_cu8)(&sObs[ra][0] + i0a);
                         asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(tAa), "+v"(tBa), "+v"(ca.op));
                         {   // two rows per iteration: the chain's carried values (previous table pairs, beta, a, b) then rotate between two
                             // register sets instead of being copied at every row (3 v_mov + a loop counter per row before)
                             int ia = 0;
-                            for (; ia + 2 <= nrA; ia += 2) { score_step(ca, La, tAa, tBa, S); score_step(ca, La, tAa, tBa, S); }
-                            if (ia < nrA) score_step(ca, La, tAa, tBa, S);
+                            for (; ia + 2 <= nrA; ia += 2) { score_step(ca, La, tAa, tBa, pA, bwA); score_step(ca, La, tAa, tBa, pA, bwA); }
+                            if (ia < nrA) score_step(ca, La, tAa, tBa, pA, bwA);
                         }
                         const float res = La.fin ? ca.b : ca.acc;
 #ifdef CCSX_EXP_NO_SCORE_LOG                                // experiment (timing only): a unit without its logarithm and fixed-point conversion
@@ -2640,7 +2689,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     const int Ia = rl(vI, k0), Ib = rl(vI, k1);
                     const LaneMut La = rl(vSt, k0) ? LR : LF;
                     const LaneMut Lb = rl(vSt, k1) ? LR : LF;
-                    const int gA_ = rl(vG, k0), bA_ = rl(vB, k0), gB_ = rl(vG, k1), bB_ = rl(vB, k1);
+                    const int gA_ = rl(vG, k0), bA_ = rl(vB, k0), gB_ = rl(vG, k1), bB_ = rl(vB, k1), bdA = rl(vBd, k0), bdB = rl(vBd, k1);
+                    const int pA = bdA & 255, dloA = (int)((unsigned)bdA >> 24) - 128; const unsigned bwA = (unsigned)(bdA >> 16) & 255u;
+                    const int pB = bdB & 255, dloB = (int)((unsigned)bdB >> 24) - 128; const unsigned bwB = (unsigned)(bdB >> 16) & 255u;
                     // SPEC "banded link": every lane scores the rows around its column's point on the window diagonal only
                     const int dA = Ia > J ? Ia - J : J - Ia, WrA = SCORE_BAND + (dA > 2 ? dA - 2 : 0);
                     const int nrA = (Ia < 2 * WrA ? Ia : 2 * WrA) + 1;
@@ -2653,8 +2704,12 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     ScoreChain ca, cb;
                     ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
                     cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f);
-                    ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, S) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, S) + La.q); ca.bq = *ca.be; ca.be += S;
-                    cb.g = (lds_cf)(sGB + gB_ + __mul24(i0b, S) + Lb.c); cb.be = (lds_cf)(sGB + bB_ + __mul24(i0b, S) + Lb.q); cb.bq = *cb.be; cb.be += S;
+                    ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, pA) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, pA) + La.q);
+                    cb.g = (lds_cf)(sGB + gB_ + __mul24(i0b, pB) + Lb.c); cb.be = (lds_cf)(sGB + bB_ + __mul24(i0b, pB) + Lb.q);
+                    ca.dg = La.c - i0a - dloA; ca.db = La.q - i0a - dloA; cb.dg = Lb.c - i0b - dloB; cb.db = Lb.q - i0b - dloB;
+                    ca.bq = *ca.be; if ((unsigned)ca.db >= bwA) ca.bq = 0.0f;
+                    cb.bq = *cb.be; if ((unsigned)cb.db >= bwB) cb.bq = 0.0f;
+                    ca.be += pA; ca.db -= 1; cb.be += pB; cb.db -= 1;
                     ca.op = (lds_cu8)(&sObs[ra][0] + i0a); cb.op = (lds_cu8)(&sObs[rb][0] + i0b);
                     // opaque to the optimiser from here: the running pointers hold complete LDS addresses (otherwise the
                     // dynamic-LDS base is re-added at every use)
@@ -2662,13 +2717,13 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     const int nmin = nrA < nrB ? nrA : nrB;
                     int i = 0;
                     for (; i + 2 <= nmin; i += 2) {                            // both chains, two rows per iteration (no register copies between rows)
-                        score_step(ca, La, tAa, tBa, S);
-                        score_step(cb, Lb, tAb, tBb, S);
-                        score_step(ca, La, tAa, tBa, S);
-                        score_step(cb, Lb, tAb, tBb, S);
+                        score_step(ca, La, tAa, tBa, pA, bwA);
+                        score_step(cb, Lb, tAb, tBb, pB, bwB);
+                        score_step(ca, La, tAa, tBa, pA, bwA);
+                        score_step(cb, Lb, tAb, tBb, pB, bwB);
                     }
-                    for (int ia = i; ia < nrA; ++ia) score_step(ca, La, tAa, tBa, S);
-                    for (int ib = i; ib < nrB; ++ib) score_step(cb, Lb, tAb, tBb, S);
+                    for (int ia = i; ia < nrA; ++ia) score_step(ca, La, tAa, tBa, pA, bwA);
+                    for (int ib = i; ib < nrB; ++ib) score_step(cb, Lb, tAb, tBb, pB, bwB);
                     {
                         const float res = La.fin ? ca.b : ca.acc;
                         dq = dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k0)));

@@ -36,7 +36,7 @@
 #endif
 
 /* ---------------- specification constants (same values as include/ccsx.h) -------------- */
-#define ORC_SPEC_VERSION 5  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
+#define ORC_SPEC_VERSION 6  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
 int orc_spec_version(void) { return ORC_SPEC_VERSION; }
 #define BAND      64
 #define ALIGN_BAND1 16      /* rows of the FIRST attempt of the subread -> draft alignment (step 3); BAND rows on failure */
@@ -55,16 +55,28 @@ void orc_set_poa_band(int bw) { g_poa_band = bw; }
 void orc_set_align_band1(int bw) { g_align_band1 = bw; }      /* 64: no narrow first attempt */
 void orc_set_score_band(int w) { g_score_band = w; }          /* >= 64: the full sum over alignments */
 void orc_set_skip_margin(int m) { g_skip_margin = m; }
-/* STUDY KNOB, not part of SPEC v5 (default -1 = off: the full matrices).  >= 0: alpha and beta are filled on the diagonals j - i in
- * [min(0, J - I) - W, max(0, J - I) + W] only, W = fill_band + the scoring half width (SCORE_BAND + max(0, |I - J| - 2)); cells outside are exact zeros
- * for BOTH matrices (the same set of paths, so alpha(I,J) and beta(0,0) still agree).  The candidate of DESIGN.md 8.8 (a fill on band diagonals:
- * seven reads per wave sweep on the GPU); tools/acc_eval.py fill_band=2 measures what it changes. */
-static int g_fill_band = -1;
-void orc_set_fill_band(int w) { g_fill_band = w; }
-/* STUDY KNOB, second form (default -1 = off): the fill stays full, but the mutation scoring reads gamma / beta OUTSIDE the same band of diagonals as zeros — what a kernel
- * does that stores only the band (eight reads per gamma / beta chunk) and masks the scoring rows' reads. */
-static int g_score_mask_band = -1;
-void orc_set_score_mask_band(int w) { g_score_mask_band = w; }
+/* SPEC v6 "banded fill": alpha and beta of a (read, window) pair exist on the diagonals d = j - i in
+ *   [max(-I, min(0, J - I) - (Wr + FILL_MARGIN_LO)),  min(J, max(0, J - I) + (Wr + FILL_MARGIN_HI))],   Wr = SCORE_BAND + max(0, |I - J| - 2)
+ * only; every cell outside is an exact zero for BOTH matrices (the same set of paths: alpha(I,J) and beta(0,0) still agree), and the mutation scoring reads
+ * zeros there.  The band holds every cell an unclamped scoring row reads: gamma(i, c) on c - i in [min(0,J-I) - Wr, max(0,J-I) + Wr], beta(i', q) with q <= c + 2 two
+ * diagonals higher — hence the asymmetric margins.  On the device gamma / beta are STORED by diagonal (15 instead of 28 floats per row: twice the reads per LDS chunk)
+ * and filled on band diagonals.  Measured against the full matrices on six data sets: bit-identical sequences, QVs, rq and round counts
+ * (profiles/r05_band_study.txt; tools/band_study.py).  Knobs for that study: orc_set_fill_band(w) = symmetric margins w, < 0 = the full matrices (SPEC v5);
+ * orc_set_fill_margins(lo, hi). */
+#define FILL_MARGIN_LO 2
+#define FILL_MARGIN_HI 2
+static int g_fill_lo = FILL_MARGIN_LO, g_fill_hi = FILL_MARGIN_HI;
+void orc_set_fill_band(int w) { g_fill_lo = g_fill_hi = w; }
+void orc_set_fill_margins(int lo, int hi) { g_fill_lo = lo; g_fill_hi = hi; }
+/* the band of one (read, window) pair */
+static inline void fill_band_of(int I, int J, int score_band, int *dlo, int *dhi)
+{
+    if (g_fill_lo < 0 || g_fill_hi < 0) { *dlo = -(1 << 20); *dhi = 1 << 20; return; }
+    int dIJ = I > J ? I - J : J - I;
+    int Wr = score_band + (dIJ > 2 ? dIJ - 2 : 0);
+    int lo = (J - I < 0 ? J - I : 0) - (Wr + g_fill_lo), hi = (J - I > 0 ? J - I : 0) + (Wr + g_fill_hi);
+    *dlo = lo < -I ? -I : lo; *dhi = hi > J ? J : hi;
+}
 /* ---- path / work counters of the tests and of bench.py's counted-work figure (SURVEY.md §8d "algorithmic work per ZMW: counted on an
  * instrumented CPU path, not estimated"); per-thread tallies are flushed into the global sums once per ZMW ---- */
 enum { CNT_TRIM, CNT_SPLIT, CNT_SPLIT_S0, CNT_SPLIT_SLD, CNT_FALLBACK, CNT_RETRY64, CNT_ZDROP, CNT_NONCONV_WIN, CNT_POA_WIDE, CNT_THIRD_DRAFT,
@@ -799,12 +811,7 @@ static void fill(const float *ME, const float *INS, const float *DL, const uint8
     orc_cnt[CNT_CELLS_FILL] += 2 * (int64_t)(I + 1) * (J + 1);
     float acol[IMAX + 2], pcol[IMAX + 2];
     memset(pcol, 0, sizeof(pcol));
-    int dlo = -(1 << 20), dhi = 1 << 20;                       /* study knob orc_set_fill_band: the band of diagonals j - i that is filled */
-    if (g_fill_band >= 0) {
-        int dIJ = I > J ? I - J : J - I;
-        int W = g_fill_band + g_score_band + (dIJ > 2 ? dIJ - 2 : 0);
-        dlo = (J - I < 0 ? J - I : 0) - W; dhi = (J - I > 0 ? J - I : 0) + W;
-    }
+    int dlo, dhi; fill_band_of(I, J, g_score_band, &dlo, &dhi);   /* SPEC v6: the band of diagonals j - i that exists */
     for (int j = 0; j <= J; ++j) {
         for (int i = 0; i <= I; ++i) {
             float g;
@@ -866,9 +873,8 @@ static float score_mut(const float *ME, const float *INS, const float *DL, const
     int rc = (J > 0) ? (2 * c * I + J) / (2 * J) : 0;
     int i0 = rc - Wr; if (i0 < 0) i0 = 0; if (i0 > I + 1 - nrows) i0 = I + 1 - nrows;
     orc_cnt[CNT_CELLS_SCORE] += (type == MT_DEL ? 1 : 2) * (int64_t)nrows;
-    int mlo = -(1 << 20), mhi = 1 << 20;                       /* study knob orc_set_score_mask_band */
-    if (g_score_mask_band >= 0) { int W = g_score_mask_band + Wr; mlo = (J - I < 0 ? J - I : 0) - W; mhi = (J - I > 0 ? J - I : 0) + W; }
-#define BANDED(mat, ii, jj) (((jj) - (ii) < mlo || (jj) - (ii) > mhi) ? 0.0f : (mat)[(ii) * GS + (jj)])
+    /* (gamma / beta outside the band of SPEC v6 are zeros as fill() leaves them: a scoring band clamped into a corner of the window reads such cells) */
+#define BANDED(mat, ii, jj) ((mat)[(ii) * GS + (jj)])
     for (int i = i0; i < i0 + nrows; ++i) {
         float insA = 0.0f, meA = 0.0f, insB = 0.0f;
         if (i > 0) {

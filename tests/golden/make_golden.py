@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/golden_v5.npz: inputs + expected outputs of the hot path at SPEC version 5.
+"""Generates tests/golden/golden_v6.npz: inputs + expected outputs of the hot path at SPEC version 6 (the banded alpha / beta fill; every array
+equals its counterpart in golden_v5.npz of round 4 — the band is exactly free, profiles/r05_band_study.txt — checked by `--compare OLD.npz`).
 
 The reference mount is documentation-only (no source, binary or test vectors: SURVEY.md §0/§8c), so these
 vectors come from this repository's own CPU restatement (oracle/ccs_oracle.c, "parity unpinned") at the
@@ -108,8 +109,14 @@ def main():
     out["model_bytes"] = np.frombuffer(bytes(m), np.uint8)
     out["spec_version"] = np.array([O.spec_version()], np.int32)
     out["cases"] = np.array(names)
-    np.savez_compressed(os.path.join(HERE, "golden_v5.npz"), **out)
-    print("wrote golden_v5.npz with", len(out), "arrays, SPEC version", O.spec_version())
+    name = "golden_v%d.npz" % O.spec_version()
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, "with", len(out), "arrays, SPEC version", O.spec_version())
+    if "--compare" in sys.argv:                       # e.g. `git show HEAD~:tests/golden/golden_v5.npz > /tmp/v5.npz`: a SPEC change that claims to be result-free
+        old = np.load(sys.argv[sys.argv.index("--compare") + 1])
+        diff = [k for k in old.files if k != "spec_version" and not (k in out and np.array_equal(old[k], out[k]))]
+        print("arrays of the old file that differ:", diff or "none", "| arrays only in the new file:", [k for k in out if k not in old.files] or "none")
+        assert not diff
 
 
 if __name__ == "__main__":

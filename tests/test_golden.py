@@ -1,5 +1,5 @@
-"""Committed golden vectors (tests/golden/golden_v5.npz, made by tests/golden/make_golden.py from the
-oracle at SPEC version 5): the oracle must keep reproducing them on CPU, the HIP path must reproduce them on the GPU; a library or
+"""Committed golden vectors (tests/golden/golden_v6.npz, made by tests/golden/make_golden.py from the
+oracle at SPEC version 6): the oracle must keep reproducing them on CPU, the HIP path must reproduce them on the GPU; a library or
 oracle of another SPEC version is refused (SPEC drift fails loudly: VERDICT r02 item 3e)."""
 import numpy as np
 import pytest
@@ -11,7 +11,7 @@ import golden_util as G
 
 def test_spec_versions_agree(built):
     """the golden vectors, the library (ccsx_spec_version) and the oracle (ORC_SPEC_VERSION) carry the same SPEC version"""
-    assert G.spec_version() == api.lib().ccsx_spec_version() == O.spec_version()
+    assert G.spec_version() == G.kin_spec_version() == api.lib().ccsx_spec_version() == O.spec_version()
     assert sorted(np.load(G.GOLDEN)["cases"].tolist()) == sorted(G.CASES)
 
 
@@ -42,7 +42,7 @@ def test_gpu_reproduces_golden(built, case):
     h.close()
 
 
-# ---- HiFi kinetics (tests/golden/golden_kin_v5.npz, made by tests/golden/make_golden_kinetics.py) --------------------
+# ---- HiFi kinetics (tests/golden/golden_kin_v6.npz, made by tests/golden/make_golden_kinetics.py) --------------------
 KIN_CASES = ["p5_l700", "mix", "partial"]
 
 
