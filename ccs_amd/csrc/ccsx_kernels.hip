@@ -1871,6 +1871,7 @@ __global__ __launch_bounds__(256) void k_wmap_fill(KParams P)     // one wave pe
 #ifndef CTXS
 #define CTXS 33                       // entries per observation row of sCTX
 #endif
+#define FILL16_MAXBW 24               // widest band (diagonals) of a read that shares a wave with three others (k_polish's quad sweep)
 #define FE_ALO 35                     // sEA holds columns -35 .. 69, sEB columns -69 .. 66 (the reach of a pair's lanes, see the fill)
 #define FE_A 105
 #define FE_BLO 69
@@ -2327,7 +2328,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         int rbeg = 0;
         while (rbeg < ng) {
             __syncthreads();
-            int rend, ntask;
+            int rend, nlong, nshort;
             {   // lane = read: the greedy plan by prefix sum and ballots.  EVERY wave computes it (identical values, benign identical
                 // LDS writes): a wave then reads only what it wrote itself, so no barrier is needed before the fill
                 const int r = lane;
@@ -2348,45 +2349,142 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     }
                 }
                 const bool inchunk = cand && r < rend_;
-                const bool lng = inchunk && n > 31, sht = inchunk && n <= 31;  // long segment: a wave of its own; short ones pair up in order
-                const unsigned long long bl = __ballot(lng), bs = __ballot(sht);
+                // a short segment whose band leaves a lane time to change rows (see the quad sweep) shares a wave with three others; the rest — more than
+                // 31 bases, or |I - J| >= 5 — takes a wave of its own (rare)
+                const bool qd = inchunk && n <= 31 && fb.bw <= FILL16_MAXBW, lng = inchunk && !qd;
+                const unsigned long long bl = __ballot(lng), bs = __ballot(qd);
                 const unsigned long long lower = (1ull << lane) - 1ull;
-                const int nl = __popcll(bl), ns = __popcll(bs);
+                const int nl_ = __popcll(bl);
                 if (lng) sTask[__popcll(bl & lower)] = make_short2((short)r, (short)-1);
-                if (sht) {
-                    const int rank = __popcll(bs & lower);
-                    if (!(rank & 1)) {
-                        const unsigned long long hi = bs & ~(lower | (1ull << lane));
-                        sTask[nl + (rank >> 1)] = make_short2((short)r, (short)(hi ? (int)__ffsll((long long)hi) - 1 : -1));
-                    }
-                }
-                rend = rfl(rend_); ntask = rfl(nl + ((ns + 1) >> 1));
+                if (qd) sTask[nl_ + __popcll(bs & lower)] = make_short2((short)r, (short)0);
+                rend = rfl(rend_); nlong = rfl(nl_); nshort = rfl(__popcll(bs));
             }
             PHASE(2);
-            // ---- A1/A2: fill.  lane = read row; alpha and beta advance together along anti-diagonals.  Work units: a task = a pair of
-            // short reads (or one long read) per wave.  When the last round of tasks would leave half of the waves idle (ntask mod 4
-            // = 1 or 2: e.g. five pairs on four waves), those tasks are SPLIT into an alpha-only and a beta-only unit on two waves —
-            // the same arithmetic per cell, the sweep of a unit is as long but issues half the instructions: 5 tasks cost 1.55
-            // task-times instead of 2.  alpha(I,J) / beta(0,0) of a read therefore meet in LDS, and every wave derives the reads'
-            // validity from them after the barrier (lane = read; identical values in every wave: no second barrier).
-#ifdef CCSX_EXP_NO_FILL
-            const int nsplit = 0, ntfull = 0, nunit_f = 0;
-#else
-            const int nrest = ntask % (PWT / 64), nsplit = (nrest > 0 && 2 * nrest <= (PWT / 64)) ? nrest : 0;
-            const int ntfull = ntask - nsplit, nunit_f = ntfull + 2 * nsplit;
-#endif
-            // (experiment, profiles/r04_fill_waves.txt: the same units on 2 / 1 of the 4 waves — same instructions, longer critical path — cost
-            // +32 / +117 ms of 157: a workgroup's critical path counts, not only its instruction total)
+            // ---- A1/A2: fill (SPEC v6: on the band of diagonals only).  Work units, one wave each, every unit ONE anti-diagonal sweep:
+            //   quad units — FOUR short reads per wave, one per 16-lane DPP row, alpha and beta of a quad on different waves;
+            //   long units — one read per wave (lane = row), alpha and beta on different waves.
+            // alpha(I,J) / beta(0,0) of a read meet in LDS, and every wave derives the reads' validity from them after the barrier (lane = read; identical values
+            // in every wave: no second barrier).  Eight short reads = two quads = four units: every wave runs one sweep per chunk.
+            const int nquad = (nshort + 3) >> 2, nunit_f = 2 * nquad + 2 * nlong;
             for (int fu = wave; fu < nunit_f; fu += (PWT / 64)) {
-                const int tk = fu < ntfull ? fu : ntfull + ((fu - ntfull) >> 1);
-                const int mode = fu < ntfull ? 0 : 1 + ((fu - ntfull) & 1);      // 0: alpha and beta, 1: alpha only, 2: beta only
-                const short2 task = sTask[tk];
-                const bool paired = rfl((int)task.y) >= 0;
-                const int myr = paired ? (half ? task.y : task.x) : task.x;
-                const int row = paired ? hrow : lane;
-                const int I = sI[myr];
-                const int Ia = rfl(sI[task.x]), Ib = paired ? rfl(sI[task.y]) : -1;
-                const int Tmax = (Ia > Ib ? Ia : Ib) + J;
+              if (fu < 2 * nquad) {
+                // ---- quad unit.  Lane l of a DPP row owns read rows l and l + 16 (a short segment has at most 32 rows): row i is on the band for the 15-or-so
+                // steps t = i + j in [2 i + dlo, 2 i + dhi], row i + 16 exactly 32 steps later, so with a band of at most FILL16_MAXBW = 24 diagonals the lane is
+                // idle for at least 8 steps in between and changes rows there.  The neighbour row's cell comes by a ROTATION inside the DPP row (row_ror: lane 0
+                // takes lane 15, whose row 15 precedes lane 0's row 16; while lane 0 is on row 0, lane 15 has not started and holds a zero).  A lane that is not on
+                // the band holds a zero running cell, which is what its neighbours must read past the band's edge.  Look-ups are software-pipelined as before: slot k
+                // holds DL and the (ME, INS) pair of the step's column and the context offset of the column four steps on, refilled right after use.  The row
+                // change therefore happens in two parts: the look-up side (observation row, column-entry pointer) at the first iteration whose look-ups no longer
+                // serve the old row, the compute side (activity window, store pointer) one iteration later.
+                const int quad = fu >> 1, isb = fu & 1;
+                const int g4 = lane >> 4, l16 = lane & 15;
+                const int qi = 4 * quad + g4;
+                const bool have = qi < nshort;
+                const int myr = sTask[nlong + (have ? qi : 4 * quad)].x;
+                const int I = sI[myr], sd = sStrand[myr], band = sBand[myr];
+                const int pitch = band & 255, rowsz = (band >> 8) & 255, bdlo = (int)((unsigned)band >> 24) - 128, bdhi = bdlo + ((band >> 16) & 255) - 1;
+                const int row0 = l16, row1 = l16 + 16;
+                const bool ok0 = have && row0 <= I, ok1 = have && row1 <= I;
+                const int jlo0 = (row0 + bdlo > 0) ? row0 + bdlo : 0, jhi0 = (row0 + bdhi < J) ? row0 + bdhi : J;
+                const int jlo1 = (row1 + bdlo > 0) ? row1 + bdlo : 0, jhi1 = (row1 + bdhi < J) ? row1 + bdhi : J;
+                int Tmax = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int iq = rfl(sI[rfl((int)sTask[nlong + (4 * quad + q < nshort ? 4 * quad + q : 4 * quad)].x)]); Tmax = iq > Tmax ? iq : Tmax; }
+                Tmax += J;
+                const int NEVER = 1 << 20;
+#define LDPR(ROWP, OFF) (*(const float2 *)((ROWP) + (OFF)))
+                if (!isb) {
+                    // alpha: row 0 first.  Step t: the lane's row i computes column j = t - i
+                    const int obA0 = OBS_CODE((row0 >= 1 && ok0) ? (int)sObs[myr][row0 - 1] : 12);     // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                    const int obA1 = OBS_CODE(ok1 ? (int)sObs[myr][row1 - 1] : 12);
+                    const char *rowA = (const char *)sCTX + obA0;
+                    const char *rowA1 = (const char *)sCTX + obA1;
+                    const int tA0 = ok0 ? row0 + jlo0 : NEVER, tA1 = row1 + jlo1;
+                    unsigned uJ = ok0 ? (unsigned)(jhi0 - jlo0) : 0u;
+                    const unsigned uJ1 = (unsigned)(jhi1 - jlo1);
+                    const int tsw = ok1 ? ((row0 + jhi0) & ~3) : NEVER;          // = the first multiple of 4 >= (last step of row i) - 3
+                    const int2 *eA = sEA[sd] + (FE_ALO - row0);                       // eA[x] = the entry of column x - row
+                    float *gA = sGB + sGoff[myr] + row0 * pitch - row0;               // gA[x] = gamma(row, x - row)
+                    const int dgA = 16 * (pitch - 1), dcnt = tA0 - tA1;
+                    float acur = (ok0 && row0 == 0) ? 1.0f : 0.0f, mnext = 0.0f;     // mnext = alpha(i-1, j-1) * ME(j-1) of the next step, formed a step ahead
+#define CCSX_A_INIT(K) const int2 ea##K = eA[K], fa##K = eA[(K) - 4]; float dl##K = __int_as_float(ea##K.x); int cx##K = ea##K.y; float2 p##K = LDPR(rowA, fa##K.y);
+                    CCSX_A_INIT(0) CCSX_A_INIT(1) CCSX_A_INIT(2) CCSX_A_INIT(3)
+#undef CCSX_A_INIT
+                    int cnt = -tA0;
+#define CCSX_A_STEP(K)                                                                                                     \
+                    {                                                                                                      \
+                        const float up = row_ror1_f32(acur);         /* alpha(i-1, j) */                                     \
+                        const float dl = acur * dl##K;                                                                     \
+                        const float gmm = mnext + dl;                                                                      \
+                        const float st = up * p##K.y;                /* row 0 and column J read zero entries: +0 */        \
+                        const bool on = (unsigned)(cnt + (K)) <= uJ;                                                       \
+                        if (on) gA[(K)] = gmm;                                                                             \
+                        acur = on ? gmm + st : 0.0f;                                                                       \
+                        mnext = up * p##K.x;                                                                               \
+                        p##K = LDPR(rowA, cx##K);                                                                          \
+                        const int2 en = eA[(K) + 4];                                                                       \
+                        dl##K = __int_as_float(en.x); cx##K = en.y;                                                        \
+                    }
+                    for (int t = 0; t <= Tmax; t += 4, eA += 4, gA += 4, cnt += 4) {
+                        if (t == tsw) { rowA = rowA1; eA -= 16; }
+                        if (t - 4 == tsw) { uJ = uJ1; cnt += dcnt; gA += dgA; }
+                        CCSX_A_STEP(0) CCSX_A_STEP(1) CCSX_A_STEP(2) CCSX_A_STEP(3)
+                    }
+#undef CCSX_A_STEP
+                    // (a lane's running cell is zero once its row has left the band: alpha(I,J) = gamma(I,J) — no stay in the final column — is read back from LDS)
+                    if (have && l16 == 0) sBase[myr] = sGB[sGoff[myr] + I * pitch + J];
+                } else {
+                    // beta: row I first.  Step t: the lane's row i computes column j = J - (t - (I - i)); a lane with two rows starts on row l + 16
+                    const int rowF = ok1 ? row1 : row0, jloF = ok1 ? jlo1 : jlo0, jhiF = ok1 ? jhi1 : jhi0;
+                    const int obB0 = OBS_CODE((ok0 && row0 < I) ? (int)sObs[myr][row0] : 12);           // o_i; 12 = no base: row I emits nothing more
+                    const int obBF = ok1 ? OBS_CODE(row1 < I ? (int)sObs[myr][row1] : 12) : obB0;
+                    const char *rowB = (const char *)sCTX + obBF;
+                    const char *rowB0 = (const char *)sCTX + obB0;
+                    const int tB0 = ok0 ? I - rowF + J - jhiF : NEVER, tB1 = I - row0 + J - jhi0;
+                    unsigned uJ = ok0 ? (unsigned)(jhiF - jloF) : 0u;
+                    const unsigned uJ1 = (unsigned)(jhi0 - jlo0);
+                    const int tsw = ok1 ? ((I - row1 + J - jlo1) & ~3) : NEVER;
+                    const int2 *eB = sEB[sd] + (FE_BLO + J + I - rowF);               // eB[-x] = the entry of column J + I - row - x
+                    float *bE = sGB + sBoff[myr] + rowF * pitch + (J + I - rowF);     // bE[-x] = beta(row, J + I - row - x)
+                    const int dbE = -16 * (pitch - 1), dcnt = tB0 - tB1;
+                    float bcur = (ok0 && rowF == I) ? 1.0f : 0.0f, t1next = 0.0f;    // t1next = ME(j) * beta(i+1, j+1) of the next step
+#define CCSX_B_INIT(K) const int2 eb##K = eB[-(K)], fb##K = eB[4 - (K)]; float dk##K = __int_as_float(eb##K.x); int cy##K = eb##K.y; float2 q##K = LDPR(rowB, fb##K.y);
+                    CCSX_B_INIT(0) CCSX_B_INIT(1) CCSX_B_INIT(2) CCSX_B_INIT(3)
+#undef CCSX_B_INIT
+                    int cnt = -tB0;
+#define CCSX_B_STEP(K, KN)                                                                                                 \
+                    {                                                                                                      \
+                        const float dn = row_rol1_f32(bcur);         /* beta(i+1, j) */                                    \
+                        const float t2 = q##K.y * dn;                                                                      \
+                        const float t3 = dk##K * bcur;                                                                     \
+                        const float bv = (t1next + t2) + t3;                                                               \
+                        const bool on = (unsigned)(cnt + (K)) <= uJ;                                                       \
+                        if (on) bE[-(K)] = bv;                                                                             \
+                        bcur = on ? bv : 0.0f;                                                                             \
+                        t1next = q##KN.x * dn;                       /* (slot KN holds the pair of the next step's column) */ \
+                        q##K = LDPR(rowB, cy##K);                                                                          \
+                        const int2 en = eB[-(K) - 4];                                                                      \
+                        dk##K = __int_as_float(en.x); cy##K = en.y;                                                        \
+                    }
+                    for (int t = 0; t <= Tmax; t += 4, eB -= 4, bE -= 4, cnt += 4) {
+                        if (t == tsw) { rowB = rowB0; eB += 16; }
+                        if (t - 4 == tsw) { uJ = uJ1; cnt += dcnt; bE += dbE; }
+                        CCSX_B_STEP(0, 1) CCSX_B_STEP(1, 2) CCSX_B_STEP(2, 3) CCSX_B_STEP(3, 0)
+                    }
+#undef CCSX_B_STEP
+                    // zero row I+1 of beta; beta(0,0)
+                    const int org_ = pitch == S ? 0 : -bdlo;
+                    if (have) for (int x = l16; x < rowsz; x += 16) sGB[sBoff[myr] - org_ + (I + 1) * rowsz + x] = 0.0f;
+                    if (have && l16 == 0) sB00[myr] = sGB[sBoff[myr]];
+                }
+#undef LDPR
+              } else {
+                // ---- long unit: one read per wave, lane = row, the plain loop (alpha-only or beta-only)
+                const int tk = (fu - 2 * nquad) >> 1, mode = 1 + ((fu - 2 * nquad) & 1);      // 1: alpha only, 2: beta only
+                const int myr = rfl((int)sTask[tk].x);
+                const int row = lane;
+                const int I = rfl(sI[myr]);
+                const int Tmax = I + J;
                 const int sd = sStrand[myr];
                 const int2 *CJ = sColJ[sd];
                 const bool rowok = row <= I;
@@ -2394,14 +2492,12 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int band = sBand[myr];
                 const int pitch = band & 255, rowsz = (band >> 8) & 255, bdlo = (int)((unsigned)band >> 24) - 128, bdhi = bdlo + ((band >> 16) & 255) - 1;
                 const int jlo = (row + bdlo > 0) ? row + bdlo : 0, jhi = (row + bdhi < J) ? row + bdhi : J;
-                // the lane's rows of sCTX, as byte offsets (sObs holds them in that form)
+                // the lane's rows of sCTX, as byte offsets
                 const int op = OBS_CODE((row >= 1 && rowok) ? (int)sObs[myr][row - 1] : 12);   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
                 const int oc = OBS_CODE((row < I) ? (int)sObs[myr][row] : 12);                  // o_i;     12 = no base: row I emits nothing more
                 const char *rowA = (const char *)sCTX + op, *rowB = (const char *)sCTX + oc;
-                // activity windows: alpha computes column j = t - row for t in [row, row+J]; beta computes column
-                // jb = J - (t - (I - row)) for t in [I-row, I-row+J].  All LDS addresses advance by a constant per step, so the steps of
-                // an iteration address with immediates.
-                // (alpha reaches column jlo at t = row + jlo; beta starts at column jhi at t = (I - row) + (J - jhi))
+                // activity windows: alpha computes column j = t - row for t in [row + jlo, row + jhi]; beta computes column
+                // jb = J - (t - (I - row)) for t in [I - row + J - jhi, I - row + J - jlo]
                 const int tA0 = rowok ? row + jlo : (1 << 20), tB0 = rowok ? I - row + J - jhi : (1 << 20);
                 const float one0 = (row == 0) ? 1.0f : 0.0f, oneI = (row == I) ? 1.0f : 0.0f;
                 const int2 *cA = CJ - row;
@@ -2414,158 +2510,64 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 float bcur = oneI, dndiag = 0.0f;
                 // a lane whose step is not on the band holds a ZERO running cell (SPEC v6: its neighbours read the cell past the band's edge as zero); row 0 / row I
                 // keep their start value until their first step, which is the sweep's first
-                const unsigned uJ = (unsigned)(jhi - jlo);
-                const int tAc = rowok ? row : (1 << 20);             // (the plain loop carries ME / DL of the previous column from column 0 on)
+                const unsigned uJ = rowok ? (unsigned)(jhi - jlo) : 0u;   // (a lane beyond the read's rows: tA0 / tB0 keep it off; its jlo .. jhi may be an empty, i.e. negative, range)
+                const int tAc = rowok ? row : (1 << 20);             // (the loop carries ME / DL of the previous column from column 0 on)
                 const unsigned uJc = (unsigned)J;
-#define CCSX_FILL_STEP(T, AOFF, BOFF, DOA, DOB, CJA, CJB)                                                                  \
-                {                                                                                                          \
-                    if (DOA) {                                                                                               \
-                        const float up = wave_shr1_f32_z(acur);      /* all rows of the read shift together (full exec) */     \
-                        float nv = 0.0f;                                                                                     \
-                        if ((unsigned)((T) - tAc) <= uJc) {          /* alpha, column j = T - row of the window */            \
-                            const float2 pr = *(const float2 *)(rowA + (CJA).y);                                             \
-                            const float dlc = __int_as_float((CJA).x);                                                       \
-                            const float m = updiag * mePrev, dl = acur * dlPrev;                                              \
-                            const float gmm = m + dl;                                                                        \
-                            const float st = up * pr.y;              /* row 0 and column J read zero entries: +0 */           \
-                            if ((unsigned)((T) - tA0) <= uJ) { gA[(AOFF)] = gmm; nv = gmm + st; }   /* ... and on the band */ \
-                            mePrev = pr.x; dlPrev = dlc;                                                                     \
-                        }                                                                                                    \
-                        acur = nv;                                                                                           \
-                        updiag = up;                                                                                         \
-                    }                                                                                                        \
-                    if (DOB) {                                                                                               \
-                        const float dn = wave_shl1_f32_z(bcur);                                                                \
-                        float nv = 0.0f;                                                                                     \
-                        if ((unsigned)((T) - tB0) <= uJ) {           /* beta, column jb = J - (T - (I - row)), on the band */ \
-                            const float2 pr = *(const float2 *)(rowB + (CJB).y);                                             \
-                            const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                                   \
-                            const float t3 = __int_as_float((CJB).x) * bcur;                                                 \
-                            const float bv = (t1 + t2) + t3;                                                                 \
-                            bB[(BOFF)] = bv;                                                                                 \
-                            nv = bv;                                                                                         \
-                        }                                                                                                    \
-                        bcur = nv;                                                                                           \
-                        dndiag = dn;                                                                                         \
-                    }                                                                                                        \
-                }
-                // the column entries (DL_j, context offset) of an iteration are loaded one iteration ahead (unconditionally: an entry
-                // outside 0..J is never used), so only ONE LDS round trip — the (ME, INS) look-up — sits between a step and its data
-#define CCSX_FILL_LOOP(DOA, DOB)                                                                                            \
-                {                                                                                                          \
-                    int2 ca0 = cA[0], ca1 = cA[1], cb0 = cB[1], cb1 = cB[0];                                               \
-                    for (int t = 0; t <= Tmax; t += 2, cA += 2, gA += 2, cB -= 2, bB -= 2) {                               \
-                        const int2 na0 = cA[2], na1 = cA[3], nb0 = cB[-1], nb1 = cB[-2];                                   \
-                        CCSX_FILL_STEP(t, 0, 1, DOA, DOB, ca0, cb0)                                                        \
-                        CCSX_FILL_STEP(t + 1, 1, 0, DOA, DOB, ca1, cb1)                                                    \
-                        ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;                                                        \
-                    }                                                                                                      \
-                }
-                if (!paired) {                                       // a long read (rows 0..63): the plain loop
-                    if (mode == 0) { CCSX_FILL_LOOP(1, 1) }
-                    else if (mode == 1) { CCSX_FILL_LOOP(1, 0) }
-                    else { CCSX_FILL_LOOP(0, 1) }
-                } else {
-                    // a pair of short reads: one sweep per direction, FOUR steps per iteration, software-pipelined look-ups.  Slot k of
-                    // the iteration holds what the step of column c needs — DL (alpha: of column c-1), the (ME, INS) pair of column c —
-                    // and, already, the context offset of the column four steps on; right after its use the slot is refilled for the
-                    // next iteration (the pair from that offset, DL and the offset after next from the staggered table), so a look-up
-                    // has four steps to arrive and nothing is copied between registers.  The only state a step changes under its
-                    // activity mask is the running cell: ME of the previous column is simply the previous slot's pair (the column
-                    // before column 0 is the zero entry with DL = 1, as the boundary cells want it).
-                    // (experiments, timing only, under CCSX_EXP_ONE_ROUND — profiles/r04_fill_lds.txt: the (ME, INS) look-up at ONE address (no bank conflicts),
-                    // the sweep without its per-step column entry, without its gamma / beta store)
-#ifdef CCSX_EXP_FILL_FIXED_PAIR
-#define LDPR(ROWP, OFF) (*(const float2 *)((const char *)sCTX + (((OFF) >> 20) << 3)))
-#else
-#define LDPR(ROWP, OFF) (*(const float2 *)((ROWP) + (OFF)))
-#endif
-#ifdef CCSX_EXP_FILL_NO_ENTRY
-#define LDEN(PTR, IDX) (PTR##0x)
-#else
-#define LDEN(PTR, IDX) ((PTR)[(IDX)])
-#endif
-#ifdef CCSX_EXP_FILL_NO_MASK                                 // (the steps without their activity test: what the two VALU + exec bookkeeping per step cost)
-#define FILL_ACTIVE(C) true
-#else
-#define FILL_ACTIVE(C) (C)
-#endif
-#ifdef CCSX_EXP_FILL_NO_STORE
-#define STGB(LV, V) ((void)(V))
-#else
-#define STGB(LV, V) ((LV) = (V))
-#endif
-                    if (mode != 2) {
-                        const int2 *eA = sEA[sd] + (FE_ALO - row);                       // eA[x] = the entry of column x - row
-#define CCSX_A_INIT(K) const int2 ea##K = eA[K], fa##K = eA[(K) - 4]; float dl##K = __int_as_float(ea##K.x); int cx##K = ea##K.y; float2 p##K = LDPR(rowA, fa##K.y);
-                        CCSX_A_INIT(0) CCSX_A_INIT(1) CCSX_A_INIT(2) CCSX_A_INIT(3)
-                        const int2 eA0x = ea0; (void)eA0x;
-#undef CCSX_A_INIT
-                        int cnt = -tA0;
-#define CCSX_A_STEP(K)                                                                                                     \
+                if (mode == 1) {
+                    int2 ca0 = cA[0], ca1 = cA[1];
+                    for (int t = 0; t <= Tmax; t += 2, cA += 2, gA += 2) {
+                        const int2 na0 = cA[2], na1 = cA[3];
+#define CCSX_LA_STEP(T, AOFF, CJA)                                                                                         \
                         {                                                                                                  \
-                            const float up = wave_shr1_f32_z(acur);                                                        \
-                            {                                        /* alpha, column j = t + K - row */                   \
-                                const float m = updiag * mePrev, dl = acur * dl##K;                                        \
+                            const float up = wave_shr1_f32_z(acur);  /* all rows of the read shift together (full exec) */ \
+                            float nv = 0.0f;                                                                               \
+                            if ((unsigned)((T) - tAc) <= uJc) {      /* alpha, column j = T - row of the window */        \
+                                const float2 pr = *(const float2 *)(rowA + (CJA).y);                                       \
+                                const float dlc = __int_as_float((CJA).x);                                                 \
+                                const float m = updiag * mePrev, dl = acur * dlPrev;                                        \
                                 const float gmm = m + dl;                                                                  \
-                                const float st = up * p##K.y;        /* row 0 and column J read zero entries: +0 */        \
-                                const bool on = FILL_ACTIVE((unsigned)(cnt + (K)) <= uJ);   /* ... if it is on the band */  \
-                                if (on) STGB(gA[(K)], gmm);                                                                \
-                                acur = on ? gmm + st : 0.0f;                                                               \
+                                const float st = up * pr.y;          /* row 0 and column J read zero entries: +0 */       \
+                                if ((unsigned)((T) - tA0) <= uJ) { gA[(AOFF)] = gmm; nv = gmm + st; }   /* ... on the band */ \
+                                mePrev = pr.x; dlPrev = dlc;                                                               \
                             }                                                                                              \
-                            updiag = up; mePrev = p##K.x;                                                                  \
-                            p##K = LDPR(rowA, cx##K);                                                                      \
-                            const int2 en = LDEN(eA, (K) + 4);                                                             \
-                            dl##K = __int_as_float(en.x); cx##K = en.y;                                                    \
+                            acur = nv;                                                                                     \
+                            updiag = up;                                                                                   \
                         }
-                        for (int t = 0; t <= Tmax; t += 4, eA += 4, gA += 4, cnt += 4) { CCSX_A_STEP(0) CCSX_A_STEP(1) CCSX_A_STEP(2) CCSX_A_STEP(3) }
-#undef CCSX_A_STEP
+                        CCSX_LA_STEP(t, 0, ca0)
+                        CCSX_LA_STEP(t + 1, 1, ca1)
+#undef CCSX_LA_STEP
+                        ca0 = na0; ca1 = na1;
                     }
-                    if (mode != 1) {
-                        const int2 *eB = sEB[sd] + (FE_BLO + J + I - row);               // eB[-x] = the entry of column J + I - row - x
-                        float *bE = sGB + sBoff[myr] + row * pitch + (J + I - row);      // bE[-x] = beta(row, J + I - row - x)
-#define CCSX_B_INIT(K) const int2 eb##K = eB[-(K)], fb##K = eB[4 - (K)]; float dk##K = __int_as_float(eb##K.x); int cy##K = eb##K.y; float2 q##K = LDPR(rowB, fb##K.y);
-                        CCSX_B_INIT(0) CCSX_B_INIT(1) CCSX_B_INIT(2) CCSX_B_INIT(3)
-                        const int2 eB0x = eb0; (void)eB0x;
-#undef CCSX_B_INIT
-                        int cnt = -tB0;
-#define CCSX_B_STEP(K)                                                                                                     \
+                    if (lane == 0) sBase[myr] = sGB[sGoff[myr] + I * pitch + J];   // (alpha(I,J) = gamma(I,J): no stay in the final column)
+                } else {
+                    int2 cb0 = cB[1], cb1 = cB[0];
+                    for (int t = 0; t <= Tmax; t += 2, cB -= 2, bB -= 2) {
+                        const int2 nb0 = cB[-1], nb1 = cB[-2];
+#define CCSX_LB_STEP(T, BOFF, CJB)                                                                                         \
                         {                                                                                                  \
                             const float dn = wave_shl1_f32_z(bcur);                                                        \
-                            {                                        /* beta, column jb = J + I - row - (t + K) */         \
-                                const float t1 = q##K.x * dndiag, t2 = q##K.y * dn;                                        \
-                                const float t3 = dk##K * bcur;                                                             \
+                            float nv = 0.0f;                                                                               \
+                            if ((unsigned)((T) - tB0) <= uJ) {       /* beta, column jb = J - (T - (I - row)), on the band */ \
+                                const float2 pr = *(const float2 *)(rowB + (CJB).y);                                       \
+                                const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                             \
+                                const float t3 = __int_as_float((CJB).x) * bcur;                                           \
                                 const float bv = (t1 + t2) + t3;                                                           \
-                                const bool on = FILL_ACTIVE((unsigned)(cnt + (K)) <= uJ);                                  \
-                                if (on) STGB(bE[-(K)], bv);                                                                \
-                                bcur = on ? bv : 0.0f;                                                                     \
+                                bB[(BOFF)] = bv;                                                                           \
+                                nv = bv;                                                                                   \
                             }                                                                                              \
+                            bcur = nv;                                                                                     \
                             dndiag = dn;                                                                                   \
-                            q##K = LDPR(rowB, cy##K);                                                                      \
-                            const int2 en = LDEN(eB, -(K) - 4);                                                            \
-                            dk##K = __int_as_float(en.x); cy##K = en.y;                                                    \
                         }
-                        for (int t = 0; t <= Tmax; t += 4, eB -= 4, bE -= 4, cnt += 4) { CCSX_B_STEP(0) CCSX_B_STEP(1) CCSX_B_STEP(2) CCSX_B_STEP(3) }
-#undef CCSX_B_STEP
+                        CCSX_LB_STEP(t, 1, cb0)
+                        CCSX_LB_STEP(t + 1, 0, cb1)
+#undef CCSX_LB_STEP
+                        cb0 = nb0; cb1 = nb1;
                     }
-#undef LDPR
-#undef LDEN
-#undef STGB
-#undef FILL_ACTIVE
-                }
-#undef CCSX_FILL_LOOP
-#undef CCSX_FILL_STEP
-                const int basel = paired ? (half << 5) : 0;
-                // (a lane's running cell is zero once its row has left the band, so alpha(I,J) = gamma(I,J) — no stay in the final column — and beta(0,0) are read back
-                // from the cells the wave has just stored)
-                if (mode != 1) {                                     // zero row I+1 of beta; beta(0,0)
                     const int org_ = pitch == S ? 0 : -bdlo;      // (row layout: no origin shift)
-                    if (row < rowsz) sGB[sBoff[myr] - org_ + (I + 1) * rowsz + row] = 0.0f;   // (rowsz <= 32 = the lanes of a pair's half)
-                    if (row == 0 && (paired || lane == 0)) sB00[myr] = sGB[sBoff[myr]];
+                    if (row < rowsz) sGB[sBoff[myr] - org_ + (I + 1) * rowsz + row] = 0.0f;
+                    if (lane == 0) sB00[myr] = sGB[sBoff[myr]];
                 }
-                if (mode != 2) {
-                    if (row == 0 && (paired || lane == 0)) sBase[myr] = sGB[sGoff[myr] + I * pitch + J];   // (alpha(I,J) itself; its log2 is taken after the barrier)
-                }
+              }
             }
             __syncthreads();
             PHASE(3);

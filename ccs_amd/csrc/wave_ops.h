@@ -21,6 +21,11 @@ __device__ __forceinline__ float wave_shl1_f32(float x, float fill) { return __i
 __device__ __forceinline__ float wave_shr1_f32_z(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), DPP_WAVE_SHR1, 0xf, 0xf, true)); }
 __device__ __forceinline__ float wave_shl1_f32_z(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), DPP_WAVE_SHL1, 0xf, 0xf, true)); }
 
+// rotation by one lane inside each 16-lane DPP row (row_ror:n = 0x120 + n): lane l <- x[(l - 1) & 15] / x[(l + 1) & 15] of its row
+#define DPP_ROW_ROR(n) (0x120 + (n))
+__device__ __forceinline__ float row_ror1_f32(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), DPP_ROW_ROR(1), 0xf, 0xf, false)); }
+__device__ __forceinline__ float row_rol1_f32(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), DPP_ROW_ROR(15), 0xf, 0xf, false)); }
+
 __device__ __forceinline__ int wave_shr1_i32_z(int x) { return __builtin_amdgcn_mov_dpp(x, DPP_WAVE_SHR1, 0xf, 0xf, true); }
 __device__ __forceinline__ int wave_shl1_i32_z(int x) { return __builtin_amdgcn_mov_dpp(x, DPP_WAVE_SHL1, 0xf, 0xf, true); }
 
