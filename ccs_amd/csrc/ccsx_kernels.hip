@@ -1996,6 +1996,23 @@ __device__ __forceinline__ FillBand fill_band_of(int I, int J, int S)
     return b;
 }
 
+// v in the lanes of the wave mask m, 0 elsewhere: one v_cndmask on a mask that already sits in scalar registers
+__device__ __forceinline__ float lanes_or_zero(unsigned long long m, float v)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+}
+
+// the windows a launch piece covers, and the XCD-contiguous order of its blocks: block b -> the (b / 8)-th window of the (b % 8)-th eighth; -1 = no window
+__device__ __forceinline__ int polish_piece_windows(int total, int slot0, int grid) { const int c = total - slot0; return c < 0 ? 0 : (c > grid ? grid : c); }
+__device__ __forceinline__ int xcd_contiguous(unsigned b, int count)
+{
+    const int per = (count + 7) >> 3;
+    const int k = (int)(b >> 3), r = (int)(b & 7u) * per + k;
+    return (k < per && r < count) ? r : -1;
+}
+
 // PWT threads, PWMIN workgroups' worth of waves per SIMD, PWCH reads per gamma/beta chunk: ONE instantiation is shipped, 256 x 4 x 4.  Round 4 measured
 // the 512-thread shape (2 workgroups of 80 KB per CU, 8 reads per chunk) at 14 / 18 / 24 passes and on the configs[4] mix: 2.2 / 2.3 / 1.8 / 1.7 times
 // SLOWER than this one (profiles/r04_c4_shapes.txt; its apparent 2.4x win at 30 passes x 20 kb came from a grid of more than 2^32 threads that covered 23 % of the windows).
@@ -2042,8 +2059,13 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     // ---- locate (zmw, window).  The prologue is a chain of dependent global loads; every level issues all of its
     // loads before the first use (clamped indices instead of branches), so the chain is 4 round trips deep
     // (z-level scalars -> window bounds + per-read metadata + tables -> entry rows -> segments), not one per array.
-    const int bid = slot0 + (int)blockIdx.x;               // (slot0: a batch of more than 2^24 - 256 window slots is launched in pieces, see ccsx_launch_all)
-    if (bid >= P.wstart[P.n_zmw]) return;                  // (the grid covers the slot capacity, the map only the windows there are)
+    // XCD-aware order: block b runs on XCD b % 8 (observed, a speed matter only), every XCD has its own L2, and neighbouring windows of a ZMW share the lines of
+    // their entry rows, dirty masks and read segments — so XCD x takes the x-th CONTIGUOUS eighth of the windows there are, not every eighth window
+    // (slot0: a batch of more than 2^24 - 256 window slots is launched in pieces, see ccsx_launch_all; the grid covers the slot capacity, a multiple of 8,
+    // the map only the windows there are)
+    const int nwin_here = polish_piece_windows(P.wstart[P.n_zmw], slot0, (int)gridDim.x);
+    const int bid = slot0 + xcd_contiguous(blockIdx.x, nwin_here);
+    if (bid < slot0) return;
     const int z = P.wslot_zmw[bid];                         // device-built compact map (k_wmap): no dependent search
     const int wbo = P.wb_off[z], nw = P.nwin[z], Ld = P.draft_len[z];
     const int r0 = P.read_off[z], nreads = P.nreads_used[z];
@@ -2365,7 +2387,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             //   long units — one read per wave (lane = row), alpha and beta on different waves.
             // alpha(I,J) / beta(0,0) of a read meet in LDS, and every wave derives the reads' validity from them after the barrier (lane = read; identical values
             // in every wave: no second barrier).  Eight short reads = two quads = four units: every wave runs one sweep per chunk.
+#ifdef CCSX_EXP_NO_FILL                                     // experiment (timing only, wrong results)
+            const int nquad = 0, nunit_f = 0;
+#else
             const int nquad = (nshort + 3) >> 2, nunit_f = 2 * nquad + 2 * nlong;
+#endif
             for (int fu = wave; fu < nunit_f; fu += (PWT / 64)) {
               if (fu < 2 * nquad) {
                 // ---- quad unit.  Lane l of a DPP row owns read rows l and l + 16 (a short segment has at most 32 rows): row i is on the band for the 15-or-so
@@ -2417,9 +2443,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         const float dl = acur * dl##K;                                                                     \
                         const float gmm = mnext + dl;                                                                      \
                         const float st = up * p##K.y;                /* row 0 and column J read zero entries: +0 */        \
-                        const bool on = (unsigned)(cnt + (K)) <= uJ;                                                       \
-                        if (on) gA[(K)] = gmm;                                                                             \
-                        acur = on ? gmm + st : 0.0f;                                                                       \
+                        const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)(cnt + (K)), uJ, 37 /* ule */);    \
+                        if (__builtin_amdgcn_inverse_ballot_w64(on)) gA[(K)] = gmm;                                        \
+                        acur = lanes_or_zero(on, gmm + st);          /* (ONE compare: the mask serves the store's exec and the select) */ \
                         mnext = up * p##K.x;                                                                               \
                         p##K = LDPR(rowA, cx##K);                                                                          \
                         const int2 en = eA[(K) + 4];                                                                       \
@@ -2458,9 +2484,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         const float t2 = q##K.y * dn;                                                                      \
                         const float t3 = dk##K * bcur;                                                                     \
                         const float bv = (t1next + t2) + t3;                                                               \
-                        const bool on = (unsigned)(cnt + (K)) <= uJ;                                                       \
-                        if (on) bE[-(K)] = bv;                                                                             \
-                        bcur = on ? bv : 0.0f;                                                                             \
+                        const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)(cnt + (K)), uJ, 37 /* ule */);    \
+                        if (__builtin_amdgcn_inverse_ballot_w64(on)) bE[-(K)] = bv;                                        \
+                        bcur = lanes_or_zero(on, bv);                                                                      \
                         t1next = q##KN.x * dn;                       /* (slot KN holds the pair of the next step's column) */ \
                         q##K = LDPR(rowB, cy##K);                                                                          \
                         const int2 en = eB[-(K) - 4];                                                                      \
@@ -2947,8 +2973,8 @@ __global__ __launch_bounds__(256) void k_kinetics(KParams P, int slot0)
     __shared__ short2 sTask[PW_MAXREADS];
     __shared__ int sNT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = slot0 + (int)blockIdx.x;
-    if (bid >= P.wstart[P.n_zmw]) return;
+    const int bid = slot0 + xcd_contiguous(blockIdx.x, polish_piece_windows(P.wstart[P.n_zmw], slot0, (int)gridDim.x));   // (as k_polish)
+    if (bid < slot0) return;
     const int z = P.wslot_zmw[bid];
     const int w = bid - P.wstart[z];
     const int nw = P.nwin[z];
@@ -3265,10 +3291,10 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
     // larger batch would silently lose its tail (round 4 met exactly this with a 512-thread experiment: 75 % of the ZMWs "failed").  The slots are therefore
     // launched in pieces of at most 2^24 - 256 workgroups (just under the limit, so that a 16384-ZMW batch of 10 kb inserts — 8.5 M slots of capacity — is ONE launch:
     // the profile's per-launch average and bench.py's per-batch duration then describe the same thing; CCSX_POLISH_MAX_BLOCKS: a test hook that forces small pieces).
-    static const long long max_blocks = [] { const char *e = getenv("CCSX_POLISH_MAX_BLOCKS"); long long v = e ? atoll(e) : 0; return v > 0 ? v : (1ll << 24) - 256; }();
+    static const long long max_blocks = [] { const char *e = getenv("CCSX_POLISH_MAX_BLOCKS"); long long v = e ? atoll(e) : 0; return v > 8 ? (v & ~7ll) : (1ll << 24) - 256; }();   // (a multiple of 8: the kernels take their windows in XCD-contiguous order)
     for (long long s0 = 0; s0 < P.total_wslots; s0 += max_blocks) {
         const unsigned nb = (unsigned)((P.total_wslots - s0) < max_blocks ? (P.total_wslots - s0) : max_blocks);
-        hipLaunchKernelGGL((k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>), dim3(nb), dim3(PW_THREADS),
+        hipLaunchKernelGGL((k_polish_t<PW_THREADS, PW_MINWAVES, PW_CHUNK_READS>), dim3((nb + 7u) & ~7u), dim3(PW_THREADS),
                            (size_t)P.pw_obs_bytes + (size_t)P.pw_gb_floats * 4, st, P, (int)s0);
         LAUNCH_CHECK("k_polish");
     }
@@ -3276,7 +3302,7 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
     if (P.opts.hifi_kinetics) {
         for (long long s0 = 0; s0 < P.total_wslots; s0 += max_blocks) {
             const unsigned nb = (unsigned)((P.total_wslots - s0) < max_blocks ? (P.total_wslots - s0) : max_blocks);
-            hipLaunchKernelGGL(k_kinetics, dim3(nb), dim3(256), 0, st, P, (int)s0);
+            hipLaunchKernelGGL(k_kinetics, dim3((nb + 7u) & ~7u), dim3(256), 0, st, P, (int)s0);
             LAUNCH_CHECK("k_kinetics");
         }
         trace_sync(st, "k_kinetics");
