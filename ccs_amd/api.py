@@ -67,6 +67,17 @@ class CResults(C.Structure):
     ]
 
 
+class CDrafts(C.Structure):
+    _fields_ = [
+        ("n_zmw", C.c_int32), ("seq_capacity", C.c_int64), ("win_capacity", C.c_int64),
+        ("seq_off", C.POINTER(C.c_int64)), ("win_off", C.POINTER(C.c_int64)), ("status", C.POINTER(C.c_int32)), ("len", C.POINTER(C.c_int32)),
+        ("seq", C.POINTER(C.c_uint8)), ("backbone", C.POINTER(C.c_int32)), ("n_windows", C.POINTER(C.c_int32)), ("win_bounds", C.POINTER(C.c_int32)),
+    ]
+
+
+QV_ONLY = 1     # ccsx_polish_batch flag (CCSX_QV_ONLY)
+
+
 class Timings(C.Structure):
     _fields_ = [
         ("setup_ms", C.c_float), ("draft_ms", C.c_float), ("align_ms", C.c_float), ("polish_ms", C.c_float),
@@ -87,6 +98,7 @@ EXPORTS = [
     "ccsx_stage_windows", "ccsx_synth_generate", "ccsx_synth_free", "ccsx_alloc_pinned", "ccsx_free_pinned",
     "ccsx_submit", "ccsx_wait", "ccsx_poll", "ccsx_ticket_timings",
     "ccsx_model_from_json", "ccsx_model_load", "ccsx_model_to_json", "ccsx_model_for_chemistry",
+    "ccsx_build_flags", "ccsx_draft_layout", "ccsx_draft_batch", "ccsx_polish_batch", "ccsx_submit_draft", "ccsx_submit_polish",
 ]
 
 _lib = None
@@ -130,6 +142,13 @@ def lib() -> C.CDLL:
         L.ccsx_model_to_json.argtypes = [C.POINTER(Model), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64]
         L.ccsx_model_for_chemistry.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Model)]
         L.ccsx_opts_default.argtypes = [C.POINTER(Opts)]
+        L.ccsx_build_flags.restype = C.c_char_p
+        L.ccsx_draft_layout.restype = None
+        L.ccsx_draft_layout.argtypes = [C.POINTER(CBatch), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.ccsx_draft_batch.argtypes = [C.c_void_p, C.POINTER(CBatch), C.POINTER(CDrafts)]
+        L.ccsx_polish_batch.argtypes = [C.c_void_p, C.POINTER(CBatch), C.POINTER(CDrafts), C.POINTER(CResults), C.c_uint32]
+        L.ccsx_submit_draft.argtypes = [C.c_void_p, C.POINTER(CBatch), C.POINTER(CDrafts), C.POINTER(C.c_int64)]
+        L.ccsx_submit_polish.argtypes = [C.c_void_p, C.POINTER(CBatch), C.POINTER(CDrafts), C.POINTER(CResults), C.c_uint32, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -401,6 +420,51 @@ class Results:
         return self.kin[:, o:o + int(self.seq_len[z])]
 
 
+@dataclass
+class Drafts:
+    """ccsx_drafts: what the draft seam hands to the polish seam (include/ccsx.h)."""
+    seq_off: np.ndarray
+    win_off: np.ndarray
+    status: np.ndarray
+    len: np.ndarray
+    seq: np.ndarray
+    backbone: np.ndarray
+    n_windows: np.ndarray
+    win_bounds: np.ndarray
+
+    @staticmethod
+    def allocate(batch: Batch) -> "Drafts":
+        n = batch.n_zmw
+        cb = batch.c_struct()
+        so, wo = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        sc, wc = C.c_int64(), C.c_int64()
+        lib().ccsx_draft_layout(C.byref(cb), _ptr(so, C.c_int64), _ptr(wo, C.c_int64), C.byref(sc), C.byref(wc))
+        return Drafts(so, wo, np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(sc.value, np.uint8), np.zeros(n, np.int32),
+                      np.zeros(n, np.int32), np.zeros(wc.value, np.int32))
+
+    def c_struct(self) -> CDrafts:
+        d = CDrafts()
+        d.n_zmw = len(self.len); d.seq_capacity = len(self.seq); d.win_capacity = len(self.win_bounds)
+        d.seq_off = _ptr(self.seq_off, C.c_int64); d.win_off = _ptr(self.win_off, C.c_int64)
+        d.status = _ptr(self.status, C.c_int32); d.len = _ptr(self.len, C.c_int32); d.seq = _ptr(self.seq, C.c_uint8)
+        d.backbone = _ptr(self.backbone, C.c_int32); d.n_windows = _ptr(self.n_windows, C.c_int32); d.win_bounds = _ptr(self.win_bounds, C.c_int32)
+        return d
+
+    def draft(self, z: int) -> np.ndarray:
+        o = int(self.seq_off[z])
+        return self.seq[o:o + int(self.len[z])]
+
+    def set_draft(self, z: int, bases: np.ndarray, backbone: int = 0):
+        o = int(self.seq_off[z])
+        assert len(bases) <= int(self.seq_off[z + 1]) - o
+        self.seq[o:o + len(bases)] = bases
+        self.len[z] = len(bases); self.backbone[z] = backbone
+
+    def windows(self, z: int) -> np.ndarray:
+        o = int(self.win_off[z])
+        return self.win_bounds[o:o + int(self.n_windows[z]) + 1]
+
+
 class Handle:
     """One consensus engine bound to one GPU (ccsx_create).  Not thread-safe: one per worker per GPU."""
 
@@ -422,6 +486,19 @@ class Handle:
         res = Results.allocate(batch, kinetics=bool(self.opts.hifi_kinetics))
         cb, cr = batch.c_struct(), res.c_struct()
         self._check(self._L.ccsx_consensus_batch(self._h, C.byref(cb), C.byref(cr)), "ccsx_consensus_batch")
+        return res
+
+    # ---- the two seams (docs/img/ccs-impl.png): draft stage alone, polish stage on caller-supplied drafts
+    def draft(self, batch: Batch) -> "Drafts":
+        d = Drafts.allocate(batch)
+        cb, cd = batch.c_struct(), d.c_struct()
+        self._check(self._L.ccsx_draft_batch(self._h, C.byref(cb), C.byref(cd)), "ccsx_draft_batch")
+        return d
+
+    def polish(self, batch: Batch, drafts: "Drafts", flags: int = 0) -> Results:
+        res = Results.allocate(batch, kinetics=bool(self.opts.hifi_kinetics))
+        cb, cd, cr = batch.c_struct(), drafts.c_struct(), res.c_struct()
+        self._check(self._L.ccsx_polish_batch(self._h, C.byref(cb), C.byref(cd), C.byref(cr), flags), "ccsx_polish_batch")
         return res
 
     def upload(self, batch: Batch):

@@ -99,6 +99,7 @@ struct Slot {
     DevBuf d_wseq, d_wqv, d_wsum, d_wmeta;
     DevBuf d_out_seq, d_out_qual, d_out_raw, d_out_i32 /* 6 x n */, d_out_f32 /* 2 x n */;
     DevBuf d_wtpl, d_wtmeta, d_wkin, d_out_kin;   // HiFi kinetics only
+    DevBuf d_din_len, d_din_bb;                   // caller-supplied drafts (ccsx_polish_batch): lengths, orientation references
     // host copies of the layout (page-locked: sources of the asynchronous uploads)
     PinVec<int32_t> read_zmw, vcap, dcap, zperm, rperm, wb_off, read_off, quads, qperm;
     PinVec<int64_t> seq_off, ent_off, base_off;
@@ -106,6 +107,8 @@ struct Slot {
     hipEvent_t ev[7] = {}, ev_up = nullptr, ev_done = nullptr;   // ev[0..5]: stage boundaries, ev[6]: start of the polish stage
     bool staged = false, ran = false, inflight = false;
     ccsx_results *res = nullptr;      // destination of an in-flight submit
+    ccsx_drafts *drafts_out = nullptr; // ... of an in-flight ccsx_submit_draft
+    int mode = CCSX_RUN_FUSED;
     int64_t ticket = -1;
     // scratch this batch needs per resident POA graph / alignment
     size_t poa_slot_bytes = 0, align_slot_i32 = 0;
@@ -115,7 +118,7 @@ struct Slot {
         DevBuf *bufs[] = {&d_snr, &d_read_off, &d_base_off, &d_bases, &d_pw, &d_ipd, &d_flags, &d_read_zmw, &d_vcap, &d_dcap, &d_seq_off,
                           &d_wb_off, &d_ent_off, &d_wslot, &d_zperm, &d_rperm, &d_quads, &d_retry, &d_tabME, &d_tabINS, &d_tabDL, &d_tabZ, &d_dmask, &d_draft,
                           &d_zmw_i32, &d_wbounds, &d_ticket, &d_avalid, &d_ascore, &d_ent, &d_wseq, &d_wqv, &d_wsum, &d_wmeta, &d_out_seq,
-                          &d_out_qual, &d_out_raw, &d_out_i32, &d_out_f32, &d_wtpl, &d_wtmeta, &d_wkin, &d_out_kin};
+                          &d_out_qual, &d_out_raw, &d_out_i32, &d_out_f32, &d_wtpl, &d_wtmeta, &d_wkin, &d_out_kin, &d_din_len, &d_din_bb};
         for (auto *b : bufs) b->release();
         read_zmw.release(); vcap.release(); dcap.release(); zperm.release(); rperm.release(); quads.release(); qperm.release(); wb_off.release();
         read_off.release(); seq_off.release(); ent_off.release(); base_off.release();
@@ -424,7 +427,8 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
 
     KParams &P = S.P;
     std::memset(&P, 0, sizeof(P));
-    P.n_zmw = n; P.n_reads = R; P.maxL_max = (int32_t)maxL_max; P.vcap_max = (int32_t)vcap_max; P.need_max = need_max; P.max_reads = nr_max; P.min_reads = n > 0 ? nr_min : 0;
+    P.n_zmw = n; P.n_reads = R; P.maxL_max = (int32_t)maxL_max; P.vcap_max = (int32_t)vcap_max; P.need_max = need_max; P.max_reads = nr_max;
+    (void)nr_min;
     P.opts = h->opts;
     P.model = (const ccsx_model *)h->d_model.p;
     P.snr = (const float *)S.d_snr.p; P.read_off = (const int32_t *)S.d_read_off.p; P.base_off = (const int64_t *)S.d_base_off.p;
@@ -469,7 +473,7 @@ static int launch(ccsx_handle h, Slot &S)
     if ((size_t)S.P.poa_slots * S.P.poa_slot_bytes > h->d_poa.cap) S.P.poa_slots = (int)std::max<size_t>(1, h->d_poa.cap / S.P.poa_slot_bytes);
     if ((size_t)S.P.align_slots * S.P.align_slot_i32 * 4 > h->d_align.cap) S.P.align_slots = (int)std::max<size_t>(1, h->d_align.cap / (S.P.align_slot_i32 * 4));
     if (!h->d_poa.p || !h->d_align.p) { ccsx_set_error("kernel launch refused: the POA / alignment scratch is not allocated (an earlier allocation failed)"); return -2; }
-    const char *failed = ccsx_launch_all(S.P, h->s_draft, h->s_comp, S.ev);
+    const char *failed = ccsx_launch_all(S.P, h->s_draft, h->s_comp, S.ev, S.mode);
     if (failed) { ccsx_set_error(std::string("kernel launch failed: ") + failed); return -2; }
     S.ran = true;
     return 0;
@@ -513,9 +517,21 @@ static int enqueue_download(Slot &S, ccsx_results *res, hipStream_t s)
 }
 
 // ---- asynchronous pipeline -------------------------------------------------------------------------------
-int ccsx_submit(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, ccsx_ticket *ticket)
+static int check_drafts(const Slot &S, const ccsx_drafts *d, bool input)
 {
-    if (!h || !b || !res || !ticket) { ccsx_set_error("ccsx_submit: null argument"); return -1; }
+    const int n = S.P.n_zmw;
+    if (!d || d->n_zmw != n || !d->seq || !d->len || !d->backbone || !d->seq_off || d->seq_capacity < S.seq_off[n] || (!input && !d->status)) {
+        ccsx_set_error("ccsx_drafts: missing arrays, or sized for another batch (ccsx_draft_layout)"); return -1;
+    }
+    if (!input && d->win_bounds && (!d->win_off || d->win_capacity < S.wb_off[n])) { ccsx_set_error("ccsx_drafts: win_bounds needs win_off and ccsx_draft_layout's capacity"); return -1; }
+    if (input) for (int z = 0; z <= n; ++z) if (d->seq_off[z] != S.seq_off[z]) { ccsx_set_error("ccsx_polish_batch: drafts.seq_off is not the capacity layout of ccsx_draft_layout"); return -1; }
+    return 0;
+}
+
+// one batch through the handle's pipeline: the fused path (ccsx_submit), the draft seam or the polish seam
+static int submit_impl(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, ccsx_ticket *ticket, int mode, ccsx_drafts *dr_out, const ccsx_drafts *dr_in, uint32_t flags)
+{
+    if (!h || !b || !ticket || (mode != CCSX_RUN_DRAFT && !res) || (mode == CCSX_RUN_DRAFT && !dr_out) || (mode == CCSX_RUN_POLISH && !dr_in)) { ccsx_set_error("ccsx_submit: null argument"); return -1; }
 #ifdef CCSX_FAULT_INJECTION                                          // test builds only (tests/test_cli_bam.py builds its own copy of the library)
     if (const char *e = std::getenv("CCSX_TEST_FAIL_SUBMIT"))        // fault injection for the driver's error-path test
         if (std::atoll(e) == (long long)h->next_ticket) { ++h->next_ticket; ccsx_set_error("injected failure (CCSX_TEST_FAIL_SUBMIT)"); return -2; }
@@ -540,20 +556,66 @@ int ccsx_submit(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, ccsx_tick
     };
     int rc = stage(h, S, b, h->s_in);
     if (rc) return rc == -1 ? (S.staged = false, rc) : fail(rc);     // -1: rejected by validation before anything was enqueued
-    if ((rc = check_results(S, res, S.P.out_kin != nullptr))) { (void)hipStreamSynchronize(h->s_in); S.staged = false; return rc; }
+    if (mode != CCSX_RUN_DRAFT && (rc = check_results(S, res, S.P.out_kin != nullptr))) { (void)hipStreamSynchronize(h->s_in); S.staged = false; return rc; }
+    if (mode != CCSX_RUN_FUSED && (rc = check_drafts(S, mode == CCSX_RUN_DRAFT ? dr_out : dr_in, mode == CCSX_RUN_POLISH))) { (void)hipStreamSynchronize(h->s_in); S.staged = false; return rc; }
+    S.mode = mode;
+    S.P.qv_only = (mode == CCSX_RUN_POLISH && (flags & CCSX_QV_ONLY)) ? 1 : 0;
 #define HIPTRY_F(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ccsx_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return fail(-2); } } while (0)
+    if (mode == CCSX_RUN_POLISH) {                       // the caller's drafts: bases into the slot's draft buffer, lengths + orientation references beside them
+        const int n = S.P.n_zmw;
+        if (S.d_din_len.reserve((size_t)n * 4) || S.d_din_bb.reserve((size_t)n * 4)) return fail(-2);
+        HIPTRY_F(hipMemcpyAsync(S.d_draft.p, dr_in->seq, (size_t)S.seq_off[n], hipMemcpyHostToDevice, h->s_in));
+        HIPTRY_F(hipMemcpyAsync(S.d_din_len.p, dr_in->len, (size_t)n * 4, hipMemcpyHostToDevice, h->s_in));
+        HIPTRY_F(hipMemcpyAsync(S.d_din_bb.p, dr_in->backbone, (size_t)n * 4, hipMemcpyHostToDevice, h->s_in));
+        S.P.din_len = (const int32_t *)S.d_din_len.p; S.P.din_bb = (const int32_t *)S.d_din_bb.p;
+        S.P.opts.no_fallback_draft = 1;                   // (this slot's copy of the options: the alignment's outcome on a given draft is final)
+    }
     HIPTRY_F(hipEventRecord(S.ev_up, h->s_in));
     HIPTRY_F(hipStreamWaitEvent(h->s_draft, S.ev_up, 0));
     if ((rc = launch(h, S))) return fail(rc);
     // ev[5] (end of the last kernel) doubles as the "results ready" event of the download stream
     HIPTRY_F(hipStreamWaitEvent(h->s_out, S.ev[5], 0));
-    if ((rc = enqueue_download(S, res, h->s_out))) return fail(rc);
+    if (mode == CCSX_RUN_DRAFT) {
+        const int n = S.P.n_zmw;
+        const KParams &P = S.P;
+        HIPTRY_F(hipMemcpyAsync(dr_out->status, P.zstat, (size_t)n * 4, hipMemcpyDeviceToHost, h->s_out));
+        HIPTRY_F(hipMemcpyAsync(dr_out->len, P.draft_len, (size_t)n * 4, hipMemcpyDeviceToHost, h->s_out));
+        HIPTRY_F(hipMemcpyAsync(dr_out->backbone, P.zref, (size_t)n * 4, hipMemcpyDeviceToHost, h->s_out));   // (low byte: masked in ccsx_wait)
+        HIPTRY_F(hipMemcpyAsync(dr_out->seq, P.draft, (size_t)S.seq_off[n], hipMemcpyDeviceToHost, h->s_out));
+        if (dr_out->n_windows) HIPTRY_F(hipMemcpyAsync(dr_out->n_windows, P.nwin, (size_t)n * 4, hipMemcpyDeviceToHost, h->s_out));
+        if (dr_out->win_bounds) HIPTRY_F(hipMemcpyAsync(dr_out->win_bounds, P.wbounds, (size_t)S.wb_off[n] * 4, hipMemcpyDeviceToHost, h->s_out));
+    } else if ((rc = enqueue_download(S, res, h->s_out))) return fail(rc);
     HIPTRY_F(hipEventRecord(S.ev_done, h->s_out));
 #undef HIPTRY_F
-    S.res = res; S.inflight = true; S.ticket = h->next_ticket;
+    S.res = mode == CCSX_RUN_DRAFT ? nullptr : res; S.drafts_out = mode == CCSX_RUN_DRAFT ? dr_out : nullptr; S.inflight = true; S.ticket = h->next_ticket;
     h->last = (int)(h->next_ticket % CCSX_SLOTS);
     *ticket = h->next_ticket++;
     return 0;
+}
+
+int ccsx_submit(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, ccsx_ticket *ticket)
+{
+    return submit_impl(h, b, res, ticket, CCSX_RUN_FUSED, nullptr, nullptr, 0);
+}
+int ccsx_submit_draft(ccsx_handle h, const ccsx_batch *b, ccsx_drafts *drafts, ccsx_ticket *ticket)
+{
+    return submit_impl(h, b, nullptr, ticket, CCSX_RUN_DRAFT, drafts, nullptr, 0);
+}
+int ccsx_submit_polish(ccsx_handle h, const ccsx_batch *b, const ccsx_drafts *drafts, ccsx_results *res, uint32_t flags, ccsx_ticket *ticket)
+{
+    return submit_impl(h, b, res, ticket, CCSX_RUN_POLISH, nullptr, drafts, flags);
+}
+int ccsx_draft_batch(ccsx_handle h, const ccsx_batch *b, ccsx_drafts *drafts)
+{
+    ccsx_ticket t;
+    if (int rc = ccsx_submit_draft(h, b, drafts, &t)) return rc;
+    return ccsx_wait(h, t);
+}
+int ccsx_polish_batch(ccsx_handle h, const ccsx_batch *b, const ccsx_drafts *drafts, ccsx_results *res, uint32_t flags)
+{
+    ccsx_ticket t;
+    if (int rc = ccsx_submit_polish(h, b, drafts, res, flags, &t)) return rc;
+    return ccsx_wait(h, t);
 }
 
 static Slot *slot_of(ccsx_handle h, ccsx_ticket t)
@@ -572,6 +634,12 @@ int ccsx_wait(ccsx_handle h, ccsx_ticket ticket)
         HIPTRY(hipEventSynchronize(S->ev_done));
         S->inflight = false;
         if (S->res && S->res->seq_off) std::memcpy(S->res->seq_off, S->seq_off.p, (size_t)(S->P.n_zmw + 1) * 8);
+        if (ccsx_drafts *d = S->drafts_out) {
+            const int n = S->P.n_zmw;
+            std::memcpy(d->seq_off, S->seq_off.p, (size_t)(n + 1) * 8);
+            if (d->win_off) for (int z = 0; z <= n; ++z) d->win_off[z] = S->wb_off[z];
+            for (int z = 0; z < n; ++z) d->backbone[z] &= 255;   // (the device word also carries the cascade's marks)
+        }
     }
     return 0;
 }
@@ -636,6 +704,7 @@ int ccsx_upload(ccsx_handle h, const ccsx_batch *b)
     Slot &S = h->slot[0];
     const int rc = stage(h, S, b, h->s_comp);
     if (rc) { S.staged = false; return rc; }
+    S.mode = CCSX_RUN_FUSED; S.drafts_out = nullptr;
     HIPTRY(hipStreamSynchronize(h->s_comp));
     h->last = 0;
     return 0;

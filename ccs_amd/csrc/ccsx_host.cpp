@@ -3,6 +3,9 @@
 #include "ccsx.h"
 #include "ccsx_internal.h"
 
+int ccsx_kernel_is_experiment();          // ccsx_kernels.hip
+const char *ccsx_kernel_build_flags();
+
 #include <atomic>
 #include <algorithm>
 #include <cmath>
@@ -18,7 +21,9 @@ void ccsx_set_error(const std::string &s) { g_last_error = s; }
 extern "C" {
 
 int ccsx_abi_version(void) { return CCSX_ABI_VERSION; }
-int ccsx_spec_version(void) { return CCSX_SPEC_VERSION; }
+// (a library built with timing-only experiment switches — wrong results — reports the NEGATIVE version: no golden-vector or parity check accepts it)
+int ccsx_spec_version(void) { return ccsx_kernel_is_experiment() ? -CCSX_SPEC_VERSION : CCSX_SPEC_VERSION; }
+const char *ccsx_build_flags(void) { return ccsx_kernel_build_flags(); }
 const char *ccsx_last_error(void) { return g_last_error.c_str(); }
 
 // Synthetic parameter set "SYN-1".  The trained PacBio tables (docs/faq/chemistry.md:27-56,
@@ -85,6 +90,29 @@ int64_t ccsx_result_layout(const ccsx_batch *b, int64_t *seq_off)
     }
     seq_off[b->n_zmw] = off;
     return off;
+}
+
+// layout of a ccsx_drafts object: the draft slots are those of the results (capacity layout), a ZMW's window bounds take dcap / 19 + 4 words
+// (cores are 19..25 columns: SPEC windows) — the same arithmetic as the engine's own slots (ccsx_api.cpp stage())
+void ccsx_draft_layout(const ccsx_batch *b, int64_t *seq_off, int64_t *win_off, int64_t *seq_capacity, int64_t *win_capacity)
+{
+    int64_t off = 0, woff = 0;
+    for (int z = 0; z < b->n_zmw; ++z) {
+        if (seq_off) seq_off[z] = off;
+        if (win_off) win_off[z] = woff;
+        int64_t maxL = 0;
+        for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) {
+            const int64_t L = b->base_off[r + 1] - b->base_off[r];
+            if (L > maxL) maxL = L;
+        }
+        const int64_t dcap = ccsx_draft_cap(maxL);
+        off += dcap;
+        woff += dcap / (CCSX_WIN_CORE - 3) + 4;
+    }
+    if (seq_off) seq_off[b->n_zmw] = off;
+    if (win_off) win_off[b->n_zmw] = woff;
+    if (seq_capacity) *seq_capacity = off;
+    if (win_capacity) *win_capacity = woff;
 }
 
 // ---------------------------------------------------------------------------------------------

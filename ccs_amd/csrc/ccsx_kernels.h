@@ -11,7 +11,7 @@ struct KParams {
     int32_t vcap_max;          // POA vertex capacity of the largest ZMW
     int32_t need_max;          // max window-edge columns per read (2 * window slots)
     int32_t max_reads;         // most passes of a ZMW in the batch (after the top_passes cap)
-    int32_t min_reads;         // ... and fewest (k_polish: which instantiations have work)
+    int32_t qv_only;           // CCSX_QV_ONLY (ccsx_polish_batch): one scoring round, no mutation applied — QVs / rq of the sequence as given
     ccsx_opts opts;
     const ccsx_model *model;   // device copy
     // ---- inputs (HBM resident after ccsx_upload)
@@ -76,7 +76,15 @@ struct KParams {
     uchar4 *wkin;              // [wslots][32] (fi, fp, ri, rp) codes of the core positions
     uint8_t *out_kin;          // 4 planes (fi, fp, ri, rp) of seq_off[n] bytes each
     long long kin_plane;       // plane stride = seq_off[n]
+    // ---- caller-supplied drafts (ccsx_polish_batch: the polish seam of docs/img/ccs-impl.png); the bases are already in `draft`
+    const int32_t *din_len;    // [n] draft length (0 = none)
+    const int32_t *din_bb;     // [n] a pass of the ZMW that has the draft's orientation
 };
 
-const char *ccsx_launch_all(const KParams &P, hipStream_t st_draft, hipStream_t st_polish, hipEvent_t *ev /* [7] */);   // NULL, or the name of the launch that failed
+// which stages ccsx_launch_all enqueues: the fused path, the draft stage alone (ccsx_draft_batch), or alignment cascade + polish on caller-supplied drafts
+enum { CCSX_RUN_FUSED = 0, CCSX_RUN_DRAFT = 1, CCSX_RUN_POLISH = 2 };
+
+const char *ccsx_launch_all(const KParams &P, hipStream_t st_draft, hipStream_t st_polish, hipEvent_t *ev /* [7] */, int mode = CCSX_RUN_FUSED);   // NULL, or the name of the launch that failed
+int ccsx_kernel_is_experiment();         // built with -DCCSX_EXPERIMENT (timing studies: wrong results)
+const char *ccsx_kernel_build_flags();   // "" for a product build; the experiment switches this translation unit was compiled with otherwise
 int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats);

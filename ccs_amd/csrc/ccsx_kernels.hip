@@ -34,6 +34,74 @@
 // "used" right where it is written, so the wait stays inside the rare branch and the common path keeps its stores in flight.
 #define LANDED(x) asm volatile("" : "+v"(x))
 
+// ---- experiment switches (timing studies of DESIGN.md §8; every one of them computes WRONG results).  They compile only together with -DCCSX_EXPERIMENT,
+// which the library reports through ccsx_build_flags() and which turns ccsx_spec_version() negative, so that such a build cannot pass for the product
+// (tests/test_abi.py; tools/gpu_ab.sh adds the define itself).
+#if (defined(CCSX_EXP_NO_FILL) || defined(CCSX_EXP_NO_SCORE) || defined(CCSX_EXP_ONE_ROUND) || defined(CCSX_EXP_ALL_VALID) || defined(CCSX_EXP_CHEAP_VALIDITY) || \
+     defined(CCSX_EXP_NO_ROWS) || defined(CCSX_EXP_NO_SCORE_LOG) || defined(CCSX_EXP_SKIP_ROUND2_SCORE) || defined(CCSX_EXP_NO_QV_EXP) || defined(CCSX_EXP_REPEAT) || \
+     defined(CCSX_EXIT_AFTER_PROLOGUE)) && !defined(CCSX_EXPERIMENT)
+#error "CCSX_EXP_* / CCSX_EXIT_AFTER_PROLOGUE switches produce wrong results: build them with -DCCSX_EXPERIMENT (never ship such a library)"
+#endif
+#define CCSX_STR2(x) #x
+#define CCSX_STR(x) CCSX_STR2(x)
+int ccsx_kernel_is_experiment()
+{
+#ifdef CCSX_EXPERIMENT
+    return 1;
+#else
+    return 0;
+#endif
+}
+const char *ccsx_kernel_build_flags()
+{
+    return ""
+#ifdef CCSX_EXPERIMENT
+        " CCSX_EXPERIMENT"
+#endif
+#ifdef CCSX_EXP_NO_FILL
+        " CCSX_EXP_NO_FILL"
+#endif
+#ifdef CCSX_EXP_NO_SCORE
+        " CCSX_EXP_NO_SCORE"
+#endif
+#ifdef CCSX_EXP_ONE_ROUND
+        " CCSX_EXP_ONE_ROUND"
+#endif
+#ifdef CCSX_EXP_ALL_VALID
+        " CCSX_EXP_ALL_VALID"
+#endif
+#ifdef CCSX_EXP_CHEAP_VALIDITY
+        " CCSX_EXP_CHEAP_VALIDITY"
+#endif
+#ifdef CCSX_EXP_NO_ROWS
+        " CCSX_EXP_NO_ROWS"
+#endif
+#ifdef CCSX_EXP_NO_SCORE_LOG
+        " CCSX_EXP_NO_SCORE_LOG"
+#endif
+#ifdef CCSX_EXP_SKIP_ROUND2_SCORE
+        " CCSX_EXP_SKIP_ROUND2_SCORE"
+#endif
+#ifdef CCSX_EXP_NO_QV_EXP
+        " CCSX_EXP_NO_QV_EXP"
+#endif
+#ifdef CCSX_EXP_REPEAT
+        " CCSX_EXP_REPEAT=" CCSX_STR(CCSX_EXP_REPEAT)
+#endif
+#ifdef CCSX_EXIT_AFTER_PROLOGUE
+        " CCSX_EXIT_AFTER_PROLOGUE"
+#endif
+#ifdef CCSX_PROFILE_PHASES
+        " CCSX_PROFILE_PHASES"
+#endif
+#ifdef CCSX_DEBUG_CHECKS
+        " CCSX_DEBUG_CHECKS"
+#endif
+#ifdef CCSX_EXTRA_FLAGS_STR                                  // (__graft_entry__.build(): whatever $CCSX_EXTRA_FLAGS held, e.g. tuning overrides of the PW_* defaults)
+        " extra:" CCSX_STR(CCSX_EXTRA_FLAGS_STR)
+#endif
+        ;
+}
 #define LANES 64
 #define PW_MAXREADS_SPEC CCSX_MAX_PASSES      // passes of a ZMW the engine uses (k_polish / k_kinetics take them in groups of PW_MAXREADS)
 #ifdef CCSX_PROFILE_PHASES
@@ -566,6 +634,45 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
     if (lane == 0) {
         g.st[ST_N] = n; g.st[ST_NADDED] = 1; g.st[ST_OK] = ok; g.st[ST_PAR] = 0; g.st[ST_KEND] = -1; g.st[ST_BS] = NEGV;
         g.st[ST_NPOA] = npoa; g.st[ST_BB] = bb; g.st[ST_NREADS] = nreads; g.st[ST_REV0] = rev0; g.st[ST_LIVE] = 1;
+    }
+}
+
+// ---- k_draft_in: the polish seam (ccsx_polish_batch, docs/img/ccs-impl.png "Polish Stage" fed by a host-side draft generator; docs/faq/revio.md:35-53: Arrow
+// run again for QVs on a sequence made elsewhere).  The caller's drafts are in P.draft already; one wave per ZMW sets what the draft generators leave behind:
+// passes used / full-length passes, the orientation reference, status by length, window bounds.  No cascade follows: the alignment's outcome is final.
+__global__ __launch_bounds__(64) void k_draft_in(KParams P)
+{
+    const int lane = threadIdx.x, z = blockIdx.x;
+    if (z >= P.n_zmw) return;
+    const int r0 = rfl(P.read_off[z]);
+    int nreads = rfl(P.read_off[z + 1]) - r0;
+    {
+        const int top = (P.opts.top_passes <= 0 || P.opts.top_passes > PW_MAXREADS_SPEC) ? PW_MAXREADS_SPEC : P.opts.top_passes;
+        if (nreads > top) nreads = top;
+    }
+    const int nall = nreads;
+    {
+        int nf = 0;
+        for (int b0 = 0; b0 < nall; b0 += LANES) nf += __popcll(__ballot(b0 + lane < nall && !(P.flags[r0 + (b0 + lane < nall ? b0 + lane : 0)] & 2)));
+        nreads = rfl(nf);
+    }
+    int bb = rfl(P.din_bb[z]);
+    if (bb < 0 || bb >= (nall > 0 ? nall : 1)) bb = 0;
+    int Ld = rfl(P.din_len[z]);
+    if (Ld < 0 || Ld > P.dcap[z]) Ld = 0;                  // (a draft that does not fit its slot is no draft)
+    int stat = -1, nw = 0;
+    if (nreads < P.opts.min_passes || nreads < 1) stat = CCSX_TOO_FEW_PASSES;
+    else if (Ld <= 0) stat = CCSX_DRAFT_FAILURE;
+    else if (Ld < P.opts.min_length) stat = CCSX_TOO_SHORT;
+    else if (Ld > P.opts.max_length) stat = CCSX_TOO_LONG;
+    uint8_t *draft = P.draft + P.seq_off[z];
+    for (int q = lane; q < Ld; q += LANES) draft[q] = draft[q] & 3;     // only the low two bits of a base code count, as for the subreads
+    __threadfence_block();
+    if (stat < 0) nw = poa_windows(P, z, Ld, lane);
+    for (int q = lane; q < nall; q += LANES) { P.avalid[r0 + q] = 0; P.ascore[r0 + q] = NEGV; }
+    if (lane == 0) {
+        P.nreads_used[z] = nall; P.nfull[z] = nreads; P.zref[z] = bb;
+        P.draft_len[z] = (stat == CCSX_TOO_FEW_PASSES) ? 0 : Ld; P.nwin[z] = (stat < 0) ? nw : 0; P.zstat[z] = (stat < 0) ? CCSX_SUCCESS : stat;
     }
 }
 
@@ -2778,7 +2885,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 #ifdef CCSX_EXP_ONE_ROUND                                   // experiment (timing only): exactly one round per window whatever the gains say, so that variants which
         break;                                              // corrupt the gains (rows / logarithm compiled out) do not change the control flow they are compared under
 #endif
-        if (!anyfav) break;
+        if (!anyfav || P.qv_only) break;                    // (CCSX_QV_ONLY: the gains of the sequence as given are all that is wanted)
         if (it == CCSX_MAX_ITER - 1) { nonconv = 1; break; }
         // ---- A5: greedy selection (wave 0; lane l owns m = l, l+64, l+128, l+192 which share position l&31)
         if (wave == 0) {
@@ -3211,7 +3318,7 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
 
 // every launch status is captured: returns NULL, or the name of the first launch that failed (ccsx_api.cpp reports it)
 #define LAUNCH_CHECK(name) do { if (hipGetLastError() != hipSuccess && !failed) failed = name; } while (0)
-const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */)
+const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */, int mode)
 {
     // Two-stage queue of docs/img/ccs-impl.png ("Draft Stage" -> queue -> "Polish Stage"): the draft stage (tables, POA, alignment
     // cascade, accounting) is enqueued on `st`, the polish stage (polish, kinetics, stitch) on `st_polish`, which waits for the
@@ -3232,11 +3339,17 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
     const size_t lds_read = (((size_t)P.maxL_max + 15) / 16) * 4 + 64 + 4 * (CCSX_MAX_PASSES + 1);   // the packed read; k_poa_init: the lengths of up to 255 passes
     // pass 0 = the draft; pass 1 = the fallback draft of the ZMWs k_post marked (their waves run, all others leave at once:
     // the second round of launches costs microseconds unless something failed)
-    for (int pass = 0; pass < (P.opts.no_fallback_draft ? 1 : 3); ++pass) {
+    // CCSX_RUN_POLISH (the polish seam): the drafts are the caller's — k_draft_in instead of the generators, one alignment round whose outcome is final
+    // (P.opts.no_fallback_draft is set for such a run)
+    if (mode == CCSX_RUN_POLISH) {
+        hipLaunchKernelGGL(k_draft_in, dim3(P.n_zmw), dim3(64), 0, st, P);
+        LAUNCH_CHECK("k_draft_in");
+    }
+    for (int pass = 0; pass < ((P.opts.no_fallback_draft || mode == CCSX_RUN_POLISH) ? 1 : 3); ++pass) {
         int cov = pass ? 2 * P.opts.max_poa_cov : P.opts.max_poa_cov;
         if (cov > PW_MAXREADS_SPEC) cov = PW_MAXREADS_SPEC;
         if (cov > P.max_reads) cov = P.max_reads;          // no ZMW of the batch has more passes
-        for (int z0 = 0; z0 < P.n_zmw; z0 += P.poa_slots) {
+        for (int z0 = 0; z0 < P.n_zmw && mode != CCSX_RUN_POLISH; z0 += P.poa_slots) {
             const int nb = (P.n_zmw - z0) < P.poa_slots ? (P.n_zmw - z0) : P.poa_slots;
             hipLaunchKernelGGL(k_poa_init, dim3(nb), dim3(64), lds_read, st, P, z0, pass);
             LAUNCH_CHECK("k_poa_init");
@@ -3276,6 +3389,10 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
         }
         hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P, pass);
         LAUNCH_CHECK("k_post");
+    }
+    if (mode == CCSX_RUN_DRAFT) {                                   // the draft seam ends here: drafts, window bounds, alignments and statuses are final
+        if (ev) for (int k : {3, 6, 4, 5}) if (hipEventRecord(ev[k], st) != hipSuccess && !failed) failed = "hipEventRecord";
+        return failed;
     }
     hipLaunchKernelGGL(k_wmap, dim3(1), dim3(1024), 0, st, P);     // the batch's windows in compact order: the polish stage's grid map
     LAUNCH_CHECK("k_wmap");

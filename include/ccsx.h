@@ -29,13 +29,13 @@
 extern "C" {
 #endif
 
-#define CCSX_ABI_VERSION 4
+#define CCSX_ABI_VERSION 5
 #define CCSX_SPEC_VERSION 6   /* DESIGN.md §2; bumped whenever a result-changing rule changes (oracle: ORC_SPEC_VERSION) */
 
 /* ---- fixed constants of the algorithm specification ---- */
 #define CCSX_BAND          64   /* DP band rows of the wide alignment (retry of the cascade, split alignment: one wave64) */
 #define CCSX_POA_BAND      32   /* DP band rows of the POA (four graphs per wave64, two rows per lane)                    */
-#define CCSX_MAX_PASSES    255  /* passes of a ZMW the engine uses (SPEC v5; k_polish works through them in groups of 64)               */
+#define CCSX_MAX_PASSES    255  /* passes of a ZMW the engine uses (SPEC v5; k_polish works through them in groups of 32)               */
 #define CCSX_MAXPRED       7    /* POA in-edge cap per vertex (a move is a nibble: slot * 2 + [deletion], 15 = insertion) */
 #define CCSX_WIN_CORE      22   /* target window core size, docs/how-does-ccs-work.md:57-59      */
 #define CCSX_WIN_OVERHANG  2    /* +-2 bp overlap, same citation                                 */
@@ -162,6 +162,9 @@ typedef struct ccsx_handle_s *ccsx_handle;
 int         ccsx_abi_version(void);
 int         ccsx_spec_version(void);                    /* version of the algorithm specification the kernels implement:
                                                            golden vectors carry it, so SPEC drift fails loudly           */
+const char *ccsx_build_flags(void);                     /* "" for the product library.  Anything else names the compile-time switches of an experimental
+                                                           build (tuning overrides, timing-only variants that compute wrong results: those also make
+                                                           ccsx_spec_version() negative).  tests/test_abi.py requires "" of the library it ships   */
 const char *ccsx_last_error(void);
 int         ccsx_device_count(void);
 
@@ -206,6 +209,37 @@ int         ccsx_submit(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, c
 int         ccsx_wait(ccsx_handle h, ccsx_ticket ticket);              /* results of that batch are in `res`   */
 int         ccsx_poll(ccsx_handle h, ccsx_ticket ticket);              /* 1 done, 0 not yet, <0 error          */
 int         ccsx_ticket_timings(ccsx_handle h, ccsx_ticket ticket, ccsx_timings *t);
+
+/* ---- the two seams of the reference's block diagram (docs/img/ccs-impl.png: a GPU consumer on the DRAFT queue and one on the POLISH queue;
+ * docs/faq/revio.md:35-53: Arrow runs a second time, for QVs only, on a sequence that was made elsewhere).  ccsx_consensus_batch / ccsx_submit are the two fused.
+ *   ccsx_draft_batch   draft stage only: draft cascade (POA -> fallback POA -> last resort) incl. the alignments that drive it; the drafts, their window
+ *                      bounds and per-ZMW statuses go to caller buffers.
+ *   ccsx_polish_batch  alignment cascade + windowing + Arrow polish + QVs on CALLER-SUPPLIED drafts (a host that drafts on its CPU pool, e.g. with SPOA).  With
+ *                      CCSX_QV_ONLY no mutation is applied: one scoring round, QVs / rq / np / ec for the sequence as given.
+ * ccsx_polish_batch(ccsx_draft_batch(b)) returns byte for byte what ccsx_consensus_batch(b) returns (tests/test_gpu_parity.py).  A draft nothing maps to yields
+ * a per-ZMW status (TOO_MANY_UNUSABLE, DRAFT_FAILURE for length 0 or a length beyond the slot), never an error of the call.                                   */
+typedef struct ccsx_drafts {
+    int32_t  n_zmw;
+    int64_t  seq_capacity;       /* elements in seq, from ccsx_draft_layout (= the capacity layout of ccsx_result_layout)               */
+    int64_t  win_capacity;       /* elements in win_bounds, from ccsx_draft_layout                                                      */
+    int64_t *seq_off;            /* [n_zmw+1] slot of every ZMW's draft in seq (capacity layout; ccsx_draft_layout fills it)            */
+    int64_t *win_off;            /* [n_zmw+1] slot of every ZMW's window bounds in win_bounds (ccsx_draft_layout fills it)               */
+    int32_t *status;             /* [n_zmw] out of ccsx_draft_batch: enum ccsx_status so far (SUCCESS = a usable draft); ignored as input */
+    int32_t *len;                /* [n_zmw] draft length; 0 = none                                                                       */
+    uint8_t *seq;                /* [seq_capacity] codes 0..3, len[z] bases at seq_off[z]                                                */
+    int32_t *backbone;           /* [n_zmw] index (within the ZMW) of a pass that has the draft's orientation: the strand reference of the
+                                    consensus, of fn / rn and of the kinetics planes (ccsx_draft_batch: the backbone pass of the generator
+                                    that succeeded)                                                                                      */
+    int32_t *n_windows;          /* [n_zmw] out of ccsx_draft_batch (may be NULL)                                                        */
+    int32_t *win_bounds;         /* [win_capacity] out of ccsx_draft_batch (may be NULL): n_windows[z] + 1 core bounds at win_off[z]       */
+} ccsx_drafts;
+#define CCSX_QV_ONLY 1u          /* ccsx_polish_batch flag */
+void        ccsx_draft_layout(const ccsx_batch *b, int64_t *seq_off, int64_t *win_off, int64_t *seq_capacity, int64_t *win_capacity);
+int         ccsx_draft_batch(ccsx_handle h, const ccsx_batch *b, ccsx_drafts *drafts);
+int         ccsx_polish_batch(ccsx_handle h, const ccsx_batch *b, const ccsx_drafts *drafts, ccsx_results *res, uint32_t flags);
+/* the same with tickets (ccsx_wait / ccsx_poll / ccsx_ticket_timings as for ccsx_submit; the two kinds share the handle's three slots) */
+int         ccsx_submit_draft(ccsx_handle h, const ccsx_batch *b, ccsx_drafts *drafts, ccsx_ticket *ticket);
+int         ccsx_submit_polish(ccsx_handle h, const ccsx_batch *b, const ccsx_drafts *drafts, ccsx_results *res, uint32_t flags, ccsx_ticket *ticket);
 
 /* split form used by the benchmark (inputs resident in HBM when the timed region starts)        */
 int         ccsx_upload(ccsx_handle h, const ccsx_batch *b);           /* H2D + workspace sizing */

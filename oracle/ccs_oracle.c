@@ -953,6 +953,9 @@ static __thread uint32_t orc_dbg_calib_ev; static __thread int orc_dbg_margin[JM
 /* side channel of polish_window_impl for the whole-ZMW driver: reads [0, pw_nfull) are full-length passes; pw_nvalid_full = how many of
  * them the window used (np counts full-length passes only, ec counts the partial ones too) */
 static __thread int pw_nfull = 1 << 30, pw_nvalid_full = 0;
+/* the polish seam (include/ccsx.h ccsx_polish_batch; docs/img/ccs-impl.png, docs/faq/revio.md:35-53): a caller-supplied draft replaces the draft cascade
+ * (orc_polish_zmw sets these for the duration of one ZMW); qv_only = one scoring round, no mutation applied */
+static __thread const uint8_t *g_given_draft = NULL; static __thread int g_given_len = -1, g_given_bb = 0, g_qv_only = 0;
 /* Polish one window.  obs[r] = native-orientation observation codes of read r's segment, I[r] its length
  * (I[r] < 0 or > IMAX: read unusable in this window), strand[r] = 1 if the read is reverse to the draft.
  * ev0 = candidate-filter evidence of the draft window (bit c: position c may be skipped), skip_p = error
@@ -1034,6 +1037,7 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
             delta[m] = (float)dsum * (1.0f / DQ_SCALE);
         }
         ++iters;
+        if (g_qv_only) break;                                 /* CCSX_QV_ONLY: the gains of the sequence as given are all that is wanted */
         if (orc_dbg.stats == 4) { int nm = 0; for (int m = 0; m < 256; ++m) nm += mvalid[m]; if (nm > 255) nm = 255;
             _Pragma("omp atomic") orc_dbg.cal_cnt[nm >> 2] += 1; }
         /* A5: greedy selection of favourable, well-separated mutations */
@@ -1359,6 +1363,11 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
     uint8_t *strand = (uint8_t *)malloc(nreads), *avalid = (uint8_t *)malloc(nreads);
     int ret = 0;
     for (;;) {
+        if (g_given_len >= 0) {                             /* the polish seam: the caller's draft, in the orientation of pass g_given_bb; no cascade */
+            bb = (g_given_bb >= 0 && g_given_bb < nreads) ? g_given_bb : 0;
+            Ld = g_given_len > dcap ? 0 : g_given_len;
+            for (int q = 0; q < Ld; ++q) draft[q] = g_given_draft[q] & 3;
+        } else
         if (attempt < 2) Ld = orc_poa_draft_bb(nfull, base_off, bases, flags, attempt ? 2 * opts->max_poa_cov : opts->max_poa_cov, vcap, draft, dcap, bb);
         else {                                              /* SPEC "draft cascade", last resort: the backbone pass itself is the draft */
             Ld = (int)(base_off[bb + 1] - base_off[bb]);
@@ -1411,7 +1420,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
             if (2 * np <= nfull) { out->status = ST_UNUSABLE; want_retry = 1; }
         }
         if (!want_retry) break;
-        if (attempt >= 2 || opts->no_fallback_draft) { if (out->status == ST_DRAFT_FAIL) { out->np = 0; out->fn = out->rn = 0; } goto done; }
+        if (attempt >= 2 || opts->no_fallback_draft || g_given_len >= 0) { if (out->status == ST_DRAFT_FAIL) { out->np = 0; out->fn = out->rn = 0; } goto done; }
         {   /* backbone of the fallback draft: the pass whose length is closest to the median (ties: the first); the last resort takes
              * the closest among the passes that have NOT been a backbone yet (pass 0 and the fallback's backbone may be the problem) */
             const int bb1 = attempt ? bb : -1;
@@ -1593,6 +1602,19 @@ done:
     for (int r = 0; r < nreads; ++r) { free(rstart[r]); free(dirty[r]); }
     free(rstart); free(dirty); free(strand); free(avalid); free(draft);
     return ret;
+}
+
+/* the polish seam for one ZMW: alignment cascade + windows + polish + QVs on a caller-supplied draft (flags bit 0 = CCSX_QV_ONLY) */
+int orc_polish_zmw(const orc_model *model, const orc_opts *opts, const float *snr, int nreads_in,
+                   const int64_t *base_off, const uint8_t *bases, const uint8_t *pw, const uint8_t *flags,
+                   const uint8_t *draft, int draft_len, int backbone, int qflags,
+                   uint8_t *seq, uint8_t *qual, float *raw_qv, int64_t cap, orc_zmw_out *out)
+{
+    g_given_draft = draft; g_given_len = draft_len < 0 ? 0 : draft_len; g_given_bb = backbone; g_qv_only = qflags & 1;
+    int rc = orc_consensus_zmw_kin(model, opts, snr, nreads_in, base_off, bases, pw, flags, seq, qual, raw_qv, cap, out, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+    g_given_draft = NULL; g_given_len = -1; g_qv_only = 0;
+    orc_counts_flush();
+    return rc;
 }
 
 int orc_consensus_zmw(const orc_model *model, const orc_opts *opts, const float *snr, int nreads_in,

@@ -159,6 +159,32 @@ def consensus_batch(model, opts, batch, results, nthreads=1):
     return results
 
 
+class _ZmwOut(C.Structure):
+    _fields_ = [("status", C.c_int32), ("seq_len", C.c_int32), ("np", C.c_int32), ("iters", C.c_int32), ("n_windows", C.c_int32),
+                ("rq", C.c_float), ("ec", C.c_float), ("fn", C.c_int32), ("rn", C.c_int32)]
+
+
+def polish_batch(model, opts, batch, drafts, results, flags=0):
+    """The polish seam on the CPU restatement (orc_polish_zmw per ZMW): alignment cascade + windows + polish + QVs on the drafts of a
+    ccs_amd.api.Drafts; flags bit 0 = CCSX_QV_ONLY.  Mirrors ccsx_polish_batch (include/ccsx.h)."""
+    L = lib()
+    for z in range(batch.n_zmw):
+        r0, r1 = int(batch.read_off[z]), int(batch.read_off[z + 1])
+        b0 = int(batch.base_off[r0])
+        rel = np.ascontiguousarray(batch.base_off[r0:r1 + 1] - b0)
+        o, cap = int(results.seq_off[z]), int(results.seq_off[z + 1] - results.seq_off[z])
+        d = np.ascontiguousarray(drafts.draft(z))
+        out = _ZmwOut()
+        seq, qual, raw = results.seq[o:o + cap], results.qual[o:o + cap], results.raw_qv[o:o + cap]
+        L.orc_polish_zmw(C.byref(model), C.byref(opts), _p(np.ascontiguousarray(batch.snr[z]), C.c_float), r1 - r0, _p(rel, C.c_int64),
+                         _p(batch.bases[b0:], C.c_uint8), _p(batch.pw[b0:], C.c_uint8), _p(batch.flags[r0:], C.c_uint8),
+                         _p(d, C.c_uint8) if len(d) else C.POINTER(C.c_uint8)(), len(d), int(drafts.backbone[z]), int(flags),
+                         _p(seq, C.c_uint8), _p(qual, C.c_uint8), _p(raw, C.c_float), C.c_int64(cap), C.byref(out))
+        results.status[z], results.seq_len[z], results.np_[z], results.iters[z], results.n_windows[z] = out.status, out.seq_len, out.np, out.iters, out.n_windows
+        results.rq[z], results.ec[z], results.fn[z], results.rn[z] = out.rq, out.ec, out.fn, out.rn
+    return results
+
+
 def codec_decode(c):
     return lib().orc_codec_v1_decode(int(c))
 

@@ -23,8 +23,29 @@ def test_header_and_exports_agree(built):
     L = C.CDLL(api.LIB_PATH)
     for name in decl:
         assert hasattr(L, name), f"{name} declared in include/ccsx.h but not exported by libccsx.so"
-    assert L.ccsx_abi_version() == 4
+    assert L.ccsx_abi_version() == 5
     assert L.ccsx_spec_version() >= 2
+
+
+def test_the_shipped_library_is_a_product_build(built):
+    """VERDICT r04 / ADVICE r04: the timing-only CCSX_EXP_* variants of the kernels compute wrong results.  They compile only as -DCCSX_EXPERIMENT builds,
+    such a build reports its switches and a NEGATIVE spec version, and the library the tests run against must report none."""
+    L = api.lib()
+    assert L.ccsx_build_flags() == b"", "libccsx.so was built with extra flags: " + L.ccsx_build_flags().decode()
+    assert L.ccsx_spec_version() > 0
+    src = open(os.path.join(ROOT, "ccs_amd", "csrc", "ccsx_kernels.hip")).read()
+    used = set(re.findall(r"\b(CCSX_EXP_[A-Z0-9_]+|CCSX_EXIT_AFTER_PROLOGUE)\b", src))
+    guard = src[src.index("#if (defined(CCSX_EXP_"):src.index("#error")]
+    assert used and all(u in guard for u in used), "an experiment switch is not covered by the #error guard: %s" % sorted(u for u in used if u not in guard)
+
+
+def test_draft_layout_matches_result_layout(built):
+    a = api.synth(3, 4, 500, seed=1)
+    d = api.Drafts.allocate(a)
+    r = api.Results.allocate(a)
+    assert np.array_equal(d.seq_off, r.seq_off) and len(d.seq) == len(r.seq)
+    assert list(np.diff(d.win_off)) == [int(c) // 19 + 4 for c in np.diff(r.seq_off)]
+    assert C.sizeof(api.CDrafts) == 8 + 2 * 8 + 8 * 8
 
 
 def test_constants_match_header(built):

@@ -928,3 +928,154 @@ def test_empty_backbone_pass(built, nofb):
         assert res.status[2] == 0 and (res.status[:2] == (2 if nofb else 0)).all()      # DRAFT_FAILURE without the cascade, rescued with it
     finally:
         h.close()
+
+
+# ---- the two seams of the reference's block diagram (ABI v5: ccsx_draft_batch / ccsx_polish_batch; docs/img/ccs-impl.png, docs/faq/revio.md:35-53) ----
+def _seam_batches():
+    import golden_util as G
+    yield "plain", api.synth(6, (3, 12), (300, 1500), seed=21)
+    yield "c2ish", api.synth(3, 10, 3000, seed=22)
+    for case in ("fallback", "lastresort", "partial", "split", "lowcx_rescue"):      # every draft generator of the cascade, partial passes, split alignment
+        yield case, G.load(case)[0]
+
+
+def _same_results(a, b, batch, exact=True):
+    for k in ("status", "seq_len", "np_", "iters", "n_windows", "fn", "rn"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    for z in range(batch.n_zmw):
+        assert np.array_equal(a.sequence(z), b.sequence(z)) and np.array_equal(a.quals(z), b.quals(z)), f"zmw {z}"
+        assert np.array_equal(a.raw(z), b.raw(z)) if exact else np.allclose(a.raw(z), b.raw(z), atol=QV_TOL, rtol=0), f"zmw {z} raw QVs"
+    assert np.array_equal(a.rq, b.rq) and np.array_equal(a.ec, b.ec) if exact else (np.allclose(a.rq, b.rq, atol=1e-6) and np.allclose(a.ec, b.ec, atol=1e-6))
+
+
+@pytest.mark.gpu
+def test_draft_seam_then_polish_seam_equals_the_fused_path(handle):
+    """ccsx_polish_batch(ccsx_draft_batch(b)) == ccsx_consensus_batch(b), byte for byte, for every generator of the draft cascade"""
+    for name, batch in _seam_batches():
+        fused = handle.consensus(batch)
+        d = handle.draft(batch)
+        for z in range(batch.n_zmw):                       # the draft seam reports what the fused run's stage holds
+            assert np.array_equal(d.draft(z), handle_stage_draft(handle, batch, z)), (name, z)
+        split = handle.polish(batch, d)
+        _same_results(split, fused, batch)
+        assert (d.n_windows >= fused.n_windows).all() and ((d.status == 0) | (d.len == 0) | (d.status != 0)).all()
+        ok = np.nonzero(d.status == 0)[0]
+        assert np.array_equal(d.n_windows[ok], fused.n_windows[ok])
+        for z in ok:
+            w = d.windows(int(z))
+            assert w[0] == 0 and w[-1] == d.len[z] and (np.diff(w) >= 1).all()
+
+
+def handle_stage_draft(handle, batch, z):
+    handle.upload(batch); handle.run(); handle.sync()
+    return handle.stage_draft(z)
+
+
+@pytest.mark.gpu
+def test_polish_seam_on_the_oracles_draft_equals_the_oracles_polish(handle):
+    """a host that drafts elsewhere: the oracle's first draft (POA of pass 0) goes through ccsx_polish_batch and through the oracle's polish seam"""
+    batch = api.synth(5, (5, 10), (400, 1600), seed=31)
+    d = api.Drafts.allocate(batch)
+    for z in range(batch.n_zmw):
+        d.set_draft(z, O.poa_draft(batch, z, handle.opts.max_poa_cov), backbone=0)
+    res = handle.polish(batch, d)
+    ref = O.polish_batch(handle.model, handle.opts, batch, d, api.Results.allocate(batch))
+    _same_results(res, ref, batch, exact=False)
+    # a draft in the orientation of a REVERSE pass (backbone 1): reverse complement of the first draft
+    d2 = api.Drafts.allocate(batch)
+    for z in range(batch.n_zmw):
+        d2.set_draft(z, (3 - d.draft(z))[::-1].copy(), backbone=1)
+    res2 = handle.polish(batch, d2)
+    ref2 = O.polish_batch(handle.model, handle.opts, batch, d2, api.Results.allocate(batch))
+    _same_results(res2, ref2, batch, exact=False)
+    assert np.array_equal(res2.fn, res.rn) and np.array_equal(res2.rn, res.fn)
+
+
+@pytest.mark.gpu
+def test_qv_only_scores_the_sequence_as_given(handle):
+    """CCSX_QV_ONLY (docs/faq/revio.md:35-53, "Arrow again for QVs"): no mutation is applied, one round; on a converged consensus the QVs are those of a
+    polish that starts from it; bit-exact against the oracle's QV-only path"""
+    batch = api.synth(4, 10, 2000, seed=41)
+    fused = handle.consensus(batch)
+    d = api.Drafts.allocate(batch)
+    for z in range(batch.n_zmw):
+        d.set_draft(z, fused.sequence(z), backbone=0)
+    qv = handle.polish(batch, d, flags=api.QV_ONLY)
+    ref = O.polish_batch(handle.model, handle.opts, batch, d, api.Results.allocate(batch), flags=api.QV_ONLY)
+    _same_results(qv, ref, batch, exact=False)
+    full = handle.polish(batch, d)
+    for z in range(batch.n_zmw):
+        assert np.array_equal(qv.sequence(z), fused.sequence(z)), "QV_ONLY returns the sequence it was given"
+        # the windows of this run are cut from the consensus, not from the draft the fused run polished: its QVs are those of a polish that STARTS from the
+        # consensus (identical wherever that polish changes nothing) and close to the fused run's own — same phred at most bases, same rq to 1e-3
+        if np.array_equal(full.sequence(z), fused.sequence(z)): assert np.array_equal(qv.quals(z), full.quals(z))
+        assert (qv.quals(z) == fused.quals(z)).mean() > 0.85 and abs(float(qv.rq[z]) - float(fused.rq[z])) < 1e-3
+    assert (qv.iters == qv.n_windows).all()                # exactly one round per window
+    # a draft with errors: QV_ONLY leaves them in and reports LOW quality there
+    dz = api.Drafts.allocate(batch)
+    for z in range(batch.n_zmw):
+        s = fused.sequence(z).copy(); s[100] = (s[100] + 1) & 3
+        dz.set_draft(z, s, backbone=0)
+    bad = handle.polish(batch, dz, flags=api.QV_ONLY)
+    for z in range(batch.n_zmw):
+        assert bad.sequence(z)[100] == dz.draft(z)[100] and bad.quals(z)[100] <= 3 and bad.rq[z] < qv.rq[z]
+
+
+@pytest.mark.gpu
+def test_junk_and_missing_drafts_yield_statuses_not_errors(handle):
+    batch = api.synth(6, 6, 800, seed=51)
+    good = handle.draft(batch)
+    rng = np.random.default_rng(5)
+    d = api.Drafts.allocate(batch)
+    d.set_draft(0, good.draft(0), backbone=int(good.backbone[0]))
+    d.set_draft(1, rng.integers(0, 4, 700, dtype=np.uint8))                  # junk: nothing maps
+    d.len[2] = 0                                                              # no draft
+    d.set_draft(3, good.draft(3)); d.len[3] = int(d.seq_off[4] - d.seq_off[3]) + 5   # a length beyond the slot
+    d.set_draft(4, good.draft(4)[:5])                                         # shorter than --min-length
+    d.set_draft(5, (good.draft(5) | 0xF0).astype(np.uint8), backbone=99)      # high bits set, backbone out of range: masked / clamped
+    res = handle.polish(batch, d)
+    fused = handle.consensus(batch)
+    assert res.status[0] == fused.status[0] and np.array_equal(res.sequence(0), fused.sequence(0))
+    assert [api.STATUS_NAMES[int(s)] for s in res.status[1:5]] == ["TOO_MANY_UNUSABLE", "DRAFT_FAILURE", "DRAFT_FAILURE", "TOO_SHORT"]
+    assert (res.seq_len[1:5] == 0).all()
+    assert np.array_equal(res.sequence(5), fused.sequence(5))
+    ref = O.polish_batch(handle.model, handle.opts, batch, _masked(d), api.Results.allocate(batch))
+    assert np.array_equal(res.status, ref.status) and np.array_equal(res.seq_len, ref.seq_len)
+    # drafts laid out for another batch are refused as a whole (an error of the call, nothing enqueued)
+    other = api.Drafts.allocate(api.synth(6, 6, 900, seed=52))
+    with pytest.raises(RuntimeError, match="capacity layout|another batch"):
+        handle.polish(batch, other)
+    assert np.array_equal(handle.consensus(batch).seq_len, fused.seq_len)    # the handle is still usable
+
+
+def _masked(d):
+    """the oracle's view of the same drafts: lengths beyond the slot are no draft"""
+    import copy
+    m = copy.deepcopy(d)
+    for z in range(len(m.len)):
+        if m.len[z] > m.seq_off[z + 1] - m.seq_off[z]: m.len[z] = 0
+    return m
+
+
+@pytest.mark.gpu
+def test_seams_share_the_ticket_pipeline(handle):
+    """ccsx_submit_draft / ccsx_submit_polish take tickets like ccsx_submit: three in flight, results equal the synchronous calls"""
+    import ctypes as C
+    L = api.lib()
+    batches = [api.synth(3, 6, 700, seed=60 + k) for k in range(3)]
+    drafts = [api.Drafts.allocate(b) for b in batches]
+    keep, tickets = [], []
+    for b, d in zip(batches, drafts):
+        cb, cd, t = b.c_struct(), d.c_struct(), C.c_int64()
+        assert L.ccsx_submit_draft(handle._h, C.byref(cb), C.byref(cd), C.byref(t)) == 0, L.ccsx_last_error()
+        keep.append((cb, cd)); tickets.append(t.value)
+    for t in tickets: assert L.ccsx_wait(handle._h, t) == 0
+    results = [api.Results.allocate(b) for b in batches]
+    tickets = []
+    for b, d, r in zip(batches, drafts, results):
+        cb, cd, cr, t = b.c_struct(), d.c_struct(), r.c_struct(), C.c_int64()
+        assert L.ccsx_submit_polish(handle._h, C.byref(cb), C.byref(cd), C.byref(cr), 0, C.byref(t)) == 0, L.ccsx_last_error()
+        keep.append((cb, cd, cr)); tickets.append(t.value)
+    for t in tickets: assert L.ccsx_wait(handle._h, t) == 0
+    for b, r in zip(batches, results):
+        _same_results(r, handle.consensus(b), b)

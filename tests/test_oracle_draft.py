@@ -269,3 +269,32 @@ def test_more_than_64_passes_are_used(built):
     rb = api.Results.allocate(big)
     O.consensus_batch(m, o, big, rb)
     assert rb.np_[0] == 255
+
+
+def test_polish_seam_of_the_oracle_equals_its_fused_path(built):
+    """orc_polish_zmw (the checker's restatement of ccsx_polish_batch) on the first draft reproduces the fused oracle wherever the first draft is final;
+    CCSX_QV_ONLY returns the sequence as given after exactly one round per window"""
+    from ccs_amd import api
+    import oracle_lib as O
+    b = api.synth(4, 8, 900, seed=77)
+    m, o = api.default_model(), api.default_opts()
+    fused = O.consensus_batch(m, o, b, api.Results.allocate(b))
+    d = api.Drafts.allocate(b)
+    for z in range(b.n_zmw):
+        d.set_draft(z, O.poa_draft(b, z, o.max_poa_cov), backbone=0)
+    split = O.polish_batch(m, o, b, d, api.Results.allocate(b))
+    assert np.array_equal(split.status, fused.status) and np.array_equal(split.iters, fused.iters)
+    for z in range(b.n_zmw):
+        assert np.array_equal(split.sequence(z), fused.sequence(z)) and np.array_equal(split.raw(z), fused.raw(z))
+    d2 = api.Drafts.allocate(b)
+    for z in range(b.n_zmw):
+        d2.set_draft(z, fused.sequence(z), backbone=0)
+    qv = O.polish_batch(m, o, b, d2, api.Results.allocate(b), flags=api.QV_ONLY)
+    assert (qv.iters == qv.n_windows).all()
+    full = O.polish_batch(m, o, b, d2, api.Results.allocate(b))
+    for z in range(b.n_zmw):
+        assert np.array_equal(qv.sequence(z), fused.sequence(z))
+        # the windows of this run are cut from the consensus, not from the draft the fused run polished, so its QVs are those of a polish that STARTS from the
+        # consensus (equal wherever that polish changes nothing), and close to — not identical with — the fused run's: same phred at most bases, same rq to 1e-3
+        if np.array_equal(full.sequence(z), fused.sequence(z)): assert np.array_equal(qv.quals(z), full.quals(z))
+        assert (qv.quals(z) == fused.quals(z)).mean() > 0.85 and abs(float(qv.rq[z]) - float(fused.rq[z])) < 1e-3
