@@ -2294,7 +2294,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     };
     load_obs(ng0, trimflag);
     // ---- step 7, candidate filter: pile-up margin of every window position over the reads with a usable segment (of every group: a ZMW
-    // of more than 64 passes walks its groups from the last to the first here, so that group 0 is the one loaded when the rounds begin)
+    // of more than 32 passes (PW_MAXREADS) walks its groups from the last to the first here, so that group 0 is the one loaded when the rounds begin)
     {
         int nuse = 0, nd = 0;                                 // (wave 0)
         for (int g0 = (ngroups - 1) * PW_MAXREADS; g0 >= 0; g0 -= PW_MAXREADS) {

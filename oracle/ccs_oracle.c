@@ -15,7 +15,7 @@
  *   The product (ccs_amd/, include/ccsx.h) never links, imports or calls it.
  *
  * Steps restated (docs/how-does-ccs-work.md):
- *   :34-51  step 2  draft      -> orc_poa_*      sparse partial-order alignment, adaptive 64-row band
+ *   :34-51  step 2  draft      -> orc_poa_*      sparse partial-order alignment, adaptive 32-row band (POA_BAND)
  *   :53-55  step 3  alignment  -> orc_align      subread -> draft banded global alignment, rstart[]
  *   :57-61  step 4  windowing  -> orc_windows    22 bp cores, +-2 bp overhang, homopolymer-safe breaks
  *   :87-101 step 8  polishing  -> orc_polish_window   Arrow pair-HMM (match/branch/stick/deletion,

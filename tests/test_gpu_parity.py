@@ -176,7 +176,7 @@ def test_empty_and_tiny_reads(handle):
 @pytest.mark.parametrize("kin", [0, 1])
 def test_more_than_64_passes(built, kin):
     """SPEC v5 (docs/faq/accuracy-vs-passes.md:49-52: `--top-passes 0` = unlimited): up to CCSX_MAX_PASSES = 255 passes
-    of a ZMW are used — k_polish and k_kinetics take them in groups of 64, the draft cascade ranks all of them.  100- and 150-pass ZMWs next
+    of a ZMW are used — k_polish and k_kinetics take them in groups of 32 (PW_MAXREADS), the draft cascade ranks all of them.  100- and 150-pass ZMWs next
     to ordinary ones, partial passes behind 70 full ones, a junk first pass (fallback backbone among > 64 passes): bit-exact against the
     oracle, np reports more than 64; a 300-pass ZMW is capped at 255"""
     o = api.default_opts(); o.top_passes = 0; o.hifi_kinetics = kin
