@@ -81,6 +81,10 @@ def kernels_changed_since(rev: str | None) -> bool | None:
     if not rev:
         return None
     try:
+        # (outside a repository `git diff` silently becomes `git diff --no-index REV PATH` and reports a difference: VERDICT r04 — ask for the repository first)
+        top = subprocess.run(["git", "-C", ROOT, "rev-parse", "--show-toplevel"], capture_output=True, text=True, timeout=20)
+        if top.returncode != 0 or os.path.realpath(top.stdout.strip()) != os.path.realpath(ROOT):
+            return None
         r = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", rev.split("+")[0], "--", "ccs_amd/csrc"], capture_output=True, timeout=20)
         return None if r.returncode not in (0, 1) else bool(r.returncode)
     except Exception:
@@ -276,7 +280,10 @@ def reference_concordance(api, np, ccs_bin, sample, cores, seconds, seed=0xC0FFE
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node.  Plain `python bench.py --gpus N`: ONE process, N worker threads, one engine handle per "
+                    "device and no collective anywhere (north_star: independent streams, no RCCL; ctypes releases the GIL inside the library) — the same "
+                    "arrangement as `ccs --gpus all`.  Under torch.distributed.run (WORLD_SIZE set): one rank per GPU, WORLD_SIZE must equal N.  "
+                    "CCSX_BENCH_DEVICES=0,0 (test hook) names the device of every worker, e.g. two workers on one GPU")
     ap.add_argument("--steps", type=int, default=13, help="timed steps (one batch each); the default 13 x 16384 ZMWs = twice the 100k-ZMW job of configs[1]")
     ap.add_argument("--warmup", type=int, default=3, help="untimed steps; at least one per batch slot (3), so that every hipMalloc of the engine happens before the timed region")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="BASELINE.json config shape: c2 (default, the "
@@ -310,9 +317,14 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "WORLD_SIZE" in os.environ                    # under torch.distributed.run: one rank per GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if launched and world != args.gpus:
+        # (a line that says n_gpus = N must have run on N GPUs, and the other way round)
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run plain `python bench.py --gpus N`)")
+    # worker threads of THIS process and their devices: one (the rank's device) under a launcher, N without
+    if launched and world > 1:
         import torch.distributed as dist
         local_rank = int(os.environ.get("CCSX_BENCH_DEVICE", local_rank))   # test hook: several ranks on one GPU (gloo)
         torch.cuda.set_device(local_rank)
@@ -320,8 +332,19 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        devices = [local_rank]
     else:
+        env_dev = os.environ.get("CCSX_BENCH_DEVICES")
+        devices = [int(x) for x in env_dev.split(",")] if env_dev else list(range(args.gpus))
+        if len(devices) != args.gpus:
+            sys.exit(f"bench.py: CCSX_BENCH_DEVICES names {len(devices)} devices, --gpus {args.gpus}")
+        ndev = torch.cuda.device_count()
+        if max(devices) >= ndev:
+            sys.exit(f"bench.py: --gpus {args.gpus} needs devices {devices}, this node has {ndev} (no figure is reported for GPUs that do not exist)")
+        world = args.gpus
+        local_rank = devices[0]
         torch.cuda.set_device(local_rank)
+    nloc = len(devices)
     if not explicit_zmws:
         args.zmws = fit_zmws(args.zmws, args.passes, args.length, world)
 
@@ -340,18 +363,46 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
 
-    # ---- the headline job: synthetic shards of this rank, distinct batches with distinct ZMW ids (deterministic), page-locked
-    job = Job(api, np, rank, world, local_rank, args.zmws, args.passes, args.length, args.distinct, args.steps, args.warmup, args.depth,
-              make_opts(), keep_sample=4096)
+    def on_workers(fn):
+        """fn(worker index) on every worker of this process at once (threads: the library calls release the GIL); results in worker order"""
+        if nloc == 1:
+            return [fn(0)]
+        import threading
+        res, err = [None] * nloc, []
+
+        def body(i):
+            try:
+                res[i] = fn(i)
+            except BaseException as e:                       # noqa: BLE001 (re-raised below)
+                err.append(e)
+        th = [threading.Thread(target=body, args=(i,)) for i in range(nloc)]
+        for t in th: t.start()
+        for t in th: t.join()
+        if err:
+            raise err[0]
+        return res
+
+    # ---- the headline job: synthetic shards of every worker, distinct batches with distinct ZMW ids (deterministic), page-locked
+    jobs = on_workers(lambda i: Job(api, np, rank + i, world, devices[i], args.zmws, args.passes, args.length, args.distinct, args.steps, args.warmup,
+                                    args.depth, make_opts(), keep_sample=4096 if i == 0 else 0))
+    job = jobs[0]
     h = job.h
     t0 = time.time()
-    job.run(max(1, args.warmup), False)                      # untimed: every hipMalloc of the engine happens here
+    on_workers(lambda i: jobs[i].run(max(1, args.warmup), False))    # untimed: every hipMalloc of the engine happens here
     warm_s = time.time() - t0
     barrier()
-    elapsed, kt, (ok, rqsum, rqn, checks) = job.run(args.steps, True)
+    timed = on_workers(lambda i: jobs[i].run(args.steps, True))
     barrier()
+    elapsed, kt, (ok, rqsum, rqn, checks) = timed[0]
+    per_gpu = [{"worker": i, "device": devices[i], "zmws_per_s": round(args.zmws * args.steps / timed[i][0], 2), "ms_per_step": round(timed[i][0] / args.steps * 1e3, 3),
+                "success_frac": timed[i][2][0] / (args.zmws * args.steps)} for i in range(nloc)]
+    if nloc > 1:
+        elapsed = max(t[0] for t in timed)                   # the job is done when its slowest worker is
+        ok = sum(t[2][0] for t in timed) / nloc; checks = sum(t[2][3] for t in timed)
+        rqsum = sum(t[2][1] for t in timed); rqn = sum(t[2][2] for t in timed)
     clocks_after = gpu_clocks(local_rank) if rank == 0 else None     # right after the last timed kernel: the clocks the run settled at
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -407,11 +458,12 @@ def main():
             "metric": "ZMWs/sec (HiFi reads/sec), 10-pass x 10 kb synthetic" if c2 else f"ZMWs/sec, {args.passes} passes x {args.length} bp synthetic",
             "value": round(value, 2), "unit": "ZMWs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            **({"per_gpu": per_gpu, "multi_gpu": "one process, one worker thread and one engine handle per device, no collective (value = all workers' ZMWs / the slowest worker's time)"} if nloc > 1 else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.passes} passes x {args.length} bp synthetic subreads (BASELINE configs[{int(args.workload[1]) - 1}] shape), "
                                    f"{args.zmws} ZMWs per GPU per step, {job.nb} distinct batches, host-pinned -> H2D -> kernels -> D2H, {args.depth} batches in flight",
                        "preset": args.workload, "zmws_per_gpu": args.zmws, "distinct_batches": job.nb, "in_flight": args.depth, "passes": args.passes,
-                       "template_len": args.length, "parallelism": f"zmw-shard x{world}", "model": "SYN-1",
+                       "template_len": args.length, "parallelism": f"zmw-shard x{world}" + ("" if launched or world == 1 else " (worker threads of one process)"), "model": "SYN-1",
                        "hifi_kinetics": bool(args.hifi_kinetics), "candidate_filter": not args.disable_heuristics,
                        "stages": "serial (one compute stream)" if args.serial_stages else "draft stage of batch k+1 under the polish stage of batch k (two compute streams)",
                        "spec_version": int(api.lib().ccsx_spec_version())},
@@ -493,7 +545,7 @@ def main():
             out["roofline"]["valu_algorithmic_frac"] = round(tot * NOMINAL_OPS_PER_CELL * value / VALU_PEAK_LANE_OPS, 4)
             out["roofline"]["valu_algorithmic_note"] = (f"{int(tot)} counted cell updates per ZMW x {NOMINAL_OPS_PER_CELL} nominal ops x {value:.0f} ZMWs/s / "
                                                         f"{VALU_PEAK_LANE_OPS:.3g} lane-ops/s (1024 SIMDs x 32 lanes/cycle x 2.4 GHz)")
-        job.close()
+        for j in jobs: j.close()
         # ---- the other BASELINE shapes through the same pipeline (N=1 only; a few steps each)
         if world == 1 and args.extra:
             extra = {}
@@ -524,7 +576,7 @@ def main():
             out["extra"] = extra
         print(json.dumps(out), flush=True)
     else:
-        job.close()
+        for j in jobs: j.close()
     if dist is not None:
         dist.destroy_process_group()
 

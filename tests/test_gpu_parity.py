@@ -482,6 +482,30 @@ def test_bench_two_ranks_on_one_device(built, tmp_path):
     assert abs(out["value"] - 2 * 48 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3      # whole-job aggregate over both ranks
 
 
+def test_bench_gpus_n_runs_n_workers_in_one_process(built):
+    """plain `python bench.py --gpus 2` must MEAN two GPUs without a launcher and without RCCL — one process, one worker thread and one
+    engine handle per device (here both on GPU 0 through CCSX_BENCH_DEVICES); per-GPU entries, aggregate = all ZMWs / the slowest worker's time"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CCSX_BENCH_DEVICES"] = "0,0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--zmws", "48", "--length", "2000", "--distinct", "2",
+           "--no-cpu-baseline", "--extra", ""]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and len(out["per_gpu"]) == 2 and [g["device"] for g in out["per_gpu"]] == [0, 0]
+    slowest = max(g["ms_per_step"] for g in out["per_gpu"])
+    assert abs(out["ms_per_step"] - slowest) < 1e-6 and abs(out["value"] - 2 * 48 * 3 / (slowest * 3e-3)) / out["value"] < 1e-3
+    assert out["success_frac"] > 0.9 and all(g["success_frac"] > 0.9 for g in out["per_gpu"])
+    # N = 1 keeps its line: no per-GPU block
+    p1 = subprocess.run([a for a in cmd if a not in ("2",)][:2] + ["--gpus", "1"] + cmd[4:], env={k: v for k, v in env.items() if k != "CCSX_BENCH_DEVICES"},
+                        capture_output=True, text=True, timeout=600, cwd=root)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    o1 = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][0])
+    assert o1["n_gpus"] == 1 and "per_gpu" not in o1
+
+
 def test_inserted_blocks_fuzz_matches_oracle(handle):
     """passes carrying 40-200 base blocks of foreign sequence (beyond what the 64-row band can follow) must end
     in the same deliberate outcome on the GPU as in the oracle — same statuses, np, sequences, QVs — never a crash or a hang"""

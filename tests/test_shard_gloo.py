@@ -61,3 +61,17 @@ def test_two_rank_gloo_matches_single_process(built, tmp_path):
     assert len(got) == 7
     for z in range(7):
         assert got[z][0] == ref.sequence(z).tobytes() and got[z][1] == float(ref.rq[z]) and got[z][2] == int(ref.status[z])
+
+
+def test_bench_refuses_gpus_it_does_not_have(built):
+    """`bench.py --gpus N` never reports a number for GPUs that are not there, and a launcher whose world size differs from
+    --gpus is an error, not a one-GPU line labelled N (CPU box: zero devices; a GPU box with one device answers the same for --gpus 2)"""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CCSX_BENCH_DEVICES")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ndev + 1), "--steps", "1", "--warmup", "1", "--zmws", "8", "--no-cpu-baseline", "--extra", ""],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode != 0 and "needs devices" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--zmws", "8", "--no-cpu-baseline", "--extra", ""],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
