@@ -143,6 +143,9 @@ const char *ccsx_kernel_build_flags()
 #define SKIP_MARGIN 6
 #define SKIP_SPREAD 3
 #define SCORE_BAND 5                  // SPEC: half width (read rows) of the mutation scoring band around the window diagonal
+#define PERR_FLOOR 1e-5f              // SPEC v7: smallest per-base error probability that is reported (Q50; nothing measured supports a higher claim)
+#define SKIP_PERR_FLOOR 1e-5f         // SPEC v7: error probability floor of a position the candidate filter skips (Q50)
+#define REP_ERRS 0.2f                 // SPEC v7 "repeat-count floor": a core base inside a period-p tandem tract of L >= REP_MINLEN(p) visible bases reports p_err >= REP_ERRS / L
 #define FILL_MARGIN 2                 // SPEC v6 "banded fill": alpha / beta exist on the diagonals j - i in [min(0, J - I) - (Wr + 2), max(0, J - I) + (Wr + 2)] only
 #define DQ_SCALE 65536.0f
 #define DQ_CLAMP 100.0f
@@ -2080,7 +2083,27 @@ __device__ __forceinline__ float skip_perr(int g)
 {
     if (g < 0) g = 0;
     if (g > 12) g = 12;
-    return 8.0f * det_exp2f(-3.0f * (float)g);
+    const float p = 8.0f * det_exp2f(-3.0f * (float)g);
+    return p < SKIP_PERR_FLOOR ? SKIP_PERR_FLOOR : p;        // SPEC v7: the pile-up supports no claim beyond Q50
+}
+
+// SPEC v7 "repeat-count floor": lane x's longest period-p tandem tract among the visible window bases, from the wave mask m (bit k: v[k] == v[k+p]); 0 = none
+__device__ __forceinline__ int tract_len(unsigned long long m, int x, int p)
+{
+    const int lo = x - p < 0 ? 0 : x - p;
+    const unsigned long long cand = m & ((2ull << x) - 1ull) & ~((1ull << lo) - 1ull);      // the runs that reach x start their last equality at k in [x - p, x]
+    if (!cand) return 0;
+    int best = 0;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {                // the lowest and the highest such k: the same run, or the two runs that touch x
+        const int k = which ? 63 - __clzll((long long)cand) : __ffsll((long long)cand) - 1;
+        const unsigned long long zb = ~m & ((1ull << k) - 1ull);
+        const int i = zb ? 64 - __clzll((long long)zb) : 0;
+        const int j = k + (__ffsll((long long)(~m >> k)) - 1);
+        const int L = j - i + p;
+        best = L > best ? L : best;
+    }
+    return best;
 }
 
 
@@ -2966,6 +2989,18 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     if (tid < 256 && sMvalid[tid]) { float dv = sDelta[tid]; if (dv > 20.0f) dv = 20.0f; sDelta[tid] = det_exp2f(dv); }
 #endif
     __syncthreads();
+    // SPEC v7 "repeat-count floor": tandem tracts (period 1..4) of the converged template with its flanks, as wave masks (the core's threads sit in wave 0)
+    unsigned long long tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;
+    const int voff = lf < 4 ? 1 : 0;
+    if (wave == 0) {
+        const int nvis = J + voff + (rf < 4 ? 1 : 0);
+        auto vat = [&](int i) -> int { return i < voff ? lf : (i - voff < J ? (int)sT[0][i - voff < 31 ? i - voff : 31] : rf); };
+        const int vx = vat(lane);
+        tm1 = __ballot(lane + 1 < nvis && vx == vat(lane + 1));
+        tm2 = __ballot(lane + 2 < nvis && vx == vat(lane + 2));
+        tm3 = __ballot(lane + 3 < nvis && vx == vat(lane + 3));
+        tm4 = __ballot(lane + 4 < nvis && vx == vat(lane + 4));
+    }
     float pl = 0.0f;                                        // this position's error probability
     if (tid < ce - cs) {
         const int c = cs + tid;
@@ -2983,7 +3018,17 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             }
             p = __fdiv_rn(s, 1.0f + s);
         }
-        if (p < 1e-10f) p = 1e-10f;
+        {
+            const int x = c + voff;
+            const int L1 = tract_len(tm1, x, 1), L2 = tract_len(tm2, x, 2), L3 = tract_len(tm3, x, 3), L4 = tract_len(tm4, x, 4);
+            float fl = 0.0f;
+            if (L1 >= 8) fl = __fdiv_rn(REP_ERRS, (float)L1);
+            if (L2 >= 10) { const float f = __fdiv_rn(REP_ERRS, (float)L2); fl = f > fl ? f : fl; }
+            if (L3 >= 12) { const float f = __fdiv_rn(REP_ERRS, (float)L3); fl = f > fl ? f : fl; }
+            if (L4 >= 16) { const float f = __fdiv_rn(REP_ERRS, (float)L4); fl = f > fl ? f : fl; }
+            if (p < fl) p = fl;
+        }
+        if (p < PERR_FLOOR) p = PERR_FLOOR;                 // SPEC v7: no base claims more than Q50
         float qv = -3.01029996f * det_log2f(p);
         if (qv < 0.0f) qv = 0.0f;
         if (qv > 93.0f) qv = 93.0f;

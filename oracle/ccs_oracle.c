@@ -36,7 +36,7 @@
 #endif
 
 /* ---------------- specification constants (same values as include/ccsx.h) -------------- */
-#define ORC_SPEC_VERSION 6  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
+#define ORC_SPEC_VERSION 7  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
 int orc_spec_version(void) { return ORC_SPEC_VERSION; }
 #define BAND      64
 #define ALIGN_BAND1 16      /* rows of the FIRST attempt of the subread -> draft alignment (step 3); BAND rows on failure */
@@ -124,6 +124,8 @@ int orc_poa_last_scores(int *out) { for (int i = 0; i < g_poa_nscores; ++i) out[
                                same neighbourhood of every applied mutation is polished in the following rounds           */
 #define DQ_SCALE  65536.0f  /* per-read log2-likelihood gains are summed as fixed point (2^-16): order independent      */
 #define DQ_CLAMP  100.0f
+#define PERR_FLOOR 1e-5f      /* SPEC v7: smallest per-base error probability that is reported (Q50; v6: 1e-10) */
+#define SKIP_PERR_FLOOR 1e-5f /* SPEC v7: error probability floor of a position the candidate filter skips (Q50) */
 
 typedef struct orc_model {
     char  name[32];
@@ -942,6 +944,7 @@ static uint32_t skip_mask(const wtpl_t *w, uint32_t ev)
     return sk;
 }
 
+static float tract_floor(const uint8_t *v, int n, int x);   /* SPEC v7 "repeat-count floor", defined with skip_perr below */
 /* statistics / calibration hooks of the tests (never used by the product, which cannot link this file) */
 struct orc_dbg_s {
     int32_t stats, calib;                 /* calib: run unfiltered and record the true p_err of skippable positions */
@@ -1089,6 +1092,10 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
     }
     /* A6: QVs from the last scoring round */
     int len = 0;
+    uint8_t vis[JMAX + 3]; int nvis = 0, voff = 0;           /* SPEC v7: the window template with its flanks, for the repeat-count floor */
+    if (w.lf < 4) { vis[nvis++] = (uint8_t)w.lf; voff = 1; }
+    for (int j = 0; j < w.J; ++j) vis[nvis++] = w.t[j];
+    if (w.rf < 4) vis[nvis++] = (uint8_t)w.rf;
     for (int c = w.cs; c < w.ce; ++c) {
         float p;
         if ((sk >> c) & 1u) p = pskip[c];                    /* skipped: error probability from the pile-up margin */
@@ -1104,7 +1111,8 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
             }
             p = s / (1.0f + s);
         }
-        if (p < 1e-10f) p = 1e-10f;
+        { float fl = tract_floor(vis, nvis, c + voff); if (p < fl) p = fl; }
+        if (p < PERR_FLOOR) p = PERR_FLOOR;                  /* SPEC v7: no base claims more than Q50 — nothing measured supports a higher claim (profiles/r05_qv_calibration.txt) */
         float qv = -3.01029996f * orc_log2f(p);
         if (qv < 0.0f) qv = 0.0f;
         if (qv > 93.0f) qv = 93.0f;
@@ -1320,7 +1328,34 @@ static inline float skip_perr(int g)
 {
     if (g < 0) g = 0;
     if (g > 12) g = 12;
-    return 8.0f * orc_exp2f(-3.0f * (float)g);
+    float p = 8.0f * orc_exp2f(-3.0f * (float)g);
+    return p < SKIP_PERR_FLOOR ? SKIP_PERR_FLOOR : p;          /* SPEC v7: the pile-up supports no claim beyond Q50 (profiles/r05_qv_calibration.txt) */
+}
+
+/* SPEC v7 "repeat-count floor" (docs/faq/low-complexity.md:11-18; docs/how-does-ccs-work.md:103-106: the predicted accuracy is the mean of the per-base QVs, so
+ * a base whose error the polish cannot see must not claim a high QV).  Windowed single-base polishing cannot tell n from n +- 1 copies of a tandem repeat's unit
+ * when every pass places its own count error somewhere else in the tract; measured on low-complexity templates the consensus carries ~ 0.2 wrong bases per visible
+ * tract whatever its length (predicted 4.2 x too few errors before, 1.1 x with the floor; on-model data is unaffected: such tracts do not occur by chance).
+ * v[0..n) = the converged window template with its flanking draft bases; a core base inside a period-p tract (p = 1..4: v[i] == v[i+p] on a maximal run) of
+ * L >= REP_MINLEN[p-1] visible bases reports p_err >= REP_ERRS / L. */
+#define REP_ERRS 0.2f
+static const int REP_MINLEN[4] = { 8, 10, 12, 16 };
+static float tract_floor(const uint8_t *v, int n, int x)
+{
+    float fl = 0.0f;
+    for (int p = 1; p <= 4; ++p) {
+        int best = 0;
+        for (int k = x - p; k <= x; ++k) {
+            if (k < 0 || k + p >= n || v[k] != v[k + p]) continue;
+            int i = k, j = k + 1;
+            while (i > 0 && v[i - 1] == v[i - 1 + p]) --i;
+            while (j + p < n && v[j] == v[j + p]) ++j;
+            int L = j - i + p;
+            if (L > best) best = L;
+        }
+        if (best >= REP_MINLEN[p - 1]) { float f = REP_ERRS / (float)best; if (f > fl) fl = f; }
+    }
+    return fl;
 }
 
 /* ---------------- whole-ZMW driver (steps 2,3,4,8,9,10) --------------------------------------------------- */

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/golden_v6.npz: inputs + expected outputs of the hot path at SPEC version 6 (the banded alpha / beta fill; every array
-equals its counterpart in golden_v5.npz of round 4 — the band is exactly free, profiles/r05_band_study.txt — checked by `--compare OLD.npz`).
+"""Generates tests/golden/golden_v7.npz: inputs + expected outputs of the hot path at SPEC version 7.  Round 5 made two steps: v6 = the banded alpha /
+beta fill — every array of golden_v6.npz equalled its counterpart in round 4's golden_v5.npz (the band is exactly free, profiles/r05_band_study.txt; `--compare
+OLD.npz` checks such a claim) — and v7 = honest QVs (skip-probability floor Q50, repeat-count floor): against v6 only qual / raw_qv / rq (and the statuses that
+follow from rq) change, sequences, np, ec, iterations and windows do not (`--compare OLD.npz --qv-only`).
 
 The reference mount is documentation-only (no source, binary or test vectors: SURVEY.md §0/§8c), so these
 vectors come from this repository's own CPU restatement (oracle/ccs_oracle.c, "parity unpinned") at the
@@ -115,6 +117,8 @@ def main():
     if "--compare" in sys.argv:                       # e.g. `git show HEAD~:tests/golden/golden_v5.npz > /tmp/v5.npz`: a SPEC change that claims to be result-free
         old = np.load(sys.argv[sys.argv.index("--compare") + 1])
         diff = [k for k in old.files if k != "spec_version" and not (k in out and np.array_equal(old[k], out[k]))]
+        if "--qv-only" in sys.argv:                   # a SPEC change that claims to touch the QVs only
+            diff = [k for k in diff if not k.endswith(("/out/qual", "/out/raw_qv", "/out/rq", "/out/status"))]
         print("arrays of the old file that differ:", diff or "none", "| arrays only in the new file:", [k for k in out if k not in old.files] or "none")
         assert not diff
 

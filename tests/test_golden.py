@@ -1,5 +1,5 @@
-"""Committed golden vectors (tests/golden/golden_v6.npz, made by tests/golden/make_golden.py from the
-oracle at SPEC version 6): the oracle must keep reproducing them on CPU, the HIP path must reproduce them on the GPU; a library or
+"""Committed golden vectors (tests/golden/golden_v7.npz, made by tests/golden/make_golden.py from the
+oracle at SPEC version 7): the oracle must keep reproducing them on CPU, the HIP path must reproduce them on the GPU; a library or
 oracle of another SPEC version is refused (SPEC drift fails loudly: VERDICT r02 item 3e)."""
 import numpy as np
 import pytest
@@ -42,7 +42,7 @@ def test_gpu_reproduces_golden(built, case):
     h.close()
 
 
-# ---- HiFi kinetics (tests/golden/golden_kin_v6.npz, made by tests/golden/make_golden_kinetics.py) --------------------
+# ---- HiFi kinetics (tests/golden/golden_kin_v7.npz, made by tests/golden/make_golden_kinetics.py) --------------------
 KIN_CASES = ["p5_l700", "mix", "partial"]
 
 

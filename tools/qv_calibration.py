@@ -5,7 +5,7 @@ error channel x 1.5, indels x 2.5 inside homopolymers, low-complexity templates 
 reads are binned by their predicted quality (rq) and the bases by their phred QV, and each bin's predicted error count is set against the
 errors found by aligning the consensus to the true template (oracle/ccs_oracle.c orc_error_positions).
 
-    python tools/qv_calibration.py [N_ZMW=96] > profiles/r04_qv_calibration.txt      (also writes profiles/r04_qv_calibration.json)
+    python tools/qv_calibration.py [N_ZMW=96] > profiles/r05_qv_calibration.txt      (also writes profiles/r05_qv_calibration.json)
 """
 import json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ from ccs_amd import api
 import oracle_lib as O
 import lowcx
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+N = int(sys.argv[1]) if (__name__ == "__main__" and len(sys.argv) > 1) else 96
 DATASETS = [("on-model", dict()), ("channel x1.5", dict(channel=1.5)), ("hp_boost 2.5", dict(hp_boost=2.5)), ("lowcx", dict(tpl="lowcx"))]
 RQ_BINS = [(0, 20), (20, 25), (25, 30), (30, 35), (35, 40), (40, 99)]
 QV_BINS = [(0, 10), (10, 20), (20, 30), (30, 40), (40, 50), (50, 60), (60, 94)]
@@ -74,7 +74,7 @@ def main():
             print(f"                                   Q{lo:2d}-{hi:2d}           {len(sel):10d}   {q(p_ / len(sel)):11.1f}   {q(e_ / len(sel)):11.1f}   {p_:10.1f} / {e_}")
             rows_b.append({"bin": [lo, hi], "bases": int(len(sel)), "predicted_q": round(q(p_ / len(sel)), 2), "empirical_q": round(q(e_ / len(sel)), 2), "errors": e_})
         out["datasets"][name] = {"by_read_rq": rows_r, "by_base_qv": rows_b}
-    json.dump(out, open(os.path.join(R, "profiles", "r04_qv_calibration.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(R, "profiles", "r05_qv_calibration.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
