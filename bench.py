@@ -558,12 +558,28 @@ def main():
                     torch.cuda.synchronize()
                     el, kt2, (ok2, rs2, rn2, _) = j2.run(args.extra_steps, True)
                     sm = stage_means(np, kt2)
+                    dom2 = max(names, key=lambda k: sm[k])
+                    ach2 = j2.alg_bytes / (sm[dom2] * 1e-3) / 1e9
                     extra[name] = {"workload": f"{p_} passes x {l_} bp", "zmws_per_step": z_, "steps": args.extra_steps,
                                    "value": round(z_ * args.extra_steps / el, 2), "unit": "ZMWs/s",
                                    "resident_zmws_per_s": round(z_ * args.extra_steps / (kernels_span_ms(kt2) * 1e-3), 2),
                                    "stage_ms": {k: round(v, 3) for k, v in sm.items()},
                                    "success_frac": round(ok2 / (z_ * args.extra_steps), 4), "mean_rq": rs2 / rn2 if rn2 else None,
-                                   "algorithmic_bytes_per_launch": j2.alg_bytes}
+                                   "algorithmic_bytes_per_launch": j2.alg_bytes,
+                                   # the same roofline object as the headline's, for this shape's dominant kernel
+                                   "roofline": {"bound": "hbm", "kernel": names[dom2], "achieved": round(ach2, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach2 / 8000.0, 6),
+                                                "avg_launch_ms": round(sm[dom2], 3), "traffic": None}}
+                    if name == "c1" and not args.no_cpu_baseline:
+                        # BASELINE configs[0]: "1k synthetic ZMWs, 3 passes x 1 kb, reference `ccs --num-threads=1` on CPU" — the reference is absent (docs-only
+                        # mount), so the figure SURVEY.md 8d asks for beside the GPU line is the port on ONE thread over a bounded sample of the same ZMWs
+                        import oracle_lib
+                        s1 = api.synth(min(1000, z_), p_, l_, seed=0xC0FFEE, first_zmw_id=0)
+                        r1 = api.Results.allocate(s1)
+                        tc = time.perf_counter()
+                        oracle_lib.consensus_batch(j2.h.model, j2.h.opts, s1, r1, nthreads=1)
+                        tc = time.perf_counter() - tc
+                        extra[name]["cpu_1thread"] = {"value": round(s1.n_zmw / tc, 2), "unit": "ZMWs/s", "cores": 1, "kind": "port",
+                                                      "sample": f"the first {s1.n_zmw} ZMWs of the c1 job (BASELINE configs[0] is 1k ZMWs), oracle/ccs_oracle.c on one thread, {tc:.2f} s"}
                     j2.close()
                     del j2
                 except Exception as e:

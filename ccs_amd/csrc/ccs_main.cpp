@@ -37,12 +37,20 @@ using namespace bamio;
 
 namespace {
 
+// default cost budget of a batch per ZMW of --batch-size (round 4 used 400 kb: 8192 mixed ZMWs became TWO tickets, nothing overlapped, 2.1 k ZMWs/s)
+constexpr long long kDefaultBasesPerZmw = 110000;
+
+// ZMWs of the k-th ticket when --batch-size is not given.  The engine wants LARGE batches (one wave per POA graph: a draft stage of 1000 graphs takes nearly as
+// long as one of 8000, the kernels being latency-bound), a short run wants several tickets in flight from the start: 1024, 1024, 2048, 2048, 4096, 4096, 8192, ...
+// — a file of 8192 ZMWs still becomes five tickets, a long run works in tickets of 8192.
+inline int auto_batch_zmws(long long k) { return k >= 6 ? 8192 : 1024 << (int)(k / 2); }
+
 struct Options {
     std::string in, out, report;
     int threads = 0;
     double min_snr = 2.5;
-    int batch = 2048;
-    long long batch_bases = 0;     // cost budget of a batch in subread bases (0 = 400 kb x --batch-size): SURVEY.md 8e "batches of ~ constant cost"
+    int batch = 0;                 // --batch-size; 0 = automatic: tickets ramp up from 1024 to 8192 ZMWs (see batch_limit)
+    long long batch_bases = 0;     // cost budget of a batch in subread bases (0 = 110 kb x --batch-size): SURVEY.md 8e "batches of ~ constant cost"
     int chunk_i = 1, chunk_n = 1;
     int workers_per_gpu = 3;      // packing threads per device (one engine handle per device keeps three batches in flight)
     std::string model_file;       // --model-file: Arrow parameter json (else: chemistry of the BAM header -> bundle dir / built-in)
@@ -175,9 +183,10 @@ void usage()
                  "      --metrics-json F      per-ZMW metrics [<OUT prefix>.zmw_metrics.json.gz]\n"
                  "      --suppress-reports    do not write the default ccs_report.txt / zmw_metrics.json.gz (files named explicitly are still written)\n"
                  "      --chunk i/N           process only the i-th of N ZMW chunks\n"
-                 "      --batch-size N        ZMWs per GPU batch, at most [2048]\n"
+                 "      --batch-size N        ZMWs per GPU batch, at most [automatic: 1024, 1024, 2048, 2048, 4096, 4096, then 8192 per ticket]\n"
                  "      --batch-bases N       ... and at most N subread bases (estimated cost, SURVEY.md 8e: batches of about constant cost for mixed\n"
-                 "                            pass counts / insert lengths) [400000 x batch-size]\n"
+                 "                            pass counts / insert lengths) [110000 x batch-size: a 10-pass x 10 kb ZMW costs ~ 102 kb, so such a batch still\n"
+                 "                            closes by count, while a Sequel-II-like mix (~ 200 kb per ZMW, 400 x spread) is cut into >= 6 tickets per 8192 ZMWs]\n"
                  "      --gpus a,b,..         device ordinals [0] ('all' = every visible device)\n"
                  "      --workers-per-gpu N   packing threads per device [3] (one engine handle per device, three batches in flight)\n"
                  "      --report-file F       ccs_report.txt path [<OUT prefix>.ccs_report.txt]\n"
@@ -247,7 +256,7 @@ bool parse(int argc, char **argv, Options &o)
         o.o.top_passes = CCSX_MAX_PASSES;
     }
     if (!o.write_synth.empty()) { if (pos.size() != 1) return false; o.out = pos[0]; return true; }
-    if (o.dump || o.host_only) { if (pos.size() != 1) return false; o.in = pos[0]; if (o.batch < 1) o.batch = 1; if (o.batch_bases <= 0) o.batch_bases = 400000ll * o.batch; return true; }
+    if (o.dump || o.host_only) { if (pos.size() != 1) return false; o.in = pos[0]; if (o.batch < 0) o.batch = 0; return true; }
     if (pos.size() != 2) return false;
     o.in = pos[0]; o.out = pos[1];
     {
@@ -255,8 +264,7 @@ bool parse(int argc, char **argv, Options &o)
         if (o.report.empty()) o.report = p + ".ccs_report.txt";
         if (o.metrics.empty()) o.metrics = p + ".zmw_metrics.json.gz";
     }
-    if (o.batch < 1) o.batch = 1;
-    if (o.batch_bases <= 0) o.batch_bases = 400000ll * o.batch;
+    if (o.batch < 0) o.batch = 0;
     return true;
 }
 
@@ -755,10 +763,12 @@ int main(int argc, char **argv)
                     // ticket the GPU workers draw from the shared queue costs about the same (and its staging stays bounded)
                     long long cost = 0;
                     if (zin.host_status == HS_OK) for (const Subread &r : zin.reads) cost += (long long)r.size();
-                    if (!batch->zmws.empty() && batch_cost + cost > opt.batch_bases) { batch->index = nb++; to_pack.push(batch); batch = std::make_shared<Batch>(); batch_cost = 0; }
+                    const int lim_zmws = opt.batch > 0 ? opt.batch : auto_batch_zmws(nb);
+                    const long long lim_bases = opt.batch_bases > 0 ? opt.batch_bases : kDefaultBasesPerZmw * lim_zmws;
+                    if (!batch->zmws.empty() && batch_cost + cost > lim_bases) { batch->index = nb++; to_pack.push(batch); batch = std::make_shared<Batch>(); batch_cost = 0; }
                     batch->zmws.push_back(std::move(zin));
                     batch_cost += cost;
-                    if ((int)batch->zmws.size() >= opt.batch) { batch->index = nb++; to_pack.push(batch); batch = std::make_shared<Batch>(); batch_cost = 0; }
+                    if ((int)batch->zmws.size() >= (opt.batch > 0 ? opt.batch : auto_batch_zmws(nb))) { batch->index = nb++; to_pack.push(batch); batch = std::make_shared<Batch>(); batch_cost = 0; }
                 }
             };
             auto flush_zmw = [&] {

@@ -43,7 +43,9 @@ struct DevBuf {
     {
         if (bytes <= cap) return 0;
         // the new block first: a failed growth leaves the old buffer (and every KParams that points into it) intact
-        size_t want = bytes + bytes / 8 + 256;
+        // (a buffer that has to grow AGAIN belongs to a stream of unequal batches — the driver's cost-binned tickets of a mixed run: every regrowth is a
+        // synchronous hipMalloc + hipFree, for the shared POA scratch tens of GB behind a stream synchronisation — so regrowth takes half as much again)
+        size_t want = bytes + (p ? bytes / 2 : bytes / 8) + 256;
         void *np_ = nullptr;
         hipError_t e = hipMalloc(&np_, want);
         if (e != hipSuccess && p) {                      // not enough room for both: give the old block back and try once more

@@ -11,8 +11,8 @@ timeout 300 $CCS --host-only /tmp/big.subreads.bam 2>&1 | tail -1
 echo "== 8192 ZMWs, 3-50 passes x 1-25 kb (configs[4] shape), --min-rq 0.99, cost-binned batches"
 timeout 300 $CCS --write-synthetic 8192,3-50,1000-25000,9 /tmp/mix.subreads.bam; ls -la /tmp/mix.subreads.bam | awk '{print $5, $9}'
 timeout 300 $CCS --host-only --batch-size 4096 /tmp/mix.subreads.bam 2>&1 | tail -1
-( time timeout 600 $CCS /tmp/mix.subreads.bam /tmp/mix.hifi.bam --batch-size 4096 --min-rq 0.99 --log-level INFO ) 2>&1 | tail -6
-( time timeout 600 $CCS /tmp/mix.subreads.bam /tmp/mix2.hifi.bam --batch-size 4096 --batch-bases 200000000 --min-rq 0.99 ) 2>&1 | tail -4
+( time timeout 600 $CCS /tmp/mix.subreads.bam /tmp/mix.hifi.bam --min-rq 0.99 --log-level INFO ) 2>&1 | tail -6        # (default --batch-size 2048, --batch-bases 110 kb x 2048)
+( time timeout 600 $CCS /tmp/mix.subreads.bam /tmp/mix2.hifi.bam --batch-size 4096 --batch-bases 800000000 --min-rq 0.99 ) 2>&1 | tail -4   # (round 4's cut: two tickets)
 cmp /tmp/mix.hifi.bam /tmp/mix2.hifi.bam && echo "hifi.bam identical for both batch cuts"
 } > $O/cli.txt 2>&1
 cat $O/cli.txt
