@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-TRAFFIC_FILE = "r04_traffic.json"       # this round's committed PMC passes (tools/prof_round.sh -> tools/mk_traffic.py)
+TRAFFIC_FILE = "r05_traffic.json"       # this round's committed PMC passes (tools/prof_round.sh -> tools/mk_traffic.py)
 QVCAL_FILE = "r05_qv_calibration.json"  # predicted vs empirical accuracy per rq bin (tools/qv_calibration.py, CPU restatement)
 VALU_PEAK_LANE_OPS = 78.6e12            # non-packed VALU issue of one MI355X: 1024 SIMDs x 32 lanes per cycle (v_add / v_mul_f32 issue a wave64
                                         # in 2 cycles, profiles/r02_valu_peak.txt) x 2.4 GHz; packed fp32 (157 TFLOP/s with FMA) is not what a DP cell can use

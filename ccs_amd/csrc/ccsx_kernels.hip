@@ -38,7 +38,7 @@
 // which the library reports through ccsx_build_flags() and which turns ccsx_spec_version() negative, so that such a build cannot pass for the product
 // (tests/test_abi.py; tools/gpu_ab.sh adds the define itself).
 #if (defined(CCSX_EXP_NO_FILL) || defined(CCSX_EXP_NO_SCORE) || defined(CCSX_EXP_ONE_ROUND) || defined(CCSX_EXP_ALL_VALID) || defined(CCSX_EXP_CHEAP_VALIDITY) || \
-     defined(CCSX_EXP_NO_ROWS) || defined(CCSX_EXP_NO_SCORE_LOG) || defined(CCSX_EXP_SKIP_ROUND2_SCORE) || defined(CCSX_EXP_NO_QV_EXP) || defined(CCSX_EXP_REPEAT) || \
+     defined(CCSX_EXP_NO_ROWS) || defined(CCSX_EXP_NO_SCORE_LOG) || defined(CCSX_EXP_SKIP_ROUND2_SCORE) || defined(CCSX_EXP_NO_QV_EXP) || defined(CCSX_EXP_REPEAT) || defined(CCSX_EXP_NO_BANDMASK) || \
      defined(CCSX_EXIT_AFTER_PROLOGUE)) && !defined(CCSX_EXPERIMENT)
 #error "CCSX_EXP_* / CCSX_EXIT_AFTER_PROLOGUE switches produce wrong results: build them with -DCCSX_EXPERIMENT (never ship such a library)"
 #endif
@@ -85,6 +85,9 @@ const char *ccsx_kernel_build_flags()
 #ifdef CCSX_EXP_NO_QV_EXP
         " CCSX_EXP_NO_QV_EXP"
 #endif
+#ifdef CCSX_EXP_NO_BANDMASK
+        " CCSX_EXP_NO_BANDMASK"
+#endif
 #ifdef CCSX_EXP_REPEAT
         " CCSX_EXP_REPEAT=" CCSX_STR(CCSX_EXP_REPEAT)
 #endif
@@ -98,7 +101,7 @@ const char *ccsx_kernel_build_flags()
         " CCSX_DEBUG_CHECKS"
 #endif
 #ifdef CCSX_EXTRA_FLAGS_STR                                  // (__graft_entry__.build(): whatever $CCSX_EXTRA_FLAGS held, e.g. tuning overrides of the PW_* defaults)
-        " extra:" CCSX_STR(CCSX_EXTRA_FLAGS_STR)
+        " extra: " CCSX_EXTRA_FLAGS_STR
 #endif
         ;
 }
@@ -2038,13 +2041,17 @@ __device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_
 {
     typedef const unsigned long long __attribute__((address_space(3))) *lds_cu64;
     float gmm = *s.g;
+#ifndef CCSX_EXP_NO_BANDMASK                                // experiment (timing only, wrong results in the corners of a window): what the two band tests per row cost
     if ((unsigned)s.dg >= bw) gmm = 0.0f;
+#endif
     const int o256 = __mul24((int)*s.op, CTXS * 8);   // byte offset of the observation's row in sCTX
     const unsigned long long va = *(lds_cu64)(tA + o256), vb = *(lds_cu64)(tB + o256);   // one ds_read_b64 each
     const float2 nA = make_float2(__uint_as_float((unsigned)va), __uint_as_float((unsigned)(va >> 32)));
     const float2 nB = make_float2(__uint_as_float((unsigned)vb), __uint_as_float((unsigned)(vb >> 32)));
     float bqn = *s.be;
+#ifndef CCSX_EXP_NO_BANDMASK
     if ((unsigned)s.db >= bw) bqn = 0.0f;
+#endif
     s.g += pitch; s.be += pitch; s.op += 1; s.dg -= 1; s.db -= 1;
     const float insA = s.pA.y, meA = s.pA.x, insB = s.pB.y;
     const float a = gmm + s.ap * insA;
@@ -3001,6 +3008,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         tm3 = __ballot(lane + 3 < nvis && vx == vat(lane + 3));
         tm4 = __ballot(lane + 4 < nvis && vx == vat(lane + 4));
     }
+    // (wave-uniform masks: whether ANY tract is long enough to matter is scalar arithmetic — on ordinary sequence none is, and the per-base work is skipped)
+    auto has_run = [](unsigned long long m, int n) -> bool { unsigned long long x = m; for (int i = 1; i < n; ++i) x &= m >> i; return x != 0; };
+    const bool any_tract = has_run(tm1, 8 - 1) || has_run(tm2, 10 - 2) || has_run(tm3, 12 - 3) || has_run(tm4, 16 - 4);
     float pl = 0.0f;                                        // this position's error probability
     if (tid < ce - cs) {
         const int c = cs + tid;
@@ -3018,7 +3028,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             }
             p = __fdiv_rn(s, 1.0f + s);
         }
-        {
+        if (any_tract) {
             const int x = c + voff;
             const int L1 = tract_len(tm1, x, 1), L2 = tract_len(tm2, x, 2), L3 = tract_len(tm3, x, 3), L4 = tract_len(tm4, x, 4);
             float fl = 0.0f;

@@ -6,6 +6,7 @@ import glob, json, os, sqlite3, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root, n = sys.argv[1], int(sys.argv[2])
 head = sys.argv[3] if len(sys.argv) > 3 else None
+workload = sys.argv[4] if len(sys.argv) > 4 else "10 passes x 10 kb"
 def kname(n):
     """kernel name without return type, template arguments and parameters: 'void k_polish_t<512, 2, 8>(KParams, ...)' -> 'k_polish'"""
     n = n.split("(")[0].split("<")[0].strip()
@@ -20,12 +21,12 @@ for db in glob.glob(os.path.join(root, "pmc_*", "pmc_results.db")):
         d_ = val.setdefault(kname(kn), {}); d_[cn] = d_.get(cn, 0) + v       # (the two instantiations of k_polish_t add up)
         c_ = cnt.setdefault(kname(kn), {}); c_[cn] = max(c_.get(cn, 0), k)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ_* (separate passes), python bench.py "
-                 f"--pmc --zmws {n} --steps 1 --warmup 1 --distinct 1 (the headline step: two-stage queue on), tools/prof_round.sh",
+                 f"--pmc --serial-stages --zmws {n} --steps 1 --warmup 1 --distinct 1 (serial stages: a kernel's GRBM_GUI_ACTIVE is then its own), tools/prof_round.sh",
        "head": head, "csrc_sha16": __import__("bench").csrc_sha16() if os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")) else None,
        "note": "hbm bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on this gfx950 stack FETCH_SIZE reports exactly half of the bytes of a "
                "coalesced streaming read at 1, 4 and 16 bytes per lane and WRITE_SIZE is exact (profiles/r01_counter_calibration.txt, "
                "tools/calib; MI355X_MICROARCH.md HBM section)",
-       "zmws": n, "workload": "10 passes x 10 kb", "kernels": {},
+       "zmws": n, "workload": workload, "kernels": {},
        "valu_note": "valu_issue_frac_if_{2,4}cyc = SQ_INSTS_VALU x {2,4} SIMD cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the bounds of the "
                     "VALU pipe occupancy (profiles/r02_valu_peak.txt: v_add/mul_f32 and v_add_u32 issue in 2 cycles per wave64, v_fma_f32, "
                     "v_max_i32, DPP ops in 4); lanes_active_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)"}
