@@ -2525,9 +2525,13 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             // alpha(I,J) / beta(0,0) of a read meet in LDS, and every wave derives the reads' validity from them after the barrier (lane = read; identical values
             // in every wave: no second barrier).  Eight short reads = two quads = four units: every wave runs one sweep per chunk.
 #ifdef CCSX_EXP_NO_FILL                                     // experiment (timing only, wrong results)
-            const int nquad = 0, nunit_f = 0;
+            const int nquad = 0, nunit_f = 0, rpq = 4;
 #else
-            const int nquad = (nshort + 3) >> 2, nunit_f = 2 * nquad + 2 * nlong;
+            // (reads per quad unit: always four.  Spreading a small chunk — three passes, the tail chunk of ten — over all the waves, two reads or one per unit, was
+            // measured and is SLOWER: k_polish 313.9 against 301.6 ms at 10 passes, 95.8 against 92.4 at 3 — the kernel is bound by its instruction count, and a
+            // sweep costs the same instructions whatever it holds)
+            const int rpq = 4;
+            const int nquad = (nshort + rpq - 1) / rpq, nunit_f = 2 * nquad + 2 * nlong;
 #endif
             for (int fu = wave; fu < nunit_f; fu += (PWT / 64)) {
               if (fu < 2 * nquad) {
@@ -2541,9 +2545,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 // serve the old row, the compute side (activity window, store pointer) one iteration later.
                 const int quad = fu >> 1, isb = fu & 1;
                 const int g4 = lane >> 4, l16 = lane & 15;
-                const int qi = 4 * quad + g4;
-                const bool have = qi < nshort;
-                const int myr = sTask[nlong + (have ? qi : 4 * quad)].x;
+                const int qi = rpq * quad + g4;
+                const bool have = g4 < rpq && qi < nshort;
+                const int myr = sTask[nlong + (have ? qi : rpq * quad)].x;
                 const int I = sI[myr], sd = sStrand[myr], band = sBand[myr];
                 const int pitch = band & 255, rowsz = (band >> 8) & 255, bdlo = (int)((unsigned)band >> 24) - 128, bdhi = bdlo + ((band >> 16) & 255) - 1;
                 const int row0 = l16, row1 = l16 + 16;
@@ -2552,7 +2556,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int jlo1 = (row1 + bdlo > 0) ? row1 + bdlo : 0, jhi1 = (row1 + bdhi < J) ? row1 + bdhi : J;
                 int Tmax = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int iq = rfl(sI[rfl((int)sTask[nlong + (4 * quad + q < nshort ? 4 * quad + q : 4 * quad)].x)]); Tmax = iq > Tmax ? iq : Tmax; }
+                for (int q = 0; q < 4; ++q) { const int iq = rfl(sI[rfl((int)sTask[nlong + ((q < rpq && rpq * quad + q < nshort) ? rpq * quad + q : rpq * quad)].x)]); Tmax = iq > Tmax ? iq : Tmax; }
                 Tmax += J;
                 const int NEVER = 1 << 20;
 #define LDPR(ROWP, OFF) (*(const float2 *)((ROWP) + (OFF)))
