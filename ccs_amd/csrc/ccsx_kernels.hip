@@ -2595,47 +2595,64 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int sstep = isb ? -(pitch + 1) : pitch + 1, ostep1 = isb ? -1 : 1;
                 lds_cc ctxb = (lds_cc)sCTX;
                 float E = 0.0f, O = (inmat && off == h0) ? 1.0f : 0.0f;     // the seed: slot (0, -1) below the unit cell
-                v4i eE = ep[0], eO = ep[1];
-                int oc = (int)*op;
+                // Software pipeline, three slots deep (a plain loop waits for two dependent LDS round trips per iteration — observation code -> table entries — and was
+                // SLOWER than the quad fill with half its instructions: 329.7 against 300 ms): iteration n computes with the table entries fetched during iteration
+                // n - 1, fetches those of iteration n + 1 (their addresses come from the observation code and the column entries fetched during n - 1), and fetches
+                // the observation code of iteration n + 2 and the column entry of n + 3.  Column entries X_k (k-th column along the lane's path: iteration n uses
+                // X_n for its E cell and X_n+1 for its O cell), observation codes and coefficient sets rotate through three named slots, no register copies.
+                typedef const float __attribute__((address_space(3))) *lds_cfp;
+                v4i X0 = ep[0], X1 = ep[1], X2 = ep[2];
+                int oc0 = (int)op[0], oc1 = (int)op[ostep], oc2 = 0;
+                float c1E0, qE0, c1O0, qO0, c1E1 = 0.f, qE1 = 0.f, c1O1 = 0.f, qO1 = 0.f, c1E2 = 0.f, qE2 = 0.f, c1O2 = 0.f, qO2 = 0.f;
+                {
+                    const int ob = __mul24(oc0, CTXS * 8);
+                    c1E0 = *(lds_cfp)(ctxb + ob + X0.y); qE0 = *(lds_cfp)(ctxb + ob + X0.z); c1O0 = *(lds_cfp)(ctxb + ob + X1.y); qO0 = *(lds_cfp)(ctxb + ob + X1.z);
+                }
+                op += 2 * ostep; ep += 3;                            // op -> the code of iteration 2, ep -> X_3
                 asm volatile("" : "+v"(op), "+v"(ep), "+v"(sp));
 #define CCSX_SEL(MASK, A, B) sel_lanes(MASK, A, B)          /* A in the lanes of MASK, B elsewhere */
-#define CCSX_ST_ITER(EE, EO, EN)                                                                                          \
+                // slot names: S = this iteration's, T = the next one's, U = the one after (column entry X_S.x = DL of the E cell, X_T.x = DL of the O cell)
+#define CCSX_ST_ITER(XS, XT, XU, OCT, OCU, C1ES, QES, C1OS, QOS, C1ET, QET, C1OT, QOT)                                     \
                 {                                                                                                          \
-                    typedef const float __attribute__((address_space(3))) *lds_cfp;                                        \
-                    const float c1E = *(lds_cfp)(ctxb + __mul24(oc, CTXS * 8) + EE.y), qE = *(lds_cfp)(ctxb + __mul24(oc, CTXS * 8) + EE.z);   \
-                    const float c1O = *(lds_cfp)(ctxb + __mul24(oc, CTXS * 8) + EO.y), qO = *(lds_cfp)(ctxb + __mul24(oc, CTXS * 8) + EO.z);   \
-                    op += ostep; ep += 1;                                                                                  \
-                    const int ocn = (int)*op;                                                                              \
-                    EN = ep[1];                                                                                            \
+                    {   /* the look-ups of the NEXT iteration: E cell entry X_T, O cell entry X_U, the row's observation code OCT */ \
+                        const int ob = __mul24(OCT, CTXS * 8);                                                             \
+                        C1ET = *(lds_cfp)(ctxb + ob + XT.y); QET = *(lds_cfp)(ctxb + ob + XT.z);                            \
+                        C1OT = *(lds_cfp)(ctxb + ob + XU.y); QOT = *(lds_cfp)(ctxb + ob + XU.z);                            \
+                    }                                                                                                      \
+                    OCU = (int)*op; op += ostep;                     /* ... the code of the iteration after next */         \
+                    const float dlE = __int_as_float(XS.x), dlO = __int_as_float(XT.x);                                    \
                     {   /* E cell */                                                                                       \
                         const float L = wave_shr1_f32_z(O);                                                                \
-                        const float A = E * c1E, l = L * __int_as_float(EE.x), u = O * qE;                                 \
+                        const float A = E * C1ES, l = L * dlE, u = O * QES;                                                \
                         const float g = A + CCSX_SEL(mB, u, l);                                                            \
                         const float val = g + CCSX_SEL(mB, l, u);                                                          \
                         const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)cntE, spanE, 37 /* ule */);         \
                         if (__builtin_amdgcn_inverse_ballot_w64(on)) *sp = CCSX_SEL(mB, val, g);                           \
                         E = lanes_or_zero(on, val);                                                                        \
                     }                                                                                                      \
+                    XS = *ep; ep += 1;                               /* X_S is spent: its slot takes the entry three columns on */ \
                     {   /* O cell */                                                                                       \
                         const float U = wave_shl1_f32_z(E);                                                                \
-                        const float A = O * c1O, l = E * __int_as_float(EO.x), u = U * qO;                                 \
+                        const float A = O * C1OS, l = E * dlO, u = U * QOS;                                                \
                         const float g = A + CCSX_SEL(mB, u, l);                                                            \
                         const float val = g + CCSX_SEL(mB, l, u);                                                          \
                         const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)cntO, spanO, 37 /* ule */);         \
                         if (__builtin_amdgcn_inverse_ballot_w64(on)) sp[ostep1] = CCSX_SEL(mB, val, g);                    \
                         O = lanes_or_zero(on, val);                                                                        \
                     }                                                                                                      \
-                    sp += sstep; cntE += 1; cntO += 1; oc = ocn;                                                           \
+                    sp += sstep; cntE += 1; cntO += 1;                                                                     \
                 }
                 {
-                    v4i eN;
                     int n = 0;
-                    for (; n + 3 <= N; n += 3) {                     // three iterations per trip: the column entries rotate through three registers, no copies
-                        CCSX_ST_ITER(eE, eO, eN)
-                        CCSX_ST_ITER(eO, eN, eE)
-                        CCSX_ST_ITER(eN, eE, eO)
+                    for (; n + 3 <= N; n += 3) {
+                        CCSX_ST_ITER(X0, X1, X2, oc1, oc2, c1E0, qE0, c1O0, qO0, c1E1, qE1, c1O1, qO1)
+                        CCSX_ST_ITER(X1, X2, X0, oc2, oc0, c1E1, qE1, c1O1, qO1, c1E2, qE2, c1O2, qO2)
+                        CCSX_ST_ITER(X2, X0, X1, oc0, oc1, c1E2, qE2, c1O2, qO2, c1E0, qE0, c1O0, qO0)
                     }
-                    if (n < N) { CCSX_ST_ITER(eE, eO, eN) ++n; if (n < N) { CCSX_ST_ITER(eO, eN, eE) } }
+                    if (n < N) {
+                        CCSX_ST_ITER(X0, X1, X2, oc1, oc2, c1E0, qE0, c1O0, qO0, c1E1, qE1, c1O1, qO1)
+                        if (n + 1 < N) { CCSX_ST_ITER(X1, X2, X0, oc2, oc0, c1E1, qE1, c1O1, qO1, c1E2, qE2, c1O2, qO2) }
+                    }
                 }
 #undef CCSX_ST_ITER
 #undef CCSX_SEL

@@ -2,7 +2,7 @@
 # SQ_INSTS_LDS SQ_WAVE_CYCLES, one 8192-ZMW step each, serial stages.   usage (through gpurun): bash tools/polish_instr.sh  -> gpurun_out/pinstr/summary.txt
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/pinstr; rm -rf $O; mkdir -p $O
-for v in "base:" "one:-DCCSX_EXP_ONE_ROUND" "one_nofill:-DCCSX_EXP_ONE_ROUND,-DCCSX_EXP_NO_FILL,-DCCSX_EXP_ALL_VALID" "one_noscore:-DCCSX_EXP_ONE_ROUND,-DCCSX_EXP_NO_SCORE" "one_nomask:-DCCSX_EXP_ONE_ROUND,-DCCSX_EXP_NO_BANDMASK" "prologue:-DCCSX_EXIT_AFTER_PROLOGUE"; do
+for v in ${PINSTR_VARIANTS:-"base:" "one:-DCCSX_EXP_ONE_ROUND" "one_nofill:-DCCSX_EXP_ONE_ROUND,-DCCSX_EXP_NO_FILL,-DCCSX_EXP_ALL_VALID" "one_noscore:-DCCSX_EXP_ONE_ROUND,-DCCSX_EXP_NO_SCORE" "one_nomask:-DCCSX_EXP_ONE_ROUND,-DCCSX_EXP_NO_BANDMASK" "prologue:-DCCSX_EXIT_AFTER_PROLOGUE"}; do
   name=${v%%:*}; flags=${v#*:}; flags=${flags//,/ }
   CCSX_EXTRA_FLAGS="$flags" python -c "import __graft_entry__ as g; g.build(force=True)" > $O/build_$name.log 2>&1 || { echo "build $name failed"; continue; }
   ( cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU -d $GRAFT_REPO_ROOT/$O/p_$name -o pmc -- python $GRAFT_REPO_ROOT/bench.py --pmc --serial-stages --zmws 8192 --steps 1 --warmup 1 --distinct 1 > $GRAFT_REPO_ROOT/$O/b_$name.json 2> $GRAFT_REPO_ROOT/$O/b_$name.err < /dev/null )
