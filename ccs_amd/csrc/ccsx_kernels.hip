@@ -1984,8 +1984,11 @@ __global__ __launch_bounds__(256) void k_wmap_fill(KParams P)     // one wave pe
 #ifndef CTXS
 #define CTXS 33                       // entries per observation row of sCTX
 #endif
-#define SE_G 2                        // sEnt: own columns -SE_G .. SE_N - SE_G - 1
-#define SE_N 40
+#define FILL16_MAXBW 24               // widest band (diagonals) of a read that shares a wave with three others (k_polish's quad sweep)
+#define FE_ALO 35                     // sEA holds columns -35 .. 69, sEB columns -69 .. 66 (the reach of a pair's lanes, see the fill)
+#define FE_A 105
+#define FE_BLO 69
+#define FE_B 136
 #define OBS_CODE(o) ((o) * (CTXS * 8))        // the byte offset of observation o's row in sCTX (sObs holds the 8-bit observation itself)
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
@@ -2138,14 +2141,6 @@ __device__ __forceinline__ float lanes_or_zero(unsigned long long m, float v)
     return r;
 }
 
-// a in the lanes of the wave mask m, b elsewhere (one v_cndmask on a mask that sits in scalar registers)
-__device__ __forceinline__ float sel_lanes(unsigned long long m, float a, float b)
-{
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
-    return r;
-}
-
 // the windows a launch piece covers, and the XCD-contiguous order of its blocks: block b -> the (b / 8)-th window of the (b % 8)-th eighth; -1 = no window
 __device__ __forceinline__ int polish_piece_windows(int total, int slot0, int grid) { const int c = total - slot0; return c < 0 ? 0 : (c > grid ? grid : c); }
 __device__ __forceinline__ int xcd_contiguous(unsigned b, int count)
@@ -2167,15 +2162,13 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     __shared__ float2 sCTX[(CCSX_NOBS + 1) * CTXS];
     __shared__ float sDL[16], sZP[32];                       // sZP: z-score MU[16], VAR[16]
     __shared__ int2 sColJ[2][32];                            // [strand][column j] = (DL[k_j] as float bits, byte offset of context k_j in a row of sCTX)
-    // what a cell of the staircase fill needs from its column, per [alpha / beta][strand][own column + SE_G]: (DL as float bits, byte offset of the ME look-up in
-    // a row of sCTX, byte offset of the INS look-up, -).  alpha cell (i, j): DL and ME of column j-1, INS of column j; beta cell (i, j), indexed by its OWN column
-    // J - j: all three of column j.  Column -1 / column J carry the conventions of sColJ (zero entry, DL = 1).
-    __shared__ int4 sEnt[2][2][SE_N];
-    __shared__ short sMat[2 * PW_MAXREADS];                  // fill plan: matrix q = 2 * (rank of the read in the chunk) + [beta] -> unit | first lane << 8
-    __shared__ uint8_t sUF[2 * PW_MAXREADS + 2];             // ... and the first matrix of every unit
+    // the same per column, staggered for the software-pipelined sweeps of a PAIR of short reads (rows 0..31 each): entry m of sEA =
+    // (DL of column m-1, context offset of column m+4), entry n of sEB = (DL of column n, context offset of column n-4); every index a
+    // lane can form before its first / after its last column exists and holds (1.0, the zero entry), so no look-up needs a guard
+    __shared__ int2 sEA[2][FE_A], sEB[2][FE_B];
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
     __shared__ uint8_t sTd[32];                              // the draft's window as it was (the large-insertion trim of a reloaded group compares with it)
-    // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: a leading "no base", 63 codes, a trailing "no base", slack), then gamma/beta.
+    // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
     // One BYTE per read row (round 3 stored the 16-bit byte offset of the observation's sCTX row: at 30 passes those 4 KB left room for only three
     // reads per gamma/beta chunk; the scoring rows are bound by their LDS round trips, the extra multiply per row is not measurable).
     uint8_t (*sObs)[68] = (uint8_t (*)[68])dyn_lds;
@@ -2303,10 +2296,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             const int r = rb + (PWT / 64) * q + wave;
             if (r < ng) {
                 const int n = sI[r];
-                // [0] = "no base" (the code of the row before row 0), [1 + i] = the code of read row i, [1 + n] = "no base"
-                sObs[r][1 + lane] = (lane < n) ? (uint8_t)obs_of(bq[q], pq[q]) : (uint8_t)(lane == n ? CCSX_NOBS : 0);
-                if (lane == 0) sObs[r][0] = (uint8_t)CCSX_NOBS;
-                if (lane < 3) sObs[r][65 + lane] = 0;
+                sObs[r][lane] = (lane < n) ? (uint8_t)obs_of(bq[q], pq[q]) : (uint8_t)(lane == n ? CCSX_NOBS : 0);   // row n: "no base"
+                if (lane < 4) sObs[r][64 + lane] = 0;
             }
         }
     }
@@ -2327,7 +2318,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             const unsigned long long mp = __ballot(in && (bp & 3) == T), ms = __ballot(in && (bs & 3) == T);
             const int tot = (lane <= J0) ? __popcll(mp & ((1ull << lane) - 1ull)) + __popcll(ms >> lane) : -1;
             const int sb = 63 - (rfl(wave_max_i32((tot << 6) | (63 - lane))) & 63);
-            if (in && lane >= sb) sObs[r][1 + lane] = (uint8_t)obs_of(bs, ps);
+            if (in && lane >= sb) sObs[r][lane] = (uint8_t)obs_of(bs, ps);
         }
     }
     };
@@ -2466,12 +2457,15 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             if (v0) sList[basew + __popcll(bal & ((1ull << lane) - 1ull))] = (short)tid;
             __syncthreads();
         }
-        for (int e = tid; e < 2 * 2 * SE_N; e += PWT) {               // (sColJ is complete: two barriers since)
-            const int isb = e / (2 * SE_N), sd = (e / SE_N) & 1, jj = e % SE_N - SE_G;     // own column jj
-            const int cme = isb ? J - jj : jj - 1, cins = isb ? J - jj : jj;             // the window columns of the ME / DL and of the INS look-up
-            const bool okm = cme >= 0 && cme <= J, oki = cins >= 0 && cins <= J;
-            const int2 vm = sColJ[sd][okm ? cme : 0], vi = sColJ[sd][oki ? cins : 0];
-            sEnt[isb][sd][e % SE_N] = make_int4(okm ? vm.x : __float_as_int(1.0f), okm ? vm.y : 32 * 8, (oki ? vi.y : 32 * 8) + 4, 0);
+        for (int e = tid; e < 2 * (FE_A + FE_B); e += PWT) {          // (sColJ is complete: two barriers since)
+            const bool isa = e < 2 * FE_A;
+            const int e2 = isa ? e : e - 2 * FE_A, len = isa ? FE_A : FE_B;
+            const int sd = e2 >= len ? 1 : 0, idx = e2 - sd * len;
+            const int cd = isa ? idx - FE_ALO - 1 : idx - FE_BLO;           // the column whose DL the entry carries
+            const int cc = isa ? idx - FE_ALO + 4 : idx - FE_BLO - 4;       // the column whose context offset it carries
+            const int2 vd = sColJ[sd][cd >= 0 && cd <= J ? cd : 0], vc = sColJ[sd][cc >= 0 && cc <= J ? cc : 0];
+            const int2 ent = make_int2((cd >= 0 && cd <= J) ? vd.x : __float_as_int(1.0f), (cc >= 0 && cc <= J) ? vc.y : 32 * 8);
+            if (isa) sEA[sd][idx] = ent; else sEB[sd][idx] = ent;
         }
         int nvm = 0;
 #pragma unroll
@@ -2493,7 +2487,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         int rbeg = 0;
         while (rbeg < ng) {
             __syncthreads();
-            int rend, nchunk;
+            int rend, nlong, nshort;
             {   // lane = read: the greedy plan by prefix sum and ballots.  EVERY wave computes it (identical values, benign identical
                 // LDS writes): a wave then reads only what it wrote itself, so no barrier is needed before the fill
                 const int r = lane;
@@ -2514,158 +2508,233 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     }
                 }
                 const bool inchunk = cand && r < rend_;
-                const unsigned long long bc = __ballot(inchunk);
-                if (inchunk) sTask[__popcll(bc & ((1ull << lane) - 1ull))] = make_short2((short)r, (short)0);
-                rend = rfl(rend_); nchunk = rfl(__popcll(bc));
+                // a short segment whose band leaves a lane time to change rows (see the quad sweep) shares a wave with three others; the rest — more than
+                // 31 bases, or |I - J| >= 5 — takes a wave of its own (rare)
+                const bool qd = inchunk && n <= 31 && fb.bw <= FILL16_MAXBW, lng = inchunk && !qd;
+                const unsigned long long bl = __ballot(lng), bs = __ballot(qd);
+                const unsigned long long lower = (1ull << lane) - 1ull;
+                const int nl_ = __popcll(bl);
+                if (lng) sTask[__popcll(bl & lower)] = make_short2((short)r, (short)-1);
+                if (qd) sTask[nl_ + __popcll(bs & lower)] = make_short2((short)r, (short)0);
+                rend = rfl(rend_); nlong = rfl(nl_); nshort = rfl(__popcll(bs));
             }
             PHASE(2);
-            // ---- A1/A2: fill (SPEC v6: on the band of diagonals only) — the STAIRCASE.  A matrix (a read's alpha, or its beta in the mirrored coordinates
-            // i' = I - i, j' = J - j, where it has alpha's dependences) occupies one lane per PAIR of band diagonals, plus a separator lane that holds zeros: lane m
-            // owns the diagonals dloX + 2 m (its E cell) and dloX + 2 m + 1 (its O cell), dloX = the band's lowest diagonal rounded down to even.  In iteration n
-            // every lane computes its E cell (ii, jj) = (n - m + h0, n + m - h0) — left neighbour = the O cell of the lane below (one wave shift), upper = its own O
-            // cell, diagonal = its own E cell of the iteration before — and then its O cell (ii, jj + 1) — left = the E cell just made, upper = the new E cell of the
-            // lane above (one wave shift), diagonal = its own old O cell: a staircase, right then down, (I + J) / 2 + 1 iterations for the whole matrix.  Eight or
-            // nine lanes carry a matrix of 15-17 diagonals, so SEVEN matrices share a wave sweep, alpha and beta ones side by side (round 5's first fill, four reads
-            // of one kind per wave in 16-lane DPP rows, kept 54 % of its lanes busy and cost 43 % of the kernel's instructions; profiles/r05_polish_instr.txt).  A cell
-            // that is not in the matrix or not on the band leaves a ZERO in its slot — which is what its neighbours must read there — and stores nothing.  Both
-            // kinds of matrix run the same instructions: u = upper * INS, l = left * DL, then alpha = (diag * ME + l) + u (gamma = the inner sum is what is stored)
-            // and beta = (diag * ME + u) + l, two selects per cell on a wave mask.  The unit cell (0, 0) gets its 1 from a seeded slot below it (column -1: DL = 1).
-            // Every wave computes the same packing plan (benign identical LDS writes), so no barrier separates plan and sweep.
-            int nunit_f;
-            {
-                const int q = lane;                                  // matrix q = 2 * (rank of its read in the chunk) + [beta]
-                const bool have = q < 2 * nchunk;
-                const int rq = sTask[have ? q >> 1 : 0].x;
-                const int Iq = sI[rq], bq = sBand[rq];
-                const int dlo_ = (int)((unsigned)bq >> 24) - 128, dhi_ = dlo_ + ((bq >> 16) & 255) - 1;
-                const int olo = (q & 1) ? (J - Iq) - dhi_ : dlo_, ohi = (q & 1) ? (J - Iq) - dlo_ : dhi_;      // the band in the matrix's own coordinates
-                const int need = have ? ((ohi - (olo - (olo & 1)) + 2) >> 1) + 1 : 0;                             // lanes: diagonal pairs + the separator
-                int acc = 0, u = 0, mine = 0;
-                for (int k = 0; k < 2 * nchunk; ++k) {               // first fit, in order (uniform loop: the plan is a few dozen scalar operations)
-                    const int w = rl(need, k);
-                    if (acc + w > 64) { if (lane == 0) sUF[u + 1] = (uint8_t)k; ++u; acc = 0; }
-                    if (lane == k) mine = u | (acc << 8);
-                    acc += w;
-                }
-                if (have) sMat[q] = (short)mine;
-                if (lane == 0) { sUF[0] = 0; sUF[u + 1] = (uint8_t)(2 * nchunk); }
+            // ---- A1/A2: fill (SPEC v6: on the band of diagonals only).  Work units, one wave each, every unit ONE anti-diagonal sweep:
+            //   quad units — FOUR short reads per wave, one per 16-lane DPP row, alpha and beta of a quad on different waves;
+            //   long units — one read per wave (lane = row), alpha and beta on different waves.
+            // alpha(I,J) / beta(0,0) of a read meet in LDS, and every wave derives the reads' validity from them after the barrier (lane = read; identical values
+            // in every wave: no second barrier).  Eight short reads = two quads = four units: every wave runs one sweep per chunk.
 #ifdef CCSX_EXP_NO_FILL                                     // experiment (timing only, wrong results)
-                nunit_f = 0;
+            const int nquad = 0, nunit_f = 0, rpq = 4;
 #else
-                nunit_f = nchunk > 0 ? u + 1 : 0;
+            // (reads per quad unit: always four.  Spreading a small chunk — three passes, the tail chunk of ten — over all the waves, two reads or one per unit, was
+            // measured and is SLOWER: k_polish 313.9 against 301.6 ms at 10 passes, 95.8 against 92.4 at 3 — the kernel is bound by its instruction count, and a
+            // sweep costs the same instructions whatever it holds)
+            const int rpq = 4;
+            const int nquad = (nshort + rpq - 1) / rpq, nunit_f = 2 * nquad + 2 * nlong;
 #endif
-            }
             for (int fu = wave; fu < nunit_f; fu += (PWT / 64)) {
-                // which matrix this lane works for, and where in it
-                const int qf = rfl((int)sUF[fu]), ql = rfl((int)sUF[fu + 1]);
-                int q = -1, lane0 = 0;
-                for (int k = qf; k < ql; ++k) { const int mk = rfl((int)sMat[k]); if (lane >= (mk >> 8)) { q = k; lane0 = mk >> 8; } }
-                const bool inmat = q >= 0;
-                const int isb = inmat ? (q & 1) : 0;
-                const int myr = sTask[inmat ? q >> 1 : 0].x;
+              if (fu < 2 * nquad) {
+                // ---- quad unit.  Lane l of a DPP row owns read rows l and l + 16 (a short segment has at most 32 rows): row i is on the band for the 15-or-so
+                // steps t = i + j in [2 i + dlo, 2 i + dhi], row i + 16 exactly 32 steps later, so with a band of at most FILL16_MAXBW = 24 diagonals the lane is
+                // idle for at least 8 steps in between and changes rows there.  The neighbour row's cell comes by a ROTATION inside the DPP row (row_ror: lane 0
+                // takes lane 15, whose row 15 precedes lane 0's row 16; while lane 0 is on row 0, lane 15 has not started and holds a zero).  A lane that is not on
+                // the band holds a zero running cell, which is what its neighbours must read past the band's edge.  Look-ups are software-pipelined as before: slot k
+                // holds DL and the (ME, INS) pair of the step's column and the context offset of the column four steps on, refilled right after use.  The row
+                // change therefore happens in two parts: the look-up side (observation row, column-entry pointer) at the first iteration whose look-ups no longer
+                // serve the old row, the compute side (activity window, store pointer) one iteration later.
+                const int quad = fu >> 1, isb = fu & 1;
+                const int g4 = lane >> 4, l16 = lane & 15;
+                const int qi = rpq * quad + g4;
+                const bool have = g4 < rpq && qi < nshort;
+                const int myr = sTask[nlong + (have ? qi : rpq * quad)].x;
                 const int I = sI[myr], sd = sStrand[myr], band = sBand[myr];
                 const int pitch = band & 255, rowsz = (band >> 8) & 255, bdlo = (int)((unsigned)band >> 24) - 128, bdhi = bdlo + ((band >> 16) & 255) - 1;
-                const int olo = isb ? (J - I) - bdhi : bdlo, ohi = isb ? (J - I) - bdlo : bdhi;
-                const int h0 = -(olo - (olo & 1)) >> 1;               // dloX = -2 h0
-                const int off = lane - lane0, m = off - 1;            // off 0 = the separator
-                const int dE = 2 * (m - h0), dO = dE + 1;
-                const bool vE = inmat && m >= 0 && dE >= olo && dE <= ohi, vO = inmat && m >= 0 && dO >= olo && dO <= ohi;
-                const int mh = m - h0;
-                // iterations in which the lane's cells are cells of the matrix: 0 <= ii <= I, 0 <= jj <= J
-                const int nElo = mh < 0 ? -mh : mh, nEhi = (I + mh < J - mh) ? I + mh : J - mh;
-                const int nOlo = mh > -mh - 1 ? mh : -mh - 1, nOhi = (I + mh < J - mh - 1) ? I + mh : J - mh - 1;
-                const bool aE = vE && nEhi >= nElo, aO = vO && nOhi >= nOlo;
-                int cntE = aE ? -nElo : -(1 << 20), cntO = aO ? -nOlo : -(1 << 20);
-                const unsigned spanE = aE ? (unsigned)(nEhi - nElo) : 0u, spanO = aO ? (unsigned)(nOhi - nOlo) : 0u;
-                int Imax = 0;
-                for (int k = qf >> 1; k <= (ql - 1) >> 1; ++k) { const int ik = rfl(sI[rfl((int)sTask[k].x)]); Imax = ik > Imax ? ik : Imax; }   // (the reads of the unit's matrices)
-                const int N = ((Imax + J) >> 1) + 1;
-                // own cell (ii, jj) at n = 0; alpha: (i, j) = (ii, jj), beta: (I - ii, J - jj)
-                const int ii0 = -mh, jj0 = mh;
-                const unsigned long long mB = __ballot(isb != 0);
-                typedef const uint8_t __attribute__((address_space(3))) *lds_u8p;
-                typedef int v4i __attribute__((ext_vector_type(4)));
-                typedef const v4i __attribute__((address_space(3))) *lds_i4p;
-                typedef float __attribute__((address_space(3))) *lds_fp;
-                // observation of the cell's row: alpha o_{i-1} = sObs[.][i], beta o_i = sObs[.][1 + i] (index 0 and 1 + I hold "no base")
-                lds_u8p op = (lds_u8p)(&sObs[myr][0] + (isb ? 1 + I - ii0 : ii0));
-                const int ostep = isb ? -1 : 1;
-                lds_i4p ep = (lds_i4p)(&sEnt[isb][sd][0] + (SE_G + jj0));
-                lds_fp sp = (lds_fp)(sGB + (isb ? sBoff[myr] + (I - ii0) * pitch + (J - jj0) : sGoff[myr] + ii0 * pitch + jj0));
-                const int sstep = isb ? -(pitch + 1) : pitch + 1, ostep1 = isb ? -1 : 1;
-                lds_cc ctxb = (lds_cc)sCTX;
-                float E = 0.0f, O = (inmat && off == h0) ? 1.0f : 0.0f;     // the seed: slot (0, -1) below the unit cell
-                // Software pipeline, three slots deep (a plain loop waits for two dependent LDS round trips per iteration — observation code -> table entries — and was
-                // SLOWER than the quad fill with half its instructions: 329.7 against 300 ms): iteration n computes with the table entries fetched during iteration
-                // n - 1, fetches those of iteration n + 1 (their addresses come from the observation code and the column entries fetched during n - 1), and fetches
-                // the observation code of iteration n + 2 and the column entry of n + 3.  Column entries X_k (k-th column along the lane's path: iteration n uses
-                // X_n for its E cell and X_n+1 for its O cell), observation codes and coefficient sets rotate through three named slots, no register copies.
-                typedef const float __attribute__((address_space(3))) *lds_cfp;
-                v4i X0 = ep[0], X1 = ep[1], X2 = ep[2];
-                int oc0 = (int)op[0], oc1 = (int)op[ostep], oc2 = 0;
-                float c1E0, qE0, c1O0, qO0, c1E1 = 0.f, qE1 = 0.f, c1O1 = 0.f, qO1 = 0.f, c1E2 = 0.f, qE2 = 0.f, c1O2 = 0.f, qO2 = 0.f;
-                {
-                    const int ob = __mul24(oc0, CTXS * 8);
-                    c1E0 = *(lds_cfp)(ctxb + ob + X0.y); qE0 = *(lds_cfp)(ctxb + ob + X0.z); c1O0 = *(lds_cfp)(ctxb + ob + X1.y); qO0 = *(lds_cfp)(ctxb + ob + X1.z);
-                }
-                op += 2 * ostep; ep += 3;                            // op -> the code of iteration 2, ep -> X_3
-                asm volatile("" : "+v"(op), "+v"(ep), "+v"(sp));
-#define CCSX_SEL(MASK, A, B) sel_lanes(MASK, A, B)          /* A in the lanes of MASK, B elsewhere */
-                // slot names: S = this iteration's, T = the next one's, U = the one after (column entry X_S.x = DL of the E cell, X_T.x = DL of the O cell)
-#define CCSX_ST_ITER(XS, XT, XU, OCT, OCU, C1ES, QES, C1OS, QOS, C1ET, QET, C1OT, QOT)                                     \
-                {                                                                                                          \
-                    {   /* the look-ups of the NEXT iteration: E cell entry X_T, O cell entry X_U, the row's observation code OCT */ \
-                        const int ob = __mul24(OCT, CTXS * 8);                                                             \
-                        C1ET = *(lds_cfp)(ctxb + ob + XT.y); QET = *(lds_cfp)(ctxb + ob + XT.z);                            \
-                        C1OT = *(lds_cfp)(ctxb + ob + XU.y); QOT = *(lds_cfp)(ctxb + ob + XU.z);                            \
-                    }                                                                                                      \
-                    OCU = (int)*op; op += ostep;                     /* ... the code of the iteration after next */         \
-                    const float dlE = __int_as_float(XS.x), dlO = __int_as_float(XT.x);                                    \
-                    {   /* E cell */                                                                                       \
-                        const float L = wave_shr1_f32_z(O);                                                                \
-                        const float A = E * C1ES, l = L * dlE, u = O * QES;                                                \
-                        const float g = A + CCSX_SEL(mB, u, l);                                                            \
-                        const float val = g + CCSX_SEL(mB, l, u);                                                          \
-                        const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)cntE, spanE, 37 /* ule */);         \
-                        if (__builtin_amdgcn_inverse_ballot_w64(on)) *sp = CCSX_SEL(mB, val, g);                           \
-                        E = lanes_or_zero(on, val);                                                                        \
-                    }                                                                                                      \
-                    XS = *ep; ep += 1;                               /* X_S is spent: its slot takes the entry three columns on */ \
-                    {   /* O cell */                                                                                       \
-                        const float U = wave_shl1_f32_z(E);                                                                \
-                        const float A = O * C1OS, l = E * dlO, u = U * QOS;                                                \
-                        const float g = A + CCSX_SEL(mB, u, l);                                                            \
-                        const float val = g + CCSX_SEL(mB, l, u);                                                          \
-                        const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)cntO, spanO, 37 /* ule */);         \
-                        if (__builtin_amdgcn_inverse_ballot_w64(on)) sp[ostep1] = CCSX_SEL(mB, val, g);                    \
-                        O = lanes_or_zero(on, val);                                                                        \
-                    }                                                                                                      \
-                    sp += sstep; cntE += 1; cntO += 1;                                                                     \
-                }
-                {
-                    int n = 0;
-                    for (; n + 3 <= N; n += 3) {
-                        CCSX_ST_ITER(X0, X1, X2, oc1, oc2, c1E0, qE0, c1O0, qO0, c1E1, qE1, c1O1, qO1)
-                        CCSX_ST_ITER(X1, X2, X0, oc2, oc0, c1E1, qE1, c1O1, qO1, c1E2, qE2, c1O2, qO2)
-                        CCSX_ST_ITER(X2, X0, X1, oc0, oc1, c1E2, qE2, c1O2, qO2, c1E0, qE0, c1O0, qO0)
+                const int row0 = l16, row1 = l16 + 16;
+                const bool ok0 = have && row0 <= I, ok1 = have && row1 <= I;
+                const int jlo0 = (row0 + bdlo > 0) ? row0 + bdlo : 0, jhi0 = (row0 + bdhi < J) ? row0 + bdhi : J;
+                const int jlo1 = (row1 + bdlo > 0) ? row1 + bdlo : 0, jhi1 = (row1 + bdhi < J) ? row1 + bdhi : J;
+                int Tmax = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int iq = rfl(sI[rfl((int)sTask[nlong + ((q < rpq && rpq * quad + q < nshort) ? rpq * quad + q : rpq * quad)].x)]); Tmax = iq > Tmax ? iq : Tmax; }
+                Tmax += J;
+                const int NEVER = 1 << 20;
+#define LDPR(ROWP, OFF) (*(const float2 *)((ROWP) + (OFF)))
+                if (!isb) {
+                    // alpha: row 0 first.  Step t: the lane's row i computes column j = t - i
+                    const int obA0 = OBS_CODE((row0 >= 1 && ok0) ? (int)sObs[myr][row0 - 1] : 12);     // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                    const int obA1 = OBS_CODE(ok1 ? (int)sObs[myr][row1 - 1] : 12);
+                    const char *rowA = (const char *)sCTX + obA0;
+                    const char *rowA1 = (const char *)sCTX + obA1;
+                    const int tA0 = ok0 ? row0 + jlo0 : NEVER, tA1 = row1 + jlo1;
+                    unsigned uJ = ok0 ? (unsigned)(jhi0 - jlo0) : 0u;
+                    const unsigned uJ1 = (unsigned)(jhi1 - jlo1);
+                    const int tsw = ok1 ? ((row0 + jhi0) & ~3) : NEVER;          // = the first multiple of 4 >= (last step of row i) - 3
+                    const int2 *eA = sEA[sd] + (FE_ALO - row0);                       // eA[x] = the entry of column x - row
+                    float *gA = sGB + sGoff[myr] + row0 * pitch - row0;               // gA[x] = gamma(row, x - row)
+                    const int dgA = 16 * (pitch - 1), dcnt = tA0 - tA1;
+                    float acur = (ok0 && row0 == 0) ? 1.0f : 0.0f, mnext = 0.0f;     // mnext = alpha(i-1, j-1) * ME(j-1) of the next step, formed a step ahead
+#define CCSX_A_INIT(K) const int2 ea##K = eA[K], fa##K = eA[(K) - 4]; float dl##K = __int_as_float(ea##K.x); int cx##K = ea##K.y; float2 p##K = LDPR(rowA, fa##K.y);
+                    CCSX_A_INIT(0) CCSX_A_INIT(1) CCSX_A_INIT(2) CCSX_A_INIT(3)
+#undef CCSX_A_INIT
+                    int cnt = -tA0;
+#define CCSX_A_STEP(K)                                                                                                     \
+                    {                                                                                                      \
+                        const float up = row_ror1_f32(acur);         /* alpha(i-1, j) */                                     \
+                        const float dl = acur * dl##K;                                                                     \
+                        const float gmm = mnext + dl;                                                                      \
+                        const float st = up * p##K.y;                /* row 0 and column J read zero entries: +0 */        \
+                        const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)(cnt + (K)), uJ, 37 /* ule */);    \
+                        if (__builtin_amdgcn_inverse_ballot_w64(on)) gA[(K)] = gmm;                                        \
+                        acur = lanes_or_zero(on, gmm + st);          /* (ONE compare: the mask serves the store's exec and the select) */ \
+                        mnext = up * p##K.x;                                                                               \
+                        p##K = LDPR(rowA, cx##K);                                                                          \
+                        const int2 en = eA[(K) + 4];                                                                       \
+                        dl##K = __int_as_float(en.x); cx##K = en.y;                                                        \
                     }
-                    if (n < N) {
-                        CCSX_ST_ITER(X0, X1, X2, oc1, oc2, c1E0, qE0, c1O0, qO0, c1E1, qE1, c1O1, qO1)
-                        if (n + 1 < N) { CCSX_ST_ITER(X1, X2, X0, oc2, oc0, c1E1, qE1, c1O1, qO1, c1E2, qE2, c1O2, qO2) }
+                    for (int t = 0; t <= Tmax; t += 4, eA += 4, gA += 4, cnt += 4) {
+                        if (t == tsw) { rowA = rowA1; eA -= 16; }
+                        if (t - 4 == tsw) { uJ = uJ1; cnt += dcnt; gA += dgA; }
+                        CCSX_A_STEP(0) CCSX_A_STEP(1) CCSX_A_STEP(2) CCSX_A_STEP(3)
                     }
+#undef CCSX_A_STEP
+                    // (a lane's running cell is zero once its row has left the band: alpha(I,J) = gamma(I,J) — no stay in the final column — is read back from LDS)
+                    if (have && l16 == 0) sBase[myr] = sGB[sGoff[myr] + I * pitch + J];
+                } else {
+                    // beta: row I first.  Step t: the lane's row i computes column j = J - (t - (I - i)); a lane with two rows starts on row l + 16
+                    const int rowF = ok1 ? row1 : row0, jloF = ok1 ? jlo1 : jlo0, jhiF = ok1 ? jhi1 : jhi0;
+                    const int obB0 = OBS_CODE((ok0 && row0 < I) ? (int)sObs[myr][row0] : 12);           // o_i; 12 = no base: row I emits nothing more
+                    const int obBF = ok1 ? OBS_CODE(row1 < I ? (int)sObs[myr][row1] : 12) : obB0;
+                    const char *rowB = (const char *)sCTX + obBF;
+                    const char *rowB0 = (const char *)sCTX + obB0;
+                    const int tB0 = ok0 ? I - rowF + J - jhiF : NEVER, tB1 = I - row0 + J - jhi0;
+                    unsigned uJ = ok0 ? (unsigned)(jhiF - jloF) : 0u;
+                    const unsigned uJ1 = (unsigned)(jhi0 - jlo0);
+                    const int tsw = ok1 ? ((I - row1 + J - jlo1) & ~3) : NEVER;
+                    const int2 *eB = sEB[sd] + (FE_BLO + J + I - rowF);               // eB[-x] = the entry of column J + I - row - x
+                    float *bE = sGB + sBoff[myr] + rowF * pitch + (J + I - rowF);     // bE[-x] = beta(row, J + I - row - x)
+                    const int dbE = -16 * (pitch - 1), dcnt = tB0 - tB1;
+                    float bcur = (ok0 && rowF == I) ? 1.0f : 0.0f, t1next = 0.0f;    // t1next = ME(j) * beta(i+1, j+1) of the next step
+#define CCSX_B_INIT(K) const int2 eb##K = eB[-(K)], fb##K = eB[4 - (K)]; float dk##K = __int_as_float(eb##K.x); int cy##K = eb##K.y; float2 q##K = LDPR(rowB, fb##K.y);
+                    CCSX_B_INIT(0) CCSX_B_INIT(1) CCSX_B_INIT(2) CCSX_B_INIT(3)
+#undef CCSX_B_INIT
+                    int cnt = -tB0;
+#define CCSX_B_STEP(K, KN)                                                                                                 \
+                    {                                                                                                      \
+                        const float dn = row_rol1_f32(bcur);         /* beta(i+1, j) */                                    \
+                        const float t2 = q##K.y * dn;                                                                      \
+                        const float t3 = dk##K * bcur;                                                                     \
+                        const float bv = (t1next + t2) + t3;                                                               \
+                        const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)(cnt + (K)), uJ, 37 /* ule */);    \
+                        if (__builtin_amdgcn_inverse_ballot_w64(on)) bE[-(K)] = bv;                                        \
+                        bcur = lanes_or_zero(on, bv);                                                                      \
+                        t1next = q##KN.x * dn;                       /* (slot KN holds the pair of the next step's column) */ \
+                        q##K = LDPR(rowB, cy##K);                                                                          \
+                        const int2 en = eB[-(K) - 4];                                                                      \
+                        dk##K = __int_as_float(en.x); cy##K = en.y;                                                        \
+                    }
+                    for (int t = 0; t <= Tmax; t += 4, eB -= 4, bE -= 4, cnt += 4) {
+                        if (t == tsw) { rowB = rowB0; eB += 16; }
+                        if (t - 4 == tsw) { uJ = uJ1; cnt += dcnt; bE += dbE; }
+                        CCSX_B_STEP(0, 1) CCSX_B_STEP(1, 2) CCSX_B_STEP(2, 3) CCSX_B_STEP(3, 0)
+                    }
+#undef CCSX_B_STEP
+                    // zero row I+1 of beta; beta(0,0)
+                    const int org_ = pitch == S ? 0 : -bdlo;
+                    if (have) for (int x = l16; x < rowsz; x += 16) sGB[sBoff[myr] - org_ + (I + 1) * rowsz + x] = 0.0f;
+                    if (have && l16 == 0) sB00[myr] = sGB[sBoff[myr]];
                 }
-#undef CCSX_ST_ITER
-#undef CCSX_SEL
-                // alpha(I,J) = gamma(I,J) (no stay in the final column) and beta(0,0) are read back from the cells the wave has just stored; row I+1 of beta: zeros
-                if (inmat && off == 0) {
-                    if (isb) sB00[myr] = sGB[sBoff[myr]];
-                    else sBase[myr] = sGB[sGoff[myr] + I * pitch + J];
+#undef LDPR
+              } else {
+                // ---- long unit: one read per wave, lane = row, the plain loop (alpha-only or beta-only)
+                const int tk = (fu - 2 * nquad) >> 1, mode = 1 + ((fu - 2 * nquad) & 1);      // 1: alpha only, 2: beta only
+                const int myr = rfl((int)sTask[tk].x);
+                const int row = lane;
+                const int I = rfl(sI[myr]);
+                const int Tmax = I + J;
+                const int sd = sStrand[myr];
+                const int2 *CJ = sColJ[sd];
+                const bool rowok = row <= I;
+                // SPEC v6: the columns of this lane's row that lie on the read's band, jlo .. jhi; the cells outside are zeros and are neither computed nor stored
+                const int band = sBand[myr];
+                const int pitch = band & 255, rowsz = (band >> 8) & 255, bdlo = (int)((unsigned)band >> 24) - 128, bdhi = bdlo + ((band >> 16) & 255) - 1;
+                const int jlo = (row + bdlo > 0) ? row + bdlo : 0, jhi = (row + bdhi < J) ? row + bdhi : J;
+                // the lane's rows of sCTX, as byte offsets
+                const int op = OBS_CODE((row >= 1 && rowok) ? (int)sObs[myr][row - 1] : 12);   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                const int oc = OBS_CODE((row < I) ? (int)sObs[myr][row] : 12);                  // o_i;     12 = no base: row I emits nothing more
+                const char *rowA = (const char *)sCTX + op, *rowB = (const char *)sCTX + oc;
+                // activity windows: alpha computes column j = t - row for t in [row + jlo, row + jhi]; beta computes column
+                // jb = J - (t - (I - row)) for t in [I - row + J - jhi, I - row + J - jlo]
+                const int tA0 = rowok ? row + jlo : (1 << 20), tB0 = rowok ? I - row + J - jhi : (1 << 20);
+                const float one0 = (row == 0) ? 1.0f : 0.0f, oneI = (row == I) ? 1.0f : 0.0f;
+                const int2 *cA = CJ - row;
+                float *gA = sGB + sGoff[myr] + row * pitch - row;
+                const int2 *cB = CJ + (J + I - row - 1);                                   // the SECOND step of an iteration; the first is one column up
+                float *bB = sGB + sBoff[myr] + row * pitch + (J + I - row - 1);
+                // start values chosen so that the general recurrence yields the boundary cells: gamma(i,0) = 0*x + one0*1,
+                // beta(i,J) = (0 + 0) + 1*oneI (column J of the tables is zero with DL = 1)
+                float acur = one0, updiag = 0.0f, mePrev = 0.0f, dlPrev = 1.0f;
+                float bcur = oneI, dndiag = 0.0f;
+                // a lane whose step is not on the band holds a ZERO running cell (SPEC v6: its neighbours read the cell past the band's edge as zero); row 0 / row I
+                // keep their start value until their first step, which is the sweep's first
+                const unsigned uJ = rowok ? (unsigned)(jhi - jlo) : 0u;   // (a lane beyond the read's rows: tA0 / tB0 keep it off; its jlo .. jhi may be an empty, i.e. negative, range)
+                const int tAc = rowok ? row : (1 << 20);             // (the loop carries ME / DL of the previous column from column 0 on)
+                const unsigned uJc = (unsigned)J;
+                if (mode == 1) {
+                    int2 ca0 = cA[0], ca1 = cA[1];
+                    for (int t = 0; t <= Tmax; t += 2, cA += 2, gA += 2) {
+                        const int2 na0 = cA[2], na1 = cA[3];
+#define CCSX_LA_STEP(T, AOFF, CJA)                                                                                         \
+                        {                                                                                                  \
+                            const float up = wave_shr1_f32_z(acur);  /* all rows of the read shift together (full exec) */ \
+                            float nv = 0.0f;                                                                               \
+                            if ((unsigned)((T) - tAc) <= uJc) {      /* alpha, column j = T - row of the window */        \
+                                const float2 pr = *(const float2 *)(rowA + (CJA).y);                                       \
+                                const float dlc = __int_as_float((CJA).x);                                                 \
+                                const float m = updiag * mePrev, dl = acur * dlPrev;                                        \
+                                const float gmm = m + dl;                                                                  \
+                                const float st = up * pr.y;          /* row 0 and column J read zero entries: +0 */       \
+                                if ((unsigned)((T) - tA0) <= uJ) { gA[(AOFF)] = gmm; nv = gmm + st; }   /* ... on the band */ \
+                                mePrev = pr.x; dlPrev = dlc;                                                               \
+                            }                                                                                              \
+                            acur = nv;                                                                                     \
+                            updiag = up;                                                                                   \
+                        }
+                        CCSX_LA_STEP(t, 0, ca0)
+                        CCSX_LA_STEP(t + 1, 1, ca1)
+#undef CCSX_LA_STEP
+                        ca0 = na0; ca1 = na1;
+                    }
+                    if (lane == 0) sBase[myr] = sGB[sGoff[myr] + I * pitch + J];   // (alpha(I,J) = gamma(I,J): no stay in the final column)
+                } else {
+                    int2 cb0 = cB[1], cb1 = cB[0];
+                    for (int t = 0; t <= Tmax; t += 2, cB -= 2, bB -= 2) {
+                        const int2 nb0 = cB[-1], nb1 = cB[-2];
+#define CCSX_LB_STEP(T, BOFF, CJB)                                                                                         \
+                        {                                                                                                  \
+                            const float dn = wave_shl1_f32_z(bcur);                                                        \
+                            float nv = 0.0f;                                                                               \
+                            if ((unsigned)((T) - tB0) <= uJ) {       /* beta, column jb = J - (T - (I - row)), on the band */ \
+                                const float2 pr = *(const float2 *)(rowB + (CJB).y);                                       \
+                                const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                             \
+                                const float t3 = __int_as_float((CJB).x) * bcur;                                           \
+                                const float bv = (t1 + t2) + t3;                                                           \
+                                bB[(BOFF)] = bv;                                                                           \
+                                nv = bv;                                                                                   \
+                            }                                                                                              \
+                            bcur = nv;                                                                                     \
+                            dndiag = dn;                                                                                   \
+                        }
+                        CCSX_LB_STEP(t, 1, cb0)
+                        CCSX_LB_STEP(t + 1, 0, cb1)
+#undef CCSX_LB_STEP
+                        cb0 = nb0; cb1 = nb1;
+                    }
+                    const int org_ = pitch == S ? 0 : -bdlo;      // (row layout: no origin shift)
+                    if (row < rowsz) sGB[sBoff[myr] - org_ + (I + 1) * rowsz + row] = 0.0f;
+                    if (lane == 0) sB00[myr] = sGB[sBoff[myr]];
                 }
-                if (inmat && isb) {
-                    const int org_ = pitch == S ? 0 : -bdlo;         // (row layout: no origin shift)
-                    const int nlan = ((ohi + 2 * h0 + 2) >> 1) + 1;   // lanes of this matrix
-                    for (int x = off; x < rowsz; x += nlan) sGB[sBoff[myr] - org_ + (I + 1) * rowsz + x] = 0.0f;
-                }
+              }
             }
             __syncthreads();
             PHASE(3);
@@ -2769,7 +2838,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         ca.dg = La.c - i0a - dloA; ca.db = La.q - i0a - dloA;
                         ca.bq = *ca.be; if ((unsigned)ca.db >= bwA) ca.bq = 0.0f;
                         ca.be += pA; ca.db -= 1;
-                        ca.op = (lds_cu8)(&sObs[ra][1] + i0a);
+                        ca.op = (lds_cu8)(&sObs[ra][0] + i0a);
                         asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(tAa), "+v"(tBa), "+v"(ca.op));
                         {   // two rows per iteration: the chain's carried values (previous table pairs, beta, a, b) then rotate between two
                             // register sets instead of being copied at every row (3 v_mov + a loop counter per row before)
@@ -2810,7 +2879,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     ca.bq = *ca.be; if ((unsigned)ca.db >= bwA) ca.bq = 0.0f;
                     cb.bq = *cb.be; if ((unsigned)cb.db >= bwB) cb.bq = 0.0f;
                     ca.be += pA; ca.db -= 1; cb.be += pB; cb.db -= 1;
-                    ca.op = (lds_cu8)(&sObs[ra][1] + i0a); cb.op = (lds_cu8)(&sObs[rb][1] + i0b);
+                    ca.op = (lds_cu8)(&sObs[ra][0] + i0a); cb.op = (lds_cu8)(&sObs[rb][0] + i0b);
                     // opaque to the optimiser from here: the running pointers hold complete LDS addresses (otherwise the
                     // dynamic-LDS base is re-added at every use)
                     asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(cb.g), "+v"(cb.be), "+v"(tAa), "+v"(tBa), "+v"(tAb), "+v"(tBb), "+v"(ca.op), "+v"(cb.op));
