@@ -2578,27 +2578,6 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     CCSX_A_INIT(0) CCSX_A_INIT(1) CCSX_A_INIT(2) CCSX_A_INIT(3)
 #undef CCSX_A_INIT
                     int cnt = -tA0;
-#ifdef PW_FILL_MASKCOEF
-                    // variant: no select in the dependent chain of a step — a step that is off the band gets ZERO coefficients instead (three selects on the
-                    // pipelined look-ups, off the chain), so its cell comes out as an exact zero by arithmetic: chain multiply-add-add instead of multiply-add-add-select
-                    unsigned long long onc = __builtin_amdgcn_uicmp((unsigned)cnt, uJ, 37 /* ule */);
-#define CCSX_A_STEP(K)                                                                                                     \
-                    {                                                                                                      \
-                        const float up = row_ror1_f32(acur);                                                               \
-                        const unsigned long long onn = __builtin_amdgcn_uicmp((unsigned)(cnt + (K) + 1), uJ, 37 /* ule */);\
-                        const float dlm = lanes_or_zero(onc, dl##K), pym = lanes_or_zero(onc, p##K.y), pxm = lanes_or_zero(onn, p##K.x); \
-                        const float dl = acur * dlm;                                                                       \
-                        const float gmm = mnext + dl;                                                                      \
-                        const float st = up * pym;                                                                         \
-                        if (__builtin_amdgcn_inverse_ballot_w64(onc)) gA[(K)] = gmm;                                       \
-                        acur = gmm + st;                                                                                   \
-                        mnext = up * pxm;                                                                                  \
-                        p##K = LDPR(rowA, cx##K);                                                                          \
-                        const int2 en = eA[(K) + 4];                                                                       \
-                        dl##K = __int_as_float(en.x); cx##K = en.y;                                                        \
-                        onc = onn;                                                                                         \
-                    }
-#else
 #define CCSX_A_STEP(K)                                                                                                     \
                     {                                                                                                      \
                         const float up = row_ror1_f32(acur);         /* alpha(i-1, j) */                                     \
@@ -2613,7 +2592,6 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         const int2 en = eA[(K) + 4];                                                                       \
                         dl##K = __int_as_float(en.x); cx##K = en.y;                                                        \
                     }
-#endif
                     for (int t = 0; t <= Tmax; t += 4, eA += 4, gA += 4, cnt += 4) {
                         if (t == tsw) { rowA = rowA1; eA -= 16; }
                         if (t - 4 == tsw) { uJ = uJ1; cnt += dcnt; gA += dgA; }
@@ -2641,25 +2619,6 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     CCSX_B_INIT(0) CCSX_B_INIT(1) CCSX_B_INIT(2) CCSX_B_INIT(3)
 #undef CCSX_B_INIT
                     int cnt = -tB0;
-#ifdef PW_FILL_MASKCOEF
-                    unsigned long long onc = __builtin_amdgcn_uicmp((unsigned)cnt, uJ, 37 /* ule */);
-#define CCSX_B_STEP(K, KN)                                                                                                 \
-                    {                                                                                                      \
-                        const float dn = row_rol1_f32(bcur);                                                               \
-                        const unsigned long long onn = __builtin_amdgcn_uicmp((unsigned)(cnt + (K) + 1), uJ, 37 /* ule */);\
-                        const float qym = lanes_or_zero(onc, q##K.y), dkm = lanes_or_zero(onc, dk##K), qnx = lanes_or_zero(onn, q##KN.x); \
-                        const float t2 = qym * dn;                                                                         \
-                        const float t3 = dkm * bcur;                                                                       \
-                        const float bv = (t1next + t2) + t3;                                                               \
-                        if (__builtin_amdgcn_inverse_ballot_w64(onc)) bE[-(K)] = bv;                                       \
-                        bcur = bv;                                                                                         \
-                        t1next = qnx * dn;                                                                                 \
-                        q##K = LDPR(rowB, cy##K);                                                                          \
-                        const int2 en = eB[-(K) - 4];                                                                      \
-                        dk##K = __int_as_float(en.x); cy##K = en.y;                                                        \
-                        onc = onn;                                                                                         \
-                    }
-#else
 #define CCSX_B_STEP(K, KN)                                                                                                 \
                     {                                                                                                      \
                         const float dn = row_rol1_f32(bcur);         /* beta(i+1, j) */                                    \
@@ -2674,7 +2633,6 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         const int2 en = eB[-(K) - 4];                                                                      \
                         dk##K = __int_as_float(en.x); cy##K = en.y;                                                        \
                     }
-#endif
                     for (int t = 0; t <= Tmax; t += 4, eB -= 4, bE -= 4, cnt += 4) {
                         if (t == tsw) { rowB = rowB0; eB += 16; }
                         if (t - 4 == tsw) { uJ = uJ1; cnt += dcnt; bE += dbE; }
