@@ -587,7 +587,7 @@ void write_report(const Options &o, const Report &r)
         std::fprintf(f, ">=Q30 Read Length (mean, bp)  : %s\n", with_commas(q30.len_mean).c_str());
         std::fprintf(f, ">=Q30 Read Length (median, bp): %s\n", with_commas(q30.len_median).c_str());
         std::fprintf(f, ">=Q30 Read Quality (median)   : %d\n", q30.qual_median);
-        std::fprintf(f, "\nBase quality >=Q30 (bp)       : %s (%.1f%%)\n", with_commas(r.bases_q30).c_str(), pct(r.bases_q30, all_bases));
+        std::fprintf(f, "\nBase quality >=Q30 (bp)       : %s (%.1f%%)\n", with_commas(r.bases_q30).c_str(), pct(r.bases_q30, hifi.yield));
         std::fclose(f);
     }
 }
@@ -1020,7 +1020,9 @@ int main(int argc, char **argv)
                     ++rep.pass;
                     const int64_t o = bt.seq_off[s]; const int32_t len = bt.seq_len[s];
                     if (opt.qv_binning) for (int32_t q = 0; q < len; ++q) { uint8_t &v = bt.qual[o + q]; v = qvbin[v > 93 ? 93 : v]; }   // after rq (qv-binning.md:19-21)
-                    for (int32_t q = 0; q < len; ++q) rep.bases_q30 += bt.qual[o + q] >= 30 ? 1 : 0;
+                    // "Base quality >=Q30 (bp)" is a statement about the HiFi yield (docs/faq/reports-aux-files.md:66: 62,526 of the 63,881 HiFi bases while <Q20 reads
+                    // are present): only reads with rq >= 0.99 count, and the percentage is taken over their bases
+                    if (bt.rq[s] >= 0.99f) for (int32_t q = 0; q < len; ++q) rep.bases_q30 += bt.qual[o + q] >= 30 ? 1 : 0;
                     const std::string qname = movie + "/" + std::to_string(z.zm) + "/ccs" + (z.strand_tag == 1 ? "/fwd" : (z.strand_tag == 2 ? "/rev" : ""));
                     if (fastq) {
                         fq.clear(); fq += '@'; fq += qname; fq += '\n';

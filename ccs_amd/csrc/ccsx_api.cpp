@@ -140,6 +140,7 @@ struct ccsx_handle_s {
     int device = 0;
     hipStream_t s_in = nullptr, s_draft = nullptr, s_comp = nullptr, s_out = nullptr;   // s_comp: polish stage (and the synchronous calls' copies)
     hipEvent_t ev_epoch = nullptr, ev_epoch_nx = nullptr;   // origin of ccsx_timings.start_ms / end_ms: recorded at creation and moved forward every few
+    float age_ms = 0.0f;              // end of the latest batch whose timings were read, relative to the current origin
     double epoch_ms = 0.0;            // minutes (epoch_ms = its distance from the creation), so that the float milliseconds HIP reports stay well below
                                       // 2^23 ms and keep their sub-microsecond resolution in long runs
     bool poisoned = false;            // a submit failed after work was enqueued: the handle refuses further batches
@@ -519,6 +520,25 @@ static int enqueue_download(Slot &S, ccsx_results *res, hipStream_t s)
 }
 
 // ---- asynchronous pipeline -------------------------------------------------------------------------------
+// The origin of ccsx_timings.start_ms / end_ms moves forward every 5 minutes of handle lifetime so that HIP's float milliseconds keep their resolution.
+// not inside the getter (it stalled behind every queued download and relied on negative elapsed times for slots recorded before the new origin) — only when
+// NO slot is in flight, i.e. every event of a completed slot lies before the new origin and none is pending: called from submit.  CCSX_EPOCH_REBASE_MS: test hook.
+static int rebase_epoch(ccsx_handle h)
+{
+    static const float limit = [] { const char *e = std::getenv("CCSX_EPOCH_REBASE_MS"); return e ? (float)std::atof(e) : 300000.0f; }();
+    if (h->age_ms <= limit) return 0;
+    for (auto &S : h->slot) if (S.inflight) return 0;
+    float d = 0.0f;
+    HIPTRY(hipEventRecord(h->ev_epoch_nx, h->s_draft));
+    HIPTRY(hipEventSynchronize(h->ev_epoch_nx));
+    HIPTRY(hipEventElapsedTime(&d, h->ev_epoch, h->ev_epoch_nx));
+    h->epoch_ms += (double)d;
+    std::swap(h->ev_epoch, h->ev_epoch_nx);
+    h->age_ms = 0.0f;
+    for (auto &S : h->slot) S.ran = false;               // timings of slots recorded before the new origin are gone (their tickets have been waited for)
+    return 0;
+}
+
 static int check_drafts(const Slot &S, const ccsx_drafts *d, bool input)
 {
     const int n = S.P.n_zmw;
@@ -540,6 +560,7 @@ static int submit_impl(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, cc
 #endif
     if (h->poisoned) { ccsx_set_error("ccsx_submit: an earlier submit failed after work had been enqueued; destroy the handle"); return -2; }
     HIPTRY(hipSetDevice(h->device));
+    if (int rc0 = rebase_epoch(h)) return rc0;
     Slot &S = h->slot[h->next_ticket % CCSX_SLOTS];
     if (S.inflight) {                                    // the slot's previous batch was never waited for: finish it first
         HIPTRY(hipEventSynchronize(S.ev_done));
@@ -675,14 +696,7 @@ static int slot_timings(ccsx_handle h, Slot &S, ccsx_timings *t)
     HIPTRY(hipEventElapsedTime(&a, h->ev_epoch, S.ev[0]));
     HIPTRY(hipEventElapsedTime(&b, h->ev_epoch, S.ev[5]));
     t->start_ms = h->epoch_ms + (double)a; t->end_ms = h->epoch_ms + (double)b;
-    if (b > 300000.0f) {              // move the origin forward (every 5 minutes of handle lifetime, on the idle download stream)
-        float d = 0.0f;
-        HIPTRY(hipEventRecord(h->ev_epoch_nx, h->s_out));
-        HIPTRY(hipEventSynchronize(h->ev_epoch_nx));
-        HIPTRY(hipEventElapsedTime(&d, h->ev_epoch, h->ev_epoch_nx));
-        h->epoch_ms += (double)d;
-        std::swap(h->ev_epoch, h->ev_epoch_nx);
-    }
+    h->age_ms = b;                    // (the origin moves forward at the next submit that finds the handle idle: rebase_epoch)
     return 0;
 }
 

@@ -1103,3 +1103,31 @@ def test_seams_share_the_ticket_pipeline(handle):
     for t in tickets: assert L.ccsx_wait(handle._h, t) == 0
     for b, r in zip(batches, results):
         _same_results(r, handle.consensus(b), b)
+
+
+@pytest.mark.gpu
+def test_timing_origin_moves_only_while_the_handle_is_idle(built):
+    """the origin of ccsx_timings.start_ms / end_ms is moved forward at a submit that finds NO slot in flight (never inside the getter, never under pending
+    tickets).  CCSX_EPOCH_REBASE_MS=0 forces a move at every idle submit: times stay monotone across moves, tickets in flight keep their timings."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys; sys.path.insert(0, %r)
+from ccs_amd import api
+h = api.Handle(0)
+bs = [api.synth(8, 5, 600, seed=70 + k) for k in range(4)]
+rs = [api.Results.allocate(b) for b in bs]
+ends = []
+t0 = h.submit(bs[0], rs[0]); h.wait(t0); a = h.ticket_timings(t0); ends.append((a.start_ms, a.end_ms)); h.release(t0)
+t1 = h.submit(bs[1], rs[1])                      # the handle was idle: the origin moved here
+t2 = h.submit(bs[2], rs[2])                      # one ticket in flight: no move
+h.wait(t1); b = h.ticket_timings(t1); ends.append((b.start_ms, b.end_ms))
+h.wait(t2); c = h.ticket_timings(t2); ends.append((c.start_ms, c.end_ms))
+h.release(t1); h.release(t2)
+t3 = h.submit(bs[3], rs[3]); h.wait(t3); d = h.ticket_timings(t3); ends.append((d.start_ms, d.end_ms))
+assert all(e > s_ > 0 for s_, e in ends), ends
+assert all(ends[k + 1][0] >= ends[k][0] for k in range(3)), ends
+print("ok", ends)
+''' % root
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CCSX_EPOCH_REBASE_MS="0"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-1500:] + p.stdout[-500:]
