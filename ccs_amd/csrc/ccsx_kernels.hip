@@ -2276,8 +2276,12 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         }
         return trimflag;
     };
-    const int ng0 = nreads < PW_MAXREADS ? nreads : PW_MAXREADS;
-    const int trimflag = load_meta(0, ng0);
+    // (the LAST group first: the candidate filter below walks the groups from the last to the first, so every group is loaded once and group 0 is the one that is
+    // resident when the rounds begin — ADVICE r04: a ZMW of 33-64 passes used to load group 0 twice here and once more in round 0)
+    const int glast = (ngroups > 1 ? ngroups - 1 : 0) * PW_MAXREADS;
+    const int ng0 = nreads - glast < PW_MAXREADS ? nreads - glast : PW_MAXREADS;
+    const int trimflag = load_meta(glast, ng0);
+    int resident = glast;                                   // the group whose per-read arrays and observation codes are in LDS (wave-uniform)
     for (int q = tid; q <= CCSX_MAX_PASSES; q += PWT) sZdrop[q] = 0;
     // level 4 for the group's ng reads: the read segments (native orientation), four reads per wave in flight; then the rare trim
     auto load_obs = [&](int ng, int tflag) {
@@ -2329,11 +2333,12 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         int nuse = 0, nd = 0;                                 // (wave 0)
         for (int g0 = (ngroups - 1) * PW_MAXREADS; g0 >= 0; g0 -= PW_MAXREADS) {
             const int ng = nreads - g0 < PW_MAXREADS ? nreads - g0 : PW_MAXREADS;
-            if (ngroups > 1) {
+            if (g0 != resident) {
                 __syncthreads();
                 const int tf = load_meta(g0, ng);
                 load_obs(ng, tf);
                 __syncthreads();
+                resident = g0;
             }
             if (wave == 0) {
                 const int vIr = lane < ng ? sI[lane] : -1;                      // lane = read: one load each, then v_readlane per read
@@ -2479,10 +2484,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         // ---- groups of PW_MAXREADS passes (one group for nearly every ZMW), and in a group: chunks of reads whose gamma/beta fit the LDS budget
         for (int g0 = 0; g0 < nreads; g0 += PW_MAXREADS) {
         const int ng = nreads - g0 < PW_MAXREADS ? nreads - g0 : PW_MAXREADS;
-        if (ngroups > 1) {                                   // (the per-read arrays and observation codes of the group; group 0 of round 0 is loaded already)
+        if (g0 != resident) {                                // (the per-read arrays and observation codes of the group; one group only: never reloaded)
             __syncthreads();
             const int tf = load_meta(g0, ng);
             load_obs(ng, tf);
+            resident = g0;
         }
         int rbeg = 0;
         while (rbeg < ng) {
