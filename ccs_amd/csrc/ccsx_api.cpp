@@ -113,7 +113,7 @@ struct Slot {
     int mode = CCSX_RUN_FUSED;
     int64_t ticket = -1;
     // scratch this batch needs per resident POA graph / alignment
-    size_t poa_slot_bytes = 0, align_slot_i32 = 0;
+    size_t poa_slot_bytes = 0, align_slot_i32 = 0, align16_slot_i32 = 0;
 
     void release()
     {
@@ -308,7 +308,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         const int wcap = S.dcap[z] / (CCSX_WIN_CORE - 3) + 4;   // cores are 19..25 columns (SPEC windows)
         S.seq_off[z + 1] = S.seq_off[z] + S.dcap[z];
         S.wb_off[z + 1] = S.wb_off[z] + wcap;
-        for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) S.ent_off[r + 1] = S.ent_off[r] + 2 * (wcap - 1);
+        for (int r = b->read_off[z]; r < b->read_off[z + 1]; ++r) S.ent_off[r + 1] = S.ent_off[r] + ((2 * (wcap - 1) + 3) & ~3);   // (a multiple of 4: k_align16_tb stores four entries at a time)
         maxL_max = std::max(maxL_max, maxL); vcap_max = std::max<int64_t>(vcap_max, S.vcap[z]); need_max = std::max(need_max, 2 * (wcap - 1));
     }
     if (maxL_max > 65535) { ccsx_set_error("ccsx_upload: subreads longer than 65535 bases are not supported"); return -1; }
@@ -401,7 +401,11 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     // 16 move bytes (a nibble per band row), 5 overflow in-edges, 6 words of order / rank / consensus / band state, two flag bytes = 238
     S.poa_slot_bytes = (((size_t)vcap_max + 64) * 238 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
     S.align_slot_i32 = (size_t)need_max * 128 + 4 * (size_t)need_max + 64;   // (origin, dirty bits) per cell and edge + band starts + best cell (score, row, entry row) per edge
-    int poa_slots, align_slots;
+    // k_align16 stores a quad's moves instead (2 bits per band row and column + 2 bits of band step and an edge flag per column: 18 words per block of 16 draft columns and pass)
+    int64_t dcap_max = 16;
+    for (int z = 0; z < n; ++z) dcap_max = std::max<int64_t>(dcap_max, S.dcap[z]);
+    S.align16_slot_i32 = (size_t)4 * (((size_t)((dcap_max + 15) / 16) * 18 + 3) & ~(size_t)3) + 16;
+    int poa_slots, align_slots, align16_slots;
     {
         std::lock_guard<std::mutex> lk(g_scratch_mutex);
         size_t freeb = 0, totalb = 0;
@@ -412,9 +416,10 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         poa_slots = h->opts.poa_slots > 0 ? h->opts.poa_slots : 16384;   // four graphs per wave: 16384 = 4 waves per SIMD
         poa_slots = std::min(poa_slots, n);
         poa_slots = (int)std::min<size_t>((size_t)poa_slots, std::max<size_t>(1, (budget * 3 / 4) / S.poa_slot_bytes));
-        align_slots = std::min(16384, std::max(R, 2));            // (the split alignment uses two slots per pass)
-        align_slots = (int)std::min<size_t>((size_t)align_slots, std::max<size_t>(2, (budget / 8) / (S.align_slot_i32 * 4)));
-        const size_t need_align = (size_t)align_slots * S.align_slot_i32 * 4;
+        align_slots = std::min(4096, std::max(R, 2));             // the 64-row retry and the split alignment (two slots per pass) run grid-stride loops of <= 4096 workgroups
+        align_slots = (int)std::min<size_t>((size_t)align_slots, std::max<size_t>(2, (budget / 16) / (S.align_slot_i32 * 4)));
+        align16_slots = (int)std::min<size_t>((size_t)std::max(n_quads, 1), std::max<size_t>(1, (budget / 8) / (S.align16_slot_i32 * 4)));   // every quad of the batch in ONE launch if it fits
+        const size_t need_align = std::max((size_t)align_slots * S.align_slot_i32, (size_t)align16_slots * S.align16_slot_i32) * 4;
         if ((size_t)poa_slots * S.poa_slot_bytes > h->d_poa.cap || need_align > h->d_align.cap) {
             HIPTRY(hipStreamSynchronize(h->s_draft));                // kernels of an earlier batch may still use the old scratch
             HIPTRY(hipStreamSynchronize(h->s_comp));
@@ -448,6 +453,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.ticket_poa = (int32_t *)S.d_ticket.p; P.ticket_align = P.ticket_poa + 1; P.debug = P.ticket_poa + 4; P.phase = (unsigned long long *)(P.ticket_poa + 16);
     P.poa_scratch = (uint8_t *)h->d_poa.p; P.poa_slot_bytes = S.poa_slot_bytes; P.poa_slots = poa_slots;
     P.align_scratch = (int32_t *)h->d_align.p; P.align_slot_i32 = S.align_slot_i32; P.align_slots = align_slots;
+    P.align16_slot_i32 = S.align16_slot_i32; P.align16_slots = align16_slots;
     P.avalid = (uint8_t *)S.d_avalid.p; P.ascore = (int32_t *)S.d_ascore.p; P.ent = (int32_t *)S.d_ent.p; P.dmask = (uint32_t *)S.d_dmask.p;
     P.total_wslots = total_wslots;
     if (ccsx_polish_lds(nr_max, &P.pw_obs_bytes, &P.pw_gb_floats)) { ccsx_set_error("ccsx_upload: cannot size the polish kernel's LDS"); return -2; }
@@ -475,6 +481,7 @@ static int launch(ccsx_handle h, Slot &S)
     S.P.poa_scratch = (uint8_t *)h->d_poa.p; S.P.align_scratch = (int32_t *)h->d_align.p;
     if ((size_t)S.P.poa_slots * S.P.poa_slot_bytes > h->d_poa.cap) S.P.poa_slots = (int)std::max<size_t>(1, h->d_poa.cap / S.P.poa_slot_bytes);
     if ((size_t)S.P.align_slots * S.P.align_slot_i32 * 4 > h->d_align.cap) S.P.align_slots = (int)std::max<size_t>(1, h->d_align.cap / (S.P.align_slot_i32 * 4));
+    if ((size_t)S.P.align16_slots * S.P.align16_slot_i32 * 4 > h->d_align.cap) S.P.align16_slots = (int)std::max<size_t>(1, h->d_align.cap / (S.P.align16_slot_i32 * 4));
     if (!h->d_poa.p || !h->d_align.p) { ccsx_set_error("kernel launch refused: the POA / alignment scratch is not allocated (an earlier allocation failed)"); return -2; }
     const char *failed = ccsx_launch_all(S.P, h->s_draft, h->s_comp, S.ev, S.mode);
     if (failed) { ccsx_set_error(std::string("kernel launch failed: ") + failed); return -2; }

@@ -79,6 +79,9 @@ struct KParams {
     // ---- caller-supplied drafts (ccsx_polish_batch: the polish seam of docs/img/ccs-impl.png); the bases are already in `draft`
     const int32_t *din_len;    // [n] draft length (0 = none)
     const int32_t *din_bb;     // [n] a pass of the ZMW that has the draft's orientation
+    // ---- k_align16 / k_align16_tb: a quad's stored moves (4 passes x (draft blocks of 16 columns) x 17 words); align_slot_i32 / align_slots are the 64-row retry's and the split alignment's
+    size_t align16_slot_i32;
+    int32_t align16_slots;
 };
 
 // which stages ccsx_launch_all enqueues: the fused path, the draft stage alone (ccsx_draft_batch), or alignment cascade + polish on caller-supplied drafts

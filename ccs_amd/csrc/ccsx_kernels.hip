@@ -1450,17 +1450,40 @@ __device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t 
 // (row_shr / row_shl with the hardware's fill, 4-step scans), the band position is a per-lane value that is uniform inside a row.
 // The band follows the best row, so this finds the path of the 64-row band unless an indel run of more than ~8 rows occurs
 // (bit-identical consensus on the test sets); a pass that is not valid here goes on a list for the 64-row retry (k_align), and
-// from there to the split alignment.  Same cell recurrence, origin / dirty tracking and edge saves as align_pass.
+// from there to the split alignment.  Same cell recurrence as align_pass.
+// Round 5 (second session): the cells no longer carry (origin, dirty bits) through the DP — three values to shift, select and permute per cell instead of one.
+// Every cell's MOVE goes to HBM instead (2 bits: diagonal match / diagonal mismatch / deletion / insertion; a lane shifts the two predicate masks of a column into a
+// register with two v_addc and stores it every 16 columns, 4 bytes per pass and column), plus the band's step per column (2 bits), and k_align16_tb — ONE LANE PER
+// PASS, 64 passes per wave — walks the moves back and writes the entry rows and dirty masks of the window-edge columns: the same path (the moves are the forward
+// pass's own decisions), so the same entries and masks, for a third fewer instructions in the kernel that saturates the VALU and half of its HBM writes.
 #define AB16 16
 #define NEG16 (-(1 << 23))           // k_align16's internal "minus infinity" (see the kernel)
 #define AB16_ABOVE 6
 #define AB16_SAT_ROWS 1               // SPEC v5 "band saturation": best row within the last AB16_SAT_ROWS rows of a band that can still move down
 #define AB16_SAT_GAIN 1               //   ... or a window's worth of columns (edge k-2 -> edge k) without this much gain of the column maximum
+#define AVALID_TB 2                   // avalid: valid in the 16-row band, entries / masks not yet traced back (k_align16 -> k_align16_tb, same stream)
+// scratch of a quad (one k_align16 workgroup): per pass h [blocks of 16 columns][16 band rows] move words, then [blocks] (band steps, edge flags): 2 bits per column each,
+// column j at bits 2 * (15 - ((j - 1) & 15)); edge flag of column j = "column j - 1 is a window-edge column" (the trace-back then needs no window bounds); then the four final band starts
+__device__ __forceinline__ int tb_blocks(int Ld) { return (Ld + 15) >> 4; }
+__device__ __forceinline__ int tb_stride(int Ld) { return (tb_blocks(Ld) * 18 + 3) & ~3; }      // (a pass's words start on a 16-byte boundary)
+// acc * 2 + (the lane's bit of the wave mask m): one v_addc
+__device__ __forceinline__ unsigned shift_in(unsigned acc, unsigned long long m)
+{
+    unsigned r; unsigned long long co;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(co) : "v"(acc), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int sel_i32(unsigned long long m, int a, int b)      // m ? a : b per lane, the mask already in scalar registers
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
 __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
 {
     const int lane = threadIdx.x, h = lane >> 4, l = lane & 15, rowb = lane & 48;
     uint32_t *sread = dyn_lds;
-    int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] (origin, dirty), then lo_need[need][4]
+    uint32_t *Osave = (uint32_t *)(P.align_scratch + (size_t)blockIdx.x * P.align16_slot_i32);
     if (qbase + (int)blockIdx.x >= P.n_quads) return;
     const int qd = rfl(P.quads[qbase + blockIdx.x]);    // (first pass << 2) | (passes - 1): up to four consecutive passes of one ZMW
     const int rfirst = qd >> 2, nq = (qd & 3) + 1;
@@ -1497,22 +1520,22 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     const int I = use ? (int)(P.base_off[r + 1] - P.base_off[r]) : 0;
     const uint32_t *myread = sread + h * wstride + 1;
     const int nneed = 2 * nw;
-    int2 *OMsave = (int2 *)Osave;
-    int32_t *lo_need = Osave + (size_t)P.need_max * 128;        // [need][4]
+    const int tbs = tb_stride(Ld);
+    uint32_t *mvL = Osave + (size_t)h * tbs + l;                        // the lane's move word of the current block of 16 columns
+    uint32_t *shL = Osave + (size_t)h * tbs + tb_blocks(Ld) * 16;       // the pass's (band steps, edge flags) of the block (stored by lane 0 of the row)
+    unsigned mvacc = 0u, shacc = 0u, edgeacc = 0u;
+    bool prev_edge = false;                             // column j - 1 is a window-edge column other than column 0 (scalar)
     int kk = 1;
     // window-edge columns ahead: lane q holds column kkb + q of the list, refilled every 64 edges (a load + wait per edge otherwise)
     int kkb = 1;
     int needv = need_col(wb, nw, Ld, (kkb + lane < nneed) ? kkb + lane : nneed - 1);
     int next_need = rl(needv, 0);
     // (round 4) inside this kernel an invalid cell is NEG16 = -2^23 instead of NEGV = -2^28: still below every cell of a valid path (> -2^19) and below the
-    // -2^22 threshold that resets a cell, but small enough that (cell + 4 * lane) << 6 cannot overflow — the insertion chain's packed key needs no clamp
+    // -2^22 threshold that resets a cell
     int Mprev = (l <= I) ? l * SC_INS : NEG16;
-    int Oprev = 0;
-    unsigned Kprev = (l >= 1) ? 1u : 0u;
-    int ecol = 0;
     int lo = 0, br = 0;                                  // per lane, uniform inside a row
     const int hiI = I - (AB16 - 1) > 0 ? I - (AB16 - 1) : 0;
-    const int lane257 = 257 * lane;                      // ((4 * lane) << 6) | lane
+    const int lane4 = 4 * lane;
     // SPEC v5 "band saturation": the narrow band's answer is not trusted (-> 64-row retry) when the best row reaches the band's last row
     // before the band has reached the read's end, or when the column maximum gains less than AB16_SAT_GAIN between two window-edge
     // columns one window apart (cmE0 / cmE1: the maxima two edges / one edge back; edge 0 is column 0 with maximum 0)
@@ -1525,8 +1548,6 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
         // VALU this kernel saturates)
         const unsigned long long dB0 = __ballot(dL & 1), dB1 = __ballot(dL & 2);
         const int nblk = (Ld - jb) < LANES ? (Ld - jb) : LANES;
-        // two columns per loop iteration (round 4): the column body is a lambda called twice, so that the carried cells (score, origin, dirty bits) rotate
-        // between two register sets instead of being copied at the end of every column
         auto column = [&](const int jj) {
             const int j = jb + jj + 1;
             const int plo = lo;
@@ -1540,6 +1561,9 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int i = lo + l;
             bi += sh;                                   // index of base i - 1 in the row's chunk (no clamps: index -1 is the guard word, indices beyond the read
                                                         // hold zero bits; neither can reach a valid cell)
+            shacc = (shacc << 2) | (unsigned)sh;
+            edgeacc = (edgeacc << 2) | (prev_edge ? 1u : 0u);
+            prev_edge = j == next_need;
             const int vb = (int)((dB0 >> jj) & 1ull) | ((int)((dB1 >> jj) & 1ull) << 1);
             // (every ~2000 columns per pass) the band reaches the end of a chunk: next chunk.  Looked at every 8th column only — the band moves at most two rows
             // per column, so 16 rows of margin cover the columns in between (the chunk holds CH16 + 32 bases)
@@ -1561,50 +1585,38 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const uint32_t bw = myread[bi >> 4];
             // rows of the previous column in the new band position.  x = cell (i - 1) of the previous column is the previous column shifted by sh - 1 lanes (one
             // of three variants, selected per row — none at all when all four bands move down by one row, the common column); y = cell i is x shifted up by one
-            // more lane, except for a band that did not move (its last lane keeps its own cell): one shift of the selected x and one select instead of a
-            // second three-way selection (round 4)
-            const unsigned bitj = 1u << (j - ecol - 1);
+            // more lane, except for a band that did not move (its last lane keeps its own cell)
             // (no "no base" code for rows 0 and > I: row 0 has no diagonal source — its x is the shift's fill — and a row beyond the read is reset below, so
             // whatever base the clamped index fetches there cannot reach a valid cell)
             const int rbv = (int)((bw >> (2 * (bi & 15))) & 3u);
-            const bool match = (vb == rbv);
-            int best, org; unsigned kd;
-            // diagonal / deletion step of the cell.  Called in BOTH variants below rather than after them: merged x / ox / kx values would cost the common
-            // variant three register copies (x = Mprev there, and Mprev is still read after x is formed in the other one)
-            auto cell = [&](const int x, const int ox, const unsigned kx, const int y, const int oy, const unsigned ky) {
-                best = x + (match ? SC_MATCH : SC_MISMATCH); org = ox;
-                kd = match ? kx : (kx | bitj);
-                const int c = y + SC_DEL;
-                if (c > best) { best = c; org = oy; kd = ky | bitj; }
-            };
+            const unsigned long long matchm = __builtin_amdgcn_uicmp((unsigned)vb, (unsigned)rbv, 32 /* eq */);
+            int x, y;
             if (__all(sh == 1)) {                         // every band moves down by one row: no selects
-                cell(Mprev, Oprev, Kprev, row_shl1_i32(Mprev, NEG16), row_shl1_i32_z(Oprev), (unsigned)row_shl1_i32_z((int)Kprev));
+                x = Mprev; y = row_shl1_i32(Mprev, NEG16);
             } else {
                 const int mR = row_shr1_i32(Mprev, NEG16), m1 = row_shl1_i32(Mprev, NEG16);
-                const int oR = row_shr1_i32_z(Oprev), o1 = row_shl1_i32_z(Oprev);
-                const int kR = row_shr1_i32_z((int)Kprev), k1 = row_shl1_i32_z((int)Kprev);
                 const bool s0 = sh == 0, s1 = sh == 1;
-                const int x = s0 ? mR : (s1 ? Mprev : m1);
-                const int ox = s0 ? oR : (s1 ? Oprev : o1);
-                const unsigned kx = (unsigned)(s0 ? kR : (s1 ? (int)Kprev : k1));
-                const int yu = row_shl1_i32(x, NEG16), oyu = row_shl1_i32_z(ox), kyu = row_shl1_i32_z((int)kx);
-                cell(x, ox, kx, s0 ? Mprev : yu, s0 ? Oprev : oyu, (unsigned)(s0 ? (int)Kprev : kyu));
+                x = s0 ? mR : (s1 ? Mprev : m1);
+                const int yu = row_shl1_i32(x, NEG16);
+                y = s0 ? Mprev : yu;
             }
-            const bool need = (j == next_need);
-            unsigned insbits = bitj | (bitj << 1);
-            if (need) {
-                OMsave[(size_t)kk * 64 + lane] = make_int2(org, (int)kd);
-                if (l == 0) lo_need[kk * 4 + h] = lo;
-                org = i;
-                kd = 0u; insbits = 0x80000001u; ecol = j;
+            // the cell: diagonal, then deletion if strictly better, then the insertion chain inside the row (x_i = max(c_i, x_{i-1} + INS): one max-scan of
+            // value + 4 * lane) if strictly better — the three decisions are the move
+            const int dg = x + sel_i32(matchm, SC_MATCH, SC_MISMATCH);
+            const int dl = y + SC_DEL;
+            const unsigned long long delm = __builtin_amdgcn_sicmp(dl, dg, 38 /* gt */);
+            int best = dl > dg ? dl : dg;
+            const int xi = row_scan_max_i32(best + lane4) - lane4;
+            const unsigned long long insm = __builtin_amdgcn_sicmp(xi, best, 38 /* gt */);
+            best = xi > best ? xi : best;
+            // move code of the cell: 0 diagonal match, 1 diagonal mismatch, 2 deletion, 3 insertion
+            mvacc = shift_in(mvacc, delm | insm);
+            mvacc = shift_in(mvacc, insm | ~(delm | matchm));
+            if ((jj & 15) == 15) {                       // 16 columns of moves per lane, 16 band steps per row
+                *mvL = mvacc; mvL += 16;
+                if (l == 0) *(uint2 *)shL = make_uint2(shacc, edgeacc);
+                shL += 2;
             }
-            // insertion chain inside the row: one packed max-scan (value << 6 | lane), origin / dirty bits of the winner by bpermute
-            const int key = row_scan_max_i32((best << 6) + lane257);             // ((best + 4 * lane) << 6) | lane
-            const int xi = (key >> 6) - 4 * lane;
-            const int ksl = key & 63;
-            const int osrc = __shfl(org, ksl);
-            const unsigned ksrc = (unsigned)__shfl((int)kd, ksl);
-            if (xi > best) { best = xi; org = osrc; kd = ksrc | insbits; }
             if (i > I) best = NEG16;                     // (a row beyond the read must not take part in the column maximum; an invalid cell inside the read may keep
                                                          // whatever it has below -2^22: it loses every comparison and cannot drift far in 65 k columns)
             // column maximum of the row and its lowest row
@@ -1614,8 +1626,8 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             const int brl = __ffs((int)m16) - 1;
             br = lo + brl;
             satm |= __builtin_amdgcn_sicmp(brl, AB16 - AB16_SAT_ROWS, 39 /* >= */) & __builtin_amdgcn_sicmp(lo, hiI, 40 /* < */);   // (wave masks: two compares, the rest scalar)
-            Mprev = best; Oprev = org; Kprev = kd;
-            if (need) {
+            Mprev = best;
+            if (j == next_need) {
                 if (kk >= 2 && cm - cmE0 < AB16_SAT_GAIN) satf = 1;       // cmE0 = the maximum two edges back, cmE1 = one edge back (a rotation: an
                 cmE0 = cmE1; cmE1 = cm;                                   // index kk & 1 made the compiler put the pair into scratch memory)
                 ++kk;
@@ -1625,39 +1637,151 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
         };
         { int jj = 0; for (; jj + 2 <= nblk; jj += 2) { column(jj); column(jj + 1); } if (jj < nblk) column(jj); }
     }
+    if (Ld & 15) {                                        // the last, partial block: its columns to the top of the word, like a full one
+        const int s2 = 2 * (16 - (Ld & 15));
+        *mvL = mvacc << s2;
+        if (l == 0) *(uint2 *)shL = make_uint2(shacc << s2, edgeacc << s2);
+    }
     const int oe = I - lo;
     const bool inr = oe >= 0 && oe < AB16;
     const int srcl = rowb + (inr ? oe : 0);
-    const int scv = __shfl(Mprev, srcl), eLv = __shfl(Oprev, srcl);
-    const unsigned kLv = (unsigned)__shfl((int)Kprev, srcl);
+    const int scv = __shfl(Mprev, srcl);
     satf |= (int)((satm >> lane) & 1ull);
     const int sc = (inr && scv > -(1 << 22)) ? scv : NEGV;     // (an invalid end cell is reported as the SPEC's NEG)
     const int valid = (sc > NEGV / 2 && sc >= Ld && !satf) ? 1 : 0;
-    __threadfence_block();
     if (l == 0 && use) {
-        P.ascore[r] = sc; P.avalid[r] = (uint8_t)valid;
+        P.ascore[r] = sc;
         if (valid) {
-            int32_t *ent = P.ent + P.ent_off[r];
-            uint32_t *dm = P.dmask + P.ent_off[r];
-            int e = eLv;
-            ent[nneed - 1] = e;
-            unsigned carry = kLv >> 31;
-            for (int k2 = nneed - 1; k2 >= 1; --k2) {
-                const int cell = e - lo_need[k2 * 4 + h];
-                const int2 om = OMsave[(size_t)k2 * 64 + rowb + cell];
-                unsigned mk = (unsigned)om.y;
-                const int cend = (k2 == nneed - 1) ? Ld : wb[(k2 + 1) >> 1] + ((k2 & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG);
-                const int cbeg = (k2 == 1) ? 0 : wb[k2 >> 1] + (((k2 - 1) & 1) ? -CCSX_WIN_OVERHANG : CCSX_WIN_OVERHANG);
-                if (carry) mk |= 1u << (cend - cbeg - 1);
-                carry = mk >> 31;
-                dm[k2] = mk & 0x7fffffffu;
-                if (k2 >= 2) { e = om.x; ent[k2 - 1] = e; }
-            }
-            ent[0] = 0; dm[0] = 0u;
+            Osave[4 * (size_t)tbs + h] = (uint32_t)lo;          // where the trace-back starts: the band of the last column
+            P.avalid[r] = AVALID_TB;
         } else {
+            P.avalid[r] = 0;
             const int idx = atomicAdd(&P.align_retry[0], 1);        // -> the 64-row retry
             P.align_retry[16 + idx] = r;
         }
+    }
+}
+
+// The trace-back of k_align16's passes: one LANE per pass, 64 passes per wave.  Walks the stored moves from (I, Ld) to (0, 0) and writes, for every window-edge
+// column, the row at which the path ENTERS it (ent) and the dirty bits of the draft positions between two edge columns (dmask) — exactly what the cells used to
+// carry forward (align_pass still does): bit (j - e - 1) of an interval that starts after edge column e for a mismatch or deletion at column j, bits of columns j
+// and j + 1 for an insertion after column j; an insertion in an edge column itself belongs to the NEXT interval (bit 0) and dirties the last position of its own.
+// The walk comes from above, so it collects an interval's bits counted from the interval's UPPER edge (bit eH - j) and reverses them when it reaches the lower one.
+// The walk is a dependent chain per lane and its 64 lanes are 64 different passes, so (1) nothing in it may wait for HBM and (2) every per-lane global access is a
+// fully divergent instruction — 64 cache lines, ~ 256 cycles of the address unit each (a first version with the loads in the walk took 20 ms per 16384 ZMWs, one
+// with per-lane window bounds and 4-byte entry stores 12).  The wave therefore works in EPOCHS of TBE blocks of 16 draft columns: per epoch it copies every pass's
+// move words of those columns to LDS with full-width loads (16 bytes per lane, a pass's 128 bytes contiguous), each lane fetches its band steps and edge flags with
+// ONE 16-byte load, the walk itself touches LDS only, and the entries go out four at a time (16-byte stores at multiples of four edge columns).
+#define TBE 2                          // blocks of 16 draft columns per epoch
+#define TB_LSTRIDE (TBE * 16 + 2 * TBE + 1)             // words per lane: odd, so the lanes' rows sit in different banks
+__global__ __launch_bounds__(64) void k_align16_tb(KParams P, int qbase, int nslots)
+{
+    __shared__ uint32_t sS[64 * TB_LSTRIDE];
+    __shared__ unsigned long long sOff[64];             // word offset of the pass's first staged move word in the alignment scratch
+    __shared__ int sCnt[64];                            // move words of the pass in this epoch (0: none)
+    const int lane = threadIdx.x;
+    const int t = (int)blockIdx.x * 64 + lane;
+    const int s = t >> 2, h = t & 3;
+    bool act = s < nslots;
+    int r = 0;
+    if (act) {
+        const int qd = P.quads[qbase + s];
+        const int rfirst = qd >> 2, nq = (qd & 3) + 1;
+        act = h < nq;
+        r = rfirst + (act ? h : 0);
+        act = act && P.avalid[r] == AVALID_TB;
+    }
+    if (!__any(act)) return;
+    const int z = act ? P.read_zmw[r] : 0;
+    const int Ld = act ? P.draft_len[z] : 0, nw = act ? P.nwin[z] : 1;
+    const int I = act ? (int)(P.base_off[r + 1] - P.base_off[r]) : 0;
+    const int tbs = tb_stride(Ld), nb = tb_blocks(Ld);
+    const size_t moff = (size_t)s * P.align16_slot_i32 + (size_t)h * tbs;
+    const uint32_t *As = (const uint32_t *)P.align_scratch;
+    const uint32_t *shw = As + moff + (size_t)nb * 16;
+    int lo = act ? (int)As[(size_t)s * P.align16_slot_i32 + 4 * (size_t)tbs + h] : 0;
+    int32_t *ent = P.ent + P.ent_off[r];                // (ent_off is a multiple of 4: the 16-byte stores below)
+    uint32_t *dm = P.dmask + P.ent_off[r];
+    const int nneed = 2 * nw;
+    uint32_t *my = sS + lane * TB_LSTRIDE;              // [0, 16 TBE) moves, then TBE (band steps, edge flags)
+    uint32_t *mySh = my + TBE * 16;
+    uint32_t e0 = 0u, e1 = 0u, e2r = 0u, e3 = 0u, d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;   // the last four entry rows / dirty masks, newest first
+    int i = I, j = act ? Ld : 0, K = nneed - 1;         // interval K = columns (eL, eH] between the edge columns K - 1 and K
+    int eH = Ld;
+    unsigned mk = 0u, pend = 0u;                        // dirty bits of interval K counted from eH / of interval K + 1 (final form) until the insertions of edge column K are known
+    bool atedge = true;                                 // the walk has just arrived at column eH
+    int bhi = nb;                                       // the next epoch covers the blocks [b0, bhi), b0 even
+    while (__any(j > 0)) {
+        const bool on = j > 0;
+        const int b0 = bhi > 0 ? (bhi - 1) & ~1 : 0;          // (a lane that has finished stays at j = 0 = its jstop)
+        sOff[lane] = on ? (unsigned long long)(moff + (size_t)b0 * 16) : 0ull;
+        sCnt[lane] = on ? (bhi - b0) * 16 : 0;
+        // (every load of the epoch is issued before the first is used — unconditional, from a clamped address: a load under a branch is waited for at once, and
+        // nine dependent round trips per epoch were what the second version spent its time on)
+        const uint4 vs = *(const uint4 *)(on ? shw + 2 * b0 : As);
+        __syncthreads();
+        // the moves: 16 bytes per lane, TBE * 4 lanes per pass
+        uint4 vm[TBE * 4];
+#pragma unroll
+        for (int q = 0; q < TBE * 4; ++q) {
+            const int rd = q * (16 / TBE) + lane / (TBE * 4), part = lane % (TBE * 4);
+            vm[q] = *(const uint4 *)(As + sOff[rd] + (part * 4 < sCnt[rd] ? part * 4 : 0));
+        }
+        mySh[0] = vs.x; mySh[1] = vs.y; mySh[2] = vs.z; mySh[3] = vs.w;
+#pragma unroll
+        for (int q = 0; q < TBE * 4; ++q) {
+            const int rd = q * (16 / TBE) + lane / (TBE * 4), part = lane % (TBE * 4);
+            if (part * 4 < sCnt[rd]) {
+                uint32_t *dst = sS + rd * TB_LSTRIDE + part * 4;
+                dst[0] = vm[q].x; dst[1] = vm[q].y; dst[2] = vm[q].z; dst[3] = vm[q].w;
+            }
+        }
+        __syncthreads();
+        const int jstop = b0 * 16;                      // column j lives in block (j - 1) >> 4
+        // (the 64 lanes are 64 different passes, so every branch of the step is taken by some lane in nearly every iteration: the step is written with selects,
+        // the last four entry rows / masks live in registers that shift at every edge column, and only the 16-byte stores are under a branch)
+        while (j > jstop) {
+            const int blk = ((j - 1) >> 4) - b0, sft = 2 * (15 - ((j - 1) & 15)), o = (i - lo) & 15;
+            const int code = (int)(my[blk * 16 + o] >> sft) & 3;
+            const unsigned w2 = mySh[2 * blk] >> sft, e2 = mySh[2 * blk + 1] >> sft;
+            const bool ins = code == 3;
+            // dirty bits: an insertion after column j = columns j and j + 1 (in an edge column: the next interval's first position and this one's last);
+            // a mismatch or deletion = column j
+            const unsigned bj = 1u << ((eH - j) & 31);
+            mk |= ins ? (atedge ? 1u : bj | (bj >> 1)) : (code != 0 ? bj : 0u);
+            if (ins && atedge) pend |= 1u;
+            const bool emit = !ins && atedge;           // the path enters edge column K at row i
+            if (emit) {
+                e3 = e2r; e2r = e1; e1 = e0; e0 = (uint32_t)i;
+                if ((K & 3) == 0) *(uint4 *)(ent + K) = make_uint4(e0, e1, e2r, e3);
+                if (K + 1 < nneed) {
+                    d3 = d2; d2 = d1; d1 = d0; d0 = pend & 0x7fffffffu;
+                    if (((K + 1) & 3) == 0) *(uint4 *)(dm + K + 1) = make_uint4(d0, d1, d2, d3);
+                }
+                atedge = false;
+            }
+            if (code != 2) --i;
+            if (ins) { if (i < 0) j = 0; continue; }    // (i < 0 cannot happen on a valid path: never spin on corrupt moves)
+            lo -= (int)(w2 & 3u);                       // the band of column j - 1
+            --j;
+            if (e2 & 1u) {                              // column j is an edge column: next interval down, the finished one's bits counted from its lower edge
+                const int len = eH - j < 32 ? eH - j : 32;
+                pend = __brev(mk) >> (32 - len); mk = 0u; --K;
+                eH = j;
+                atedge = true;
+            }
+        }
+        bhi = b0;
+        __syncthreads();
+    }
+    if (act) {
+        // column 0: the bits of interval 1; rows above the path's start are insertions before the first column (its bit 0).  The last edge column entered was 1.
+        const int len = eH < 32 ? eH : 32;
+        unsigned m1 = len > 0 ? __brev(mk) >> (32 - len) : 0u;
+        if (i > 0) m1 |= 1u;
+        *(uint4 *)ent = make_uint4(0u, e0, e1, e2r);
+        *(uint4 *)dm = make_uint4(0u, m1 & 0x7fffffffu, d0, d1);
+        P.avalid[r] = 1;
     }
 }
 
@@ -3435,10 +3559,12 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
         if (hipMemsetAsync(P.align_retry, 0, 64, st) != hipSuccess && !failed) failed = "hipMemsetAsync";
         {
             const size_t lds16 = 4 * (CH16 / 16 + 3) * sizeof(uint32_t);
-            for (int qb = 0; qb < P.n_quads; qb += P.align_slots) {
-                const int nb = (P.n_quads - qb) < P.align_slots ? (P.n_quads - qb) : P.align_slots;
+            for (int qb = 0; qb < P.n_quads; qb += P.align16_slots) {
+                const int nb = (P.n_quads - qb) < P.align16_slots ? (P.n_quads - qb) : P.align16_slots;
                 hipLaunchKernelGGL(k_align16, dim3(nb), dim3(64), lds16, st, P, qb, pass);
                 LAUNCH_CHECK("k_align16");
+                hipLaunchKernelGGL(k_align16_tb, dim3((4 * nb + 63) / 64), dim3(64), 0, st, P, qb, nb);   // one lane per pass: entry rows / dirty masks from the stored moves
+                LAUNCH_CHECK("k_align16_tb");
             }
         }
         {
