@@ -419,6 +419,8 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         align_slots = std::min(4096, std::max(R, 2));             // the 64-row retry and the split alignment (two slots per pass) run grid-stride loops of <= 4096 workgroups
         align_slots = (int)std::min<size_t>((size_t)align_slots, std::max<size_t>(2, (budget / 16) / (S.align_slot_i32 * 4)));
         align16_slots = (int)std::min<size_t>((size_t)std::max(n_quads, 1), std::max<size_t>(1, (budget / 8) / (S.align16_slot_i32 * 4)));   // every quad of the batch in ONE launch if it fits
+        static const int max16 = [] { const char *e = getenv("CCSX_ALIGN16_MAX_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // test hook: forces several launches
+        if (max16 > 0 && align16_slots > max16) align16_slots = max16;
         const size_t need_align = std::max((size_t)align_slots * S.align_slot_i32, (size_t)align16_slots * S.align16_slot_i32) * 4;
         if ((size_t)poa_slots * S.poa_slot_bytes > h->d_poa.cap || need_align > h->d_align.cap) {
             HIPTRY(hipStreamSynchronize(h->s_draft));                // kernels of an earlier batch may still use the old scratch

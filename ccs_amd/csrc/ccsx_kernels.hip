@@ -39,7 +39,7 @@
 // (tests/test_abi.py; tools/gpu_ab.sh adds the define itself).
 #if (defined(CCSX_EXP_NO_FILL) || defined(CCSX_EXP_NO_SCORE) || defined(CCSX_EXP_ONE_ROUND) || defined(CCSX_EXP_ALL_VALID) || defined(CCSX_EXP_CHEAP_VALIDITY) || \
      defined(CCSX_EXP_NO_ROWS) || defined(CCSX_EXP_NO_SCORE_LOG) || defined(CCSX_EXP_SKIP_ROUND2_SCORE) || defined(CCSX_EXP_NO_QV_EXP) || defined(CCSX_EXP_REPEAT) || defined(CCSX_EXP_NO_BANDMASK) || \
-     defined(CCSX_EXIT_AFTER_PROLOGUE)) && !defined(CCSX_EXPERIMENT)
+     defined(CCSX_EXP_HOT_PROLOGUE) || defined(CCSX_EXIT_AFTER_PROLOGUE)) && !defined(CCSX_EXPERIMENT)
 #error "CCSX_EXP_* / CCSX_EXIT_AFTER_PROLOGUE switches produce wrong results: build them with -DCCSX_EXPERIMENT (never ship such a library)"
 #endif
 #define CCSX_STR2(x) #x
@@ -87,6 +87,9 @@ const char *ccsx_kernel_build_flags()
 #endif
 #ifdef CCSX_EXP_NO_BANDMASK
         " CCSX_EXP_NO_BANDMASK"
+#endif
+#ifdef CCSX_EXP_HOT_PROLOGUE
+        " CCSX_EXP_HOT_PROLOGUE"
 #endif
 #ifdef CCSX_EXP_REPEAT
         " CCSX_EXP_REPEAT=" CCSX_STR(CCSX_EXP_REPEAT)
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
         {
             const int f = -(1 << 24);
             const int k0_ = ((b0 > f ? b0 : f) * 64) | kRow0, k1_ = ((b1 > f ? b1 : f) * 64) | kRow1;
-            const int key = __builtin_amdgcn_ds_bpermute(bcastAddr, row_scan_max_i32(k0_ > k1_ ? k0_ : k1_));
+            const int key = row_allmax_i32(k0_ > k1_ ? k0_ : k1_);       // (an all-reduce by row rotations: no ds_bpermute broadcast on the chain that places the next band)
             cm = key >> 6; br = (lo + 63) - (key & 63);
         }
         // ---- the read's last row: best end cell over all columns (first in topological order)
@@ -1619,11 +1622,11 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
             }
             if (i > I) best = NEG16;                     // (a row beyond the read must not take part in the column maximum; an invalid cell inside the read may keep
                                                          // whatever it has below -2^22: it loses every comparison and cannot drift far in 65 k columns)
-            // column maximum of the row and its lowest row
-            const int cm = __shfl(row_scan_max_i32(best), lane | 15);
-            const unsigned long long bal = __ballot(best == cm);
-            const unsigned m16 = (unsigned)(bal >> rowb) & 0xffffu;
-            const int brl = __ffs((int)m16) - 1;
+            // column maximum of the row and the lowest row that attains it, in every lane of the row: ONE all-reduce of (value * 16 + 15 - row) by four row rotations
+            // (second session of round 5; before: a prefix scan, a ds_bpermute broadcast — an LDS round trip on the chain that places the next column's band —, a
+            // ballot, a 64-bit shift and a find-first)
+            const int ck = row_allmax_i32((best << 4) | (15 - l));
+            const int cm = ck >> 4, brl = 15 - (ck & 15);
             br = lo + brl;
             satm |= __builtin_amdgcn_sicmp(brl, AB16 - AB16_SAT_ROWS, 39 /* >= */) & __builtin_amdgcn_sicmp(lo, hiI, 40 /* < */);   // (wave masks: two compares, the rest scalar)
             Mprev = best;
@@ -2325,7 +2328,12 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     // (slot0: a batch of more than 2^24 - 256 window slots is launched in pieces, see ccsx_launch_all; the grid covers the slot capacity, a multiple of 8,
     // the map only the windows there are)
     const int nwin_here = polish_piece_windows(P.wstart[P.n_zmw], slot0, (int)gridDim.x);
+#ifdef CCSX_EXP_HOT_PROLOGUE                                // experiment (timing only, wrong results): every workgroup takes one of the same 4096 windows, so the
+    const int bid_ = slot0 + xcd_contiguous(blockIdx.x, nwin_here);   // prologue's loads come from the L2 — what its HBM latency costs the whole kernel
+    const int bid = bid_ < slot0 ? bid_ : slot0 + ((bid_ - slot0) & 4095);
+#else
     const int bid = slot0 + xcd_contiguous(blockIdx.x, nwin_here);
+#endif
     if (bid < slot0) return;
     const int z = P.wslot_zmw[bid];                         // device-built compact map (k_wmap): no dependent search
     const int wbo = P.wb_off[z], nw = P.nwin[z], Ld = P.draft_len[z];

@@ -86,6 +86,15 @@ __device__ __forceinline__ int row_scan_max_i32(int v)
     s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_SHR(8), 0xf, 0xf, false));
     return s;
 }
+// maximum over each 16-lane row, in every lane of the row: four rotations (no broadcast afterwards, nothing through the LDS pipe)
+__device__ __forceinline__ int row_allmax_i32(int v)
+{
+    int s = imax(v, __builtin_amdgcn_update_dpp(WAVE_IMIN, v, DPP_ROW_ROR(1), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_ROR(2), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_ROR(4), 0xf, 0xf, false));
+    s = imax(s, __builtin_amdgcn_update_dpp(WAVE_IMIN, s, DPP_ROW_ROR(8), 0xf, 0xf, false));
+    return s;
+}
 
 // wave-wide maximum, returned uniformly (scan + readlane 63)
 __device__ __forceinline__ int wave_reduce_max_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_max_i32(v), 63); }

@@ -904,7 +904,9 @@ def test_reference_concordance_harness(built, tmp_path, monkeypatch):
 def test_polish_grid_is_launched_in_pieces(built, tmp_path):
     """a grid may not exceed 2^32 threads: k_polish / k_kinetics run one 256-thread workgroup per window slot, so a batch of more than 16.7 M
     slots (16 k ZMWs of 25 kb) would silently lose its tail — the slots are launched in pieces of at most 2^24 - 256 workgroups.  CCSX_POLISH_MAX_BLOCKS forces
-    pieces of 37 here (in a fresh process: the hook is read once): same results as the oracle, with and without kinetics"""
+    pieces of 37 here (in a fresh process: the hook is read once): same results as the oracle, with and without kinetics.  CCSX_ALIGN16_MAX_SLOTS does the
+    same for k_align16 / k_align16_tb, whose quads otherwise go in one launch: five scratch slots, so the 9 ZMWs' quads take several launches and the
+    trace-back addresses its slots relative to each launch"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r"""
@@ -926,7 +928,7 @@ for kin in (0, 1):
     h.close()
 print("pieces ok")
 """ % (root, os.path.join(root, "tests"))
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CCSX_POLISH_MAX_BLOCKS="37"), capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CCSX_POLISH_MAX_BLOCKS="37", CCSX_ALIGN16_MAX_SLOTS="5"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "pieces ok" in p.stdout, p.stderr[-2000:]
 
 
