@@ -418,7 +418,14 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         poa_slots = (int)std::min<size_t>((size_t)poa_slots, std::max<size_t>(1, (budget * 3 / 4) / S.poa_slot_bytes));
         align_slots = std::min(4096, std::max(R, 2));             // the 64-row retry and the split alignment (two slots per pass) run grid-stride loops of <= 4096 workgroups
         align_slots = (int)std::min<size_t>((size_t)align_slots, std::max<size_t>(2, (budget / 16) / (S.align_slot_i32 * 4)));
-        align16_slots = (int)std::min<size_t>((size_t)std::max(n_quads, 1), std::max<size_t>(1, (budget / 8) / (S.align16_slot_i32 * 4)));   // every quad of the batch in ONE launch if it fits
+        // every quad of the batch in ONE launch if that fits 12 GB (16384 ZMWs x 10 passes x 10 kb: 9.3 GB — the slot is sized for the draft CAPACITY of the batch's
+        // longest insert); a batch of long inserts and many passes takes a few equal launches instead of tens of GB of scratch (a launch's trace-back still has
+        // thousands of waves)
+        {
+            const size_t fit = std::max<size_t>(1, std::min<size_t>(budget / 8, (size_t)12 << 30) / (S.align16_slot_i32 * 4));
+            const size_t nq = (size_t)std::max(n_quads, 1), launches = (nq + fit - 1) / fit;
+            align16_slots = (int)((nq + launches - 1) / launches);
+        }
         static const int max16 = [] { const char *e = getenv("CCSX_ALIGN16_MAX_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // test hook: forces several launches
         if (max16 > 0 && align16_slots > max16) align16_slots = max16;
         const size_t need_align = std::max((size_t)align_slots * S.align_slot_i32, (size_t)align16_slots * S.align16_slot_i32) * 4;

@@ -1539,6 +1539,9 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
     int lo = 0, br = 0;                                  // per lane, uniform inside a row
     const int hiI = I - (AB16 - 1) > 0 ? I - (AB16 - 1) : 0;
     const int lane4 = 4 * lane;
+    // the band never leaves the read (lo <= hiI = I - 15) unless the read is shorter than the band: only then can a row lie beyond the read and must be kept out of
+    // the column maximum (wave-uniform: two VALU per column that ordinary passes do not need)
+    const bool tiny = __any(use && I < AB16 - 1);
     // SPEC v5 "band saturation": the narrow band's answer is not trusted (-> 64-row retry) when the best row reaches the band's last row
     // before the band has reached the read's end, or when the column maximum gains less than AB16_SAT_GAIN between two window-edge
     // columns one window apart (cmE0 / cmE1: the maxima two edges / one edge back; edge 0 is column 0 with maximum 0)
@@ -1561,7 +1564,6 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
                 lo = t < hiI ? t : hiI;
             }
             const int sh = lo - plo;                    // 0..2, per row
-            const int i = lo + l;
             bi += sh;                                   // index of base i - 1 in the row's chunk (no clamps: index -1 is the guard word, indices beyond the read
                                                         // hold zero bits; neither can reach a valid cell)
             shacc = (shacc << 2) | (unsigned)sh;
@@ -1580,7 +1582,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
                         __syncthreads();
                         load_read_chunk(sread + hh * wstride + 1, P.bases + P.base_off[rr], Ih, rfl(((P.flags[rr] & 1) != fl0) ? 1 : 0), nc0, lane);
                         __syncthreads();
-                        if (h == hh) { c0 = nc0; bi = i - 1 - nc0; }
+                        if (h == hh) { c0 = nc0; bi = lo + l - 1 - nc0; }
                     }
                 }
             }
@@ -1620,7 +1622,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
                 if (l == 0) *(uint2 *)shL = make_uint2(shacc, edgeacc);
                 shL += 2;
             }
-            if (i > I) best = NEG16;                     // (a row beyond the read must not take part in the column maximum; an invalid cell inside the read may keep
+            if (tiny && lo + l > I) best = NEG16;        // (a row beyond the read must not take part in the column maximum; an invalid cell inside the read may keep
                                                          // whatever it has below -2^22: it loses every comparison and cannot drift far in 65 k columns)
             // column maximum of the row and the lowest row that attains it, in every lane of the row: ONE all-reduce of (value * 16 + 15 - row) by four row rotations
             // (second session of round 5; before: a prefix scan, a ds_bpermute broadcast — an LDS round trip on the chain that places the next column's band —, a
