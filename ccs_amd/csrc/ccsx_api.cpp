@@ -107,6 +107,7 @@ struct Slot {
     PinVec<int64_t> seq_off, ent_off, base_off;
     KParams P;
     hipEvent_t ev[7] = {}, ev_up = nullptr, ev_done = nullptr;   // ev[0..5]: stage boundaries, ev[6]: start of the polish stage
+    hipEvent_t ev_aux[3] = {};                                   // fork / first DP done / join of the POA stage's second stream
     bool staged = false, ran = false, inflight = false;
     ccsx_results *res = nullptr;      // destination of an in-flight submit
     ccsx_drafts *drafts_out = nullptr; // ... of an in-flight ccsx_submit_draft
@@ -125,6 +126,7 @@ struct Slot {
         read_zmw.release(); vcap.release(); dcap.release(); zperm.release(); rperm.release(); quads.release(); qperm.release(); wb_off.release();
         read_off.release(); seq_off.release(); ent_off.release(); base_off.release();
         for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto &e : ev_aux) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_up) { (void)hipEventDestroy(ev_up); ev_up = nullptr; }
         if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
     }
@@ -139,6 +141,7 @@ std::mutex g_scratch_mutex;
 struct ccsx_handle_s {
     int device = 0;
     hipStream_t s_in = nullptr, s_draft = nullptr, s_comp = nullptr, s_out = nullptr;   // s_comp: polish stage (and the synchronous calls' copies)
+    hipStream_t s_aux = nullptr;                              // second stream of the POA stage (forked from and joined into s_draft inside one launch)
     hipEvent_t ev_epoch = nullptr, ev_epoch_nx = nullptr;   // origin of ccsx_timings.start_ms / end_ms: recorded at creation and moved forward every few
     float age_ms = 0.0f;              // end of the latest batch whose timings were read, relative to the current origin
     double epoch_ms = 0.0;            // minutes (epoch_ms = its distance from the creation), so that the float milliseconds HIP reports stay well below
@@ -159,6 +162,7 @@ static void destroy_handle(ccsx_handle h)
     (void)hipSetDevice(h->device);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->s_draft) (void)hipStreamSynchronize(h->s_draft);
+    if (h->s_aux) (void)hipStreamSynchronize(h->s_aux);
     if (h->s_comp) (void)hipStreamSynchronize(h->s_comp);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
     for (auto &s : h->slot) s.release();
@@ -167,6 +171,7 @@ static void destroy_handle(ccsx_handle h)
     h->d_model.release(); h->d_poa.release(); h->d_align.release();
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_draft && h->s_draft != h->s_comp) (void)hipStreamDestroy(h->s_draft);
+    if (h->s_aux) (void)hipStreamDestroy(h->s_aux);
     if (h->s_comp) (void)hipStreamDestroy(h->s_comp);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     delete h;
@@ -197,10 +202,13 @@ void ccsx_free_pinned(void *p)
 static int create_impl(ccsx_handle h)
 {
     HIPTRY(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
-    // experiment knob (tools/r03_prio.sh): CCSX_STAGE_PRIO=draft|polish gives that stage's stream the device's highest priority
+    // The polish stream gets the device's highest priority, the draft stage's streams the lowest: without the second POA stream the priorities change nothing
+    // (tools/r03_prio.sh), with it they decide — three plain streams: 473 ms per 16384-ZMW step, polish high: 436, draft high: 438, no second stream: 441
+    // (profiles/r05_poa_half_batches.txt).  CCSX_STAGE_PRIO=draft|polish|none overrides (none: plain streams).
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const char *pe = getenv("CCSX_STAGE_PRIO");
+    const char *pe_env = getenv("CCSX_STAGE_PRIO");
+    const char *pe = pe_env ? (strcmp(pe_env, "none") ? pe_env : nullptr) : "polish";
     const int p_draft = (pe && !strcmp(pe, "draft")) ? prio_hi : prio_lo, p_polish = (pe && !strcmp(pe, "polish")) ? prio_hi : prio_lo;
     if (pe) HIPTRY(hipStreamCreateWithPriority(&h->s_comp, hipStreamNonBlocking, p_polish));
     else HIPTRY(hipStreamCreateWithFlags(&h->s_comp, hipStreamNonBlocking));
@@ -208,11 +216,16 @@ static int create_impl(ccsx_handle h)
     else if (pe) HIPTRY(hipStreamCreateWithPriority(&h->s_draft, hipStreamNonBlocking, p_draft));
     else HIPTRY(hipStreamCreateWithFlags(&h->s_draft, hipStreamNonBlocking));
     HIPTRY(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    // the POA stage's second stream (two half-batches, the threading of one under the DP of the other; not with serial stages, whose point is that a kernel's
+    // counters are its own — CCSX_POA_SPLIT=2 forces it there for a measurement of the draft stage alone —; CCSX_POA_SPLIT=0 turns it off for an A/B; plain streams
+    // (CCSX_STAGE_PRIO=none) get none: the three-way competition costs more than the overlap buys)
+    { const char *e = getenv("CCSX_POA_SPLIT"); if (((!h->opts.serial_stages && pe) || (e && !strcmp(e, "2"))) && !(e && !strcmp(e, "0"))) { if (pe) HIPTRY(hipStreamCreateWithPriority(&h->s_aux, hipStreamNonBlocking, p_draft)); else HIPTRY(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking)); } }
     HIPTRY(hipEventCreate(&h->ev_epoch));
     HIPTRY(hipEventCreate(&h->ev_epoch_nx));
     HIPTRY(hipEventRecord(h->ev_epoch, h->s_draft));         // the stream the tickets' first events are recorded on
     for (auto &s : h->slot) {
         for (auto &ev : s.ev) HIPTRY(hipEventCreate(&ev));
+        for (auto &ev : s.ev_aux) HIPTRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIPTRY(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
         HIPTRY(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     }
@@ -492,7 +505,7 @@ static int launch(ccsx_handle h, Slot &S)
     if ((size_t)S.P.align_slots * S.P.align_slot_i32 * 4 > h->d_align.cap) S.P.align_slots = (int)std::max<size_t>(1, h->d_align.cap / (S.P.align_slot_i32 * 4));
     if ((size_t)S.P.align16_slots * S.P.align16_slot_i32 * 4 > h->d_align.cap) S.P.align16_slots = (int)std::max<size_t>(1, h->d_align.cap / (S.P.align16_slot_i32 * 4));
     if (!h->d_poa.p || !h->d_align.p) { ccsx_set_error("kernel launch refused: the POA / alignment scratch is not allocated (an earlier allocation failed)"); return -2; }
-    const char *failed = ccsx_launch_all(S.P, h->s_draft, h->s_comp, S.ev, S.mode);
+    const char *failed = ccsx_launch_all(S.P, h->s_draft, h->s_comp, S.ev, S.mode, h->s_aux, h->s_aux ? S.ev_aux : nullptr);
     if (failed) { ccsx_set_error(std::string("kernel launch failed: ") + failed); return -2; }
     S.ran = true;
     return 0;
@@ -586,7 +599,7 @@ static int submit_impl(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, cc
     // (ADVICE r02): drain every stream, mark the slot unusable and refuse further batches on this handle.
     auto fail = [&](int rc_) {
         const std::string msg = ccsx_last_error();
-        (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->s_draft); (void)hipStreamSynchronize(h->s_comp); (void)hipStreamSynchronize(h->s_out);
+        (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->s_draft); if (h->s_aux) (void)hipStreamSynchronize(h->s_aux); (void)hipStreamSynchronize(h->s_comp); (void)hipStreamSynchronize(h->s_out);
         (void)hipGetLastError();
         S.staged = false; S.ran = false; S.inflight = false; S.ticket = -1;
         h->poisoned = true;

@@ -87,7 +87,8 @@ struct KParams {
 // which stages ccsx_launch_all enqueues: the fused path, the draft stage alone (ccsx_draft_batch), or alignment cascade + polish on caller-supplied drafts
 enum { CCSX_RUN_FUSED = 0, CCSX_RUN_DRAFT = 1, CCSX_RUN_POLISH = 2 };
 
-const char *ccsx_launch_all(const KParams &P, hipStream_t st_draft, hipStream_t st_polish, hipEvent_t *ev /* [7] */, int mode = CCSX_RUN_FUSED);   // NULL, or the name of the launch that failed
+const char *ccsx_launch_all(const KParams &P, hipStream_t st_draft, hipStream_t st_polish, hipEvent_t *ev /* [7] */, int mode = CCSX_RUN_FUSED,
+                            hipStream_t st_aux = nullptr, hipEvent_t *ev_aux /* [3] */ = nullptr);   // NULL, or the name of the launch that failed; st_aux: second stream of the POA stage (half-batches)
 int ccsx_kernel_is_experiment();         // built with -DCCSX_EXPERIMENT (timing studies: wrong results)
 const char *ccsx_kernel_build_flags();   // "" for a product build; the experiment switches this translation unit was compiled with otherwise
 int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats);

@@ -547,13 +547,14 @@ __device__ __forceinline__ int poa_windows(const KParams &P, int z, int Ld, int 
 }
 
 // ---- k_poa_init: which passes, the backbone chain, the first column records.  One wave per graph (slot = block).
-__global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass)
+__global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass, int b0)
 {
+    const int bx = (int)blockIdx.x + b0;                // (b0: the launch's first workgroup — the POA stage runs as two half-batches on two streams)
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
-    PoaSlot g = poa_slot(P, blockIdx.x);
-    if (z0 + (int)blockIdx.x >= P.n_zmw) return;
-    const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);     // longest ZMWs first
+    PoaSlot g = poa_slot(P, bx);
+    if (z0 + bx >= P.n_zmw) return;
+    const int z = rfl(P.zmw_perm[z0 + bx]);     // longest ZMWs first
     if (lane < ST_WORDS) g.st[lane] = 0;                // (ST_LIVE = 0: the other kernels skip this graph unless it is set below)
     __threadfence_block();
     const int r0 = rfl(P.read_off[z]);
@@ -696,16 +697,17 @@ __device__ __forceinline__ void load_read_chunk_m1(uint32_t *sread, const uint8_
 // (branch layout: a taken branch costs the wave ~ 20 cycles of instruction fetch and this kernel runs two waves per SIMD, so the conditions of the rare blocks
 // below carry __builtin_expect(., 0) — the blocks move out of line and the common column falls through.  The "two or more in-edges" blocks (43 % of the
 // wave's columns) carry none: either hint measured slower, profiles/r04_poa_dp_vmcnt.txt)
-__global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int rr)
+__global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int rr, int b0)
 {
+    const int bx = (int)blockIdx.x + b0;                // (b0: the launch's first workgroup — the POA stage runs as two half-batches on two streams)
     __shared__ __attribute__((aligned(16))) int32_t sRing[4][PRING + 1][PGS];
     __shared__ __attribute__((aligned(16))) int4 sKin[4][PRING + 1];
     __shared__ __attribute__((aligned(16))) int4 sCrec[4][16];
     __shared__ uint32_t sRead[4][CH16 / 16 + 2];
     const int lane = threadIdx.x, gq = lane >> 4, l = lane & 15;
-    const int zi = z0 + 4 * (int)blockIdx.x + gq;
-    const bool have = zi < P.n_zmw && 4 * (int)blockIdx.x + gq < P.poa_slots;
-    const PoaSlot G = poa_slot(P, have ? 4 * (int)blockIdx.x + gq : 4 * (int)blockIdx.x);   // per lane, uniform inside a 16-lane group
+    const int zi = z0 + 4 * bx + gq;
+    const bool have = zi < P.n_zmw && 4 * bx + gq < P.poa_slots;
+    const PoaSlot G = poa_slot(P, have ? 4 * bx + gq : 4 * bx);   // per lane, uniform inside a 16-lane group
     int32_t *st = G.st;
     int32_t *Mcol = G.M;
     int4 *kinfo = G.kinfo;
@@ -937,16 +939,17 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
 }
 
 // ---- k_poa_thread: gate, traceback and threading of pass rr, then the column records of the next DP.  One wave per graph.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa_thread(KParams P, int z0, int pass, int rr)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa_thread(KParams P, int z0, int pass, int rr, int b0)
 {
+    const int bx = (int)blockIdx.x + b0;                // (b0: the launch's first workgroup — the POA stage runs as two half-batches on two streams)
     __shared__ __attribute__((aligned(16))) uint8_t sMv[TB_BLOCK * POA_MV_BYTES];   // move rows (a nibble per cell) of the traceback's current block
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
-    PoaSlot g = poa_slot(P, blockIdx.x);
-    if (z0 + (int)blockIdx.x >= P.n_zmw) return;
+    PoaSlot g = poa_slot(P, bx);
+    if (z0 + bx >= P.n_zmw) return;
     if (!g.st[ST_LIVE] || !g.st[ST_OK] || rr >= g.st[ST_NPOA]) return;
     TPH_T0();
-    const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);
+    const int z = rfl(P.zmw_perm[z0 + bx]);
     const int r0 = rfl(P.read_off[z]);
     const int bb = rfl(g.st[ST_BB]), nreads = rfl(g.st[ST_NREADS]), npoa = rfl(g.st[ST_NPOA]);
     const int r = r0 + (bb + rr < nreads ? bb + rr : bb + rr - nreads);
@@ -1203,13 +1206,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 // ---- k_poa_finish: consensus (heaviest path), draft, window bounds.  One wave per graph.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa_finish(KParams P, int z0, int pass)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_poa_finish(KParams P, int z0, int pass, int b0)
 {
+    const int bx = (int)blockIdx.x + b0;                // (b0: the launch's first workgroup — the POA stage runs as two half-batches on two streams)
     const int lane = threadIdx.x;
-    PoaSlot g = poa_slot(P, blockIdx.x);
-    if (z0 + (int)blockIdx.x >= P.n_zmw) return;
+    PoaSlot g = poa_slot(P, bx);
+    if (z0 + bx >= P.n_zmw) return;
     if (!g.st[ST_LIVE]) return;
-    const int z = rfl(P.zmw_perm[z0 + blockIdx.x]);
+    const int z = rfl(P.zmw_perm[z0 + bx]);
     const int ok = rfl(g.st[ST_OK]), n = rfl(g.st[ST_N]), nadded = rfl(g.st[ST_NADDED]);
     const int32_t *order = g.st[ST_PAR] ? g.order1 : g.order0;
     // ---- consensus: heaviest path (uniform walk).  The column records of the last prepass give every column's base, pass count and the
@@ -3517,7 +3521,7 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
 
 // every launch status is captured: returns NULL, or the name of the first launch that failed (ccsx_api.cpp reports it)
 #define LAUNCH_CHECK(name) do { if (hipGetLastError() != hipSuccess && !failed) failed = name; } while (0)
-const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */, int mode)
+const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */, int mode, hipStream_t st_aux, hipEvent_t *ev_aux /* [3] or NULL */)
 {
     // Two-stage queue of docs/img/ccs-impl.png ("Draft Stage" -> queue -> "Polish Stage"): the draft stage (tables, POA, alignment
     // cascade, accounting) is enqueued on `st`, the polish stage (polish, kinetics, stitch) on `st_polish`, which waits for the
@@ -3550,18 +3554,34 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
         if (cov > P.max_reads) cov = P.max_reads;          // no ZMW of the batch has more passes
         for (int z0 = 0; z0 < P.n_zmw && mode != CCSX_RUN_POLISH; z0 += P.poa_slots) {
             const int nb = (P.n_zmw - z0) < P.poa_slots ? (P.n_zmw - z0) : P.poa_slots;
-            hipLaunchKernelGGL(k_poa_init, dim3(nb), dim3(64), lds_read, st, P, z0, pass);
-            LAUNCH_CHECK("k_poa_init");
-            for (int rr = 1; rr < cov && pass < 2; ++rr) { // one DP (four graphs per wave) + one threading kernel per pass of the POA
-                hipLaunchKernelGGL(k_poa_dp, dim3((nb + 3) / 4), dim3(64), 0, st, P, z0, pass, rr);
-                LAUNCH_CHECK("k_poa_dp");
-                hipLaunchKernelGGL(k_poa_thread, dim3(nb), dim3(64), lds_read, st, P, z0, pass, rr);
-                LAUNCH_CHECK("k_poa_thread");
-            }
-            if (pass < 2) {                                // (pass 2 = last resort: k_poa_init writes the draft itself)
-                hipLaunchKernelGGL(k_poa_finish, dim3(nb), dim3(64), 0, st, P, z0, pass);
-                LAUNCH_CHECK("k_poa_finish");
-            }
+            // the graphs [g0, g0 + ng) on stream s: initial graph, one DP (four graphs per wave) + one threading kernel per pass of the POA, heaviest path
+            auto poa_range = [&](hipStream_t s, int g0, int ng, hipEvent_t after_first_dp, hipEvent_t before_first_dp) {
+                hipLaunchKernelGGL(k_poa_init, dim3(ng), dim3(64), lds_read, s, P, z0, pass, g0);
+                LAUNCH_CHECK("k_poa_init");
+                if (before_first_dp && hipStreamWaitEvent(s, before_first_dp, 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
+                for (int rr = 1; rr < cov && pass < 2; ++rr) {
+                    hipLaunchKernelGGL(k_poa_dp, dim3((ng + 3) / 4), dim3(64), 0, s, P, z0, pass, rr, g0 / 4);
+                    LAUNCH_CHECK("k_poa_dp");
+                    if (rr == 1 && after_first_dp && hipEventRecord(after_first_dp, s) != hipSuccess && !failed) failed = "hipEventRecord";
+                    hipLaunchKernelGGL(k_poa_thread, dim3(ng), dim3(64), lds_read, s, P, z0, pass, rr, g0);
+                    LAUNCH_CHECK("k_poa_thread");
+                }
+                if (pass < 2) {                            // (pass 2 = last resort: k_poa_init writes the draft itself)
+                    hipLaunchKernelGGL(k_poa_finish, dim3(ng), dim3(64), 0, s, P, z0, pass, g0);
+                    LAUNCH_CHECK("k_poa_finish");
+                }
+            };
+            // Pass 0 of a large batch runs as TWO half-batches on two streams, the second one a DP behind the first: k_poa_dp saturates the VALU and k_poa_thread
+            // waits for HBM, their registers and LDS fit one SIMD together (94 + 64 VGPRs), so the threading of one half runs under the DP of the other.
+            if (st_aux && ev_aux && pass == 0 && cov > 1 && nb >= 4096) {
+                const int ha = ((nb / 2) + 3) & ~3;
+                if (hipEventRecord(ev_aux[0], st) != hipSuccess && !failed) failed = "hipEventRecord";
+                if (hipStreamWaitEvent(st_aux, ev_aux[0], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
+                poa_range(st, 0, ha, ev_aux[1], nullptr);
+                poa_range(st_aux, ha, nb - ha, nullptr, ev_aux[1]);
+                if (hipEventRecord(ev_aux[2], st_aux) != hipSuccess && !failed) failed = "hipEventRecord";
+                if (hipStreamWaitEvent(st, ev_aux[2], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
+            } else poa_range(st, 0, nb, nullptr, nullptr);
         }
         trace_sync(st, "k_poa");
         if (ev && pass == 0) (void)hipEventRecord(ev[2], st);
