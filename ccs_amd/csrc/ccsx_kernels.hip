@@ -1800,7 +1800,7 @@ __global__ __launch_bounds__(64) void k_align(KParams P, int pass)
 {
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
-    int32_t *Osave = P.align_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] then lo_need[need]
+    int32_t *Osave = P.retry_scratch + (size_t)blockIdx.x * P.align_slot_i32;   // [need][64] then lo_need[need]
     const int nretry = rfl(P.align_retry[0]);
     for (int it = blockIdx.x; it < nretry; it += gridDim.x) {
     const int r = rfl(P.align_retry[16 + it]);
@@ -1864,7 +1864,7 @@ __global__ __launch_bounds__(64) void k_rescue(KParams P, int pass)
 {
     const int lane = threadIdx.x;
     uint32_t *sread = dyn_lds;
-    int32_t *OsF = P.align_scratch + (size_t)(2 * blockIdx.x) * P.align_slot_i32, *OsR = OsF + P.align_slot_i32;
+    int32_t *OsF = P.retry_scratch + (size_t)(2 * blockIdx.x) * P.align_slot_i32, *OsR = OsF + P.align_slot_i32;
     for (int rbase = blockIdx.x * LANES; rbase < P.n_reads; rbase += gridDim.x * LANES) {
       // 64 passes per look: nearly all of them aligned
       unsigned long long todo = __ballot(rbase + lane < P.n_reads && !P.avalid[P.read_perm[rbase + lane < P.n_reads ? rbase + lane : 0]]);
@@ -3521,7 +3521,7 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
 
 // every launch status is captured: returns NULL, or the name of the first launch that failed (ccsx_api.cpp reports it)
 #define LAUNCH_CHECK(name) do { if (hipGetLastError() != hipSuccess && !failed) failed = name; } while (0)
-const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */, int mode, hipStream_t st_aux, hipEvent_t *ev_aux /* [3] or NULL */)
+const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */, int mode, hipStream_t st_aux, hipEvent_t *ev_aux /* [5] or NULL */)
 {
     // Two-stage queue of docs/img/ccs-impl.png ("Draft Stage" -> queue -> "Polish Stage"): the draft stage (tables, POA, alignment
     // cascade, accounting) is enqueued on `st`, the polish stage (polish, kinetics, stitch) on `st_polish`, which waits for the
@@ -3587,15 +3587,28 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
         if (ev && pass == 0) (void)hipEventRecord(ev[2], st);
         // alignment cascade: four passes per wave in 16-row bands, then the 64-row retry of the few that failed there
         if (hipMemsetAsync(P.align_retry, 0, 64, st) != hipSuccess && !failed) failed = "hipMemsetAsync";
+        bool tb_aside_out = false;
         {
             const size_t lds16 = 4 * (CH16 / 16 + 3) * sizeof(uint32_t);
+            // (the trace-back of the LAST launch runs on the second stream, beside the 64-row retry and the split alignment: those read the retry list the
+            // 16-row kernel wrote, not the entries the trace-back writes, and their scratch lies behind the stored moves; k_post waits for both)
+            bool tb_aside = false;
             for (int qb = 0; qb < P.n_quads; qb += P.align16_slots) {
                 const int nb = (P.n_quads - qb) < P.align16_slots ? (P.n_quads - qb) : P.align16_slots;
                 hipLaunchKernelGGL(k_align16, dim3(nb), dim3(64), lds16, st, P, qb, pass);
                 LAUNCH_CHECK("k_align16");
-                hipLaunchKernelGGL(k_align16_tb, dim3((4 * nb + 63) / 64), dim3(64), 0, st, P, qb, nb);   // one lane per pass: entry rows / dirty masks from the stored moves
+                hipStream_t s_tb = st;
+                static const bool aside_ok = [] { const char *e = getenv("CCSX_TB_ASIDE"); return !(e && e[0] == '0'); }();   // (A/B switch)
+                if (aside_ok && st_aux && ev_aux && pass == 0 && qb + P.align16_slots >= P.n_quads && nb >= 4096) {
+                    if (hipEventRecord(ev_aux[3], st) != hipSuccess && !failed) failed = "hipEventRecord";
+                    if (hipStreamWaitEvent(st_aux, ev_aux[3], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
+                    s_tb = st_aux; tb_aside = true;
+                }
+                hipLaunchKernelGGL(k_align16_tb, dim3((4 * nb + 63) / 64), dim3(64), 0, s_tb, P, qb, nb);   // one lane per pass: entry rows / dirty masks from the stored moves
                 LAUNCH_CHECK("k_align16_tb");
+                if (tb_aside && hipEventRecord(ev_aux[4], st_aux) != hipSuccess && !failed) failed = "hipEventRecord";
             }
+            tb_aside_out = tb_aside;
         }
         {
             const int g = P.align_slots < 1 ? 1 : (P.align_slots > 4096 ? 4096 : P.align_slots);
@@ -3608,6 +3621,7 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
             hipLaunchKernelGGL(k_rescue, dim3(g), dim3(64), lds_read, st, P, pass);
             LAUNCH_CHECK("k_rescue");
         }
+        if (tb_aside_out && hipStreamWaitEvent(st, ev_aux[4], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
         hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P, pass);
         LAUNCH_CHECK("k_post");
     }
