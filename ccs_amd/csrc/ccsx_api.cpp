@@ -107,7 +107,7 @@ struct Slot {
     PinVec<int64_t> seq_off, ent_off, base_off;
     KParams P;
     hipEvent_t ev[7] = {}, ev_up = nullptr, ev_done = nullptr;   // ev[0..5]: stage boundaries, ev[6]: start of the polish stage
-    hipEvent_t ev_aux[5] = {};                                   // second stream: fork / first DP done / join of the POA stage; fork / join of the last trace-back
+    hipEvent_t ev_aux[7] = {};                                   // second stream: fork / first DP done / join of the POA stage; k_align16 launch done x 2, its trace-back done x 2
     bool staged = false, ran = false, inflight = false;
     ccsx_results *res = nullptr;      // destination of an in-flight submit
     ccsx_drafts *drafts_out = nullptr; // ... of an in-flight ccsx_submit_draft
@@ -115,6 +115,7 @@ struct Slot {
     int64_t ticket = -1;
     // scratch this batch needs per resident POA graph / alignment
     size_t poa_slot_bytes = 0, align_slot_i32 = 0, align16_slot_i32 = 0;
+    int align16_regions = 1;
 
     void release()
     {
@@ -434,14 +435,23 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
         // every quad of the batch in ONE launch if that fits 12 GB (16384 ZMWs x 10 passes x 10 kb: 9.3 GB — the slot is sized for the draft CAPACITY of the batch's
         // longest insert); a batch of long inserts and many passes takes a few equal launches instead of tens of GB of scratch (a launch's trace-back still has
         // thousands of waves)
+        int align16_regions = 1;
         {
             const size_t fit = std::max<size_t>(1, std::min<size_t>(budget / 8, (size_t)12 << 30) / (S.align16_slot_i32 * 4));
-            const size_t nq = (size_t)std::max(n_quads, 1), launches = (nq + fit - 1) / fit;
-            align16_slots = (int)((nq + launches - 1) / launches);
+            const size_t nq = (size_t)std::max(n_quads, 1);
+            static const bool one_region = [] { const char *e = getenv("CCSX_A16_ONE_REGION"); return e && e[0] == '1'; }();   // (A/B switch: equal launches in ONE region, in sequence)
+            if (nq <= fit) align16_slots = (int)nq;
+            else if (one_region) { const size_t launches = (nq + fit - 1) / fit; align16_slots = (int)((nq + launches - 1) / launches); }
+            else {                                                       // two regions of half the space: launch c's trace-back runs under launch c + 1
+                const size_t half = std::max<size_t>(1, fit / 2), launches = (nq + half - 1) / half;
+                align16_slots = (int)((nq + launches - 1) / launches);
+                align16_regions = 2;
+            }
         }
         static const int max16 = [] { const char *e = getenv("CCSX_ALIGN16_MAX_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // test hook: forces several launches
-        if (max16 > 0 && align16_slots > max16) align16_slots = max16;
-        const size_t need_align = ((size_t)align_slots * S.align_slot_i32 + (size_t)align16_slots * S.align16_slot_i32) * 4;   // the retry's slots behind k_align16's
+        if (max16 > 0 && align16_slots > max16) { align16_slots = max16; align16_regions = 2; }
+        const size_t need_align = ((size_t)align_slots * S.align_slot_i32 + (size_t)align16_regions * align16_slots * S.align16_slot_i32) * 4;   // the retry's slots behind k_align16's
+        S.align16_regions = align16_regions;
         if ((size_t)poa_slots * S.poa_slot_bytes > h->d_poa.cap || need_align > h->d_align.cap) {
             HIPTRY(hipStreamSynchronize(h->s_draft));                // kernels of an earlier batch may still use the old scratch
             HIPTRY(hipStreamSynchronize(h->s_comp));
@@ -476,7 +486,8 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.poa_scratch = (uint8_t *)h->d_poa.p; P.poa_slot_bytes = S.poa_slot_bytes; P.poa_slots = poa_slots;
     P.align_scratch = (int32_t *)h->d_align.p; P.align_slot_i32 = S.align_slot_i32; P.align_slots = align_slots;
     P.align16_slot_i32 = S.align16_slot_i32; P.align16_slots = align16_slots;
-    P.retry_scratch = P.align_scratch + (size_t)align16_slots * S.align16_slot_i32;
+    P.align16_regions = S.align16_regions;
+    P.retry_scratch = P.align_scratch + (size_t)S.align16_regions * align16_slots * S.align16_slot_i32;
     P.avalid = (uint8_t *)S.d_avalid.p; P.ascore = (int32_t *)S.d_ascore.p; P.ent = (int32_t *)S.d_ent.p; P.dmask = (uint32_t *)S.d_dmask.p;
     P.total_wslots = total_wslots;
     if (ccsx_polish_lds(nr_max, &P.pw_obs_bytes, &P.pw_gb_floats)) { ccsx_set_error("ccsx_upload: cannot size the polish kernel's LDS"); return -2; }
@@ -504,13 +515,13 @@ static int launch(ccsx_handle h, Slot &S)
     S.P.poa_scratch = (uint8_t *)h->d_poa.p; S.P.align_scratch = (int32_t *)h->d_align.p;
     if ((size_t)S.P.poa_slots * S.P.poa_slot_bytes > h->d_poa.cap) S.P.poa_slots = (int)std::max<size_t>(1, h->d_poa.cap / S.P.poa_slot_bytes);
     {   // (the scratch only grows, so what was sized at staging still fits; the clamps are for a failed growth)
-        const size_t words = h->d_align.cap / 4;
-        if ((size_t)S.P.align_slots * S.P.align_slot_i32 + (size_t)S.P.align16_slots * S.P.align16_slot_i32 > words) {
+        const size_t words = h->d_align.cap / 4, reg = (size_t)std::max(1, S.P.align16_regions);
+        if ((size_t)S.P.align_slots * S.P.align_slot_i32 + reg * S.P.align16_slots * S.P.align16_slot_i32 > words) {
             if ((size_t)S.P.align_slots * S.P.align_slot_i32 > words / 2) S.P.align_slots = (int)std::max<size_t>(1, (words / 2) / S.P.align_slot_i32);
             const size_t used = (size_t)S.P.align_slots * S.P.align_slot_i32, left = words > used ? words - used : 0;
-            S.P.align16_slots = (int)std::max<size_t>(1, left / S.P.align16_slot_i32);
+            S.P.align16_slots = (int)std::max<size_t>(1, left / (reg * S.P.align16_slot_i32));
         }
-        S.P.retry_scratch = S.P.align_scratch + (size_t)S.P.align16_slots * S.P.align16_slot_i32;
+        S.P.retry_scratch = S.P.align_scratch + reg * S.P.align16_slots * S.P.align16_slot_i32;
     }
     if (!h->d_poa.p || !h->d_align.p) { ccsx_set_error("kernel launch refused: the POA / alignment scratch is not allocated (an earlier allocation failed)"); return -2; }
     const char *failed = ccsx_launch_all(S.P, h->s_draft, h->s_comp, S.ev, S.mode, h->s_aux, h->s_aux ? S.ev_aux : nullptr);

@@ -82,14 +82,15 @@ struct KParams {
     // ---- k_align16 / k_align16_tb: a quad's stored moves (4 passes x (draft blocks of 16 columns) x 17 words); align_slot_i32 / align_slots are the 64-row retry's and the split alignment's
     size_t align16_slot_i32;
     int32_t align16_slots;
-    int32_t *retry_scratch;    // the 64-row retry's / split alignment's slots: behind k_align16's in the same buffer (the last launch's trace-back runs beside the retry)
+    int32_t *retry_scratch;    // the 64-row retry's / split alignment's slots: behind k_align16's in the same buffer (the trace-backs run beside the next launch / the retry)
+    int32_t align16_regions;   // 1, or 2 when the batch's quads take several launches: launch c uses region c & 1, so its trace-back runs under launch c + 1
 };
 
 // which stages ccsx_launch_all enqueues: the fused path, the draft stage alone (ccsx_draft_batch), or alignment cascade + polish on caller-supplied drafts
 enum { CCSX_RUN_FUSED = 0, CCSX_RUN_DRAFT = 1, CCSX_RUN_POLISH = 2 };
 
 const char *ccsx_launch_all(const KParams &P, hipStream_t st_draft, hipStream_t st_polish, hipEvent_t *ev /* [7] */, int mode = CCSX_RUN_FUSED,
-                            hipStream_t st_aux = nullptr, hipEvent_t *ev_aux /* [5] */ = nullptr);   // NULL, or the name of the launch that failed; st_aux: second stream of the POA stage (half-batches)
+                            hipStream_t st_aux = nullptr, hipEvent_t *ev_aux /* [7] */ = nullptr);   // NULL, or the name of the launch that failed; st_aux: second stream of the POA stage (half-batches)
 int ccsx_kernel_is_experiment();         // built with -DCCSX_EXPERIMENT (timing studies: wrong results)
 const char *ccsx_kernel_build_flags();   // "" for a product build; the experiment switches this translation unit was compiled with otherwise
 int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats);

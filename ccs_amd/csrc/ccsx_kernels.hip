@@ -1486,11 +1486,11 @@ __device__ __forceinline__ int sel_i32(unsigned long long m, int a, int b)      
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
     return r;
 }
-__global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
+__global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass, int region)
 {
     const int lane = threadIdx.x, h = lane >> 4, l = lane & 15, rowb = lane & 48;
     uint32_t *sread = dyn_lds;
-    uint32_t *Osave = (uint32_t *)(P.align_scratch + (size_t)blockIdx.x * P.align16_slot_i32);
+    uint32_t *Osave = (uint32_t *)(P.align_scratch + ((size_t)region * P.align16_slots + blockIdx.x) * P.align16_slot_i32);
     if (qbase + (int)blockIdx.x >= P.n_quads) return;
     const int qd = rfl(P.quads[qbase + blockIdx.x]);    // (first pass << 2) | (passes - 1): up to four consecutive passes of one ZMW
     const int rfirst = qd >> 2, nq = (qd & 3) + 1;
@@ -1683,7 +1683,7 @@ __global__ __launch_bounds__(64) void k_align16(KParams P, int qbase, int pass)
 // ONE 16-byte load, the walk itself touches LDS only, and the entries go out four at a time (16-byte stores at multiples of four edge columns).
 #define TBE 2                          // blocks of 16 draft columns per epoch
 #define TB_LSTRIDE (TBE * 16 + 2 * TBE + 1)             // words per lane: odd, so the lanes' rows sit in different banks
-__global__ __launch_bounds__(64) void k_align16_tb(KParams P, int qbase, int nslots)
+__global__ __launch_bounds__(64) void k_align16_tb(KParams P, int qbase, int nslots, int region)
 {
     __shared__ uint32_t sS[64 * TB_LSTRIDE];
     __shared__ unsigned long long sOff[64];             // word offset of the pass's first staged move word in the alignment scratch
@@ -1705,10 +1705,11 @@ __global__ __launch_bounds__(64) void k_align16_tb(KParams P, int qbase, int nsl
     const int Ld = act ? P.draft_len[z] : 0, nw = act ? P.nwin[z] : 1;
     const int I = act ? (int)(P.base_off[r + 1] - P.base_off[r]) : 0;
     const int tbs = tb_stride(Ld), nb = tb_blocks(Ld);
-    const size_t moff = (size_t)s * P.align16_slot_i32 + (size_t)h * tbs;
+    const size_t sbase = ((size_t)region * P.align16_slots + s) * P.align16_slot_i32;
+    const size_t moff = sbase + (size_t)h * tbs;
     const uint32_t *As = (const uint32_t *)P.align_scratch;
     const uint32_t *shw = As + moff + (size_t)nb * 16;
-    int lo = act ? (int)As[(size_t)s * P.align16_slot_i32 + 4 * (size_t)tbs + h] : 0;
+    int lo = act ? (int)As[sbase + 4 * (size_t)tbs + h] : 0;
     int32_t *ent = P.ent + P.ent_off[r];                // (ent_off is a multiple of 4: the 16-byte stores below)
     uint32_t *dm = P.dmask + P.ent_off[r];
     const int nneed = 2 * nw;
@@ -3521,7 +3522,7 @@ int ccsx_polish_lds(int max_reads, int *obs_bytes, int *gb_floats)
 
 // every launch status is captured: returns NULL, or the name of the first launch that failed (ccsx_api.cpp reports it)
 #define LAUNCH_CHECK(name) do { if (hipGetLastError() != hipSuccess && !failed) failed = name; } while (0)
-const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */, int mode, hipStream_t st_aux, hipEvent_t *ev_aux /* [5] or NULL */)
+const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_polish, hipEvent_t *ev /* [7] or NULL */, int mode, hipStream_t st_aux, hipEvent_t *ev_aux /* [7] or NULL */)
 {
     // Two-stage queue of docs/img/ccs-impl.png ("Draft Stage" -> queue -> "Polish Stage"): the draft stage (tables, POA, alignment
     // cascade, accounting) is enqueued on `st`, the polish stage (polish, kinetics, stitch) on `st_polish`, which waits for the
@@ -3587,27 +3588,35 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
         if (ev && pass == 0) (void)hipEventRecord(ev[2], st);
         // alignment cascade: four passes per wave in 16-row bands, then the 64-row retry of the few that failed there
         if (hipMemsetAsync(P.align_retry, 0, 64, st) != hipSuccess && !failed) failed = "hipMemsetAsync";
-        bool tb_aside_out = false;
+        bool tb_aside_out = false; int tb_launches = 0;
         {
             const size_t lds16 = 4 * (CH16 / 16 + 3) * sizeof(uint32_t);
-            // (the trace-back of the LAST launch runs on the second stream, beside the 64-row retry and the split alignment: those read the retry list the
-            // 16-row kernel wrote, not the entries the trace-back writes, and their scratch lies behind the stored moves; k_post waits for both)
+            // The trace-back of a launch runs on the second stream: beside the NEXT launch of k_align16 (a batch whose quads take several launches has two
+            // scratch regions, launch c uses region c & 1 and waits for the trace-back of launch c - 2) and, the last one, beside the 64-row retry and the split
+            // alignment — those read the retry list the 16-row kernel wrote, not the entries the trace-back writes, and their scratch lies behind the stored
+            // moves.  k_post waits for all of them.  (A trace-back is a long dependent walk of few waves: 42 % of k_align16's time on the 3-50-pass mix.)
+            static const bool aside_ok = [] { const char *e = getenv("CCSX_TB_ASIDE"); return !(e && e[0] == '0'); }();   // (A/B switch)
+            const bool aside = aside_ok && st_aux && ev_aux && pass == 0 && P.n_quads >= 4096;
             bool tb_aside = false;
-            for (int qb = 0; qb < P.n_quads; qb += P.align16_slots) {
+            int c = 0;
+            for (int qb = 0; qb < P.n_quads; qb += P.align16_slots, ++c) {
                 const int nb = (P.n_quads - qb) < P.align16_slots ? (P.n_quads - qb) : P.align16_slots;
-                hipLaunchKernelGGL(k_align16, dim3(nb), dim3(64), lds16, st, P, qb, pass);
+                const int region = P.align16_regions > 1 ? (c & 1) : 0;
+                if (aside && c >= 2 && hipStreamWaitEvent(st, ev_aux[5 + (c & 1)], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";   // the region's last reader
+                if (aside && c >= 1 && P.align16_regions <= 1 && hipStreamWaitEvent(st, ev_aux[5 + ((c - 1) & 1)], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";   // (one region: in sequence)
+                hipLaunchKernelGGL(k_align16, dim3(nb), dim3(64), lds16, st, P, qb, pass, region);
                 LAUNCH_CHECK("k_align16");
                 hipStream_t s_tb = st;
-                static const bool aside_ok = [] { const char *e = getenv("CCSX_TB_ASIDE"); return !(e && e[0] == '0'); }();   // (A/B switch)
-                if (aside_ok && st_aux && ev_aux && pass == 0 && qb + P.align16_slots >= P.n_quads && nb >= 4096) {
-                    if (hipEventRecord(ev_aux[3], st) != hipSuccess && !failed) failed = "hipEventRecord";
-                    if (hipStreamWaitEvent(st_aux, ev_aux[3], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
+                if (aside) {
+                    if (hipEventRecord(ev_aux[3 + (c & 1)], st) != hipSuccess && !failed) failed = "hipEventRecord";
+                    if (hipStreamWaitEvent(st_aux, ev_aux[3 + (c & 1)], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
                     s_tb = st_aux; tb_aside = true;
                 }
-                hipLaunchKernelGGL(k_align16_tb, dim3((4 * nb + 63) / 64), dim3(64), 0, s_tb, P, qb, nb);   // one lane per pass: entry rows / dirty masks from the stored moves
+                hipLaunchKernelGGL(k_align16_tb, dim3((4 * nb + 63) / 64), dim3(64), 0, s_tb, P, qb, nb, region);   // one lane per pass: entry rows / dirty masks from the stored moves
                 LAUNCH_CHECK("k_align16_tb");
-                if (tb_aside && hipEventRecord(ev_aux[4], st_aux) != hipSuccess && !failed) failed = "hipEventRecord";
+                if (aside && hipEventRecord(ev_aux[5 + (c & 1)], st_aux) != hipSuccess && !failed) failed = "hipEventRecord";
             }
+            tb_launches = c;
             tb_aside_out = tb_aside;
         }
         {
@@ -3621,7 +3630,8 @@ const char *ccsx_launch_all(const KParams &P, hipStream_t st, hipStream_t st_pol
             hipLaunchKernelGGL(k_rescue, dim3(g), dim3(64), lds_read, st, P, pass);
             LAUNCH_CHECK("k_rescue");
         }
-        if (tb_aside_out && hipStreamWaitEvent(st, ev_aux[4], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
+        if (tb_aside_out) for (int c = tb_launches > 2 ? tb_launches - 2 : 0; c < tb_launches; ++c)      // (the trace-backs run in order on one stream: the last one per region)
+            if (hipStreamWaitEvent(st, ev_aux[5 + (c & 1)], 0) != hipSuccess && !failed) failed = "hipStreamWaitEvent";
         hipLaunchKernelGGL(k_post, dim3((P.n_zmw + 255) / 256), dim3(256), 0, st, P, pass);
         LAUNCH_CHECK("k_post");
     }
