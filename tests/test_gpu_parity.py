@@ -105,6 +105,19 @@ def test_batch_split_invariance(handle):
             assert part.rq[z - z0] == whole.rq[z]
 
 
+def test_large_batch_takes_the_two_stream_paths(handle):
+    """a batch of >= 4096 ZMWs / quads runs its POA stage as two half-batches on two streams (the second half's kernels start at a block offset) and the
+    trace-back of k_align16 beside the 64-row retry: every ZMW of BOTH halves against the oracle (bench.py compares the first few thousand ZMWs of a batch,
+    i.e. the first half only), and the same batch cut into pieces that stay below the threshold"""
+    batch = api.synth(4608, (3, 5), (150, 420), seed=77)
+    res = handle.consensus(batch)
+    _compare(res, _oracle(handle, batch), batch)
+    for z0, z1 in [(0, 1500), (3000, 4608)]:                 # below 4096: one stream
+        part = handle.consensus(batch.slice(z0, z1))
+        for z in range(z0, z1, 7):
+            assert part.status[z - z0] == res.status[z] and np.array_equal(part.sequence(z - z0), res.sequence(z)) and np.array_equal(part.raw(z - z0), res.raw(z))
+
+
 def test_recovers_truth_at_full_size(handle):
     """size-independent property at the BASELINE config-2 shape (10 passes x 10 kb): consensus ~= template."""
     batch = api.synth(8, 10, 10000, seed=21)
