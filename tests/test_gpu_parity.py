@@ -945,6 +945,31 @@ print("pieces ok")
     assert p.returncode == 0 and "pieces ok" in p.stdout, p.stderr[-2000:]
 
 
+def test_align16_launches_with_trace_backs_aside(built):
+    """k_align16 over several launches in a batch large enough for the second stream: launch c writes scratch region c & 1, its trace-back runs on the second
+    stream under launch c + 1, launch c + 2 waits for it.  CCSX_ALIGN16_MAX_SLOTS=900 cuts the 4608-ZMW batch's quads into six launches (fresh process: the
+    hook is read once); every ZMW against the oracle"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from ccs_amd import api
+import oracle_lib as O
+b = api.synth(4608, (3, 5), (150, 420), seed=78)
+h = api.Handle(0)
+r = h.consensus(b)
+ref = api.Results.allocate(b)
+O.consensus_batch(h.model, h.opts, b, ref, nthreads=8)
+bad = [z for z in range(b.n_zmw) if r.status[z] != ref.status[z] or not np.array_equal(r.sequence(z), ref.sequence(z)) or not np.array_equal(r.raw(z), ref.raw(z))]
+assert not bad, bad[:10]
+h.close()
+print("launches ok")
+""" % (root, os.path.join(root, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CCSX_ALIGN16_MAX_SLOTS="900"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "launches ok" in p.stdout, p.stderr[-2000:]
+
+
 @pytest.mark.parametrize("nofb", [0, 1])
 def test_empty_backbone_pass(built, nofb):
     """found by tools/corruption_fuzz.py in round 4 (batch 47 of seed 11000): pass 0 of a ZMW has no bases.  SPEC: the backbone pass becomes the chain
