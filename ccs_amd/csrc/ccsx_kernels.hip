@@ -2127,6 +2127,7 @@ __global__ __launch_bounds__(256) void k_wmap_fill(KParams P)     // one wave pe
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
     int c, q, kA, kB, isdel, fin;    // kA / kB index sCTX; +16 selects the copy whose INS component is zero
+    int qoff;                        // q - c - 1 (0: insertion, 1: substitution / deletion): how far beta(i+1, q) sits above gamma(i, c) in diagonals (SPEC v8 joint band test)
     float dlA, dlL;
 };
 
@@ -2144,7 +2145,7 @@ __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_
     if (pA > 3) pA = (xA + 2) & 3;
     const int kA = pA * 4 + xA, kB = (type == 1) ? kA : xA * 4 + nx;
     const int q = (type == 2) ? c + 1 : c + 2;
-    L.c = c; L.q = q > J ? J : q; L.isdel = (type == 1); L.fin = fin;
+    L.c = c; L.q = q > J ? J : q; L.isdel = (type == 1); L.fin = fin; L.qoff = (type == 2) ? 0 : 1;
     L.dlA = sDL[kA]; L.dlL = sDL[kB];
     // the SPEC's "no stay move" cases (a deletion whose extension is the final column: INS[kA] unused; any extension
     // that reaches the final column: INS[kB] unused) read the table copy whose INS component is an exact zero
@@ -2163,37 +2164,46 @@ struct ScoreChain {                  // running state of one (lane, read) mutati
     float2 pA, pB;
     lds_cf g, be;                    // gamma(i, c) and beta(i+1, q) of the row about to be processed: both advance by the read's pitch per row
     lds_cu8 op;                      // observation of that row (0..11, 12 = none)
-    int dg, db;                      // SPEC v6: their diagonals relative to the read's band, c - i - dlo and q - (i + 1) - dlo: outside 0 .. bw-1 the cell is a zero
+    int dg;                          // SPEC v6/v8: gamma's diagonal relative to the read's band, c - i - dlo; the row's two cells are on the band iff 0 <= dg <= bw - 1 - (q - c - 1)
 };
+
+// v in the lanes of the wave mask m, 0 elsewhere: one v_cndmask on a mask that already sits in scalar registers
+__device__ __forceinline__ float lanes_or_zero(unsigned long long m, float v)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+}
 
 // one row of the extend+link recursion.  tA / tB = the lane's columns of sCTX (context kA / kB).  Every lane walks
 // its own rows (the SPEC's band around the window diagonal starts at a per-lane row), so the row's observation code comes from LDS;
 // row I of a read carries code 12 = the all-zero row of sCTX ("no base left": the SPEC's i < I cases become exact +0 products).
 // SPEC v6: gamma / beta are stored on the read's band only; a scoring band that is clamped into a corner of the window reads cells outside it, which are zeros
 // (the address of such a cell aliases a neighbouring row's: the value is replaced, never used).
-__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_cc tA, lds_cc tB, int pitch, unsigned bw)
+__device__ __forceinline__ void score_step(ScoreChain &s, const LaneMut &L, lds_cc tA, lds_cc tB, int pitch, unsigned lim)
 {
     typedef const unsigned long long __attribute__((address_space(3))) *lds_cu64;
-    float gmm = *s.g;
-#ifndef CCSX_EXP_NO_BANDMASK                                // experiment (timing only, wrong results in the corners of a window): what the two band tests per row cost
-    if ((unsigned)s.dg >= bw) gmm = 0.0f;
+    // SPEC v8 "joint band test": gamma(i, c) and beta(i+1, q) of the row sit q - c - 1 diagonals apart; both are zeros unless both are on the band — one compare
+    // (lim = bw - 1 - (q - c - 1)) whose mask serves both selects (v7: a test per cell)
+#ifndef CCSX_EXP_NO_BANDMASK                                // experiment (timing only, wrong results in the corners of a window): what the band test costs
+    const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)s.dg, lim, 37 /* ule */);
+    const float gmm = lanes_or_zero(on, *s.g);
+    const float bqn = lanes_or_zero(on, *s.be);
+#else
+    const float gmm = *s.g, bqn = *s.be;
 #endif
     const int o256 = __mul24((int)*s.op, CTXS * 8);   // byte offset of the observation's row in sCTX
     const unsigned long long va = *(lds_cu64)(tA + o256), vb = *(lds_cu64)(tB + o256);   // one ds_read_b64 each
     const float2 nA = make_float2(__uint_as_float((unsigned)va), __uint_as_float((unsigned)(va >> 32)));
     const float2 nB = make_float2(__uint_as_float((unsigned)vb), __uint_as_float((unsigned)(vb >> 32)));
-    float bqn = *s.be;
-#ifndef CCSX_EXP_NO_BANDMASK
-    if ((unsigned)s.db >= bw) bqn = 0.0f;
-#endif
-    s.g += pitch; s.be += pitch; s.op += 1; s.dg -= 1; s.db -= 1;
+    s.g += pitch; s.be += pitch; s.op += 1; s.dg -= 1;
     const float insA = s.pA.y, meA = s.pA.x, insB = s.pB.y;
-    const float a = gmm + s.ap * insA;
+    // SPEC v8 "fused recurrences": every multiply-add is one fma, nested as written in DESIGN.md §2
+    const float a = __builtin_fmaf(s.ap, insA, gmm);
     float b;
     if (L.isdel) b = a;
-    else b = ((s.ap * meA) + (a * L.dlA)) + s.bp * insB;
-    const float term = (nB.x * bqn) + (L.dlL * s.bq);
-    s.acc = s.acc + b * term;
+    else b = __builtin_fmaf(s.bp, insB, __builtin_fmaf(a, L.dlA, s.ap * meA));
+    s.acc = __builtin_fmaf(b, __builtin_fmaf(L.dlL, s.bq, nB.x * bqn), s.acc);
     s.ap = a; s.bp = b; s.b = b; s.pA = nA; s.pB = nB; s.bq = bqn;
 }
 
@@ -2265,14 +2275,6 @@ __device__ __forceinline__ FillBand fill_band_of(int I, int J, int S)
     const bool diag = bwp < S;
     b.rowsz = diag ? bwp : S; b.pitch = diag ? bwp - 1 : S; b.org = diag ? -b.dlo : 0;
     return b;
-}
-
-// v in the lanes of the wave mask m, 0 elsewhere: one v_cndmask on a mask that already sits in scalar registers
-__device__ __forceinline__ float lanes_or_zero(unsigned long long m, float v)
-{
-    float r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
-    return r;
 }
 
 // the windows a launch piece covers, and the XCD-contiguous order of its blocks: block b -> the (b / 8)-th window of the (b % 8)-th eighth; -1 = no window
@@ -2726,12 +2728,10 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 #define CCSX_A_STEP(K)                                                                                                     \
                     {                                                                                                      \
                         const float up = row_ror1_f32(acur);         /* alpha(i-1, j) */                                     \
-                        const float dl = acur * dl##K;                                                                     \
-                        const float gmm = mnext + dl;                                                                      \
-                        const float st = up * p##K.y;                /* row 0 and column J read zero entries: +0 */        \
+                        const float gmm = __builtin_fmaf(acur, dl##K, mnext);   /* SPEC v8: fused */                      \
                         const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)(cnt + (K)), uJ, 37 /* ule */);    \
                         if (__builtin_amdgcn_inverse_ballot_w64(on)) gA[(K)] = gmm;                                        \
-                        acur = lanes_or_zero(on, gmm + st);          /* (ONE compare: the mask serves the store's exec and the select) */ \
+                        acur = lanes_or_zero(on, __builtin_fmaf(up, p##K.y, gmm));   /* row 0 and column J read zero entries: + 0.  (ONE compare: the mask serves the store's exec and the select) */ \
                         mnext = up * p##K.x;                                                                               \
                         p##K = LDPR(rowA, cx##K);                                                                          \
                         const int2 en = eA[(K) + 4];                                                                       \
@@ -2767,9 +2767,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 #define CCSX_B_STEP(K, KN)                                                                                                 \
                     {                                                                                                      \
                         const float dn = row_rol1_f32(bcur);         /* beta(i+1, j) */                                    \
-                        const float t2 = q##K.y * dn;                                                                      \
-                        const float t3 = dk##K * bcur;                                                                     \
-                        const float bv = (t1next + t2) + t3;                                                               \
+                        const float bv = __builtin_fmaf(dk##K, bcur, __builtin_fmaf(q##K.y, dn, t1next));   /* SPEC v8: fused */ \
                         const unsigned long long on = __builtin_amdgcn_uicmp((unsigned)(cnt + (K)), uJ, 37 /* ule */);    \
                         if (__builtin_amdgcn_inverse_ballot_w64(on)) bE[-(K)] = bv;                                        \
                         bcur = lanes_or_zero(on, bv);                                                                      \
@@ -2836,10 +2834,8 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                             if ((unsigned)((T) - tAc) <= uJc) {      /* alpha, column j = T - row of the window */        \
                                 const float2 pr = *(const float2 *)(rowA + (CJA).y);                                       \
                                 const float dlc = __int_as_float((CJA).x);                                                 \
-                                const float m = updiag * mePrev, dl = acur * dlPrev;                                        \
-                                const float gmm = m + dl;                                                                  \
-                                const float st = up * pr.y;          /* row 0 and column J read zero entries: +0 */       \
-                                if ((unsigned)((T) - tA0) <= uJ) { gA[(AOFF)] = gmm; nv = gmm + st; }   /* ... on the band */ \
+                                const float gmm = __builtin_fmaf(acur, dlPrev, updiag * mePrev);                           \
+                                if ((unsigned)((T) - tA0) <= uJ) { gA[(AOFF)] = gmm; nv = __builtin_fmaf(up, pr.y, gmm); }   /* ... on the band; row 0 and column J read zero entries: + 0 */ \
                                 mePrev = pr.x; dlPrev = dlc;                                                               \
                             }                                                                                              \
                             acur = nv;                                                                                     \
@@ -2861,9 +2857,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                             float nv = 0.0f;                                                                               \
                             if ((unsigned)((T) - tB0) <= uJ) {       /* beta, column jb = J - (T - (I - row)), on the band */ \
                                 const float2 pr = *(const float2 *)(rowB + (CJB).y);                                       \
-                                const float t1 = pr.x * dndiag, t2 = pr.y * dn;                                             \
-                                const float t3 = __int_as_float((CJB).x) * bcur;                                           \
-                                const float bv = (t1 + t2) + t3;                                                           \
+                                const float bv = __builtin_fmaf(__int_as_float((CJB).x), bcur, __builtin_fmaf(pr.y, dn, pr.x * dndiag)); \
                                 bB[(BOFF)] = bv;                                                                           \
                                 nv = bv;                                                                                   \
                             }                                                                                              \
@@ -2980,16 +2974,17 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         ScoreChain ca;
                         ca.ap = ca.bp = ca.acc = ca.b = 0.0f; ca.pA = ca.pB = make_float2(0.f, 0.f);
                         ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, pA) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, pA) + La.q);
-                        ca.dg = La.c - i0a - dloA; ca.db = La.q - i0a - dloA;
-                        ca.bq = *ca.be; if ((unsigned)ca.db >= bwA) ca.bq = 0.0f;
-                        ca.be += pA; ca.db -= 1;
+                        ca.dg = La.c - i0a - dloA;
+                        ca.bq = *ca.be; if ((unsigned)(La.q - i0a - dloA) >= bwA) ca.bq = 0.0f;   // beta(i0, q): the first row's own cell, a zero off the band
+                        ca.be += pA;
+                        const unsigned limA = bwA - 1u - (unsigned)La.qoff;
                         ca.op = (lds_cu8)(&sObs[ra][0] + i0a);
                         asm volatile("" : "+v"(ca.g), "+v"(ca.be), "+v"(tAa), "+v"(tBa), "+v"(ca.op));
                         {   // two rows per iteration: the chain's carried values (previous table pairs, beta, a, b) then rotate between two
                             // register sets instead of being copied at every row (3 v_mov + a loop counter per row before)
                             int ia = 0;
-                            for (; ia + 2 <= nrA; ia += 2) { score_step(ca, La, tAa, tBa, pA, bwA); score_step(ca, La, tAa, tBa, pA, bwA); }
-                            if (ia < nrA) score_step(ca, La, tAa, tBa, pA, bwA);
+                            for (; ia + 2 <= nrA; ia += 2) { score_step(ca, La, tAa, tBa, pA, limA); score_step(ca, La, tAa, tBa, pA, limA); }
+                            if (ia < nrA) score_step(ca, La, tAa, tBa, pA, limA);
                         }
                         const float res = La.fin ? ca.b : ca.acc;
 #ifdef CCSX_EXP_NO_SCORE_LOG                                // experiment (timing only): a unit without its logarithm and fixed-point conversion
@@ -3020,10 +3015,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     cb.ap = cb.bp = cb.acc = cb.b = 0.0f; cb.pA = cb.pB = make_float2(0.f, 0.f);
                     ca.g = (lds_cf)(sGB + gA_ + __mul24(i0a, pA) + La.c); ca.be = (lds_cf)(sGB + bA_ + __mul24(i0a, pA) + La.q);
                     cb.g = (lds_cf)(sGB + gB_ + __mul24(i0b, pB) + Lb.c); cb.be = (lds_cf)(sGB + bB_ + __mul24(i0b, pB) + Lb.q);
-                    ca.dg = La.c - i0a - dloA; ca.db = La.q - i0a - dloA; cb.dg = Lb.c - i0b - dloB; cb.db = Lb.q - i0b - dloB;
-                    ca.bq = *ca.be; if ((unsigned)ca.db >= bwA) ca.bq = 0.0f;
-                    cb.bq = *cb.be; if ((unsigned)cb.db >= bwB) cb.bq = 0.0f;
-                    ca.be += pA; ca.db -= 1; cb.be += pB; cb.db -= 1;
+                    ca.dg = La.c - i0a - dloA; cb.dg = Lb.c - i0b - dloB;
+                    ca.bq = *ca.be; if ((unsigned)(La.q - i0a - dloA) >= bwA) ca.bq = 0.0f;
+                    cb.bq = *cb.be; if ((unsigned)(Lb.q - i0b - dloB) >= bwB) cb.bq = 0.0f;
+                    ca.be += pA; cb.be += pB;
+                    const unsigned limA = bwA - 1u - (unsigned)La.qoff, limB = bwB - 1u - (unsigned)Lb.qoff;
                     ca.op = (lds_cu8)(&sObs[ra][0] + i0a); cb.op = (lds_cu8)(&sObs[rb][0] + i0b);
                     // opaque to the optimiser from here: the running pointers hold complete LDS addresses (otherwise the
                     // dynamic-LDS base is re-added at every use)
@@ -3031,13 +3027,13 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                     const int nmin = nrA < nrB ? nrA : nrB;
                     int i = 0;
                     for (; i + 2 <= nmin; i += 2) {                            // both chains, two rows per iteration (no register copies between rows)
-                        score_step(ca, La, tAa, tBa, pA, bwA);
-                        score_step(cb, Lb, tAb, tBb, pB, bwB);
-                        score_step(ca, La, tAa, tBa, pA, bwA);
-                        score_step(cb, Lb, tAb, tBb, pB, bwB);
+                        score_step(ca, La, tAa, tBa, pA, limA);
+                        score_step(cb, Lb, tAb, tBb, pB, limB);
+                        score_step(ca, La, tAa, tBa, pA, limA);
+                        score_step(cb, Lb, tAb, tBb, pB, limB);
                     }
-                    for (int ia = i; ia < nrA; ++ia) score_step(ca, La, tAa, tBa, pA, bwA);
-                    for (int ib = i; ib < nrB; ++ib) score_step(cb, Lb, tAb, tBb, pB, bwB);
+                    for (int ia = i; ia < nrA; ++ia) score_step(ca, La, tAa, tBa, pA, limA);
+                    for (int ib = i; ib < nrB; ++ib) score_step(cb, Lb, tAb, tBb, pB, limB);
                     {
                         const float res = La.fin ? ca.b : ca.acc;
                         dq = dq_fix(det_log2f(res) - __int_as_float(rl(__float_as_int(vBase), k0)));

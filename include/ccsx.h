@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define CCSX_ABI_VERSION 5
-#define CCSX_SPEC_VERSION 7   /* DESIGN.md §2; bumped whenever a result-changing rule changes (oracle: ORC_SPEC_VERSION) */
+#define CCSX_SPEC_VERSION 8   /* DESIGN.md §2; bumped whenever a result-changing rule changes (oracle: ORC_SPEC_VERSION) */
 
 /* ---- fixed constants of the algorithm specification ---- */
 #define CCSX_BAND          64   /* DP band rows of the wide alignment (retry of the cascade, split alignment: one wave64) */

@@ -36,7 +36,7 @@
 #endif
 
 /* ---------------- specification constants (same values as include/ccsx.h) -------------- */
-#define ORC_SPEC_VERSION 7  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
+#define ORC_SPEC_VERSION 8  /* = CCSX_SPEC_VERSION of include/ccsx.h (tests/test_abi.py); the golden vectors carry it */
 int orc_spec_version(void) { return ORC_SPEC_VERSION; }
 #define BAND      64
 #define ALIGN_BAND1 16      /* rows of the FIRST attempt of the subread -> draft alignment (step 3); BAND rows on failure */
@@ -68,6 +68,20 @@ void orc_set_skip_margin(int m) { g_skip_margin = m; }
 static int g_fill_lo = FILL_MARGIN_LO, g_fill_hi = FILL_MARGIN_HI;
 void orc_set_fill_band(int w) { g_fill_lo = g_fill_hi = w; }
 void orc_set_fill_margins(int lo, int hi) { g_fill_lo = lo; g_fill_hi = hi; }
+/* SPEC v8 "fused recurrences": every multiply-add of the alpha / beta fill (A1/A2), of the mutation extension (A3) and of the link (A4) is ONE fused
+ * multiply-add (IEEE fma: a single rounding), nested in the order written in DESIGN.md §2 — 3 instead of 5 floating-point operations per fill cell and per
+ * scoring-row half, and a dependent chain of fma-fma instead of mul-add-add on the device.  SURVEY.md §7.3 H1(a) names "explicit fmaf everywhere on both" as
+ * the sanctioned alternative to -ffp-contract=off.  orc_set_fma(0) restores the separate roundings of SPEC v7 (the study of profiles/r06_spec_v8_study.txt). */
+#define FMA_DEFAULT 1
+static int g_fma = FMA_DEFAULT;
+void orc_set_fma(int on) { g_fma = on; }
+/* SPEC v8 "joint band test": row i of a mutation's scoring band reads gamma(i, c) and beta(i+1, q), which sit q - c - 1 (0 or 1) diagonals apart; BOTH are taken as
+ * zeros unless both lie on the fill band of SPEC v6: dlo <= c - i <= dhi - (q - c - 1) (v7 tested each cell's own diagonal).  Only rows of a scoring band that is
+ * clamped into a corner of the window are affected, at the band's outermost diagonal; the device needs one compare per row in place of two. */
+#define CLIP_DEFAULT 1
+static int g_clip = CLIP_DEFAULT;
+void orc_set_score_clip(int on) { g_clip = on; }
+static inline float mad(float a, float b, float c) { return g_fma ? __builtin_fmaf(a, b, c) : (a * b) + c; }   /* a*b + c */
 /* the band of one (read, window) pair */
 static inline void fill_band_of(int I, int J, int score_band, int *dlo, int *dhi)
 {
@@ -821,12 +835,10 @@ static void fill(const float *ME, const float *INS, const float *DL, const uint8
             if (j == 0) g = (i == 0) ? 1.0f : 0.0f;
             else {
                 float m = (i > 0) ? pcol[i - 1] * ME[k[j - 1] * NOBS + o[i - 1]] : 0.0f;
-                float dl = pcol[i] * DL[k[j - 1]];
-                g = m + dl;
+                g = mad(pcol[i], DL[k[j - 1]], m);            /* v7: m + pcol[i] * DL */
             }
             gam[i * GS + j] = g;
-            float st = (i > 0 && j < J) ? acol[i - 1] * INS[k[j] * NOBS + o[i - 1]] : 0.0f;
-            acol[i] = g + st;
+            acol[i] = (i > 0 && j < J) ? mad(acol[i - 1], INS[k[j] * NOBS + o[i - 1]], g) : g;   /* v7: g + acol[i-1] * INS */
         }
         memcpy(pcol, acol, sizeof(float) * (I + 1));
     }
@@ -837,9 +849,8 @@ static void fill(const float *ME, const float *INS, const float *DL, const uint8
         for (int i = I; i >= 0; --i) {
             if (j - i < dlo || j - i > dhi) { bet[i * GS + j] = 0.0f; continue; }
             float t1 = (i < I) ? ME[k[j] * NOBS + o[i]] * bet[(i + 1) * GS + j + 1] : 0.0f;
-            float t2 = (i < I) ? INS[k[j] * NOBS + o[i]] * bet[(i + 1) * GS + j] : 0.0f;
-            float t3 = DL[k[j]] * bet[i * GS + j + 1];
-            bet[i * GS + j] = (t1 + t2) + t3;
+            float t12 = (i < I) ? mad(INS[k[j] * NOBS + o[i]], bet[(i + 1) * GS + j], t1) : t1;   /* v7: t1 + INS * beta(i+1, j) */
+            bet[i * GS + j] = mad(DL[k[j]], bet[i * GS + j + 1], t12);                               /* v7: (t1 + t2) + DL * beta(i, j+1) */
         }
     }
     *b00 = bet[0];
@@ -877,22 +888,27 @@ static float score_mut(const float *ME, const float *INS, const float *DL, const
     orc_cnt[CNT_CELLS_SCORE] += (type == MT_DEL ? 1 : 2) * (int64_t)nrows;
     /* (gamma / beta outside the band of SPEC v6 are zeros as fill() leaves them: a scoring band clamped into a corner of the window reads such cells) */
 #define BANDED(mat, ii, jj) ((mat)[(ii) * GS + (jj)])
+    int fdlo, fdhi; fill_band_of(I, J, g_score_band, &fdlo, &fdhi);
+    float bq = fin ? 0.0f : BANDED(bet, i0, q);              /* beta(i, q) of the row at hand: the first row's own cell (a zero off the band), then what the row before read */
+    const int dmax = fdhi - (q - c - 1);                     /* SPEC v8 "joint band test": the largest diagonal c - i at which gamma(i, c) AND beta(i+1, q) are on the band */
     for (int i = i0; i < i0 + nrows; ++i) {
+        const int off = g_clip && (c - i < fdlo || c - i > dmax);   /* (v7: fill() left zeros in the off-band cells, each tested by itself) */
         float insA = 0.0f, meA = 0.0f, insB = 0.0f;
         if (i > 0) {
             if (!(type == MT_DEL && fin)) insA = INS[kA * NOBS + o[i - 1]];
             meA = ME[kA * NOBS + o[i - 1]];
             if (!fin) insB = INS[kB * NOBS + o[i - 1]];
         }
-        float a = BANDED(gam, i, c) + ap * insA;
+        float a = mad(ap, insA, off ? 0.0f : BANDED(gam, i, c));         /* v7: gamma + ap * insA */
         float b;
         if (type == MT_DEL) b = a;
-        else b = ((ap * meA) + (a * DL[kA])) + bp * insB;
+        else b = mad(bp, insB, mad(a, DL[kA], ap * meA));                /* v7: ((ap * meA) + (a * DL)) + bp * insB */
         if (fin) res = b;
         else {
-            float t1 = (i < I) ? ME[kB * NOBS + o[i]] * BANDED(bet, i + 1, q) : 0.0f;
-            float t3 = DL[kB] * BANDED(bet, i, q);
-            acc = acc + b * (t1 + t3);
+            float bqn = off ? 0.0f : BANDED(bet, i + 1, q);                /* (row I + 1 of beta is zeros) */
+            float t1 = (i < I) ? ME[kB * NOBS + o[i]] * bqn : 0.0f;
+            acc = mad(b, mad(DL[kB], bq, t1), acc);                      /* v7: acc + b * (t1 + DL * beta(i, q)) */
+            bq = bqn;
         }
         ap = a; bp = b;
     }

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/golden_kin_v7.npz: HiFi-kinetics expectations (SPEC DESIGN.md §2 "HiFi kinetics") on top of two
-cases of golden_v7.npz (same subreads, pw untouched, ipd replaced by seeded CodecV1 codes over the whole 0..255 range).
+"""Generates tests/golden/golden_kin_v8.npz: HiFi-kinetics expectations (SPEC DESIGN.md §2 "HiFi kinetics") on top of two
+cases of golden_v8.npz (same subreads, pw untouched, ipd replaced by seeded CodecV1 codes over the whole 0..255 range).
 
-Like golden_v7 these vectors come from the repository's own CPU restatement (docs-only reference, "parity unpinned");
+Like golden_v8 these vectors come from the repository's own CPU restatement (docs-only reference, "parity unpinned");
 they freeze the kinetics specification.   python tests/golden/make_golden_kinetics.py
 """
 import os
@@ -35,10 +35,10 @@ def main():
         out[f"{case}/kin"] = r.kin
         out[f"{case}/fn"] = r.fn
         out[f"{case}/rn"] = r.rn
-    out["spec_version"] = np.array([O.spec_version()], np.int32)      # (the kinetics vectors carry the SPEC version like golden_v7.npz)
+    out["spec_version"] = np.array([O.spec_version()], np.int32)      # (the kinetics vectors carry the SPEC version like golden_v8.npz)
     assert O.spec_version() == G.spec_version()
-    np.savez_compressed(os.path.join(HERE, "golden_kin_v7.npz"), **out)
-    print("wrote golden_kin_v7.npz with", len(out), "arrays")
+    np.savez_compressed(os.path.join(HERE, "golden_kin_v8.npz"), **out)
+    print("wrote golden_kin_v8.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -4,8 +4,8 @@ import numpy as np
 
 from ccs_amd import api
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v7.npz")
-GOLDEN_KIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_kin_v7.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v8.npz")
+GOLDEN_KIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_kin_v8.npz")
 # every case of the file (tests/golden/make_golden.py): four plain shapes, one ZMW at the headline size, and one case per SPEC path that
 # plain synthetic data does not take (the generator asserts that the path fired)
 CASES = ["p3_l300", "p5_l700", "p10_l2000", "mix", "c2_one", "trim", "split", "fallback", "lastresort", "retry64", "lowcx", "lowcx_rescue", "partial", "split2"]

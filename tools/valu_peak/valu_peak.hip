@@ -13,9 +13,11 @@
 #define ITERS 2048
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-enum { OP_FMA, OP_ADD, OP_MUL, OP_MAXI, OP_ADDU, OP_CNDMASK, OP_MAXI_DPP, OP_MOV_DPP, OP_PKFMA, OP_READLANE, OP_LSHLADD, OP_MOV, OP_CMP, OP_DSREAD, OP_CNDMASK_S, OP_CMP_CND, OP_MED3, OP_MINMAX, NOPS };
+enum { OP_FMA, OP_ADD, OP_MUL, OP_MAXI, OP_ADDU, OP_CNDMASK, OP_MAXI_DPP, OP_MOV_DPP, OP_PKFMA, OP_READLANE, OP_LSHLADD, OP_MOV, OP_CMP, OP_DSREAD, OP_CNDMASK_S, OP_CMP_CND, OP_MED3, OP_MINMAX, OP_FMAC, OP_PKMUL, OP_PKADD, OP_FMA3, OP_ADD_E64, OP_MUL_DPP, OP_FMAC_DPP, OP_DEP_FMA, OP_DEP_MULADD, OP_DEP_FMAC_DPP, OP_DEP_MULADD_DPP, NOPS };
 static const char *opname[NOPS] = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_max_i32", "v_add_u32", "v_cndmask_b32", "v_max_i32_dpp row_shr:1",
-                                   "v_mov_b32_dpp wave_shr:1", "v_pk_fma_f32", "v_readlane_b32 (to SGPR)", "v_lshl_add_u32", "v_mov_b32", "v_cmp_gt_u32 (to vcc)", "ds_read_b32 (bank-conflict free)", "v_cndmask_b32_e64 (SGPR-pair mask)", "v_cmp_gt_u32 + v_cndmask_b32 (pair)", "v_med3_i32", "v_min_i32 + v_max_i32 (pair)"};
+                                   "v_mov_b32_dpp wave_shr:1", "v_pk_fma_f32", "v_readlane_b32 (to SGPR)", "v_lshl_add_u32", "v_mov_b32", "v_cmp_gt_u32 (to vcc)", "ds_read_b32 (bank-conflict free)", "v_cndmask_b32_e64 (SGPR-pair mask)", "v_cmp_gt_u32 + v_cndmask_b32 (pair)", "v_med3_i32", "v_min_i32 + v_max_i32 (pair)",
+                                   "v_fmac_f32 (VOP2)", "v_pk_mul_f32", "v_pk_add_f32", "v_fma_f32 (three distinct sources)", "v_add_f32_e64 (VOP3 encoding)", "v_mul_f32_dpp row_ror:1", "v_fmac_f32_dpp row_ror:1",
+                                   "DEPENDENT chain: v_fma_f32 (1 per step)", "DEPENDENT chain: v_mul_f32 + v_add_f32 (2 per step)", "DEPENDENT chain: v_fmac_f32_dpp row_ror:1 (1 per step)", "DEPENDENT chain: v_mov_dpp + v_mul + v_add (3 per step)"};
 
 template <int OP> __global__ void k(unsigned long long *cyc, float *sink, float seed)
 {
@@ -53,6 +55,17 @@ template <int OP> __global__ void k(unsigned long long *cyc, float *sink, float 
     else if (OP == OP_CNDMASK_S) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "s"(smask)); \
     else if (OP == OP_CMP_CND) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(b[i]) : "v"(b[(i + 1) & 7]) : "vcc"); \
     else if (OP == OP_MED3) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7]));   \
+    else if (OP == OP_FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(a[(i + 1) & 7]));                  \
+    else if (OP == OP_PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));                      \
+    else if (OP == OP_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));                      \
+    else if (OP == OP_FMA3) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(c), "v"(a[(i + 1) & 7]));               \
+    else if (OP == OP_ADD_E64) asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(c));                                \
+    else if (OP == OP_MUL_DPP) asm volatile("v_mul_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(c)); \
+    else if (OP == OP_FMAC_DPP) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(c)); \
+    else if (OP == OP_DEP_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(c), "v"(a[1]));                      \
+    else if (OP == OP_DEP_MULADD) asm volatile("v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(a[0]) : "v"(c), "v"(a[1])); \
+    else if (OP == OP_DEP_FMAC_DPP) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[0]) : "v"(c)); \
+    else if (OP == OP_DEP_MULADD_DPP) asm volatile("v_mov_b32_dpp %1, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_mul_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %1" : "+v"(a[0]), "+v"(a[2]) : "v"(c)); \
     else if (OP == OP_MINMAX) asm volatile("v_min_i32 %0, %0, %1\n\tv_max_i32 %0, %0, %2" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7]));
             REP8(ONE)
 #undef ONE
@@ -117,6 +130,17 @@ int main()
         run<OP_CMP_CND>(w, p.multiProcessorCount, clk);
         run<OP_MED3>(w, p.multiProcessorCount, clk);
         run<OP_MINMAX>(w, p.multiProcessorCount, clk);
+        run<OP_FMAC>(w, p.multiProcessorCount, clk);
+        run<OP_PKMUL>(w, p.multiProcessorCount, clk);
+        run<OP_PKADD>(w, p.multiProcessorCount, clk);
+        run<OP_FMA3>(w, p.multiProcessorCount, clk);
+        run<OP_ADD_E64>(w, p.multiProcessorCount, clk);
+        run<OP_MUL_DPP>(w, p.multiProcessorCount, clk);
+        run<OP_FMAC_DPP>(w, p.multiProcessorCount, clk);
+        run<OP_DEP_FMA>(w, p.multiProcessorCount, clk);
+        run<OP_DEP_MULADD>(w, p.multiProcessorCount, clk);
+        run<OP_DEP_FMAC_DPP>(w, p.multiProcessorCount, clk);
+        run<OP_DEP_MULADD_DPP>(w, p.multiProcessorCount, clk);
     }
     return 0;
 }
