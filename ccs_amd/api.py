@@ -41,7 +41,7 @@ class Opts(C.Structure):
     _fields_ = [
         ("max_poa_cov", C.c_int32), ("min_passes", C.c_int32), ("top_passes", C.c_int32),
         ("min_length", C.c_int32), ("max_length", C.c_int32), ("min_rq", C.c_float),
-        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("disable_heuristics", C.c_int32), ("min_zscore", C.c_float), ("handles_per_device", C.c_int32), ("no_fallback_draft", C.c_int32), ("max_insertion_size", C.c_int32), ("serial_stages", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("poa_slots", C.c_int32), ("hifi_kinetics", C.c_int32), ("disable_heuristics", C.c_int32), ("min_zscore", C.c_float), ("handles_per_device", C.c_int32), ("no_fallback_draft", C.c_int32), ("max_insertion_size", C.c_int32), ("serial_stages", C.c_int32), ("max_qv", C.c_int32),
     ]
 
 
@@ -98,7 +98,7 @@ EXPORTS = [
     "ccsx_stage_windows", "ccsx_synth_generate", "ccsx_synth_free", "ccsx_alloc_pinned", "ccsx_free_pinned",
     "ccsx_submit", "ccsx_wait", "ccsx_poll", "ccsx_ticket_timings",
     "ccsx_model_from_json", "ccsx_model_load", "ccsx_model_to_json", "ccsx_model_for_chemistry",
-    "ccsx_build_flags", "ccsx_draft_layout", "ccsx_draft_batch", "ccsx_polish_batch", "ccsx_submit_draft", "ccsx_submit_polish",
+    "ccsx_build_flags", "ccsx_runtime_switches", "ccsx_draft_layout", "ccsx_draft_batch", "ccsx_polish_batch", "ccsx_submit_draft", "ccsx_submit_polish",
 ]
 
 _lib = None
@@ -143,6 +143,7 @@ def lib() -> C.CDLL:
         L.ccsx_model_for_chemistry.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Model)]
         L.ccsx_opts_default.argtypes = [C.POINTER(Opts)]
         L.ccsx_build_flags.restype = C.c_char_p
+        L.ccsx_runtime_switches.restype = C.c_char_p
         L.ccsx_draft_layout.restype = None
         L.ccsx_draft_layout.argtypes = [C.POINTER(CBatch), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.ccsx_draft_batch.argtypes = [C.c_void_p, C.POINTER(CBatch), C.POINTER(CDrafts)]

@@ -195,6 +195,7 @@ void usage()
                  "      --log-level L         ERROR|WARN|INFO [WARN]\n"
                  "      --log-file F          write log lines to F instead of stderr\n"
                  "      --refresh-rate S      seconds between progress lines at --log-level INFO [5]\n"
+                 "      --max-qv Q            largest per-base QV reported; rq follows [50 = this build's calibrated cap; 93 = the reference's range]\n"
                  "  test helpers (not in the reference):\n"
                  "      --write-synthetic N,P,L[,seed]  write a synthetic subreads.bam to OUT (no IN)\n"
                  "      --dump-zmws                     list ZMWs after the step-1 filters (no GPU, no OUT)\n"
@@ -219,6 +220,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--min-rq") o.o.min_rq = (float)std::atof(need(a.c_str()).c_str());
         else if (a == "--maxPoaCoverage") o.o.max_poa_cov = std::atoi(need(a.c_str()).c_str());
         else if (a == "--max-insertion-size") { const int v = std::atoi(need(a.c_str()).c_str()); o.o.max_insertion_size = v > 0 ? v : -1; }
+        else if (a == "--max-qv") { const int v = std::atoi(need(a.c_str()).c_str()); o.o.max_qv = v < 1 ? 50 : (v > 93 ? 93 : v); }
         else if (a == "--batch-size") o.batch = std::atoi(need(a.c_str()).c_str());
         else if (a == "--batch-bases") o.batch_bases = std::atoll(need(a.c_str()).c_str());
         else if (a == "--report-file") { o.report = need(a.c_str()); o.report_named = true; }

@@ -254,6 +254,8 @@ int ccsx_create(int device_ordinal, const ccsx_model *model, const ccsx_opts *op
     h->model = *model;
     h->opts = *opts;
     if (h->opts.max_poa_cov < 1) h->opts.max_poa_cov = 1;
+    if (h->opts.max_qv <= 0) h->opts.max_qv = 50;                    // (0 = default; a caller that zero-initialises the struct gets SPEC v7's cap)
+    if (h->opts.max_qv > 93) h->opts.max_qv = 93;
     if (const char *e = std::getenv("CCSX_SERIAL_STAGES")) h->opts.serial_stages = std::atoi(e) != 0;   // A/B switch without a rebuild
     h->handles_on_device = opts->handles_per_device > 1 ? opts->handles_per_device : 1;
     const int rc = create_impl(h);
@@ -411,9 +413,8 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
 
     // ---- resident POA graphs / alignment slots: as many as fit this handle's share of the free memory, never more than
     // the work.  The scratch is shared by the handle's batch slots; it only grows, and growing waits for the compute stream.
-    // per vertex (ccsx_kernels.hip poa_slot): the 32-row score column of far-read columns 128, three 16-byte records, 32 move bytes,
-    // 16 move bytes (a nibble per band row), 5 overflow in-edges, 6 words of order / rank / consensus / band state, two flag bytes = 238
-    S.poa_slot_bytes = (((size_t)vcap_max + 64) * 238 + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
+    // (per vertex CCSX_POA_BYTES_PER_VERTEX, ccsx_kernels.h; the kernels' layout static_asserts the same figure) + the pass's path + the state block
+    S.poa_slot_bytes = (((size_t)vcap_max + 64) * CCSX_POA_BYTES_PER_VERTEX + (size_t)maxL_max * 4 + 1024 + 255) & ~(size_t)255;
     S.align_slot_i32 = (size_t)need_max * 128 + 4 * (size_t)need_max + 64;   // (origin, dirty bits) per cell and edge + band starts + best cell (score, row, entry row) per edge
     // k_align16 stores a quad's moves instead (2 bits per band row and column + 2 bits of band step and an edge flag per column: 18 words per block of 16 draft columns and pass)
     int64_t dcap_max = 16;
@@ -470,6 +471,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     P.n_zmw = n; P.n_reads = R; P.maxL_max = (int32_t)maxL_max; P.vcap_max = (int32_t)vcap_max; P.need_max = need_max; P.max_reads = nr_max;
     (void)nr_min;
     P.opts = h->opts;
+    P.perr_floor = ccsx_perr_floor(h->opts.max_qv);
     P.model = (const ccsx_model *)h->d_model.p;
     P.snr = (const float *)S.d_snr.p; P.read_off = (const int32_t *)S.d_read_off.p; P.base_off = (const int64_t *)S.d_base_off.p;
     P.bases = (const uint8_t *)S.d_bases.p; P.pw = (const uint8_t *)S.d_pw.p; P.flags = (const uint8_t *)S.d_flags.p;

@@ -25,6 +25,17 @@ int ccsx_abi_version(void) { return CCSX_ABI_VERSION; }
 int ccsx_spec_version(void) { return ccsx_kernel_is_experiment() ? -CCSX_SPEC_VERSION : CCSX_SPEC_VERSION; }
 const char *ccsx_build_flags(void) { return ccsx_kernel_build_flags(); }
 const char *ccsx_last_error(void) { return g_last_error.c_str(); }
+// every environment variable the library reads for scheduling / debugging (ccsx_api.cpp, ccsx_kernels.hip ccsx_launch_all): results never depend on them
+const char *ccsx_runtime_switches(void)
+{
+    static const char *names[] = {"CCSX_STAGE_PRIO", "CCSX_POA_SPLIT", "CCSX_SERIAL_STAGES", "CCSX_A16_ONE_REGION", "CCSX_ALIGN16_MAX_SLOTS", "CCSX_TB_ASIDE",
+                                  "CCSX_POLISH_MAX_BLOCKS", "CCSX_EPOCH_REBASE_MS", "CCSX_TRACE", "CCSX_NUMA"};
+    static thread_local std::string out;
+    out.clear();
+    for (const char *n : names)
+        if (const char *v = std::getenv(n)) { if (!out.empty()) out += ' '; out += n; out += '='; out += v; }
+    return out.c_str();
+}
 
 // Synthetic parameter set "SYN-1".  The trained PacBio tables (docs/faq/chemistry.md:27-56,
 // $SMRT_CHEMISTRY_BUNDLE_DIR/arrow/*.json) are not in the mount; this set has the documented shape:
@@ -74,6 +85,7 @@ void ccsx_opts_default(ccsx_opts *o)
     o->poa_slots = 0;
     o->min_zscore = -3.4f;   // [RECALL] unanimity's MinZScore; DESIGN.md §2 "z-score gate"
     o->max_insertion_size = 30;   // docs/how-does-ccs-work.md:74-78
+    o->max_qv = 50;               // SPEC v7 "honest QVs"; 93 = the reference's documented range (docs/faq/qv-binning.md:31)
 }
 
 int64_t ccsx_result_layout(const ccsx_batch *b, int64_t *seq_off)

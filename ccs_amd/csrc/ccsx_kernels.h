@@ -2,8 +2,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 
 #include "ccsx.h"
+
+// bytes of POA scratch per vertex (ccsx_kernels.hip poa_slot, all by topological position): the 32-row score column of far-read columns 128, five 16-byte
+// records (kinfo, column records x 2, overflow in-edges x 2), 16 move bytes (a nibble per band row), 3 words of consensus / band state, two flag bytes
+#define CCSX_POA_BYTES_PER_VERTEX 238
+
+// the floor of every reported per-base error probability for opts.max_qv (SPEC v7: Q50 = exactly 1e-5f; the oracle computes the same expression)
+static inline float ccsx_perr_floor(int max_qv) { return max_qv == 50 ? 1e-5f : (float)pow(10.0, -(double)max_qv / 10.0); }
 
 struct KParams {
     int32_t n_zmw, n_reads;
@@ -13,6 +21,7 @@ struct KParams {
     int32_t max_reads;         // most passes of a ZMW in the batch (after the top_passes cap)
     int32_t qv_only;           // CCSX_QV_ONLY (ccsx_polish_batch): one scoring round, no mutation applied — QVs / rq of the sequence as given
     ccsx_opts opts;
+    float perr_floor;          // 10^(-opts.max_qv / 10): floor of every reported per-base error probability (ccsx_perr_floor)
     const ccsx_model *model;   // device copy
     // ---- inputs (HBM resident after ccsx_upload)
     const float *snr;

@@ -149,8 +149,8 @@ const char *ccsx_kernel_build_flags()
 #define SKIP_MARGIN 6
 #define SKIP_SPREAD 3
 #define SCORE_BAND 5                  // SPEC: half width (read rows) of the mutation scoring band around the window diagonal
-#define PERR_FLOOR 1e-5f              // SPEC v7: smallest per-base error probability that is reported (Q50; nothing measured supports a higher claim)
-#define SKIP_PERR_FLOOR 1e-5f         // SPEC v7: error probability floor of a position the candidate filter skips (Q50)
+// (SPEC v7 / ABI v6: the smallest per-base error probability that is reported — also for a position the candidate filter skips — is P.perr_floor = 10^(-opts.max_qv/10),
+// 1e-5 = Q50 by default: nothing measured supports a higher claim; max_qv 93 = the reference's documented range)
 #define REP_ERRS 0.2f                 // SPEC v7 "repeat-count floor": a core base inside a period-p tandem tract of L >= REP_MINLEN(p) visible bases reports p_err >= REP_ERRS / L
 #define FILL_MARGIN 2                 // SPEC v6 "banded fill": alpha / beta exist on the diagonals j - i in [min(0, J - I) - (Wr + 2), max(0, J - I) + (Wr + 2)] only
 #define DQ_SCALE 65536.0f
@@ -389,11 +389,15 @@ __device__ __forceinline__ int base_at(const BaseCursor &c, int t)
 //                 of every column an in-edge skipped to + the record).
 //   k_poa_thread  one wave per graph: the gate, traceback, threading of the pass into the graph (wave-parallel list insertion),
 //                 and the prepass for the next DP: column records by topological position {base, in-edge count, positions of
-//                 in-edges 0..2, "a far in-edge reads this column back"}
+//                 in-edges 0..2, "a far in-edge reads this column back"} — round 6: the threading itself produces them (see the layout note below)
 //   k_poa_finish  heaviest path, draft, window bounds
-// Layout by vertex id: vrec {base | npred<<8 | reads<<16, pred0, pred1, pred2}, predx (in-edges 3..7), rank (topological
-// position).  By topological position: order (ping-pong), crec (the DP's column record), kinfo {lo, colmax, bestrow, position of
-// in-edge 0} and the move row mvK[32] of the current DP pass, M[32] for the far-read columns.
+// Round 6: a vertex IS its topological position.  Everything is laid out by position: crec {base | in-edges << 8 | flags | passes << 20, positions of
+// in-edges 0..2} and px {positions of in-edges 3..6} (both ping-pong: threading a pass writes the next numbering while it reads the current one), kinfo {lo,
+// colmax, bestrow, position of in-edge 0} and the move row mvK[32] of the current DP pass, M[32] for the far-read columns.  Until round 5 the graph lived by
+// vertex ID (record, overflow in-edges, rank, passes-through) beside two order arrays, and every pass gathered / scattered all of them by id to produce the
+// column records of the next DP: 8.5 MB of 4- and 16-byte gathers per ZMW.  Now a pass is threaded by ONE streaming merge: the records of the vertices that
+// are not on the pass's path shift to their new positions, the path's elements write theirs (existing: in-edges remapped, passes + 1, the new edge; new: a
+// fresh record), and the result IS the next DP's column records.
 #define PB CCSX_POA_BAND              // rows of the POA band
 #define PRING 8                       // columns of a graph the DP keeps in LDS (+ the START column in slot PRING)
 #define PGS 40                        // words per ring column: 4 guards, 32 rows, 4 guards
@@ -403,12 +407,13 @@ __device__ __forceinline__ int base_at(const BaseCursor &c, int t)
 enum { ST_N, ST_NADDED, ST_OK, ST_PAR, ST_KEND, ST_BS, ST_NPOA, ST_BB, ST_NREADS, ST_REV0, ST_LIVE, ST_WORDS = 16 };
 struct PoaSlot {
     int32_t *st;                      // [ST_WORDS] per-graph state that travels between the kernels
-    int4 *vrec, *kinfo, *crec;
-    int32_t *predx, *M, *rank, *order0, *order1, *bestK, *bpK, *pathv, *loK;
-    uint8_t *mvK, *needK, *nrV;
+    int4 *kinfo, *crec0, *crec1, *px0, *px1;
+    int32_t *M, *bestK, *bpK, *pathv, *loK;
+    uint8_t *mvK, *needK, *onpK;
 };
 #define POA_MV_BYTES (PB / 2)         // a column's moves: one nibble per band row (0..13 = in-edge slot * 2 + [deletion], 15 = insertion)
-#define POA_BYTES_PER_VERTEX (PB * 4 + 16 * 3 + POA_MV_BYTES + 5 * 4 + 6 * 4 + 2)
+#define POA_BYTES_PER_VERTEX (PB * 4 + 16 * 5 + POA_MV_BYTES + 3 * 4 + 2)       // = 238 (the host sizes a slot with it: ccsx_kernels.h CCSX_POA_BYTES_PER_VERTEX)
+static_assert(POA_BYTES_PER_VERTEX == CCSX_POA_BYTES_PER_VERTEX, "the host's slot size and the kernels' layout disagree");
 
 __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
 {
@@ -417,19 +422,17 @@ __device__ __forceinline__ PoaSlot poa_slot(const KParams &P, int slot)
     uint8_t *p = P.poa_scratch + (size_t)slot * P.poa_slot_bytes;
     s.st = (int32_t *)p;      p += 256;
     s.M = (int32_t *)p;       p += vc * PB * 4;
-    s.vrec = (int4 *)p;       p += vc * 16;
     s.kinfo = (int4 *)p;      p += vc * 16;
-    s.crec = (int4 *)p;       p += vc * 16;
+    s.crec0 = (int4 *)p;      p += vc * 16;     // column records, ping-pong (ST_PAR names the current one)
+    s.crec1 = (int4 *)p;      p += vc * 16;
+    s.px0 = (int4 *)p;        p += vc * 16;     // positions of in-edges 3..6, ping-pong like the records; an entry is meaningful only where the record counts more than three
+    s.px1 = (int4 *)p;        p += vc * 16;
     s.mvK = p;                p += vc * POA_MV_BYTES;
-    s.predx = (int32_t *)p;   p += vc * 5 * 4;
-    s.rank = (int32_t *)p;    p += vc * 4;
-    s.order0 = (int32_t *)p;  p += vc * 4;
-    s.order1 = (int32_t *)p;  p += vc * 4;
     s.bestK = (int32_t *)p;   p += vc * 4;      // also the run-count / shift array while threading a read
     s.bpK = (int32_t *)p;     p += vc * 4;
-    s.loK = (int32_t *)p;     p += vc * 4;      // by topological position: band start of the column in the current DP pass (the traceback's half of kinfo)
-    s.needK = p;              p += (vc + 3) & ~(size_t)3;   // by topological position: 1 = some in-edge reaches this column from more than PRING positions ahead
-    s.nrV = p;                p += (vc + 3) & ~(size_t)3;   // by vertex id: passes through the vertex
+    s.loK = (int32_t *)p;     p += vc * 4;      // band start of the column in the current DP pass (the traceback's half of kinfo)
+    s.needK = p;              p += (vc + 3) & ~(size_t)3;   // 1 = some in-edge reaches this column from more than PRING positions ahead
+    s.onpK = p;               p += (vc + 3) & ~(size_t)3;   // (while threading) 1 = the vertex is on the pass's path
     s.pathv = (int32_t *)p;
     return s;
 }
@@ -438,22 +441,8 @@ __device__ __forceinline__ int imed3(int x, int lo, int hi) { x = x > lo ? x : l
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ int poa_pred(const PoaSlot &g, const int4 &rec, int v, int q)
-{
-    return q == 0 ? rec.y : (q == 1 ? rec.z : (q == 2 ? rec.w : g.predx[v * 5 + (q - 3)]));
-}
-
-// append edge from -> to (to's record in registers); SPEC: duplicates ignored, in-edge cap CCSX_MAXPRED = 7
-__device__ __forceinline__ bool poa_add_edge(const PoaSlot &g, int4 &rec, int to, int from)
-{
-    const int np = (rec.x >> 8) & 255;
-    bool found = false;
-    for (int q = 0; q < np; ++q) found |= (poa_pred(g, rec, to, q) == from);
-    if (found || np >= CCSX_MAXPRED) return false;
-    if (np == 0) rec.y = from; else if (np == 1) rec.z = from; else if (np == 2) rec.w = from; else g.predx[to * 5 + (np - 3)] = from;
-    rec.x += 1 << 8;
-    return true;                                        // the record changed: the caller writes it back
-}
+__device__ __forceinline__ int int4_get(const int4 &v, int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void int4_set(int4 &v, int q, int x) { if (q == 0) v.x = x; else if (q == 1) v.y = x; else if (q == 2) v.z = x; else v.w = x; }
 
 extern __shared__ uint32_t dyn_lds[];
 #define TB_BLOCK 64                   // positions cached per traceback block (64 move rows of 32 bytes)
@@ -464,46 +453,6 @@ extern __shared__ uint32_t dyn_lds[];
 #define ZREF_RETRY2 1024                // k_post: the fallback draft failed as well (bits 0-5: its backbone)
 #define ZREF_DONE2 2048                 // the last-resort draft (pass 2: the backbone pass itself) has been made
 #define ZREF_PASSBIT(pass) ((pass) == 1 ? ZREF_DONE : ZREF_DONE2)
-
-// the prepass of a DP: column records by topological position — {base | in-edges << 8 | flags | passes << 20, positions of in-edges
-// 0..2} — and the flags of the columns some in-edge reads back from more than PRING positions ahead (needK; the DP ORs them into the
-// record when it prefetches a block).  One pass over the graph: order -> vertex record -> ranks of its in-edges.
-__device__ __forceinline__ void poa_column_records(const PoaSlot &g, const int32_t *order, int n, int lane)
-{
-    for (int q = lane; q < n; q += LANES) g.needK[q] = 0;
-    __threadfence_block();
-    // two blocks of 64 columns per iteration: the chain order -> vertex record -> rank of the in-edges is three dependent gathers deep,
-    // so the loads of both blocks are issued level by level before anything is stored (one wave per graph: latency is all it costs)
-    for (int kb = 0; kb < n; kb += 2 * LANES) {
-        const int kA = kb + lane, kB = kb + LANES + lane;
-        const bool inA = kA < n, inB = kB < n;
-        const int vA = inA ? order[kA] : 0, vB = inB ? order[kB] : 0;
-        const int4 rA = inA ? g.vrec[vA] : make_int4(0, -1, -1, -1), rB = inB ? g.vrec[vB] : make_int4(0, -1, -1, -1);
-        const int nrA = inA ? (int)g.nrV[vA] : 0, nrB = inB ? (int)g.nrV[vB] : 0;
-        const int npA = (rA.x >> 8) & 255, npB = (rB.x >> 8) & 255;
-        // in-edges 0..2 of both blocks (nearly every column has at most two)
-        int pA0 = -1, pA1 = -1, pA2 = -1, pB0 = -1, pB1 = -1, pB2 = -1;
-        if (npA > 0) pA0 = g.rank[rA.y];
-        if (npB > 0) pB0 = g.rank[rB.y];
-        if (npA > 1) pA1 = g.rank[rA.z];
-        if (npB > 1) pB1 = g.rank[rB.z];
-        if (npA > 2) pA2 = g.rank[rA.w];
-        if (npB > 2) pB2 = g.rank[rB.w];
-#define CCSX_CREC_OUT(KK, IN, V, REC, NP, NR, P0, P1, P2)                                                                  \
-        if (IN) {                                                                                                          \
-            int4 c = make_int4(((REC).x & 255) | ((NP) << 8) | ((NR) << CREC_NREADS_SHIFT), P0, P1, P2);                   \
-            if ((NP) > 0 && (KK) - (P0) > PRING) { g.needK[P0] = 1; c.x |= CREC_FAR0; }                                    \
-            if ((NP) > 1 && (KK) - (P1) > PRING) g.needK[P1] = 1;                                                          \
-            if ((NP) > 2 && (KK) - (P2) > PRING) g.needK[P2] = 1;                                                          \
-            for (int q = 3; q < (NP); ++q) { const int pu = g.rank[poa_pred(g, REC, V, q)]; if ((KK) - pu > PRING) g.needK[pu] = 1; }   \
-            g.crec[KK] = c;                                                                                                \
-        }
-        CCSX_CREC_OUT(kA, inA, vA, rA, npA, nrA, pA0, pA1, pA2)
-        CCSX_CREC_OUT(kB, inB, vB, rB, npB, nrB, pB0, pB1, pB2)
-#undef CCSX_CREC_OUT
-    }
-    __threadfence_block();
-}
 
 // step 4: window bounds of a draft of Ld bases (one wave); returns the number of windows
 __device__ __forceinline__ int poa_windows(const KParams &P, int z, int Ld, int lane)
@@ -634,9 +583,8 @@ __global__ __launch_bounds__(64) void k_poa_init(KParams P, int z0, int pass, in
     else {                                              // first read: backbone chain; its column records are trivial
         for (int i = lane; i < I; i += LANES) {
             const int b = read_base_packed(sread, i);
-            g.vrec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8), i - 1, -1, -1);
-            g.rank[i] = i; g.order0[i] = i; g.nrV[i] = 1;
-            g.crec[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8) | (1 << CREC_NREADS_SHIFT), i - 1, -1, -1);
+            g.crec0[i] = make_int4(b | ((i > 0 ? 1 : 0) << 8) | (1 << CREC_NREADS_SHIFT), i - 1, -1, -1);
+            g.needK[i] = 0;                               // (a chain has no far in-edge)
         }
         n = I;
     }
@@ -711,7 +659,9 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
     int32_t *st = G.st;
     int32_t *Mcol = G.M;
     int4 *kinfo = G.kinfo;
-    const int4 *crec = G.crec;
+    const int par_ = have ? st[ST_PAR] : 0;
+    const int4 *crec = par_ ? G.crec1 : G.crec0;        // the current numbering's column records / overflow in-edges (ST_PAR)
+    const int32_t *pxw = (const int32_t *)(par_ ? G.px1 : G.px0);
     const uint8_t *needK = G.needK;
     uint8_t *mvK = G.mvK;
     bool live = have && st[ST_LIVE] && st[ST_OK] && rr < st[ST_NPOA];
@@ -790,11 +740,8 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
             for (int q = 1; q < CCSX_MAXPRED; ++q) {
                 if ((actm & M_SGT(np, q)) == 0ull) break;
                 int pq = q == 1 ? rec.z : rec.w;
-                if (q >= 3) {                           // in-edges 3..7 (rare): through the vertex id
-                    if (act && np > q) {
-                        const int32_t *order = st[ST_PAR] ? G.order1 : G.order0;
-                        pq = G.rank[G.predx[order[k] * 5 + (q - 3)]];
-                    }
+                if (q >= 3) {                           // in-edges 3..6 (rare): the overflow record of the column
+                    if (act && np > q) pq = pxw[(size_t)k * 4 + (q - 3)];
                     LANDED(pq);
                 }
                 const bool on = act && np > q;
@@ -858,8 +805,7 @@ __global__ __launch_bounds__(64) void k_poa_dp(KParams P, int z0, int pass, int 
                 int pq = q == 1 ? rec.z : rec.w, plo = q == 1 ? plo1 : plo2;
                 if (q >= 3) {
                     if (on) {
-                        const int32_t *order = st[ST_PAR] ? G.order1 : G.order0;
-                        pq = G.rank[G.predx[order[k] * 5 + (q - 3)]];
+                        pq = pxw[(size_t)k * 4 + (q - 3)];
                         if (k - pq > PRING) plo = kinfo[pq].x; else plo = LDS_I32(kinBase + (uint32_t)(pq & (PRING - 1)) * 16);
                     }
                     LANDED(pq); LANDED(plo);
@@ -961,24 +907,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int rev = rfl(((P.flags[r] & 1) != g.st[ST_REV0]) ? 1 : 0);
     const int vcap = rfl(P.vcap[z]);
     const int n0 = rfl(g.st[ST_N]);
-    int32_t *order = g.st[ST_PAR] ? g.order1 : g.order0, *order_nx = g.st[ST_PAR] ? g.order0 : g.order1;
+    const int par = rfl(g.st[ST_PAR]);
+    const int4 *crec = par ? g.crec1 : g.crec0, *pxc = par ? g.px1 : g.px0;      // the current numbering ...
+    int4 *crec_nx = par ? g.crec0 : g.crec1, *px_nx = par ? g.px0 : g.px1;       // ... and the one this pass writes
     load_read_packed(sread, rb, I, rev, lane);
     __syncthreads();
     TPH(8);
     // ---- traceback: lane 0 walks, the block of TB_BLOCK positions it is in is cached in LDS.  Round 3: the per-position words come
     // from the DP's column record (base, in-edge count and the positions of in-edges 0..2 by position: no vertex-record gather), and
-    // the NEXT block (the walk goes down the positions) is fetched into registers while the current one is walked
+    // the NEXT block (the walk goes down the positions) is fetched into registers while the current one is walked.  Round 6: the path
+    // holds POSITIONS (of the current numbering; -1 = a new vertex)
     {
         int k = kend, i = I;
         int4 kiN = make_int4(0, 0, 0, -1), crN = make_int4(0, -1, -1, -1);
-        int vN = 0, kbN = -1;
+        int kbN = -1;
         uint4 mvN0 = make_uint4(0, 0, 0, 0);
         auto fetch = [&](int kb_) {
             const int kk = kb_ + lane;
             kbN = kb_;
-            kiN = make_int4(0, 0, 0, -1); crN = make_int4(0, -1, -1, -1); vN = 0;
+            kiN = make_int4(0, 0, 0, -1); crN = make_int4(0, -1, -1, -1);
             if (kb_ >= 0) {
-                if (kk < n0) { crN = g.crec[kk]; kiN = make_int4(g.loK[kk], 0, 0, crN.y); vN = order[kk]; }
+                if (kk < n0) { crN = crec[kk]; kiN = make_int4(g.loK[kk], 0, 0, crN.y); }
                 mvN0 = ((const uint4 *)(g.mvK + (size_t)kb_ * POA_MV_BYTES))[lane];     // 64 columns x 16 bytes
             }
         };
@@ -990,7 +939,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             // block cache: the TB_BLOCK move rows go to LDS, the per-position words (band start, position of in-edge 0,
             // vertex id, record words) stay in lane registers and are handed out with v_readlane
             const int4 kiL = kiN, crL = crN;
-            const int vLt = vN, metaL = crN.x;
+            const int metaL = crN.x;
             ((uint4 *)sMv)[lane] = mvN0;
             fetch(kb - TB_BLOCK);                              // in flight while this block is walked
             __syncthreads();
@@ -1009,10 +958,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const unsigned long long simple = __ballot(m_s == 0 && pp_s == k - lane - 1);
                     const int R = (simple == ~0ull) ? 64 : __ffsll((long long)~simple) - 1;
                     if (R > 0) {
-                        const int meta_s = __shfl(metaL, src), v_s = __shfl(vLt, src);
+                        const int meta_s = __shfl(metaL, src);
                         if (lane < R) {
                             const int ir = i - lane - 1;
-                            g.pathv[ir] = ((meta_s & 3) == read_base_packed(sread, ir)) ? v_s : -1;
+                            g.pathv[ir] = ((meta_s & 3) == read_base_packed(sread, ir)) ? k - lane : -1;
                         }
                         k -= R; i -= R;
                         if (R >= 64 || k < kb) continue;
@@ -1036,9 +985,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 else if (slot == 0) up = rl(kiL.w, kl);
                 else if (slot == 1) up = rl(crL.z, kl);
                 else if (slot == 2) up = rl(crL.w, kl);
-                else { const int v = rl(vLt, kl); up = rfl(g.rank[g.predx[v * 5 + (slot - 3)]]); }
+                else up = rfl(((const int32_t *)pxc)[(size_t)k * 4 + (slot - 3)]);
                 if (t == MV_DIAG) {
-                    if (lane == 0) g.pathv[i - 1] = ((meta & 3) == read_base_packed(sread, i - 1)) ? rl(vLt, kl) : -1;
+                    if (lane == 0) g.pathv[i - 1] = ((meta & 3) == read_base_packed(sread, i - 1)) ? k : -1;
                     --i;
                 }
                 CHK(up < k && up >= -1, 103);
@@ -1050,93 +999,63 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     __threadfence_block();
     TPH(9);
-    // ---- thread the read into the graph (wave-parallel; identical result to the serial list insertion)
+    // ---- thread the read into the graph (wave-parallel; identical result to the serial list insertion).  Round 6: ONE streaming merge by position.
+    //   A  runs of new vertices: the last element of a run records the run's length at its anchor (the path vertex before it; list head if none), path
+    //      vertices are flagged;                                   B  prefix sum: S[q] = how far position q moves to the right;
+    //   C  the vertices that are NOT on the path shift (in-edges remapped p -> p + S[p], far flags recomputed);
+    //   D  the path's elements write their records at their new positions — an existing vertex: its record remapped, passes + 1, the edge from the path
+    //      vertex before it (unless present / the in-edge cap is hit); a new vertex: a fresh record — and that IS the next DP's column records.
     int32_t *cnt = g.bestK;
-    int carry = 0;
-    // (second session of round 4: the passes below take TWO / FOUR blocks of 64 path elements per iteration and issue the loads of one dependence level for all
-    // of them before the first is used — one wave per graph, so a pass costs its dependent memory round trips: ~ 1660 per threaded pass before, ~ 700 now)
-    for (int c0 = 0; c0 < I; c0 += 4 * LANES) {                    // pass 1: vertex ids of the path
-        int pv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = c0 + u * LANES + lane; pv[u] = g.pathv[i < I ? i : I - 1]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = c0 + u * LANES + lane;
-            const int isnew = (i < I && pv[u] < 0) ? 1 : 0;
-            const int incl = wave_scan_add_i32(isnew);
-            if (i < I && isnew) g.pathv[i] = n0 + carry + incl - 1;        // (an existing vertex keeps its entry)
-            carry += rl(incl, 63);
-        }
-    }
-    const int nnew = carry;
-    if (n0 + nnew > vcap) { if (lane == 0) g.st[ST_OK] = 0; return; }
-    for (int q = lane; q <= n0; q += LANES) cnt[q] = 0;
+    // the new position of the vertex at (current) position q; the record of the current numbering at q carried over to the next one
+    auto newpos = [&](int q) -> int { return q + cnt[q]; };
+    for (int q = lane; q <= n0; q += LANES) { cnt[q] = 0; g.onpK[q] = 0; }
     __threadfence_block();
     TPH(10);
-    int lastEx = -1;
-    for (int c0 = 0; c0 < I; c0 += 2 * LANES) {                    // pass 2: records, edges, run counts
-        int w[2], pw[2], wn[2], ex[2], apos[2];
+    int lastEx = -1, nnew = 0;
+    for (int c0 = 0; c0 < I; c0 += 2 * LANES) {                    // A: run lengths at the anchors, path flags (two blocks of loads in flight)
+        int w[2], wn[2], ex[2];
         bool valid[2], isnew[2], lastOfRun[2];
-        // level 1: the path entries of the element, its predecessor and its successor
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = c0 + u * LANES + lane;
             valid[u] = i < I;
             const int ic = valid[u] ? i : I - 1;
             w[u] = g.pathv[ic];
-            pw[u] = g.pathv[ic > 0 ? ic - 1 : 0];
             wn[u] = g.pathv[ic + 1 < I ? ic + 1 : ic];
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = c0 + u * LANES + lane;
-            if (!valid[u]) w[u] = 0;
-            if (!(valid[u] && i > 0)) pw[u] = -1;
-            isnew[u] = valid[u] && w[u] >= n0;
+            isnew[u] = valid[u] && w[u] < 0;
+            nnew += __popcll(__ballot(isnew[u]));
             const int incl = wave_scan_max_i32((valid[u] && !isnew[u]) ? i : -1);
             int e = wave_shr1_i32(incl, -1);
             e = e > lastEx ? e : lastEx;                           // last existing path element before i
             ex[u] = e;
             const int li = rl(incl, 63);
             lastEx = li > lastEx ? li : lastEx;
-            // the last vertex of a run of new vertices records the run length at its anchor (plain store, one writer)
-            lastOfRun[u] = isnew[u] && ((i + 1 >= I) || (wn[u] < n0));
+            lastOfRun[u] = isnew[u] && ((i + 1 >= I) || (wn[u] >= 0));
         }
-        // level 2: the vertex records (existing vertices), the anchors' vertex ids (ends of runs of new vertices)
-        int4 rec[2]; int nr[2], av[2];
+        int av[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int wc = (valid[u] && !isnew[u]) ? w[u] : 0;
-            rec[u] = g.vrec[wc]; nr[u] = (int)g.nrV[wc];
-            av[u] = g.pathv[(lastOfRun[u] && ex[u] >= 0) ? ex[u] : 0];
-        }
-        // level 3: the anchors' positions
-#pragma unroll
-        for (int u = 0; u < 2; ++u) apos[u] = g.rank[(lastOfRun[u] && ex[u] >= 0) ? av[u] : 0];
+        for (int u = 0; u < 2; ++u) av[u] = g.pathv[(lastOfRun[u] && ex[u] >= 0) ? ex[u] : 0];     // the anchor's position
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = c0 + u * LANES + lane;
-            if (valid[u]) {
-                bool dirty = isnew[u];
-                if (!isnew[u]) g.nrV[w[u]] = nr[u] + 1;            // (a vertex is on the path once: one writer)
-                else {
-                    g.nrV[w[u]] = 1;
-                    rec[u] = make_int4(read_base_packed(sread, i), -1, -1, -1);
-                    if (lastOfRun[u]) {
-                        const int ap = ex[u] >= 0 ? apos[u] : -1;
-                        CHK(ap >= -1 && ap < n0, 106);
-                        cnt[ap + 1] = i - ex[u];
-                    }
-                }
-                if (pw[u] >= 0) dirty |= poa_add_edge(g, rec[u], w[u], pw[u]);
-                if (dirty) g.vrec[w[u]] = rec[u];                // most path vertices match and keep their record
+            if (valid[u] && !isnew[u]) g.onpK[w[u]] = 1;           // (a vertex is on the path once: one writer)
+            if (lastOfRun[u]) {
+                const int ap = ex[u] >= 0 ? av[u] : -1;
+                CHK(ap >= -1 && ap < n0, 106);
+                cnt[ap + 1] = i - ex[u];                           // (distinct runs have distinct anchors: one writer)
             }
         }
     }
+    nnew = rfl(nnew);
+    if (n0 + nnew > vcap) { if (lane == 0) g.st[ST_OK] = 0; return; }
     __threadfence_block();
     TPH(11);
-    carry = 0;
-    for (int c0 = 0; c0 <= n0; c0 += 4 * LANES) {                  // inclusive prefix sum of run counts
+    int carry = 0;
+    for (int c0 = 0; c0 <= n0; c0 += 4 * LANES) {                  // B: inclusive prefix sum of the run counts
         int cv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int q = c0 + u * LANES + lane; cv[u] = cnt[q <= n0 ? q : n0]; }
@@ -1148,60 +1067,91 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             carry += rl(incl, 63);
         }
     }
-    __threadfence_block();
-    lastEx = -1;
-    for (int c0 = 0; c0 < I; c0 += 2 * LANES) {                    // new vertices: position right after their anchor
-        int w[2], ex[2], av[2], ap[2], ca[2];
-        bool isnew[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = c0 + u * LANES + lane; w[u] = g.pathv[i < I ? i : I - 1]; }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = c0 + u * LANES + lane;
-            const bool valid = i < I;
-            isnew[u] = valid && w[u] >= n0;
-            const int incl = wave_scan_max_i32((valid && !isnew[u]) ? i : -1);
-            int e = wave_shr1_i32(incl, -1);
-            e = e > lastEx ? e : lastEx;
-            ex[u] = e;
-            const int li = rl(incl, 63);
-            lastEx = li > lastEx ? li : lastEx;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) av[u] = g.pathv[(isnew[u] && ex[u] >= 0) ? ex[u] : 0];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) ap[u] = g.rank[(isnew[u] && ex[u] >= 0) ? av[u] : 0];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) ca[u] = cnt[(isnew[u] && ex[u] >= 0) ? ap[u] : 0];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = c0 + u * LANES + lane;
-            if (isnew[u]) {
-                int pos = i - ex[u] - 1;
-                if (ex[u] >= 0) pos += ap[u] + ca[u] + 1;
-                CHK(pos >= 0 && pos < n0 + nnew && w[u] < vcap, 104);
-                order_nx[pos] = w[u]; g.rank[w[u]] = pos;
-            }
-        }
-    }
-    __threadfence_block();
-    for (int q0 = 0; q0 < n0; q0 += 4 * LANES) {                   // existing vertices shift right (four blocks of loads in flight)
-        int v[4], np2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int q = q0 + u * LANES + lane; v[u] = q < n0 ? order[q] : -1; np2[u] = q < n0 ? q + cnt[q] : 0; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (v[u] >= 0) {
-            CHK(np2[u] >= 0 && np2[u] < n0 + nnew && v[u] < n0, 105);
-            order_nx[np2[u]] = v[u]; g.rank[v[u]] = np2[u];
-        }
-    }
-    __threadfence_block();
     const int n = n0 + nnew;
-    if (lane == 0) { g.st[ST_N] = n; g.st[ST_NADDED] += 1; g.st[ST_PAR] ^= 1; }
-    // ---- the column records of the next pass's DP; after the last pass k_poa_finish walks them
-    (void)npoa;
+    for (int q = lane; q < n; q += LANES) g.needK[q] = 0;
+    __threadfence_block();
+    // the record at current position q in the next numbering (position kn): in-edges remapped, the far flags of the DP recomputed
+    auto carry_over = [&](int q, int kn, int4 rec, int4 &pxr) -> int4 {
+        const int np = (rec.x >> 8) & 15;
+        rec.x &= ~CREC_FAR0;
+        if (np > 0) { rec.y = newpos(rec.y); if (kn - rec.y > PRING) { g.needK[rec.y] = 1; rec.x |= CREC_FAR0; } }
+        if (np > 1) { rec.z = newpos(rec.z); if (kn - rec.z > PRING) g.needK[rec.z] = 1; }
+        if (np > 2) { rec.w = newpos(rec.w); if (kn - rec.w > PRING) g.needK[rec.w] = 1; }
+        if (np > 3) {
+            pxr = pxc[q];
+            for (int e = 3; e < np; ++e) { const int pn = newpos(int4_get(pxr, e - 3)); int4_set(pxr, e - 3, pn); if (kn - pn > PRING) g.needK[pn] = 1; }
+        }
+        return rec;
+    };
+    for (int q0 = 0; q0 < n0; q0 += 2 * LANES) {                   // C: the vertices off the path shift right
+        int4 rec[2]; int kn[2]; bool go[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = q0 + u * LANES + lane;
+            go[u] = q < n0 && !g.onpK[q < n0 ? q : 0];
+            rec[u] = make_int4(0, -1, -1, -1); kn[u] = 0;
+            if (go[u]) { rec[u] = crec[q]; kn[u] = newpos(q); }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (go[u]) {
+            const int q = q0 + u * LANES + lane;
+            int4 pxr = make_int4(-1, -1, -1, -1);
+            const int4 r = carry_over(q, kn[u], rec[u], pxr);
+            CHK(kn[u] >= 0 && kn[u] < n, 105);
+            crec_nx[kn[u]] = r;
+            if (((r.x >> 8) & 15) > 3) px_nx[kn[u]] = pxr;
+        }
+    }
     TPH(12);
-    poa_column_records(g, order_nx, n, lane);
+    lastEx = -1;
+    int prevP = -1;                                                // new position of the path element before the block's first one
+    for (int c0 = 0; c0 < I; c0 += LANES) {                        // D: the path's elements
+        const int i = c0 + lane;
+        const bool valid = i < I;
+        const int w = g.pathv[valid ? i : I - 1];
+        const bool isnew = valid && w < 0;
+        const int incl = wave_scan_max_i32((valid && !isnew) ? i : -1);
+        int ex = wave_shr1_i32(incl, -1);
+        ex = ex > lastEx ? ex : lastEx;
+        { const int li = rl(incl, 63); lastEx = li > lastEx ? li : lastEx; }
+        const int av = g.pathv[(isnew && ex >= 0) ? ex : 0];       // a new vertex: the position of its run's anchor
+        int4 rec = make_int4(0, -1, -1, -1);
+        if (valid && !isnew) rec = crec[w];
+        const int qa = valid ? (isnew ? (ex >= 0 ? av : 0) : w) : 0;
+        int P = newpos(qa);                                        // existing: its own new position; new: the anchor's ...
+        if (isnew) P = (ex >= 0 ? P + 1 : 0) + (i - ex - 1);       // ... + its place in the run (list head: the run starts at position 0)
+        if (!valid) P = -1;
+        int Pp = wave_shr1_i32(P, prevP);                          // new position of the path element before this one (-1: none)
+        prevP = rl(P, 63);
+        if (valid) {
+            CHK(P >= 0 && P < n, 104);
+            int4 pxr = make_int4(-1, -1, -1, -1);
+            bool pxdirty = false;
+            if (isnew) rec = make_int4(read_base_packed(sread, i) | ((Pp >= 0 ? 1 : 0) << 8) | (1 << CREC_NREADS_SHIFT), Pp, -1, -1);
+            else {
+                rec = carry_over(w, P, rec, pxr);
+                rec.x += 1 << CREC_NREADS_SHIFT;                   // one more pass goes through the vertex
+                if (Pp >= 0) {                                      // SPEC: the edge is appended unless present or the in-edge cap (7) is hit
+                    const int np = (rec.x >> 8) & 15;
+                    bool found = false;
+                    if (np > 0) found |= rec.y == Pp;
+                    if (np > 1) found |= rec.z == Pp;
+                    if (np > 2) found |= rec.w == Pp;
+                    for (int e = 3; e < np; ++e) found |= int4_get(pxr, e - 3) == Pp;
+                    if (!found && np < CCSX_MAXPRED) {
+                        if (np == 0) rec.y = Pp; else if (np == 1) rec.z = Pp; else if (np == 2) rec.w = Pp; else { int4_set(pxr, np - 3, Pp); pxdirty = true; }
+                        rec.x += 1 << 8;
+                        if (P - Pp > PRING) { g.needK[Pp] = 1; if (np == 0) rec.x |= CREC_FAR0; }
+                    }
+                }
+            }
+            crec_nx[P] = rec;
+            if (((rec.x >> 8) & 15) > 3 || pxdirty) px_nx[P] = pxr;
+        }
+    }
+    __threadfence_block();
+    if (lane == 0) { g.st[ST_N] = n; g.st[ST_NADDED] += 1; g.st[ST_PAR] ^= 1; }
+    (void)npoa;
     TPH(13);
 }
 
@@ -1215,7 +1165,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (!g.st[ST_LIVE]) return;
     const int z = rfl(P.zmw_perm[z0 + bx]);
     const int ok = rfl(g.st[ST_OK]), n = rfl(g.st[ST_N]), nadded = rfl(g.st[ST_NADDED]);
-    const int32_t *order = g.st[ST_PAR] ? g.order1 : g.order0;
+    const int4 *crec = g.st[ST_PAR] ? g.crec1 : g.crec0;
+    const int32_t *pxw = (const int32_t *)(g.st[ST_PAR] ? g.px1 : g.px0);
     // ---- consensus: heaviest path (uniform walk).  The column records of the last prepass give every column's base, pass count and the
     // topological positions of its in-edges 0..2 by position: one coalesced load per 64 columns, no order -> vertex record -> rank
     // chain of dependent gathers (round 3; in-edges 3..7 still go through the vertex id)
@@ -1229,7 +1180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (int kb = 0; kb < n; kb += LANES) {
             const int kkL = kb + lane;
             int4 cL = make_int4(0, -1, -1, -1);
-            if (kkL < n) cL = g.crec[kkL];
+            if (kkL < n) cL = crec[kkL];
             const int nblk = (n - kb) < LANES ? (n - kb) : LANES;
             const int npL = (cL.x >> 8) & 15;
             const int wL = kkL < n ? 2 * ((cL.x >> CREC_NREADS_SHIFT) & 127) - nadded : 0;
@@ -1247,7 +1198,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 for (int q = 0; q < np; ++q) {
                     int pu;
                     if (q < 3) pu = q == 0 ? rl(cL.y, j) : (q == 1 ? rl(cL.z, j) : rl(cL.w, j));
-                    else { const int v = rfl(order[k]); pu = rfl(g.rank[g.predx[v * 5 + (q - 3)]]); }
+                    else pu = rfl(pxw[(size_t)k * 4 + (q - 3)]);
                     CHK(pu >= 0 && pu < k, 108);
                     int bu;
                     if (pu >= kb) {                                                // inside the block: its head's value + the weights since
@@ -1275,7 +1226,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     for (int q = 0; q < np; ++q) {
                         int pu;
                         if (q < 3) pu = q == 0 ? rl(cL.y, j) : (q == 1 ? rl(cL.z, j) : rl(cL.w, j));
-                        else { const int v = rfl(order[k]); pu = rfl(g.rank[g.predx[v * 5 + (q - 3)]]); }
+                        else pu = rfl(pxw[(size_t)k * 4 + (q - 3)]);
                         const int bu = pu == k - 1 ? bprev : ((pu >= kb) ? rl(myBest, pu - kb) : rfl(g.bestK[pu]));
                         if (bu > b) { b = bu; p = pu; }
                     }
@@ -1300,7 +1251,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int kb = (k >> 6) << 6;
             const int kk = kb + lane;
             const int bpL = kk < n ? g.bpK[kk] : -1;
-            const int bL = kk < n ? (g.crec[kk].x & 255) : 0;
+            const int bL = kk < n ? (crec[kk].x & 255) : 0;
             // whole runs per step: `chain` marks the positions whose back pointer is the position before; from kl the path takes every position down to the
             // highest one at or below kl whose bit is clear (t), each lane stores its own base, and the walk continues at t's back pointer (one position per
             // step and a lane-0 store before: ~ 10 k dependent steps per graph)
@@ -2230,12 +2181,12 @@ __device__ __forceinline__ int dq_fix(float d)
 }
 
 // error probability reported for a position the candidate filter skipped (pile-up margin g = clean - dirty)
-__device__ __forceinline__ float skip_perr(int g)
+__device__ __forceinline__ float skip_perr(int g, float floor_)
 {
     if (g < 0) g = 0;
     if (g > 12) g = 12;
     const float p = 8.0f * det_exp2f(-3.0f * (float)g);
-    return p < SKIP_PERR_FLOOR ? SKIP_PERR_FLOOR : p;        // SPEC v7: the pile-up supports no claim beyond Q50
+    return p < floor_ ? floor_ : p;                          // SPEC v7: the pile-up supports no claim beyond Q50 (opts.max_qv)
 }
 
 // SPEC v7 "repeat-count floor": lane x's longest period-p tandem tract among the visible window bases, from the wave mask m (bit k: v[k] == v[k+p]); 0 = none
@@ -2497,7 +2448,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             const bool ok = inw && !P.opts.disable_heuristics && margin >= SKIP_MARGIN && !((nearneg >> lane) & 1u);
             const unsigned ev = (unsigned)__ballot(ok);
             if (lane == 0) sCtl[7] = (int)ev;
-            if (lane < 36) sPskip[lane] = inw ? skip_perr(margin) : 0.0f;
+            if (lane < 36) sPskip[lane] = inw ? skip_perr(margin, P.perr_floor) : 0.0f;
         }
     }
     const int half = lane >> 5, hrow = lane & 31;          // fill: which read of the pair, row within it
@@ -3183,7 +3134,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             if (L4 >= 16) { const float f = __fdiv_rn(REP_ERRS, (float)L4); fl = f > fl ? f : fl; }
             if (p < fl) p = fl;
         }
-        if (p < PERR_FLOOR) p = PERR_FLOOR;                 // SPEC v7: no base claims more than Q50
+        if (p < P.perr_floor) p = P.perr_floor;             // SPEC v7: no base claims more than Q50 (opts.max_qv)
         float qv = -3.01029996f * det_log2f(p);
         if (qv < 0.0f) qv = 0.0f;
         if (qv > 93.0f) qv = 93.0f;

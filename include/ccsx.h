@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCSX_ABI_VERSION 5
+#define CCSX_ABI_VERSION 6   /* v6: ccsx_opts.max_qv (was reserved), ccsx_runtime_switches() */
 #define CCSX_SPEC_VERSION 8   /* DESIGN.md §2; bumped whenever a result-changing rule changes (oracle: ORC_SPEC_VERSION) */
 
 /* ---- fixed constants of the algorithm specification ---- */
@@ -95,7 +95,10 @@ typedef struct ccsx_opts {
                                  * 0 = the default 30, < 0 = never trim (such a segment then leaves the window when it exceeds 63 bases) */
     int32_t serial_stages;      /* 1: draft and polish stage of all batches on ONE compute stream (A/B switch; default 0: the draft stage
                                  * of batch k+1 runs on its own stream under the polish stage of batch k, docs/img/ccs-impl.png)            */
-    int32_t reserved[1];
+    int32_t max_qv;             /* largest per-base QV that is reported: every per-base error probability (and with it rq) is floored at 10^(-max_qv/10).
+                                 * 0 = the default 50 (SPEC v7 "honest QVs": nothing measured on synthetic data supports a higher claim);
+                                 * 93 = the reference's documented range (docs/faq/qv-binning.md:31 bins [40, 93]); values above 93 mean 93.  A deviation
+                                 * from the reference's output that a caller can switch off: INTEGRATION.md "QV policy"                                  */
 } ccsx_opts;
 
 /* ---- input batch: SoA + CSR ---- */
@@ -165,6 +168,9 @@ int         ccsx_spec_version(void);                    /* version of the algori
 const char *ccsx_build_flags(void);                     /* "" for the product library.  Anything else names the compile-time switches of an experimental
                                                            build (tuning overrides, timing-only variants that compute wrong results: those also make
                                                            ccsx_spec_version() negative).  tests/test_abi.py requires "" of the library it ships   */
+const char *ccsx_runtime_switches(void);                /* the CCSX_* scheduling / debugging overrides found in this process's environment, "NAME=VALUE ..." ("" = none).
+                                                           They never change a result, they change timings: a benchmark line states them (bench.py config.runtime_switches)
+                                                           and tests/test_abi.py requires "" under a clean environment                                                       */
 const char *ccsx_last_error(void);
 int         ccsx_device_count(void);
 

@@ -138,8 +138,8 @@ int orc_poa_last_scores(int *out) { for (int i = 0; i < g_poa_nscores; ++i) out[
                                same neighbourhood of every applied mutation is polished in the following rounds           */
 #define DQ_SCALE  65536.0f  /* per-read log2-likelihood gains are summed as fixed point (2^-16): order independent      */
 #define DQ_CLAMP  100.0f
-#define PERR_FLOOR 1e-5f      /* SPEC v7: smallest per-base error probability that is reported (Q50; v6: 1e-10) */
-#define SKIP_PERR_FLOOR 1e-5f /* SPEC v7: error probability floor of a position the candidate filter skips (Q50) */
+#define PERR_FLOOR g_perr_floor      /* SPEC v7: smallest per-base error probability that is reported (Q50 by default; opts.max_qv; v6: 1e-10) */
+#define SKIP_PERR_FLOOR g_perr_floor /* SPEC v7: the same floor for a position the candidate filter skips */
 
 typedef struct orc_model {
     char  name[32];
@@ -160,8 +160,12 @@ typedef struct orc_opts {
     int32_t handles_per_device;     /* (engine only) */
     int32_t no_fallback_draft;      /* 1: a failed / unmappable first draft is final */
     int32_t max_insertion_size;     /* trim segments longer than window + this (0 = 30, < 0 = off) */
-    int32_t reserved[2];
+    int32_t serial_stages;          /* (engine only) */
+    int32_t max_qv;                 /* largest per-base QV reported: p_err >= 10^(-max_qv/10); <= 0 = 50 (SPEC v7), > 93 = 93 (include/ccsx.h ccsx_opts.max_qv) */
 } orc_opts;
+/* the floor of every reported per-base error probability (the same expression as ccsx_kernels.h ccsx_perr_floor) */
+static float perr_floor_of(int max_qv) { if (max_qv <= 0) max_qv = 50; if (max_qv > 93) max_qv = 93; return max_qv == 50 ? 1e-5f : (float)pow(10.0, -(double)max_qv / 10.0); }
+static __thread float g_perr_floor = 1e-5f;   /* set per ZMW from its options */
 
 /* ---------------- deterministic log2 / exp2 (DESIGN.md §SPEC "det math") -------------------------------- */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -1391,6 +1395,7 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                       const uint8_t *ipd /* NULL = no kinetics */, uint8_t *fi, uint8_t *fp, uint8_t *ri, uint8_t *rp)
 {
     memset(out, 0, sizeof(*out));
+    g_perr_floor = perr_floor_of(opts->max_qv);
     int nreads = nreads_in;
     {   /* SPEC v5: at most MAX_PASSES = 255 passes are used (--top-passes 0 = "all"; SPEC v4 stopped at 64) */
         int top = (opts->top_passes <= 0 || opts->top_passes > MAX_PASSES) ? MAX_PASSES : opts->top_passes;

@@ -23,7 +23,7 @@ def test_header_and_exports_agree(built):
     L = C.CDLL(api.LIB_PATH)
     for name in decl:
         assert hasattr(L, name), f"{name} declared in include/ccsx.h but not exported by libccsx.so"
-    assert L.ccsx_abi_version() == 5
+    assert L.ccsx_abi_version() == 6
     assert L.ccsx_spec_version() >= 2
 
 
@@ -37,6 +37,25 @@ def test_the_shipped_library_is_a_product_build(built):
     used = set(re.findall(r"\b(CCSX_EXP_[A-Z0-9_]+|CCSX_EXIT_AFTER_PROLOGUE)\b", src))
     guard = src[src.index("#if (defined(CCSX_EXP_"):src.index("#error")]
     assert used and all(u in guard for u in used), "an experiment switch is not covered by the #error guard: %s" % sorted(u for u in used if u not in guard)
+
+
+def test_runtime_switches_are_reported(built, monkeypatch):
+    """the library reads scheduling overrides from the environment (timings change, results do not); it names the ones it finds,
+    bench.py prints them, and a clean environment reports none"""
+    L = api.lib()
+    for k in [k for k in os.environ if k.startswith("CCSX_")]:
+        monkeypatch.delenv(k)
+    assert L.ccsx_runtime_switches() == b""
+    monkeypatch.setenv("CCSX_SERIAL_STAGES", "1")
+    monkeypatch.setenv("CCSX_TB_ASIDE", "0")
+    assert L.ccsx_runtime_switches() == b"CCSX_SERIAL_STAGES=1 CCSX_TB_ASIDE=0"
+    # every getenv("CCSX_...") of the library's sources is either on that list or a test / generator hook that cannot touch the engine's schedule
+    names = set()
+    for f in ("ccsx_api.cpp", "ccsx_kernels.hip", "ccsx_host.cpp"):
+        names |= set(re.findall(r'getenv\("(CCSX_[A-Z0-9_]+)"\)', open(os.path.join(ROOT, "ccs_amd", "csrc", f)).read()))
+    host = open(os.path.join(ROOT, "ccs_amd", "csrc", "ccsx_host.cpp")).read()
+    listed = set(re.findall(r'"(CCSX_[A-Z0-9_]+)"', host[host.index("ccsx_runtime_switches(void)\n{"):host.index("thread_local std::string out")]))
+    assert names - listed <= {"CCSX_TEST_FAIL_SUBMIT", "CCSX_SYNTH_THREADS"}, names - listed
 
 
 def test_draft_layout_matches_result_layout(built):
