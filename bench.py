@@ -38,8 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-TRAFFIC_FILE = "r05_traffic.json"       # this round's committed PMC passes (tools/prof_round.sh -> tools/mk_traffic.py)
-QVCAL_FILE = "r05_qv_calibration.json"  # predicted vs empirical accuracy per rq bin (tools/qv_calibration.py, CPU restatement)
+TRAFFIC_FILE = "r06_traffic.json"       # this round's committed PMC passes (tools/prof_round.sh -> tools/mk_traffic.py)
+TRAFFIC_FILES_EXTRA = {"c4": "r06_traffic_c4.json", "c5": "r06_traffic_c5.json"}   # the same passes for the other BASELINE shapes (extra.<shape>.roofline.traffic)
+QVCAL_FILE = "r06_qv_calibration.json"  # predicted vs empirical accuracy per rq bin (tools/qv_calibration.py)
 VALU_PEAK_LANE_OPS = 78.6e12            # non-packed VALU issue of one MI355X: 1024 SIMDs x 32 lanes per cycle (v_add / v_mul_f32 issue a wave64
                                         # in 2 cycles, profiles/r02_valu_peak.txt) x 2.4 GHz; packed fp32 (157 TFLOP/s with FMA) is not what a DP cell can use
 NOMINAL_OPS_PER_CELL = 8                # "8 flop/cell nominal"
@@ -190,11 +191,12 @@ class Job:
         # the optional float QVs (raw_qv) are not requested in the pipelined job: the HiFi record needs seq + qual + rq/ec/np/status
         self.results = [api.Results.allocate(big, kinetics=kin, pinned=True, raw=False) for _ in range(depth)]
 
-    def run(self, nsteps, collect):
-        """nsteps batches through the asynchronous boundary, `depth` in flight; returns (elapsed, per-ticket timings, stats)"""
+    def run(self, nsteps, collect, t_origin=None):
+        """nsteps batches through the asynchronous boundary, `depth` in flight; returns (elapsed, per-ticket timings, stats).  t_origin: the common start
+        of every worker's timed region (perf_counter of the launching thread): a worker that starts late is charged for it"""
         h, depth, nb = self.h, self.depth, self.nb
         tick, kt, ok, rqsum, rqn, checks = [], [], 0, 0.0, 0, 0
-        t_start = time.perf_counter()
+        t_start = time.perf_counter() if t_origin is None else t_origin
         for k in range(nsteps + depth):
             if k >= depth:                                   # retire the oldest batch before its slot / result buffer is reused
                 t_old = tick[k - depth]
@@ -366,15 +368,22 @@ def main():
         for d in sorted(set(devices)):
             torch.cuda.synchronize(d)
 
+    numa_bound = [None] * nloc                               # NUMA node every worker's thread was bound to (-1: not bound)
+
     def on_workers(fn):
-        """fn(worker index) on every worker of this process at once (threads: the library calls release the GIL); results in worker order"""
+        """fn(worker index) on every worker of this process at once (threads: the library calls release the GIL); results in worker order.  With several
+        workers every worker thread is first bound to the CPUs of ITS device's NUMA node (ccsx_bind_thread_to_device: sysfs, no libnuma), so the page-locked
+        batches it allocates and the host side of its copies are node-local.  The single worker of an N = 1 run stays unbound: the CPU
+        baseline that follows uses every core."""
         if nloc == 1:
+            numa_bound[0] = -1
             return [fn(0)]
         import threading
         res, err = [None] * nloc, []
 
         def body(i):
             try:
+                numa_bound[i] = int(api.lib().ccsx_bind_thread_to_device(devices[i]))
                 res[i] = fn(i)
             except BaseException as e:                       # noqa: BLE001 (re-raised below)
                 err.append(e)
@@ -394,11 +403,22 @@ def main():
     on_workers(lambda i: jobs[i].run(max(1, args.warmup), False))    # untimed: every hipMalloc of the engine happens here
     warm_s = time.time() - t0
     barrier()
-    timed = on_workers(lambda i: jobs[i].run(args.steps, True))
+    t_origin = time.perf_counter()                           # ONE origin for every worker's timed region
+    timed = on_workers(lambda i: jobs[i].run(args.steps, True, t_origin))
     barrier()
     elapsed, kt, (ok, rqsum, rqn, checks) = timed[0]
     per_gpu = [{"worker": i, "device": devices[i], "zmws_per_s": round(args.zmws * args.steps / timed[i][0], 2), "ms_per_step": round(timed[i][0] / args.steps * 1e3, 3),
-                "success_frac": timed[i][2][0] / (args.zmws * args.steps)} for i in range(nloc)]
+                "success_frac": timed[i][2][0] / (args.zmws * args.steps),
+                "numa_node": int(api.lib().ccsx_device_numa_node(devices[i])), "thread_bound_to_node": numa_bound[i],
+                "copies_hidden_frac": round(min(1.0, kernels_span_ms(timed[i][1]) * 1e-3 / timed[i][0]), 4)} for i in range(nloc)]
+    if nloc > 1 and not args.pmc:
+        # every worker uploads one batch AT THE SAME TIME, nothing else running: the H2D rate a GPU gets while its neighbours pull too (cross-socket staging shows here)
+        def h2d(i):
+            b = jobs[i].batches[0]
+            t0 = time.perf_counter(); jobs[i].h.upload(b); jobs[i].h.sync()
+            return (b.bases.nbytes + b.pw.nbytes + (b.ipd.nbytes if args.hifi_kinetics else 0)) / (time.perf_counter() - t0) / 1e9
+        for i, g in enumerate(on_workers(h2d)):
+            per_gpu[i]["h2d_GBps"] = round(g, 2)
     if nloc > 1:
         elapsed = max(t[0] for t in timed)                   # the job is done when its slowest worker is
         ok = sum(t[2][0] for t in timed) / nloc; checks = sum(t[2][3] for t in timed)
@@ -438,8 +458,9 @@ def main():
             if args.passes == 10 and args.length == 10000 and not args.hifi_kinetics and not args.disable_heuristics:
                 traffic = int(kz["hbm_bytes_per_zmw"] * args.zmws)
                 valu = {k: kz[k] for k in ("valu_wave_instr_per_zmw", "valu_issue_frac_if_2cyc", "valu_issue_frac_if_4cyc", "lanes_active_frac",
-                                           "valu_frac_of_calibrated_peak", "cell_updates_per_zmw") if k in kz}
-                valu["calibration"] = "profiles/r02_valu_peak.txt: v_add/mul_f32, v_add_u32 issue in 2 SIMD cycles per wave64, v_fma_f32, v_max_i32, DPP ops in 4"
+                                           "valu_cycles_from_isa_histogram", "valu_issue_frac_from_isa_histogram", "cell_updates_per_zmw") if k in kz}
+                # (no figure fitted to the counters it is compared with — the two bounds, and the kernel's own opcode histogram x the single-opcode table)
+                valu["calibration"] = "profiles/r06_valu_peak.txt: VOP2 / three-source FMA float ops and v_add_u32 issue in ~2.5 SIMD cycles per wave64, integer max, compares, selects and DPP ops in ~4.3"
         except Exception:
             traffic, valu = None, None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
@@ -454,6 +475,11 @@ def main():
                     "note": "DP matrices stay in LDS/registers; arithmetic intensity ~kFLOP/B so the HBM fraction is <<1% by construction (SURVEY.md 8d); "
                             "the kernel is bound by VALU issue and dependent-chain latency (DESIGN.md 4)"}
         c2 = args.workload == "c2" and args.passes == 10 and args.length == 10000
+        switches = api.lib().ccsx_runtime_switches().decode()     # CCSX_* scheduling overrides the library found in the environment ("" = none)
+        env_serial = os.environ.get("CCSX_SERIAL_STAGES")
+        serial_effective = (int(env_serial) != 0) if (env_serial is not None and env_serial.lstrip("-").isdigit()) else bool(args.serial_stages)
+        if switches:
+            print(f"bench.py: runtime switches in effect: {switches}", file=sys.stderr)
         out = {
             "metric": "ZMWs/sec (HiFi reads/sec), 10-pass x 10 kb synthetic" if c2 else f"ZMWs/sec, {args.passes} passes x {args.length} bp synthetic",
             "value": round(value, 2), "unit": "ZMWs/s",
@@ -465,8 +491,9 @@ def main():
                        "preset": args.workload, "zmws_per_gpu": args.zmws, "distinct_batches": job.nb, "in_flight": args.depth, "passes": args.passes,
                        "template_len": args.length, "parallelism": f"zmw-shard x{world}" + ("" if launched or world == 1 else " (worker threads of one process)"), "model": "SYN-1",
                        "hifi_kinetics": bool(args.hifi_kinetics), "candidate_filter": not args.disable_heuristics,
-                       "stages": "serial (one compute stream)" if args.serial_stages else "draft stage of batch k+1 under the polish stage of batch k (two compute streams)",
-                       "spec_version": int(api.lib().ccsx_spec_version())},
+                       # what the LIBRARY did, not what this script asked for: the environment can override the option
+                       "stages": "serial (one compute stream)" if serial_effective else "draft stage of batch k+1 under the polish stage of batch k (two compute streams)",
+                       "runtime_switches": switches, "spec_version": int(api.lib().ccsx_spec_version())},
             "timed_region": "first ccsx_submit to last ccsx_wait: pinned host -> H2D -> kernels -> D2H (PCIe-inclusive); downloaded per ZMW: status, sequence, phred QVs, rq, ec, np, fn/rn, iterations (the optional float QVs are not requested)",
             "resident_zmws_per_s": round(args.zmws * args.steps / (span_ms * 1e-3), 2),
             "kernels_ms_per_step": round(span_ms / args.steps, 3),
@@ -536,7 +563,6 @@ def main():
                 vt = sum(kz.get("valu_wave_instr_per_zmw", 0) for kz in tj["kernels"].values())
                 if vt:
                     work["valu_lane_ops_per_cell"] = round(vt * 64 / tot, 1)
-                    work["valu_frac_of_calibrated_peak"] = tj.get("valu_frac_of_calibrated_peak_whole_step")
             except Exception:
                 pass
             out["roofline"]["work"] = work
@@ -560,7 +586,15 @@ def main():
                     sm = stage_means(np, kt2)
                     dom2 = max(names, key=lambda k: sm[k])
                     ach2 = j2.alg_bytes / (sm[dom2] * 1e-3) / 1e9
+                    traffic2 = None
+                    try:
+                        t2j = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILES_EXTRA[name])))
+                        traffic2 = {"bytes_per_launch": int(t2j["kernels"][names[dom2]]["hbm_bytes_per_zmw"] * z_), "whole_step_bytes_per_zmw": int(sum(k.get("hbm_bytes_per_zmw", 0) for k in t2j["kernels"].values())),
+                                    "source": f"profiles/{TRAFFIC_FILES_EXTRA[name]}", "head": t2j.get("head"), "matches_these_sources": t2j.get("csrc_sha16") == csrc_sha16()}
+                    except Exception:
+                        pass
                     extra[name] = {"workload": f"{p_} passes x {l_} bp", "zmws_per_step": z_, "steps": args.extra_steps,
+                                   **({"metric": "ZMWs/s (0 HiFi reads: three passes never reach --min-rq 0.99; BASELINE configs[0] is a plumbing shape)"} if name == "c1" else {}),
                                    "value": round(z_ * args.extra_steps / el, 2), "unit": "ZMWs/s",
                                    "resident_zmws_per_s": round(z_ * args.extra_steps / (kernels_span_ms(kt2) * 1e-3), 2),
                                    "stage_ms": {k: round(v, 3) for k, v in sm.items()},
@@ -568,7 +602,7 @@ def main():
                                    "algorithmic_bytes_per_launch": j2.alg_bytes,
                                    # the same roofline object as the headline's, for this shape's dominant kernel
                                    "roofline": {"bound": "hbm", "kernel": names[dom2], "achieved": round(ach2, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach2 / 8000.0, 6),
-                                                "avg_launch_ms": round(sm[dom2], 3), "traffic": None}}
+                                                "avg_launch_ms": round(sm[dom2], 3), "traffic": traffic2["bytes_per_launch"] if traffic2 else None, "traffic_detail": traffic2}}
                     if name == "c1" and not args.no_cpu_baseline:
                         # BASELINE configs[0]: "1k synthetic ZMWs, 3 passes x 1 kb, reference `ccs --num-threads=1` on CPU" — the reference is absent (docs-only
                         # mount), so the figure SURVEY.md 8d asks for beside the GPU line is the port on ONE thread over a bounded sample of the same ZMWs

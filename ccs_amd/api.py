@@ -98,7 +98,7 @@ EXPORTS = [
     "ccsx_stage_windows", "ccsx_synth_generate", "ccsx_synth_free", "ccsx_alloc_pinned", "ccsx_free_pinned",
     "ccsx_submit", "ccsx_wait", "ccsx_poll", "ccsx_ticket_timings",
     "ccsx_model_from_json", "ccsx_model_load", "ccsx_model_to_json", "ccsx_model_for_chemistry",
-    "ccsx_build_flags", "ccsx_runtime_switches", "ccsx_draft_layout", "ccsx_draft_batch", "ccsx_polish_batch", "ccsx_submit_draft", "ccsx_submit_polish",
+    "ccsx_build_flags", "ccsx_runtime_switches", "ccsx_pci_numa_node", "ccsx_device_numa_node", "ccsx_bind_thread_to_node", "ccsx_bind_thread_to_device", "ccsx_draft_layout", "ccsx_draft_batch", "ccsx_polish_batch", "ccsx_submit_draft", "ccsx_submit_polish",
 ]
 
 _lib = None

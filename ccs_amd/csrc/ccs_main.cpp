@@ -124,6 +124,7 @@ struct Batch {
     int32_t *status = nullptr, *seq_len = nullptr, *np = nullptr, *iters = nullptr, *n_windows = nullptr, *fn = nullptr, *rn = nullptr;
     uint8_t *seq = nullptr, *qual = nullptr, *kin = nullptr;   // kin: 4 planes (fi, fp, ri, rp) of cap bytes each (--hifi-kinetics)
     float *rq = nullptr, *ec = nullptr;
+    int dev = 0;                  // which device's packers / worker / staging pools handle the batch (index into the handle list)
     bool have_results = false;    // false: packing or the engine failed for this batch
     std::unique_ptr<struct Arena> in_arena, out_arena;
     ccsx_batch cb; ccsx_results cr; // the structs handed to ccsx_submit live as long as the ticket
@@ -685,15 +686,26 @@ int main(int argc, char **argv)
             if (opt.all_gpus) for (int d = 0; d < ndev; ++d) opt.gpus.push_back(d);
             if (opt.gpus.empty()) opt.gpus.push_back(0);
             for (int d : opt.gpus) {
+                // (the handle's page-locked layout arrays are allocated by the creating thread: create it from the device's NUMA node, then come back)
+                cpu_set_t aff; const bool have_aff = sched_getaffinity(0, sizeof(aff), &aff) == 0;
+                const int node = ccsx_bind_thread_to_device(d);
                 ccsx_handle h = nullptr;
-                if (ccsx_create(d, &model, &opt.o, &h)) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); return 1; }
+                const int rc_create = ccsx_create(d, &model, &opt.o, &h);
+                if (have_aff) sched_setaffinity(0, sizeof(aff), &aff);
+                if (rc_create) { std::fprintf(stderr, "ccs: %s\n", ccsx_last_error()); return 1; }
+                if (opt.log_level >= 2) std::fprintf(stderr, "ccs: device %d: NUMA node %d%s\n", d, ccsx_device_numa_node(d), node >= 0 ? " (its threads and page-locked staging are bound to it)" : " (no binding)");
                 handles.push_back(h);
             }
         }
 
         g_plain_arenas = opt.host_only;
-        Channel<std::shared_ptr<Batch>> to_pack(2 * std::max<size_t>(1, handles.size())), to_gpu(2 * std::max<size_t>(1, handles.size())),
-            to_writer(4 * std::max<size_t>(1, handles.size()));
+        // Round 6 (NUMA): every device has its own packing threads, staging pools and queue to its worker, all bound to the device's NUMA node, so a batch's
+        // page-locked staging is local to the GPU that uploads it.  The ZMW stream is still ONE queue (to_pack): a packer whose device queue is full stops
+        // drawing from it, so the work flows to the devices that are free (dynamic, not an i/N split).
+        const size_t ndev_q = std::max<size_t>(1, handles.size());
+        Channel<std::shared_ptr<Batch>> to_pack(2 * ndev_q), to_writer(4 * ndev_q);
+        std::vector<std::unique_ptr<Channel<std::shared_ptr<Batch>>>> to_gpu_q;
+        for (size_t d = 0; d < ndev_q; ++d) to_gpu_q.emplace_back(new Channel<std::shared_ptr<Batch>>(2));
         std::string movie;
         const auto t_start = std::chrono::steady_clock::now();
 
@@ -857,18 +869,25 @@ int main(int argc, char **argv)
 
         // ---- pack workers: SoA packing off the reader thread, straight into page-locked staging; result views are carved from a
         // second page-locked arena (the downloads are asynchronous DMA)
-        ArenaPool in_pool, out_pool;
+        std::vector<std::unique_ptr<ArenaPool>> in_pools, out_pools;
+        for (size_t d = 0; d < ndev_q; ++d) { in_pools.emplace_back(new ArenaPool()); out_pools.emplace_back(new ArenaPool()); }
         std::atomic<long long> us_pack{0}, us_engine{0}, us_wait{0};       // summed over workers (--log-level INFO)
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto us_since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
         const bool kin = opt.o.hifi_kinetics != 0;
         std::vector<std::thread> packers;
         const size_t n_packers = std::max<size_t>(1, handles.size()) * (size_t)opt.workers_per_gpu;
-        std::atomic<int> packers_left{(int)n_packers};
-        for (size_t pk = 0; pk < n_packers; ++pk) packers.emplace_back([&] {
+        std::vector<std::atomic<int>> packers_left(ndev_q);
+        for (size_t d = 0; d < ndev_q; ++d) packers_left[d] = (int)(n_packers / ndev_q);
+        for (size_t pk = 0; pk < n_packers; ++pk) packers.emplace_back([&, pk] {
+            const int dev = (int)(pk % ndev_q);
+            if (!handles.empty()) ccsx_bind_thread_to_device(opt.gpus[dev]);
+            ArenaPool &in_pool = *in_pools[dev], &out_pool = *out_pools[dev];
+            Channel<std::shared_ptr<Batch>> &to_gpu = *to_gpu_q[dev];
             std::shared_ptr<Batch> b;
             while (to_pack.pop(b)) {
                 auto t0 = now();
+                b->dev = dev;
                 try {
                     b->in_arena = in_pool.get();
                     pack(*b, *b->in_arena);
@@ -900,14 +919,14 @@ int main(int argc, char **argv)
                 us_pack += us_since(t0);
                 to_gpu.push(b);
             }
-            if (--packers_left == 0) to_gpu.close();
+            if (--packers_left[dev] == 0) to_gpu.close();
         });
 
         if (opt.host_only) {                                  // no engine: count what arrives, hand the staging back
             int64_t nz = 0, nzok = 0, nbases = 0, nbatches = 0;
             std::thread sink([&] {
                 std::shared_ptr<Batch> b;
-                while (to_gpu.pop(b)) { ++nbatches; nz += (int64_t)b->zmws.size(); if (b->n > 0) { nzok += b->n; nbases += b->n_bases; } in_pool.put(std::move(b->in_arena)); }
+                while (to_gpu_q[0]->pop(b)) { ++nbatches; nz += (int64_t)b->zmws.size(); if (b->n > 0) { nzok += b->n; nbases += b->n_bases; } in_pools[0]->put(std::move(b->in_arena)); }
             });
             reader.join();
             for (auto &w : packers) w.join();
@@ -923,7 +942,11 @@ int main(int argc, char **argv)
 
         // ---- GPU workers: one per device; up to three batches in flight through the asynchronous boundary
         std::vector<std::thread> workers;
-        for (ccsx_handle h : handles) workers.emplace_back([&, h] {
+        for (size_t wd = 0; wd < handles.size(); ++wd) workers.emplace_back([&, wd] {
+            ccsx_handle h = handles[wd];
+            ccsx_bind_thread_to_device(opt.gpus[wd]);
+            ArenaPool &in_pool = *in_pools[wd];
+            Channel<std::shared_ptr<Batch>> &to_gpu = *to_gpu_q[wd];
             std::deque<std::pair<ccsx_ticket, std::shared_ptr<Batch>>> inflight;
             auto retire = [&] {
                 auto t0 = now();
@@ -1068,7 +1091,7 @@ int main(int argc, char **argv)
                 hold[b->index] = b;
                 while (!hold.empty() && hold.begin()->first == next) {
                     emit(*hold.begin()->second);
-                    out_pool.put(std::move(hold.begin()->second->out_arena));
+                    out_pools[hold.begin()->second->dev]->put(std::move(hold.begin()->second->out_arena));
                     hold.erase(hold.begin()); ++next;
                 }
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

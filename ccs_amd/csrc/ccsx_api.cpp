@@ -187,6 +187,15 @@ int ccsx_device_count(void)
     return n;
 }
 
+int ccsx_device_numa_node(int device)
+{
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof(id), device) != hipSuccess) return -1;
+    return ccsx_pci_numa_node(id);
+}
+
+int ccsx_bind_thread_to_device(int device) { return ccsx_bind_thread_to_node(ccsx_device_numa_node(device)); }
+
 void *ccsx_alloc_pinned(size_t bytes)
 {
     void *p = nullptr;

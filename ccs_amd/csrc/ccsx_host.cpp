@@ -12,6 +12,9 @@ const char *ccsx_kernel_build_flags();
 #include <thread>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
+#include <cstdio>
+#include <sched.h>
 #include <string>
 #include <vector>
 
@@ -86,6 +89,66 @@ void ccsx_opts_default(ccsx_opts *o)
     o->min_zscore = -3.4f;   // [RECALL] unanimity's MinZScore; DESIGN.md §2 "z-score gate"
     o->max_insertion_size = 30;   // docs/how-does-ccs-work.md:74-78
     o->max_qv = 50;               // SPEC v7 "honest QVs"; 93 = the reference's documented range (docs/faq/qv-binning.md:31)
+}
+
+// ---- NUMA placement of a device's host threads (docs/faq/parallelize.md:8-29: one node, several GPUs).  Sysfs only: no libnuma in the image.
+// The PCI address names the device's NUMA node; binding a thread to that node's CPUs BEFORE it allocates page-locked staging makes the staging node-local by
+// first touch (hipHostMalloc populates and pins the pages on the calling thread), so that the H2D copies of eight GPUs do not all cross the socket link.
+static bool read_small_file(const std::string &path, std::string &out)
+{
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096];
+    const size_t n = std::fread(buf, 1, sizeof(buf) - 1, f);
+    std::fclose(f);
+    buf[n] = 0; out = buf;
+    return true;
+}
+static const char *sysfs_root() { const char *r = std::getenv("CCSX_SYSFS_ROOT"); return r ? r : ""; }   // (tests point this at a fake tree)
+
+int ccsx_pci_numa_node(const char *pci_bus_id)
+{
+    if (!pci_bus_id || !*pci_bus_id) return -1;
+    std::string id(pci_bus_id), txt;
+    for (char &c : id) c = (char)std::tolower((unsigned char)c);
+    if (!read_small_file(std::string(sysfs_root()) + "/sys/bus/pci/devices/" + id + "/numa_node", txt)) return -1;
+    char *end = nullptr;
+    const long v = std::strtol(txt.c_str(), &end, 10);
+    return (end == txt.c_str() || v < 0) ? -1 : (int)v;      // (-1 in the file: the platform reports no affinity)
+}
+
+// "0-15,64-79" -> CPU set; returns the number of CPUs
+static int parse_cpulist(const std::string &s, cpu_set_t &set)
+{
+    CPU_ZERO(&set);
+    int n = 0;
+    const char *p = s.c_str();
+    while (*p) {
+        while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+        if (!*p) break;
+        char *e = nullptr;
+        long a = std::strtol(p, &e, 10), b = a;
+        if (e == p) break;
+        p = e;
+        if (*p == '-') { b = std::strtol(p + 1, &e, 10); if (e == p + 1) break; p = e; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0) { CPU_SET((int)c, &set); ++n; }
+    }
+    return n;
+}
+
+int ccsx_bind_thread_to_node(int node)
+{
+    if (node < 0) return -1;
+    if (const char *e = std::getenv("CCSX_NUMA")) if (e[0] == '0') return -1;      // switch: leave the threads where the OS puts them
+    std::string txt;
+    if (!read_small_file(std::string(sysfs_root()) + "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", txt)) return -1;
+    cpu_set_t want, have, both;
+    if (parse_cpulist(txt, want) <= 0) return -1;
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return -1;
+    CPU_AND(&both, &want, &have);                             // never outside what the process may use (cgroup cpusets, taskset)
+    if (CPU_COUNT(&both) <= 0) return -1;
+    if (sched_setaffinity(0, sizeof(both), &both) != 0) return -1;
+    return node;
 }
 
 int64_t ccsx_result_layout(const ccsx_batch *b, int64_t *seq_off)

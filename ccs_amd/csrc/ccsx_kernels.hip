@@ -151,6 +151,7 @@ const char *ccsx_kernel_build_flags()
 #define SCORE_BAND 5                  // SPEC: half width (read rows) of the mutation scoring band around the window diagonal
 // (SPEC v7 / ABI v6: the smallest per-base error probability that is reported — also for a position the candidate filter skips — is P.perr_floor = 10^(-opts.max_qv/10),
 // 1e-5 = Q50 by default: nothing measured supports a higher claim; max_qv 93 = the reference's documented range)
+#define REP_NP0 10                    // SPEC v8: a CLOSED tract's floor (both ends inside the visible template) is scaled by (REP_NP0 / passes used)^2 beyond REP_NP0 passes
 #define REP_ERRS 0.2f                 // SPEC v7 "repeat-count floor": a core base inside a period-p tandem tract of L >= REP_MINLEN(p) visible bases reports p_err >= REP_ERRS / L
 #define FILL_MARGIN 2                 // SPEC v6 "banded fill": alpha / beta exist on the diagonals j - i in [min(0, J - I) - (Wr + 2), max(0, J - I) + (Wr + 2)] only
 #define DQ_SCALE 65536.0f
@@ -2032,9 +2033,9 @@ __global__ __launch_bounds__(256) void k_wmap_fill(KParams P)     // one wave pe
 // ------------------------------------------------------------------------------------------------
 // A1-A7 + step 7: Arrow polish of one window per workgroup (PW_THREADS = 4 waves).
 //
-// v4 (round 3).  LDS holds: sCTX[obs][ctx] = (ME, INS) as float2, 33 entries per observation row (16 contexts, 16 copies with INS = 0,
-// one zero entry; row 12 = all zeros); per-column entries (DL, offset of the column's context in a row of sCTX) — plain (sColJ, for
-// a long read's sweep) and staggered for the software-pipelined sweeps of a pair (sEA / sEB); gamma/beta of one chunk of FOUR reads
+// v4 (round 3; tables: round 6).  LDS holds: sCTX[obs][ctx] = (ME, INS) as float2, 17 entries per observation row (16 contexts, one zero entry;
+// row 12 = all zeros): the scoring's table; per-column entries (DL, offset of the column's context in a row of sCTX) for a long read's sweep (sColJ);
+// the quad fill's per-column table sTC[strand][obs][column] + sDLC (see TC_LO below); gamma/beta of one chunk of up to EIGHT reads
 // (sGB, even row stride: the fill's lane = row stores step by S - 1 words from lane to lane, the scoring's lane = column loads by 1:
 // both conflict free).  Fill: lane = read row, anti-diagonal sweep, neighbours via DPP wave shifts; two short reads per wave (lanes
 // 0-31 / 32-63); a chunk's two pair tasks run as four alpha-only / beta-only sweeps, one per wave.  Candidate filter
@@ -2067,17 +2068,28 @@ __global__ __launch_bounds__(256) void k_wmap_fill(KParams P)     // one wave pe
                                       // 40960 184.6 / 264.8, 40448 189.6 / 273.3, 38912 195.0 / 279.3, 36864 199.7 / 281.1, 32256 (5 per CU) 225.6 / 307.8
 #endif
 #ifndef CTXS
-#define CTXS 33                       // entries per observation row of sCTX
+#define CTXS 17                       // entries per observation row of sCTX: 16 contexts + one zero entry (odd stride: (obs + ctx) mod 16 spreads the scoring's look-ups over the bank pairs)
 #endif
 #define FILL16_MAXBW 24               // widest band (diagonals) of a read that shares a wave with three others (k_polish's quad sweep)
-#define FE_ALO 35                     // sEA holds columns -35 .. 69, sEB columns -69 .. 66 (the reach of a pair's lanes, see the fill)
-#define FE_A 105
-#define FE_BLO 69
-#define FE_B 136
+// Round 6: the quad fill's per-COLUMN table.  sTC[strand][obs][column] = (ME, INS) of the column's context for that observation (row 12 and the columns from
+// J on: zeros) — the lane of a quad unit (a read row: fixed observation, a new column every step) reads it with ONE ds_read_b64 at a running address + immediate;
+// the 16 lanes of a DPP row are on 16 CONSECUTIVE columns, so whatever their observations they hit 16 different bank pairs (row stride 32 entries).  Until round 5 a
+// lane took the column's context offset from a staggered per-column entry and then the pair from its observation's row of sCTX[obs][ctx]: two dependent LDS reads,
+// the second at (obs + ctx) mod 16 — 42 % of the kernel's LDS cycles were bank conflicts.  sDLC[strand][column] = DL of the column's context (1 outside 0 .. J-1).
+// A lane forms column indices from TC_LO .. 31 + TC_HI while it is off the band; what it reads there is never used but has to be FINITE (0 * x), so the tables sit
+// between guards of finite floats: [sDL, sZP, padding] in front, sDLC behind.
+#define TC_LO 56                      // columns below 0 / above 31 a quad lane may form: alpha -27 .. 67, beta -53 .. 62 (a read much shorter than its quad's longest keeps
+#define TC_HI 38                      // stepping after its own last column), DL one column lower
+#define TC_ROW 32                     // entries per observation row
+#define TC_STRAND ((CCSX_NOBS + 1) * TC_ROW)                 // entries per strand
+#define DLC_S (33 + TC_LO)            // sDLC: [TC_LO pad | strand 0: columns 0 .. 32 | TC_LO pad | strand 1 | TC_HI pad] — the middle pad serves both strands
+#define DLC_TOTAL (TC_LO + DLC_S + 33 + TC_HI)
+#define TAB_TAIL (2 * TC_HI - 48)     // floats of padding behind sDL / sZP, which with them are the guard behind sTC
+#define OBS_TC(o) ((o) * (TC_ROW * 8))         // the byte offset of observation o's row in a strand of sTC
 #define OBS_CODE(o) ((o) * (CTXS * 8))        // the byte offset of observation o's row in sCTX (sObs holds the 8-bit observation itself)
 
 struct LaneMut {                     // per-lane constants of one mutation on one strand
-    int c, q, kA, kB, isdel, fin;    // kA / kB index sCTX; +16 selects the copy whose INS component is zero
+    int c, q, kA, kB, isdel, fin;    // kA / kB index a row of sCTX; 16 = the zero entry (see lane_mut)
     int qoff;                        // q - c - 1 (0: insertion, 1: substitution / deletion): how far beta(i+1, q) sits above gamma(i, c) in diagonals (SPEC v8 joint band test)
     float dlA, dlL;
 };
@@ -2098,10 +2110,11 @@ __device__ __forceinline__ LaneMut lane_mut(int type, int c, int x, const uint8_
     const int q = (type == 2) ? c + 1 : c + 2;
     L.c = c; L.q = q > J ? J : q; L.isdel = (type == 1); L.fin = fin; L.qoff = (type == 2) ? 0 : 1;
     L.dlA = sDL[kA]; L.dlL = sDL[kB];
-    // the SPEC's "no stay move" cases (a deletion whose extension is the final column: INS[kA] unused; any extension
-    // that reaches the final column: INS[kB] unused) read the table copy whose INS component is an exact zero
-    L.kA = kA + ((type == 1 && fin) ? 16 : 0);
-    L.kB = kB + (fin ? 16 : 0);
+    // the SPEC's "no stay move" cases read the ZERO entry of the observation's row: a deletion whose extension is the final column (INS[kA] is unused and
+    // b = a, so ME[kA] is not needed either), and any extension that reaches the final column (INS[kB] unused; ME[kB] only feeds the link, which such a lane does
+    // not report).  Until round 5 the table carried a second half of (ME, 0) copies for them: 1.6 KB of LDS
+    L.kA = (type == 1 && fin) ? (CTXS - 1) : kA;
+    L.kB = fin ? (CTXS - 1) : kB;
     return L;
 }
 
@@ -2190,7 +2203,8 @@ __device__ __forceinline__ float skip_perr(int g, float floor_)
 }
 
 // SPEC v7 "repeat-count floor": lane x's longest period-p tandem tract among the visible window bases, from the wave mask m (bit k: v[k] == v[k+p]); 0 = none
-__device__ __forceinline__ int tract_len(unsigned long long m, int x, int p)
+// (SPEC v8: bit 8 of the result = the tract is OPEN, i.e. runs into an end of the visible template of nvis bases; on equal lengths the flags are ORed)
+__device__ __forceinline__ int tract_len(unsigned long long m, int x, int p, int nvis)
 {
     const int lo = x - p < 0 ? 0 : x - p;
     const unsigned long long cand = m & ((2ull << x) - 1ull) & ~((1ull << lo) - 1ull);      // the runs that reach x start their last equality at k in [x - p, x]
@@ -2202,8 +2216,8 @@ __device__ __forceinline__ int tract_len(unsigned long long m, int x, int p)
         const unsigned long long zb = ~m & ((1ull << k) - 1ull);
         const int i = zb ? 64 - __clzll((long long)zb) : 0;
         const int j = k + (__ffsll((long long)(~m >> k)) - 1);
-        const int L = j - i + p;
-        best = L > best ? L : best;
+        const int L = j - i + p, op = ((i == 0) || (j + p >= nvis)) ? 256 : 0;
+        if (L > (best & 255)) best = L | op; else if (L == (best & 255)) best |= op;
     }
     return best;
 }
@@ -2243,16 +2257,17 @@ __device__ __forceinline__ int xcd_contiguous(unsigned b, int count)
 template <int PWT, int PWMIN, int PWCH>
 __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 {
-    // [obs][ctx] = (ME, INS); ctx 16..31 = (ME, 0); row 12 = zeros ("no base").  Row stride CTXS = 33 entries: with the banded link every
-    // lane looks up its OWN observation row, and with 32 entries per row all lanes of one context hit the same bank pair whatever
-    // their rows (35 % of the LDS cycles were bank conflicts in round 2); 33 spreads them by (obs + ctx) mod 16
+    // [obs][ctx] = (ME, INS); entry 16 of a row and row 12 = zeros ("no base").  Odd row stride: with the banded link every lane looks up its OWN
+    // observation row, and with an even stride all lanes of one context hit the same bank pair whatever their rows (35 % of the LDS cycles were bank
+    // conflicts in round 2); 17 spreads them by (obs + ctx) mod 16
     __shared__ float2 sCTX[(CCSX_NOBS + 1) * CTXS];
-    __shared__ float sDL[16], sZP[32];                       // sZP: z-score MU[16], VAR[16]
-    __shared__ int2 sColJ[2][32];                            // [strand][column j] = (DL[k_j] as float bits, byte offset of context k_j in a row of sCTX)
-    // the same per column, staggered for the software-pipelined sweeps of a PAIR of short reads (rows 0..31 each): entry m of sEA =
-    // (DL of column m-1, context offset of column m+4), entry n of sEB = (DL of column n, context offset of column n-4); every index a
-    // lane can form before its first / after its last column exists and holds (1.0, the zero entry), so no look-up needs a guard
-    __shared__ int2 sEA[2][FE_A], sEB[2][FE_B];
+    // one float array: [sDLC] [sTC: 2 strands x 13 observation rows x 32 columns x (ME, INS)] [sDL 16 | sZP 32 | padding] — the first and the last part
+    // double as the finite guards of sTC (see TC_LO): 2 TC_LO floats in front, 2 TC_HI behind
+    static_assert(DLC_TOTAL >= 2 * TC_LO && TAB_TAIL >= 0 && (DLC_TOTAL & 1) == 0, "sTab: guards / alignment of sTC");
+    __shared__ __attribute__((aligned(16))) float sTab[DLC_TOTAL + 2 * TC_STRAND * 2 + 48 + TAB_TAIL];
+    float *const sDLC = sTab;
+    float2 *const sTC = (float2 *)(sTab + DLC_TOTAL);
+    float *const sDL = sTab + DLC_TOTAL + 2 * TC_STRAND * 2, *const sZP = sDL + 16;         // sZP: z-score MU[16], VAR[16]
     __shared__ uint8_t sT[2][32];                            // template: [0] forward, [1] reverse complement
     __shared__ uint8_t sTd[32];                              // the draft's window as it was (the large-insertion trim of a reloaded group compares with it)
     // dynamic LDS: observation codes of the batch's largest ZMW ([reads][68]: 63 codes + look-ahead slack), then gamma/beta.
@@ -2265,7 +2280,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     __shared__ int sBand[PW_MAXREADS];                       // the read's band and layout (SPEC v6): pitch | rowsz << 8 | bw << 16 | (dlo + 128) << 24
     __shared__ unsigned sDirty[PW_MAXREADS];                 // window-relative pile-up dirty bits of each read
     __shared__ uint8_t sStrand[PW_MAXREADS], sValid[PW_MAXREADS];
-    __shared__ uint8_t sZdrop[CCSX_MAX_PASSES + 1];          // z-score gate, by PASS (all groups): decided on the draft window (round 0), then kept
+    __shared__ unsigned sZdrop[(CCSX_MAX_PASSES + 32) / 32]; // z-score gate, one BIT per pass (all groups; a group is one word): decided on the draft window (round 0), then kept
     __shared__ float sBase[PW_MAXREADS], sB00[PW_MAXREADS];   // alpha(I,J) / beta(0,0) of the chunk's reads (the fill's two halves meet here)
     __shared__ short2 sTask[PW_MAXREADS];                    // fill tasks: (read A, read B or -1)
     __shared__ int sDeltaI[256];                             // fixed-point sums of the per-read gains; converted in place to float
@@ -2275,7 +2290,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     __shared__ float sZS[4];                                 // z-score sums: M fwd, V fwd, M rev, V rev
     __shared__ float sPskip[36];                             // error probability of a position if it is skipped (travels with the base)
     __shared__ int sCnt[(PWT / 64)];
-    __shared__ short sList[256];                             // compacted valid mutation lanes
+    __shared__ uint8_t sList[256];                           // compacted valid mutation lanes (a lane index < 256)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);      // wave-uniform values are made scalar explicitly (rfl):
     // loop counters, read indices and observation codes then live in SGPRs and cost no vector instructions
@@ -2315,18 +2330,18 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     const int maxins = P.opts.max_insertion_size == 0 ? 30 : P.opts.max_insertion_size;
     {
         // level 2: everything that needs only z / r0 / the window bounds
-        const int e0 = tid < CCSX_NOBS * 32 ? tid : 0, e1 = tid + PWT < CCSX_NOBS * 32 ? tid + PWT : e0;
+        const int e0 = tid < CCSX_NOBS * 16 ? tid : 0;      // (observation e0 >> 4, context e0 & 15)
         const size_t tz = (size_t)z * 192;
-        const int i0 = (e0 & 15) * CCSX_NOBS + (e0 >> 5), i1 = (e1 & 15) * CCSX_NOBS + (e1 >> 5);
-        const float me0 = P.tabME[tz + i0], in0 = P.tabINS[tz + i0], me1 = P.tabME[tz + i1], in1 = P.tabINS[tz + i1];
+        const int i0 = (e0 & 15) * CCSX_NOBS + (e0 >> 4);
+        const float me0 = P.tabME[tz + i0], in0 = P.tabINS[tz + i0];
         const float dl = P.tabDL[(size_t)z * 16 + (tid & 15)];
         const float zp = P.tabZ[(size_t)z * 32 + (tid & 31)];
         const int tcl = tid < we - ws ? tid : we - ws - 1;
         const uint8_t dr = draft[ws + tcl];
-        if (tid < CCSX_NOBS * 32) sCTX[(e0 >> 5) * CTXS + (e0 & 31)] = make_float2(me0, (e0 & 16) ? 0.0f : in0);
-        if (tid + PWT < CCSX_NOBS * 32) sCTX[(e1 >> 5) * CTXS + (e1 & 31)] = make_float2(me1, (e1 & 16) ? 0.0f : in1);
+        if (tid < CCSX_NOBS * 16) sCTX[(e0 >> 4) * CTXS + (e0 & 15)] = make_float2(me0, in0);
         if (tid < CTXS) sCTX[CCSX_NOBS * CTXS + tid] = make_float2(0.0f, 0.0f);
-        if (CTXS > 32 && tid < CCSX_NOBS) sCTX[tid * CTXS + 32] = make_float2(0.0f, 0.0f);     // (the padding entry of every row)
+        if (tid < CCSX_NOBS) sCTX[tid * CTXS + (CTXS - 1)] = make_float2(0.0f, 0.0f);     // (the zero entry of every row)
+        if (tid < TAB_TAIL) sZP[32 + tid] = 0.0f;            // (the padding behind sZP: part of the guard behind sTC)
         if (tid < 16) sDL[tid] = dl;
         if (tid < 32) sZP[tid] = zp;
         if (tid < we - ws) { sT[0][tid] = dr; sTd[tid] = dr; }
@@ -2374,7 +2389,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     const int ng0 = nreads - glast < PW_MAXREADS ? nreads - glast : PW_MAXREADS;
     const int trimflag = load_meta(glast, ng0);
     int resident = glast;                                   // the group whose per-read arrays and observation codes are in LDS (wave-uniform)
-    for (int q = tid; q <= CCSX_MAX_PASSES; q += PWT) sZdrop[q] = 0;
+    if (tid < (CCSX_MAX_PASSES + 32) / 32) sZdrop[tid] = 0u;
     // level 4 for the group's ng reads: the read segments (native orientation), four reads per wave in flight; then the rare trim
     auto load_obs = [&](int ng, int tflag) {
     const int anytrim = __syncthreads_or(tflag);
@@ -2466,7 +2481,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     __syncthreads();
     if (tid < 32) sT[0][tid] = (uint8_t)xr_t;
     if (tid < 36) sPskip[tid] = xr_p;
-    for (int q = tid; q <= CCSX_MAX_PASSES; q += PWT) sZdrop[q] = 0;
+    if (tid < (CCSX_MAX_PASSES + 32) / 32) sZdrop[tid] = 0u;
     if (tid == 0) { sCtl[0] = xr_c0; sCtl[1] = xr_c1; sCtl[2] = xr_c2; sCtl[7] = xr_c7; }
     __syncthreads();
 #endif
@@ -2486,25 +2501,6 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         __syncthreads();
         auto tbase = [&](int sd, int j) -> int { return (int)sT[sd][j]; };   // base j of the window template on strand sd
         const int lfr = (rf < 4) ? 3 - rf : 4;
-        // per-column table of the fill: column j's deletion weight and WHERE its context sits in a row of sCTX — the fill's lane
-        // (= read row, fixed observation) looks (ME, INS) up in its own sCTX row.  Round 3: a per-column copy of the tables
-        // ([strand][column][obs], 6.6 KB) made this one load instead of two dependent ones, but those 6.6 KB are worth a fourth
-        // / fifth read per gamma/beta chunk.  Two conventions make the sweep branch-free: observation code 12 is the all-zero row of
-        // sCTX ("no base" of row 0 / row I: the SPEC's "no diagonal / no stay there" becomes an exact +0 product), and column J
-        // points at the zero padding entry of every row with DL = 1 (no stay in the final column; beta's start value passes through
-        // 1 * beta).
-        if (tid < 64) {
-            const int sd = tid >> 5, j = tid & 31;
-            if (j <= J) {
-                int k = 32; float dlv = 1.0f;
-                if (j < J) {
-                    const int prev = j > 0 ? tbase(sd, j - 1) : (sd ? lfr : lf);
-                    k = ctx_of(prev, tbase(sd, j));
-                    dlv = sDL[k];
-                }
-                sColJ[sd][j] = make_int2(__float_as_int(dlv), k * 8);
-            }
-        }
         // z-score expectation of the window template on each strand, summed in column order (SPEC); the gate is decided in round 0
         // only.  Lane j fetches column j's terms, the ordered sum takes them with v_readlane (no chain of dependent LDS loads).
         if (it == 0 && wave < 2 && P.opts.min_zscore != 0.0f) {
@@ -2551,18 +2547,32 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
             __syncthreads();
             int basew = 0;
             for (int q = 0; q < wave; ++q) basew += sCnt[q];
-            if (v0) sList[basew + __popcll(bal & ((1ull << lane) - 1ull))] = (short)tid;
+            if (v0) sList[basew + __popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)tid;
             __syncthreads();
         }
-        for (int e = tid; e < 2 * (FE_A + FE_B); e += PWT) {          // (sColJ is complete: two barriers since)
-            const bool isa = e < 2 * FE_A;
-            const int e2 = isa ? e : e - 2 * FE_A, len = isa ? FE_A : FE_B;
-            const int sd = e2 >= len ? 1 : 0, idx = e2 - sd * len;
-            const int cd = isa ? idx - FE_ALO - 1 : idx - FE_BLO;           // the column whose DL the entry carries
-            const int cc = isa ? idx - FE_ALO + 4 : idx - FE_BLO - 4;       // the column whose context offset it carries
-            const int2 vd = sColJ[sd][cd >= 0 && cd <= J ? cd : 0], vc = sColJ[sd][cc >= 0 && cc <= J ? cc : 0];
-            const int2 ent = make_int2((cd >= 0 && cd <= J) ? vd.x : __float_as_int(1.0f), (cc >= 0 && cc <= J) ? vc.y : 32 * 8);
-            if (isa) sEA[sd][idx] = ent; else sEB[sd][idx] = ent;
+        // the fill's per-column tables of this round's template (sT[1] is complete: barriers since).  sTC[strand][obs][column]: the pair of the column's context in
+        // the observation's row of sCTX — zeros from column J on ("no stay in the final column") and for observation 12 ("no base": the zero row);
+        // sDLC[strand][column]: DL of the column's context, 1 outside 0 .. J-1 (beta's start value passes through column J as 1 * beta).  Boundary cells are data,
+        // not control: the sweeps are branch-free.
+        for (int e = tid; e < 2 * TC_STRAND; e += PWT) {
+            const int sd = e >= TC_STRAND ? 1 : 0, e2 = e - sd * TC_STRAND, o = e2 >> 5, j = e2 & 31;
+            float2 v = make_float2(0.0f, 0.0f);
+            if (j < J) {
+                const int prev = j > 0 ? tbase(sd, j - 1) : (sd ? lfr : lf);
+                v = sCTX[o * CTXS + ctx_of(prev, tbase(sd, j))];
+            }
+            sTC[e] = v;
+        }
+        for (int e = tid; e < DLC_TOTAL; e += PWT) {
+            const int sd = e >= TC_LO + 33 ? 1 : 0, j = e - TC_LO - sd * DLC_S;
+            float v = 1.0f;
+            if (j >= 0 && j < J) {
+                const int prev = j > 0 ? tbase(sd, j - 1) : (sd ? lfr : lf);
+                v = sDL[ctx_of(prev, tbase(sd, j))];
+            }
+            // (the entry right in front of sTC is column -1 of strand 0's observation row 0: row 1's lane reads it at step 0 while row 0's start value 1 is still in its
+            // neighbour, so its ME has to be an exact zero like column 31 of the row before every other observation row — no lane uses a DL that far out)
+            sDLC[e] = e >= DLC_TOTAL - 2 ? 0.0f : v;
         }
         int nvm = 0;
 #pragma unroll
@@ -2660,19 +2670,21 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 #define LDPR(ROWP, OFF) (*(const float2 *)((ROWP) + (OFF)))
                 if (!isb) {
                     // alpha: row 0 first.  Step t: the lane's row i computes column j = t - i
-                    const int obA0 = OBS_CODE((row0 >= 1 && ok0) ? (int)sObs[myr][row0 - 1] : 12);     // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
-                    const int obA1 = OBS_CODE(ok1 ? (int)sObs[myr][row1 - 1] : 12);
-                    const char *rowA = (const char *)sCTX + obA0;
-                    const char *rowA1 = (const char *)sCTX + obA1;
+                    const int obA0 = OBS_TC((row0 >= 1 && ok0) ? (int)sObs[myr][row0 - 1] : 12);       // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                    const int obA1 = OBS_TC(ok1 ? (int)sObs[myr][row1 - 1] : 12);
+                    // tA[x] (bytes: 8 x) = the pair of column x - row in the lane's observation row of sTC; dA[x] = DL of column x - row - 1.  Both run with t; the
+                    // look-up side changes rows (observation row, 16 columns back) one iteration before the compute side
+                    const char *tA = (const char *)(sTC + sd * TC_STRAND) + obA0 - 8 * row0;
+                    const int dtA = obA1 - obA0 - 8 * 16;
+                    const float *dA = sDLC + sd * DLC_S + (TC_LO - 1 - row0);
                     const int tA0 = ok0 ? row0 + jlo0 : NEVER, tA1 = row1 + jlo1;
                     unsigned uJ = ok0 ? (unsigned)(jhi0 - jlo0) : 0u;
                     const unsigned uJ1 = (unsigned)(jhi1 - jlo1);
                     const int tsw = ok1 ? ((row0 + jhi0) & ~3) : NEVER;          // = the first multiple of 4 >= (last step of row i) - 3
-                    const int2 *eA = sEA[sd] + (FE_ALO - row0);                       // eA[x] = the entry of column x - row
                     float *gA = sGB + sGoff[myr] + row0 * pitch - row0;               // gA[x] = gamma(row, x - row)
                     const int dgA = 16 * (pitch - 1), dcnt = tA0 - tA1;
                     float acur = (ok0 && row0 == 0) ? 1.0f : 0.0f, mnext = 0.0f;     // mnext = alpha(i-1, j-1) * ME(j-1) of the next step, formed a step ahead
-#define CCSX_A_INIT(K) const int2 ea##K = eA[K], fa##K = eA[(K) - 4]; float dl##K = __int_as_float(ea##K.x); int cx##K = ea##K.y; float2 p##K = LDPR(rowA, fa##K.y);
+#define CCSX_A_INIT(K) float dl##K = dA[K]; float2 p##K = LDPR(tA, 8 * (K));
                     CCSX_A_INIT(0) CCSX_A_INIT(1) CCSX_A_INIT(2) CCSX_A_INIT(3)
 #undef CCSX_A_INIT
                     int cnt = -tA0;
@@ -2684,12 +2696,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         if (__builtin_amdgcn_inverse_ballot_w64(on)) gA[(K)] = gmm;                                        \
                         acur = lanes_or_zero(on, __builtin_fmaf(up, p##K.y, gmm));   /* row 0 and column J read zero entries: + 0.  (ONE compare: the mask serves the store's exec and the select) */ \
                         mnext = up * p##K.x;                                                                               \
-                        p##K = LDPR(rowA, cx##K);                                                                          \
-                        const int2 en = eA[(K) + 4];                                                                       \
-                        dl##K = __int_as_float(en.x); cx##K = en.y;                                                        \
+                        p##K = LDPR(tA, 8 * ((K) + 4));              /* the slot's next use: four steps on */              \
+                        dl##K = dA[(K) + 4];                                                                               \
                     }
-                    for (int t = 0; t <= Tmax; t += 4, eA += 4, gA += 4, cnt += 4) {
-                        if (t == tsw) { rowA = rowA1; eA -= 16; }
+                    for (int t = 0; t <= Tmax; t += 4, tA += 32, dA += 4, gA += 4, cnt += 4) {
+                        if (t == tsw) { tA += dtA; dA -= 16; }
                         if (t - 4 == tsw) { uJ = uJ1; cnt += dcnt; gA += dgA; }
                         CCSX_A_STEP(0) CCSX_A_STEP(1) CCSX_A_STEP(2) CCSX_A_STEP(3)
                     }
@@ -2699,19 +2710,20 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 } else {
                     // beta: row I first.  Step t: the lane's row i computes column j = J - (t - (I - i)); a lane with two rows starts on row l + 16
                     const int rowF = ok1 ? row1 : row0, jloF = ok1 ? jlo1 : jlo0, jhiF = ok1 ? jhi1 : jhi0;
-                    const int obB0 = OBS_CODE((ok0 && row0 < I) ? (int)sObs[myr][row0] : 12);           // o_i; 12 = no base: row I emits nothing more
-                    const int obBF = ok1 ? OBS_CODE(row1 < I ? (int)sObs[myr][row1] : 12) : obB0;
-                    const char *rowB = (const char *)sCTX + obBF;
-                    const char *rowB0 = (const char *)sCTX + obB0;
+                    const int obB0 = OBS_TC((ok0 && row0 < I) ? (int)sObs[myr][row0] : 12);             // o_i; 12 = no base: row I emits nothing more
+                    const int obBF = ok1 ? OBS_TC(row1 < I ? (int)sObs[myr][row1] : 12) : obB0;
+                    // tB[-x] (bytes: -8 x) = the pair of column J + I - row - x in the lane's observation row of sTC; dB[-x] = DL of that column
+                    const char *tB = (const char *)(sTC + sd * TC_STRAND) + obBF + 8 * (J + I - rowF);
+                    const int dtB = obB0 - obBF + 8 * 16;
+                    const float *dB = sDLC + sd * DLC_S + (TC_LO + J + I - rowF);
                     const int tB0 = ok0 ? I - rowF + J - jhiF : NEVER, tB1 = I - row0 + J - jhi0;
                     unsigned uJ = ok0 ? (unsigned)(jhiF - jloF) : 0u;
                     const unsigned uJ1 = (unsigned)(jhi0 - jlo0);
                     const int tsw = ok1 ? ((I - row1 + J - jlo1) & ~3) : NEVER;
-                    const int2 *eB = sEB[sd] + (FE_BLO + J + I - rowF);               // eB[-x] = the entry of column J + I - row - x
                     float *bE = sGB + sBoff[myr] + rowF * pitch + (J + I - rowF);     // bE[-x] = beta(row, J + I - row - x)
                     const int dbE = -16 * (pitch - 1), dcnt = tB0 - tB1;
                     float bcur = (ok0 && rowF == I) ? 1.0f : 0.0f, t1next = 0.0f;    // t1next = ME(j) * beta(i+1, j+1) of the next step
-#define CCSX_B_INIT(K) const int2 eb##K = eB[-(K)], fb##K = eB[4 - (K)]; float dk##K = __int_as_float(eb##K.x); int cy##K = eb##K.y; float2 q##K = LDPR(rowB, fb##K.y);
+#define CCSX_B_INIT(K) float dk##K = dB[-(K)]; float2 q##K = LDPR(tB, -8 * (K));
                     CCSX_B_INIT(0) CCSX_B_INIT(1) CCSX_B_INIT(2) CCSX_B_INIT(3)
 #undef CCSX_B_INIT
                     int cnt = -tB0;
@@ -2723,12 +2735,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                         if (__builtin_amdgcn_inverse_ballot_w64(on)) bE[-(K)] = bv;                                        \
                         bcur = lanes_or_zero(on, bv);                                                                      \
                         t1next = q##KN.x * dn;                       /* (slot KN holds the pair of the next step's column) */ \
-                        q##K = LDPR(rowB, cy##K);                                                                          \
-                        const int2 en = eB[-(K) - 4];                                                                      \
-                        dk##K = __int_as_float(en.x); cy##K = en.y;                                                        \
+                        q##K = LDPR(tB, -8 * ((K) + 4));                                                                   \
+                        dk##K = dB[-(K) - 4];                                                                              \
                     }
-                    for (int t = 0; t <= Tmax; t += 4, eB -= 4, bE -= 4, cnt += 4) {
-                        if (t == tsw) { rowB = rowB0; eB += 16; }
+                    for (int t = 0; t <= Tmax; t += 4, tB -= 32, dB -= 4, bE -= 4, cnt += 4) {
+                        if (t == tsw) { tB += dtB; dB += 16; }
                         if (t - 4 == tsw) { uJ = uJ1; cnt += dcnt; bE += dbE; }
                         CCSX_B_STEP(0, 1) CCSX_B_STEP(1, 2) CCSX_B_STEP(2, 3) CCSX_B_STEP(3, 0)
                     }
@@ -2747,23 +2758,21 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int I = rfl(sI[myr]);
                 const int Tmax = I + J;
                 const int sd = sStrand[myr];
-                const int2 *CJ = sColJ[sd];
+                const float *dlcol = sDLC + sd * DLC_S + TC_LO;      // DL by column (1 at column J)
                 const bool rowok = row <= I;
                 // SPEC v6: the columns of this lane's row that lie on the read's band, jlo .. jhi; the cells outside are zeros and are neither computed nor stored
                 const int band = sBand[myr];
                 const int pitch = band & 255, rowsz = (band >> 8) & 255, bdlo = (int)((unsigned)band >> 24) - 128, bdhi = bdlo + ((band >> 16) & 255) - 1;
                 const int jlo = (row + bdlo > 0) ? row + bdlo : 0, jhi = (row + bdhi < J) ? row + bdhi : J;
-                // the lane's rows of sCTX, as byte offsets
-                const int op = OBS_CODE((row >= 1 && rowok) ? (int)sObs[myr][row - 1] : 12);   // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
-                const int oc = OBS_CODE((row < I) ? (int)sObs[myr][row] : 12);                  // o_i;     12 = no base: row I emits nothing more
-                const char *rowA = (const char *)sCTX + op, *rowB = (const char *)sCTX + oc;
+                // the lane's observation rows of the per-column table sTC
+                const int op = OBS_TC((row >= 1 && rowok) ? (int)sObs[myr][row - 1] : 12);     // o_{i-1}; 12 = no base: row 0 has no diagonal / stay
+                const int oc = OBS_TC((row < I) ? (int)sObs[myr][row] : 12);                    // o_i;     12 = no base: row I emits nothing more
+                const float2 *rowA = (const float2 *)((const char *)(sTC + sd * TC_STRAND) + op), *rowB = (const float2 *)((const char *)(sTC + sd * TC_STRAND) + oc);
                 // activity windows: alpha computes column j = t - row for t in [row + jlo, row + jhi]; beta computes column
                 // jb = J - (t - (I - row)) for t in [I - row + J - jhi, I - row + J - jlo]
                 const int tA0 = rowok ? row + jlo : (1 << 20), tB0 = rowok ? I - row + J - jhi : (1 << 20);
                 const float one0 = (row == 0) ? 1.0f : 0.0f, oneI = (row == I) ? 1.0f : 0.0f;
-                const int2 *cA = CJ - row;
                 float *gA = sGB + sGoff[myr] + row * pitch - row;
-                const int2 *cB = CJ + (J + I - row - 1);                                   // the SECOND step of an iteration; the first is one column up
                 float *bB = sGB + sBoff[myr] + row * pitch + (J + I - row - 1);
                 // start values chosen so that the general recurrence yields the boundary cells: gamma(i,0) = 0*x + one0*1,
                 // beta(i,J) = (0 + 0) + 1*oneI (column J of the tables is zero with DL = 1)
@@ -2775,16 +2784,14 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 const int tAc = rowok ? row : (1 << 20);             // (the loop carries ME / DL of the previous column from column 0 on)
                 const unsigned uJc = (unsigned)J;
                 if (mode == 1) {
-                    int2 ca0 = cA[0], ca1 = cA[1];
-                    for (int t = 0; t <= Tmax; t += 2, cA += 2, gA += 2) {
-                        const int2 na0 = cA[2], na1 = cA[3];
-#define CCSX_LA_STEP(T, AOFF, CJA)                                                                                         \
+                    for (int t = 0; t <= Tmax; t += 2, gA += 2) {
+#define CCSX_LA_STEP(T, AOFF)                                                                                         \
                         {                                                                                                  \
                             const float up = wave_shr1_f32_z(acur);  /* all rows of the read shift together (full exec) */ \
                             float nv = 0.0f;                                                                               \
                             if ((unsigned)((T) - tAc) <= uJc) {      /* alpha, column j = T - row of the window */        \
-                                const float2 pr = *(const float2 *)(rowA + (CJA).y);                                       \
-                                const float dlc = __int_as_float((CJA).x);                                                 \
+                                const float2 pr = rowA[(T) - row];                                                         \
+                                const float dlc = dlcol[(T) - row];                                                        \
                                 const float gmm = __builtin_fmaf(acur, dlPrev, updiag * mePrev);                           \
                                 if ((unsigned)((T) - tA0) <= uJ) { gA[(AOFF)] = gmm; nv = __builtin_fmaf(up, pr.y, gmm); }   /* ... on the band; row 0 and column J read zero entries: + 0 */ \
                                 mePrev = pr.x; dlPrev = dlc;                                                               \
@@ -2792,33 +2799,30 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                             acur = nv;                                                                                     \
                             updiag = up;                                                                                   \
                         }
-                        CCSX_LA_STEP(t, 0, ca0)
-                        CCSX_LA_STEP(t + 1, 1, ca1)
+                        CCSX_LA_STEP(t, 0)
+                        CCSX_LA_STEP(t + 1, 1)
 #undef CCSX_LA_STEP
-                        ca0 = na0; ca1 = na1;
                     }
                     if (lane == 0) sBase[myr] = sGB[sGoff[myr] + I * pitch + J];   // (alpha(I,J) = gamma(I,J): no stay in the final column)
                 } else {
-                    int2 cb0 = cB[1], cb1 = cB[0];
-                    for (int t = 0; t <= Tmax; t += 2, cB -= 2, bB -= 2) {
-                        const int2 nb0 = cB[-1], nb1 = cB[-2];
-#define CCSX_LB_STEP(T, BOFF, CJB)                                                                                         \
+                    for (int t = 0; t <= Tmax; t += 2, bB -= 2) {
+#define CCSX_LB_STEP(T, BOFF)                                                                                         \
                         {                                                                                                  \
                             const float dn = wave_shl1_f32_z(bcur);                                                        \
                             float nv = 0.0f;                                                                               \
                             if ((unsigned)((T) - tB0) <= uJ) {       /* beta, column jb = J - (T - (I - row)), on the band */ \
-                                const float2 pr = *(const float2 *)(rowB + (CJB).y);                                       \
-                                const float bv = __builtin_fmaf(__int_as_float((CJB).x), bcur, __builtin_fmaf(pr.y, dn, pr.x * dndiag)); \
+                                const int jb = J + I - row - (T);    /* the column the step computes */                   \
+                                const float2 pr = rowB[jb];                                                                \
+                                const float bv = __builtin_fmaf(dlcol[jb], bcur, __builtin_fmaf(pr.y, dn, pr.x * dndiag)); \
                                 bB[(BOFF)] = bv;                                                                           \
                                 nv = bv;                                                                                   \
                             }                                                                                              \
                             bcur = nv;                                                                                     \
                             dndiag = dn;                                                                                   \
                         }
-                        CCSX_LB_STEP(t, 1, cb0)
-                        CCSX_LB_STEP(t + 1, 0, cb1)
+                        CCSX_LB_STEP(t, 1)
+                        CCSX_LB_STEP(t + 1, 0)
 #undef CCSX_LB_STEP
-                        cb0 = nb0; cb1 = nb1;
                     }
                     const int org_ = pitch == S ? 0 : -bdlo;      // (row layout: no origin shift)
                     if (row < rowsz) sGB[sBoff[myr] - org_ + (I + 1) * rowsz + row] = 0.0f;
@@ -2841,11 +2845,11 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
 #endif
                     float df = vLa - lb; if (df < 0.0f) df = -df;
                     vOk = !(df > AB_TOL);
-                    if (sZdrop[g0 + lane]) vOk = 0;
+                    if ((sZdrop[g0 >> 5] >> lane) & 1u) vOk = 0;       // (g0 is a multiple of PW_MAXREADS = 32, lane < 32 here)
                     else if (vOk && it == 0 && P.opts.min_zscore != 0.0f) {   // A7 z-score gate, round 0 only (x4 per emitted base = 2 bits per read base)
                         const float zd = (vLa - (float)(2 * I)) - sZS[2 * sd];
                         const float zm = P.opts.min_zscore;
-                        if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) { vOk = 0; sZdrop[g0 + lane] = 1; }   // (every wave writes the same 1)
+                        if (zd < 0.0f && zd * zd > (zm * zm) * sZS[2 * sd + 1]) { vOk = 0; atomicOr(&sZdrop[g0 >> 5], 1u << lane); }   // (every wave sets the same bit)
                     }
                 }
             }
@@ -3126,12 +3130,15 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
         }
         if (any_tract) {
             const int x = c + voff;
-            const int L1 = tract_len(tm1, x, 1), L2 = tract_len(tm2, x, 2), L3 = tract_len(tm3, x, 3), L4 = tract_len(tm4, x, 4);
+            const int nvis_ = J + voff + (rf < 4 ? 1 : 0);
+            const int T1 = tract_len(tm1, x, 1, nvis_), T2 = tract_len(tm2, x, 2, nvis_), T3 = tract_len(tm3, x, 3, nvis_), T4 = tract_len(tm4, x, 4, nvis_);
+            // SPEC v8: a CLOSED tract (both ends inside the visible template) is resolved by the likelihood — its floor falls with the square of the passes used beyond REP_NP0
+            const int npw = nvalid_last;
+            const float closed_scale = npw > REP_NP0 ? __fdiv_rn((float)(REP_NP0 * REP_NP0), (float)(npw * npw)) : 1.0f;
             float fl = 0.0f;
-            if (L1 >= 8) fl = __fdiv_rn(REP_ERRS, (float)L1);
-            if (L2 >= 10) { const float f = __fdiv_rn(REP_ERRS, (float)L2); fl = f > fl ? f : fl; }
-            if (L3 >= 12) { const float f = __fdiv_rn(REP_ERRS, (float)L3); fl = f > fl ? f : fl; }
-            if (L4 >= 16) { const float f = __fdiv_rn(REP_ERRS, (float)L4); fl = f > fl ? f : fl; }
+#define CCSX_TRACT_FLOOR(TT, MINL) if (((TT) & 255) >= (MINL)) { float f = __fdiv_rn(REP_ERRS, (float)((TT) & 255)); if (!((TT) & 256) && npw > REP_NP0) f = f * closed_scale; fl = f > fl ? f : fl; }
+            CCSX_TRACT_FLOOR(T1, 8) CCSX_TRACT_FLOOR(T2, 10) CCSX_TRACT_FLOOR(T3, 12) CCSX_TRACT_FLOOR(T4, 16)
+#undef CCSX_TRACT_FLOOR
             if (p < fl) p = fl;
         }
         if (p < P.perr_floor) p = P.perr_floor;             // SPEC v7: no base claims more than Q50 (opts.max_qv)

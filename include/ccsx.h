@@ -197,6 +197,14 @@ int         ccsx_destroy(ccsx_handle h);
 
 /* page-locked host memory for batch arrays (optional: any host memory works; pinned buffers upload by DMA at PCIe
  * rate instead of through the runtime's staging copy).  NULL on failure (ccsx_last_error). */
+/* NUMA placement of a device's host threads on a multi-GPU node (docs/faq/parallelize.md:8-29): the device's NUMA node from its PCI address
+ * (/sys/bus/pci/devices/<id>/numa_node; -1 = unknown / the platform reports none), and binding the CALLING thread to that node's CPUs (intersected with the
+ * CPUs the process may use).  Bind a device's worker / packing threads BEFORE they allocate page-locked staging: first touch then puts the staging on the
+ * device's node.  Both return the node, or -1 when nothing was (or could be) done — never an error: placement is an optimisation.  CCSX_NUMA=0 turns binding off. */
+int         ccsx_pci_numa_node(const char *pci_bus_id);
+int         ccsx_device_numa_node(int device);
+int         ccsx_bind_thread_to_node(int node);
+int         ccsx_bind_thread_to_device(int device);
 void       *ccsx_alloc_pinned(size_t bytes);
 void        ccsx_free_pinned(void *p);
 

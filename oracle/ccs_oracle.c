@@ -94,7 +94,7 @@ static inline void fill_band_of(int I, int J, int score_band, int *dlo, int *dhi
 /* ---- path / work counters of the tests and of bench.py's counted-work figure (SURVEY.md §8d "algorithmic work per ZMW: counted on an
  * instrumented CPU path, not estimated"); per-thread tallies are flushed into the global sums once per ZMW ---- */
 enum { CNT_TRIM, CNT_SPLIT, CNT_SPLIT_S0, CNT_SPLIT_SLD, CNT_FALLBACK, CNT_RETRY64, CNT_ZDROP, CNT_NONCONV_WIN, CNT_POA_WIDE, CNT_THIRD_DRAFT,
-       CNT_PARTIAL_USED, CNT_CELLS_POA, CNT_CELLS_ALIGN, CNT_CELLS_FILL, CNT_CELLS_SCORE, CNT_ZMWS, CNT_SPLIT2, CNT_SATURATED, CNT_N };
+       CNT_PARTIAL_USED, CNT_CELLS_POA, CNT_CELLS_ALIGN, CNT_CELLS_FILL, CNT_CELLS_SCORE, CNT_ZMWS, CNT_SPLIT2, CNT_SATURATED, CNT_CLOSED_TRACT, CNT_N };
 static int64_t orc_cnt_global[CNT_N];
 static __thread int64_t orc_cnt[CNT_N];
 static __thread int g_cells_kind = CNT_CELLS_ALIGN;         /* which tally dp_column feeds */
@@ -964,7 +964,7 @@ static uint32_t skip_mask(const wtpl_t *w, uint32_t ev)
     return sk;
 }
 
-static float tract_floor(const uint8_t *v, int n, int x);   /* SPEC v7 "repeat-count floor", defined with skip_perr below */
+static float tract_floor(const uint8_t *v, int n, int x, int np);   /* SPEC v7 "repeat-count floor", defined with skip_perr below */
 /* statistics / calibration hooks of the tests (never used by the product, which cannot link this file) */
 struct orc_dbg_s {
     int32_t stats, calib;                 /* calib: run unfiltered and record the true p_err of skippable positions */
@@ -1132,7 +1132,7 @@ static int polish_window_impl(const float *ME, const float *INS, const float *DL
             p = s / (1.0f + s);
         }
         if (orc_dbg.calib) { if (p < 1e-10f) p = 1e-10f; }   /* (the calibration hook of tests/test_oracle_filter.py measures the HMM's own value) */
-        else { float fl = tract_floor(vis, nvis, c + voff); if (p < fl) p = fl; }
+        else { float fl = tract_floor(vis, nvis, c + voff, nvalid); if (p < fl) p = fl; }
         if (!orc_dbg.calib && p < PERR_FLOOR) p = PERR_FLOOR;                /* SPEC v7: no base claims more than Q50 — nothing measured supports a higher claim (profiles/r05_qv_calibration.txt) */
         float qv = -3.01029996f * orc_log2f(p);
         if (qv < 0.0f) qv = 0.0f;
@@ -1361,20 +1361,32 @@ static inline float skip_perr(int g)
  * L >= REP_MINLEN[p-1] visible bases reports p_err >= REP_ERRS / L. */
 #define REP_ERRS 0.2f
 static const int REP_MINLEN[4] = { 8, 10, 12, 16 };
-static float tract_floor(const uint8_t *v, int n, int x)
+/* SPEC v8: the floor was calibrated at 10 passes.  Measured by pass count (profiles/r06_tract_floor_by_passes*.txt): a tract that runs into an END of the
+ * visible template (an "open" tract: the window cannot see where it stops) carries 0.65 - 0.77 count errors whatever the coverage (3 .. 30 passes) — the floor stays;
+ * a tract that begins and ends INSIDE the visible template ("closed": every pass shows the whole run to one window) is resolved by the likelihood, and its
+ * errors fall with the square of the coverage (0.135 per tract at 10 passes, 0.06 at 15, 0.015 at 30): its floor is scaled by (REP_NP0 / np)^2 for np > REP_NP0
+ * passes used in the window.  orc_set_rep_np0(0) restores the v7 rule. */
+#define REP_NP0 10
+static int g_rep_np0 = REP_NP0;
+void orc_set_rep_np0(int n) { g_rep_np0 = n; }
+static float tract_floor(const uint8_t *v, int n, int x, int np)
 {
     float fl = 0.0f;
     for (int p = 1; p <= 4; ++p) {
-        int best = 0;
+        int best = 0, open = 0;
         for (int k = x - p; k <= x; ++k) {
             if (k < 0 || k + p >= n || v[k] != v[k + p]) continue;
             int i = k, j = k + 1;
             while (i > 0 && v[i - 1] == v[i - 1 + p]) --i;
             while (j + p < n && v[j] == v[j + p]) ++j;
-            int L = j - i + p;
-            if (L > best) best = L;
+            int L = j - i + p, op = (i == 0) || (j + p >= n);
+            if (L > best) { best = L; open = op; } else if (L == best) open |= op;
         }
-        if (best >= REP_MINLEN[p - 1]) { float f = REP_ERRS / (float)best; if (f > fl) fl = f; }
+        if (best >= REP_MINLEN[p - 1]) {
+            float f = REP_ERRS / (float)best;
+            if (!open && g_rep_np0 > 0 && np > g_rep_np0) { f = f * ((float)(g_rep_np0 * g_rep_np0) / (float)(np * np)); orc_cnt[CNT_CLOSED_TRACT] += 1; }
+            if (f > fl) fl = f;
+        }
     }
     return fl;
 }

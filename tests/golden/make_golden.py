@@ -79,10 +79,12 @@ def cases():
     yield "lowcx_rescue", lowcx.make(3, 10, (1500, 3000), 402, tpl="lowcx"), {"saturated": 10}
     yield "partial", T.partial_pass_batch(n=2, seed=58, nfull=5, length=(800, 1500)), {"partial_used": 4}
     import test_oracle_filter as TF
+    # SPEC v8: a tandem tract that begins and ends inside the visible window template at more than ten passes: its repeat-count floor is scaled down by the coverage
+    yield "closed_tract", lowcx.make(2, 16, 1200, 811, tpl="lowcx"), {"closed_tract": 1}
     yield "split2", TF._two_block_batch(sizes=(250, 250, 250), fr=(0.2, 0.5, 0.8))[1], {"split2": 2}     # SPEC v4: three blocks per pass
 
 
-PATH_KEYS = O.COUNT_NAMES[:11] + ["split2", "saturated"]          # = tests/golden_util.py PATHS
+PATH_KEYS = O.COUNT_NAMES[:11] + ["split2", "saturated", "closed_tract"]          # = tests/golden_util.py PATHS
 
 
 def main():

@@ -8,8 +8,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gol
 GOLDEN_KIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_kin_v8.npz")
 # every case of the file (tests/golden/make_golden.py): four plain shapes, one ZMW at the headline size, and one case per SPEC path that
 # plain synthetic data does not take (the generator asserts that the path fired)
-CASES = ["p3_l300", "p5_l700", "p10_l2000", "mix", "c2_one", "trim", "split", "fallback", "lastresort", "retry64", "lowcx", "lowcx_rescue", "partial", "split2"]
-PATHS = ["trim", "split", "split_s0", "split_sLd", "fallback", "retry64", "zdrop", "nonconv_win", "poa_wide", "third_draft", "partial_used", "split2", "saturated"]
+CASES = ["p3_l300", "p5_l700", "p10_l2000", "mix", "c2_one", "trim", "split", "fallback", "lastresort", "retry64", "lowcx", "lowcx_rescue", "partial", "split2", "closed_tract"]
+PATHS = ["trim", "split", "split_s0", "split_sLd", "fallback", "retry64", "zdrop", "nonconv_win", "poa_wide", "third_draft", "partial_used", "split2", "saturated", "closed_tract"]
 OUT_KEYS = ("seq_off", "status", "seq_len", "seq", "qual", "raw_qv", "rq", "np_", "ec", "iters", "n_windows", "fn", "rn")
 
 

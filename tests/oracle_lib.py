@@ -206,7 +206,7 @@ def kinetics_read(tpl_read_orient, read_bases, ipd, pw, strand):
 
 
 COUNT_NAMES = ["trim", "split", "split_s0", "split_sLd", "fallback", "retry64", "zdrop", "nonconv_win", "poa_wide", "third_draft",
-               "partial_used", "cells_poa", "cells_align", "cells_fill", "cells_score", "zmws", "split2", "saturated"]
+               "partial_used", "cells_poa", "cells_align", "cells_fill", "cells_score", "zmws", "split2", "saturated", "closed_tract"]
 
 
 def counts_reset():

@@ -55,7 +55,36 @@ def test_runtime_switches_are_reported(built, monkeypatch):
         names |= set(re.findall(r'getenv\("(CCSX_[A-Z0-9_]+)"\)', open(os.path.join(ROOT, "ccs_amd", "csrc", f)).read()))
     host = open(os.path.join(ROOT, "ccs_amd", "csrc", "ccsx_host.cpp")).read()
     listed = set(re.findall(r'"(CCSX_[A-Z0-9_]+)"', host[host.index("ccsx_runtime_switches(void)\n{"):host.index("thread_local std::string out")]))
-    assert names - listed <= {"CCSX_TEST_FAIL_SUBMIT", "CCSX_SYNTH_THREADS"}, names - listed
+    assert names - listed <= {"CCSX_TEST_FAIL_SUBMIT", "CCSX_SYNTH_THREADS", "CCSX_SYSFS_ROOT"}, names - listed
+
+
+def test_numa_binding_and_its_fallbacks(built, monkeypatch, tmp_path):
+    """a device's host threads are bound to the CPUs of the device's NUMA node (sysfs only).  With a fake sysfs tree: the node of a PCI address, the
+    binding itself (never outside the CPUs the process may use), and every way it can be absent — no such device, a node of -1, no cpulist, CCSX_NUMA=0 — ends in -1
+    with the affinity untouched.  (No GPU: ccsx_device_numa_node itself is covered by the -m gpu bench test.)"""
+    L = api.lib()
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = sorted(before)
+        dev = tmp_path / "sys" / "bus" / "pci" / "devices"
+        (dev / "0000:c1:00.0").mkdir(parents=True); (dev / "0000:c1:00.0" / "numa_node").write_text("1\n")
+        (dev / "0000:05:00.0").mkdir(parents=True); (dev / "0000:05:00.0" / "numa_node").write_text("-1\n")
+        node = tmp_path / "sys" / "devices" / "system" / "node"
+        (node / "node1").mkdir(parents=True); (node / "node1" / "cpulist").write_text(f"{cpus[0]},{cpus[-1]}-{cpus[-1] + 3}\n")
+        (node / "node2").mkdir(parents=True); (node / "node2" / "cpulist").write_text("4090-4095\n")       # CPUs this process does not have
+        monkeypatch.setenv("CCSX_SYSFS_ROOT", str(tmp_path))
+        monkeypatch.delenv("CCSX_NUMA", raising=False)
+        assert L.ccsx_pci_numa_node(b"0000:C1:00.0") == 1              # (hipDeviceGetPCIBusId prints upper-case hex, sysfs uses lower case)
+        assert L.ccsx_pci_numa_node(b"0000:05:00.0") == -1 and L.ccsx_pci_numa_node(b"ffff:ff:ff.f") == -1 and L.ccsx_pci_numa_node(b"") == -1
+        assert L.ccsx_bind_thread_to_node(-1) == -1 and L.ccsx_bind_thread_to_node(7) == -1 and L.ccsx_bind_thread_to_node(2) == -1
+        assert os.sched_getaffinity(0) == before
+        monkeypatch.setenv("CCSX_NUMA", "0")
+        assert L.ccsx_bind_thread_to_node(1) == -1 and os.sched_getaffinity(0) == before
+        monkeypatch.delenv("CCSX_NUMA")
+        assert L.ccsx_bind_thread_to_node(1) == 1
+        assert os.sched_getaffinity(0) == {cpus[0], cpus[-1]}
+    finally:
+        os.sched_setaffinity(0, before)
 
 
 def test_draft_layout_matches_result_layout(built):

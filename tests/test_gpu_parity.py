@@ -56,6 +56,26 @@ def test_full_path_bit_exact(handle, n, passes, length, seed):
     _compare(res, ref, batch)
 
 
+@pytest.mark.parametrize("max_qv", [93, 30, 0])
+def test_max_qv_option_bit_exact(built, max_qv):
+    """ABI v6: opts.max_qv floors every per-base error probability at 10^(-max_qv/10) — 50 by default (SPEC v7 "honest QVs"), 93 = the
+    reference's documented range (docs/faq/qv-binning.md:31).  Kernel and restatement agree bit for bit at every setting; the cap is what it says."""
+    o = api.default_opts(); o.max_qv = max_qv; o.min_rq = 0.0
+    batch = api.synth(6, 10, 900, seed=77)
+    h = api.Handle(0, opts=o)
+    try:
+        res = h.consensus(batch)
+        ref = _oracle(h, batch)
+        _compare(res, ref, batch)
+        cap = 50 if max_qv == 0 else max_qv
+        top = max(int(res.quals(z).max()) for z in range(batch.n_zmw) if res.seq_len[z])
+        assert top <= cap and (top == cap or cap == 93), (top, cap)
+        if max_qv == 93:
+            assert top > 50                                  # the HMM itself claims more than Q50 on clean synthetic data: the default caps it, 93 shows it
+    finally:
+        h.close()
+
+
 def test_stages_match_oracle(handle):
     batch = api.synth(4, 6, 900, seed=11)
     handle.upload(batch); handle.run(); handle.sync()
@@ -511,6 +531,20 @@ def test_bench_gpus_n_runs_n_workers_in_one_process(built):
     slowest = max(g["ms_per_step"] for g in out["per_gpu"])
     assert abs(out["ms_per_step"] - slowest) < 1e-6 and abs(out["value"] - 2 * 48 * 3 / (slowest * 3e-3)) / out["value"] < 1e-3
     assert out["success_frac"] > 0.9 and all(g["success_frac"] > 0.9 for g in out["per_gpu"])
+    # every worker reports its device's NUMA node, where its thread was bound (that node, or -1 when the platform names none / binding is off),
+    # the H2D rate it gets while its neighbour uploads too, and how much of its run the kernels covered; both workers of GPU 0 sit on GPU 0's node
+    node = api.lib().ccsx_device_numa_node(0)
+    for g in out["per_gpu"]:
+        assert g["numa_node"] == node and g["thread_bound_to_node"] in (node, -1)
+        assert g["h2d_GBps"] > 0.1 and 0.0 < g["copies_hidden_frac"] <= 1.0
+    if node >= 0 and os.environ.get("CCSX_NUMA", "1") != "0":
+        assert all(g["thread_bound_to_node"] == node for g in out["per_gpu"])
+    assert out["config"]["runtime_switches"] == "" and "two compute streams" in out["config"]["stages"]
+    # the stage label says what the library DID: an override from the environment is named and changes it
+    ps = subprocess.run(cmd, env={**env, "CCSX_SERIAL_STAGES": "1"}, capture_output=True, text=True, timeout=600, cwd=root)
+    assert ps.returncode == 0, ps.stderr[-2000:]
+    os_ = json.loads([l for l in ps.stdout.splitlines() if l.startswith("{")][0])
+    assert os_["config"]["runtime_switches"] == "CCSX_SERIAL_STAGES=1" and os_["config"]["stages"].startswith("serial")
     # N = 1 keeps its line: no per-GPU block
     p1 = subprocess.run([a for a in cmd if a not in ("2",)][:2] + ["--gpus", "1"] + cmd[4:], env={k: v for k, v in env.items() if k != "CCSX_BENCH_DEVICES"},
                         capture_output=True, text=True, timeout=600, cwd=root)
