@@ -434,14 +434,32 @@ class Drafts:
     win_bounds: np.ndarray
 
     @staticmethod
-    def allocate(batch: Batch) -> "Drafts":
+    def allocate(batch: Batch, pinned: bool | None = None) -> "Drafts":
+        """pinned (default wherever there is a device): the arrays the ticketed seams copy asynchronously live in page-locked memory, as include/ccsx.h asks
+        (with pageable arrays the copies block the submitting thread until the stage has finished)"""
+        if pinned is None:
+            pinned = lib().ccsx_device_count() > 0
         n = batch.n_zmw
         cb = batch.c_struct()
         so, wo = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
         sc, wc = C.c_int64(), C.c_int64()
         lib().ccsx_draft_layout(C.byref(cb), _ptr(so, C.c_int64), _ptr(wo, C.c_int64), C.byref(sc), C.byref(wc))
-        return Drafts(so, wo, np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(sc.value, np.uint8), np.zeros(n, np.int32),
-                      np.zeros(n, np.int32), np.zeros(wc.value, np.int32))
+        keep = []
+
+        def z(count, dt):
+            if not pinned:
+                return np.zeros(count, dt)
+            nb = max(1, int(count) * np.dtype(dt).itemsize)
+            p = lib().ccsx_alloc_pinned(nb)
+            if not p:
+                raise RuntimeError("ccsx_alloc_pinned failed: " + lib().ccsx_last_error().decode())
+            keep.append(_Pinned(p))
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nb,))[: int(count) * np.dtype(dt).itemsize].view(dt)
+            a[...] = 0
+            return a
+        d = Drafts(so, wo, z(n, np.int32), z(n, np.int32), z(sc.value, np.uint8), z(n, np.int32), z(n, np.int32), z(wc.value, np.int32))
+        d._pinned = keep
+        return d
 
     def c_struct(self) -> CDrafts:
         d = CDrafts()

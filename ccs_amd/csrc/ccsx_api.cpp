@@ -45,13 +45,19 @@ struct DevBuf {
         // the new block first: a failed growth leaves the old buffer (and every KParams that points into it) intact
         // (a buffer that has to grow AGAIN belongs to a stream of unequal batches — the driver's cost-binned tickets of a mixed run: every regrowth is a
         // synchronous hipMalloc + hipFree, for the shared POA scratch tens of GB behind a stream synchronisation — so regrowth takes half as much again)
-        size_t want = bytes + (p ? bytes / 2 : bytes / 8) + 256;
+        // (the headroom is capped at 1 GB, and a request that fails WITH headroom is repeated at the exact size before anything is given up — the
+        // POA scratch is sized to 3/4 of the handle's budget, half as much again may simply not exist)
+        const size_t head = std::min<size_t>(p ? bytes / 2 : bytes / 8, (size_t)1 << 30);
+        size_t want = bytes + head + 256;
         void *np_ = nullptr;
         hipError_t e = hipMalloc(&np_, want);
-        if (e != hipSuccess && p) {                      // not enough room for both: give the old block back and try once more
+        if (e != hipSuccess) { (void)hipGetLastError(); want = bytes + 256; e = hipMalloc(&np_, want); }
+        if (e != hipSuccess && p) {                      // not enough room for both: give the old block back and try once more, with and without headroom
             (void)hipGetLastError();
             (void)hipFree(p); p = nullptr; cap = 0;
+            want = bytes + head + 256;
             e = hipMalloc(&np_, want);
+            if (e != hipSuccess) { (void)hipGetLastError(); want = bytes + 256; e = hipMalloc(&np_, want); }
         }
         if (e != hipSuccess) { (void)hipGetLastError(); ccsx_set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return -2; }
         if (p) (void)hipFree(p);
@@ -109,6 +115,7 @@ struct Slot {
     hipEvent_t ev[7] = {}, ev_up = nullptr, ev_done = nullptr;   // ev[0..5]: stage boundaries, ev[6]: start of the polish stage
     hipEvent_t ev_aux[7] = {};                                   // second stream: fork / first DP done / join of the POA stage; k_align16 launch done x 2, its trace-back done x 2
     bool staged = false, ran = false, inflight = false;
+    bool tm_ok = false; ccsx_timings tm{};   // the slot's timings as taken by ccsx_wait (valid until the slot is staged again)
     ccsx_results *res = nullptr;      // destination of an in-flight submit
     ccsx_drafts *drafts_out = nullptr; // ... of an in-flight ccsx_submit_draft
     int mode = CCSX_RUN_FUSED;
@@ -428,7 +435,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     // k_align16 stores a quad's moves instead (2 bits per band row and column + 2 bits of band step and an edge flag per column: 18 words per block of 16 draft columns and pass)
     int64_t dcap_max = 16;
     for (int z = 0; z < n; ++z) dcap_max = std::max<int64_t>(dcap_max, S.dcap[z]);
-    S.align16_slot_i32 = (size_t)4 * (((size_t)((dcap_max + 15) / 16) * 18 + 3) & ~(size_t)3) + 16;
+    S.align16_slot_i32 = (size_t)4 * (size_t)ccsx_tb_stride((int)dcap_max) + 16;        // (four passes' moves + the four final band starts, padded)
     int poa_slots, align_slots, align16_slots;
     {
         std::lock_guard<std::mutex> lk(g_scratch_mutex);
@@ -514,7 +521,7 @@ static int stage(ccsx_handle h, Slot &S, const ccsx_batch *b, hipStream_t st)
     }
     float *of = (float *)S.d_out_f32.p;
     P.out_rq = of; P.out_ec = of + n;
-    S.staged = true; S.ran = false;
+    S.staged = true; S.ran = false; S.tm_ok = false;
     return 0;
 }
 
@@ -594,7 +601,7 @@ static int rebase_epoch(ccsx_handle h)
     h->epoch_ms += (double)d;
     std::swap(h->ev_epoch, h->ev_epoch_nx);
     h->age_ms = 0.0f;
-    for (auto &S : h->slot) S.ran = false;               // timings of slots recorded before the new origin are gone (their tickets have been waited for)
+    for (auto &S : h->slot) S.ran = false;               // events recorded before the new origin can no longer be measured against it; what ccsx_wait took (Slot::tm) stays readable
     return 0;
 }
 
@@ -707,6 +714,8 @@ static Slot *slot_of(ccsx_handle h, ccsx_ticket t)
     return S.ticket == t ? &S : nullptr;
 }
 
+static int slot_timings(ccsx_handle h, Slot &S, ccsx_timings *t);
+
 int ccsx_wait(ccsx_handle h, ccsx_ticket ticket)
 {
     Slot *S = slot_of(h, ticket);
@@ -715,6 +724,9 @@ int ccsx_wait(ccsx_handle h, ccsx_ticket ticket)
     if (S->inflight) {
         HIPTRY(hipEventSynchronize(S->ev_done));
         S->inflight = false;
+        // (the ticket's timings are taken NOW, as doubles against the current origin — a later move of the origin (rebase_epoch) cannot invalidate them,
+        // and a caller may read them any time before the slot is reused)
+        S->tm_ok = S->ran && slot_timings(h, *S, &S->tm) == 0;
         if (S->res && S->res->seq_off) std::memcpy(S->res->seq_off, S->seq_off.p, (size_t)(S->P.n_zmw + 1) * 8);
         if (ccsx_drafts *d = S->drafts_out) {
             const int n = S->P.n_zmw;
@@ -762,9 +774,10 @@ static int slot_timings(ccsx_handle h, Slot &S, ccsx_timings *t)
 int ccsx_ticket_timings(ccsx_handle h, ccsx_ticket ticket, ccsx_timings *t)
 {
     Slot *S = slot_of(h, ticket);
-    if (!S || !t || !S->ran) { ccsx_set_error("ccsx_ticket_timings: unknown ticket"); return -1; }
+    if (!S || !t || !(S->ran || S->tm_ok)) { ccsx_set_error("ccsx_ticket_timings: unknown ticket"); return -1; }
     HIPTRY(hipSetDevice(h->device));
-    if (int rc = slot_timings(h, *S, t)) return rc;
+    if (S->tm_ok) *t = S->tm;                         // taken when the ticket was waited for
+    else if (int rc = slot_timings(h, *S, t)) return rc;
     t->polish_workgroups = 0;
     if (!S->inflight && S->res && S->res->n_windows) for (int z = 0; z < S->P.n_zmw; ++z) t->polish_workgroups += S->res->n_windows[z];
     return 0;

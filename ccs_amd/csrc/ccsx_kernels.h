@@ -13,6 +13,12 @@
 // the floor of every reported per-base error probability for opts.max_qv (SPEC v7: Q50 = exactly 1e-5f; the oracle computes the same expression)
 static inline float ccsx_perr_floor(int max_qv) { return max_qv == 50 ? 1e-5f : (float)pow(10.0, -(double)max_qv / 10.0); }
 
+// words of stored moves per pass of a k_align16 quad: per block of 16 draft columns 16 move words (one per band row) + 2 words of band steps / edge flags = 18,
+// rounded up so that a pass's words start on a 16-byte boundary.  ONE definition for the kernels (tb_stride) and the host's slot size.
+#define CCSX_TB_WORDS_PER_BLOCK 18
+static inline __host__ __device__ int ccsx_tb_blocks(int Ld) { return (Ld + 15) >> 4; }
+static inline __host__ __device__ int ccsx_tb_stride(int Ld) { return (ccsx_tb_blocks(Ld) * CCSX_TB_WORDS_PER_BLOCK + 3) & ~3; }
+
 struct KParams {
     int32_t n_zmw, n_reads;
     int32_t maxL_max;          // longest subread of the batch
@@ -88,7 +94,7 @@ struct KParams {
     // ---- caller-supplied drafts (ccsx_polish_batch: the polish seam of docs/img/ccs-impl.png); the bases are already in `draft`
     const int32_t *din_len;    // [n] draft length (0 = none)
     const int32_t *din_bb;     // [n] a pass of the ZMW that has the draft's orientation
-    // ---- k_align16 / k_align16_tb: a quad's stored moves (4 passes x (draft blocks of 16 columns) x 17 words); align_slot_i32 / align_slots are the 64-row retry's and the split alignment's
+    // ---- k_align16 / k_align16_tb: a quad's stored moves (4 passes x ccsx_tb_stride(draft length) words + the 4 final band starts, see below); align_slot_i32 / align_slots are the 64-row retry's and the split alignment's
     size_t align16_slot_i32;
     int32_t align16_slots;
     int32_t *retry_scratch;    // the 64-row retry's / split alignment's slots: behind k_align16's in the same buffer (the trace-backs run beside the next launch / the retry)

@@ -1423,8 +1423,8 @@ __device__ __forceinline__ AlignEnd align_pass(const KParams &P, const uint32_t 
 #define AVALID_TB 2                   // avalid: valid in the 16-row band, entries / masks not yet traced back (k_align16 -> k_align16_tb, same stream)
 // scratch of a quad (one k_align16 workgroup): per pass h [blocks of 16 columns][16 band rows] move words, then [blocks] (band steps, edge flags): 2 bits per column each,
 // column j at bits 2 * (15 - ((j - 1) & 15)); edge flag of column j = "column j - 1 is a window-edge column" (the trace-back then needs no window bounds); then the four final band starts
-__device__ __forceinline__ int tb_blocks(int Ld) { return (Ld + 15) >> 4; }
-__device__ __forceinline__ int tb_stride(int Ld) { return (tb_blocks(Ld) * 18 + 3) & ~3; }      // (a pass's words start on a 16-byte boundary)
+__device__ __forceinline__ int tb_blocks(int Ld) { return ccsx_tb_blocks(Ld); }
+__device__ __forceinline__ int tb_stride(int Ld) { return ccsx_tb_stride(Ld); }                  // (ccsx_kernels.h: shared with the host's slot size)
 // acc * 2 + (the lane's bit of the wave mask m): one v_addc
 __device__ __forceinline__ unsigned shift_in(unsigned acc, unsigned long long m)
 {
@@ -1703,9 +1703,26 @@ __global__ __launch_bounds__(64) void k_align16_tb(KParams P, int qbase, int nsl
         // (the 64 lanes are 64 different passes, so every branch of the step is taken by some lane in nearly every iteration: the step is written with selects,
         // the last four entry rows / masks live in registers that shift at every edge column, and only the 16-byte stores are under a branch)
         while (j > jstop) {
-            const int blk = ((j - 1) >> 4) - b0, sft = 2 * (15 - ((j - 1) & 15)), o = (i - lo) & 15;
-            const int code = (int)(my[blk * 16 + o] >> sft) & 3;
-            const unsigned w2 = mySh[2 * blk] >> sft, e2 = mySh[2 * blk + 1] >> sft;
+            const int blk = ((j - 1) >> 4) - b0, o = (i - lo) & 15;
+            int sft = 2 * (15 - ((j - 1) & 15));
+            const uint32_t Wm = my[blk * 16 + o], Ws = mySh[2 * blk], We = mySh[2 * blk + 1];
+            if (!atedge) {
+                // Round 6: a RUN of plain matches per iteration.  A diagonal match with a band step of 1 keeps the band row (i - lo), so the run's moves are consecutive
+                // 2-bit fields of the SAME move word, and its band steps / edge flags consecutive fields of the block's two other words: the run ends at the first
+                // field that is not (move 0, step 1, no edge) — the fields shifted in above the word's last column read as "step 0", i.e. end it too.  Matches
+                // touch neither the dirty bits nor the entry rows, so i, j and the band start just move by the run's length (one move per iteration before:
+                // ~ 12 k iterations of a 64-way divergent walk per 10 kb pass, now ~ one per mismatch / indel / word)
+                uint32_t bad = (Wm >> sft) | ((Ws >> sft) ^ 0x55555555u) | ((We >> sft) & 0x55555555u);
+                bad = (bad | (bad >> 1)) & 0x55555555u;
+                const int k = bad ? (__ffs((int)bad) - 1) >> 1 : 16;
+                if (k > 0) {
+                    i -= k; j -= k; lo -= k; sft += 2 * k;
+                    if (i < 0) { j = 0; continue; }     // (cannot happen on a valid path: never spin on corrupt moves)
+                    if (sft >= 32) continue;            // the run reached the word's last column: the next word at the loop's head
+                }
+            }
+            const int code = (int)(Wm >> sft) & 3;
+            const unsigned w2 = Ws >> sft, e2 = We >> sft;
             const bool ins = code == 3;
             // dirty bits: an insertion after column j = columns j and j + 1 (in an edge column: the next interval's first position and this one's last);
             // a mismatch or deletion = column j

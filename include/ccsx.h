@@ -232,6 +232,10 @@ int         ccsx_ticket_timings(ccsx_handle h, ccsx_ticket ticket, ccsx_timings 
  *                      CCSX_QV_ONLY no mutation is applied: one scoring round, QVs / rq / np / ec for the sequence as given.
  * ccsx_polish_batch(ccsx_draft_batch(b)) returns byte for byte what ccsx_consensus_batch(b) returns (tests/test_gpu_parity.py).  A draft nothing maps to yields
  * a per-ZMW status (TOO_MANY_UNUSABLE, DRAFT_FAILURE for length 0 or a length beyond the slot), never an error of the call.                                   */
+/* Lifetime and memory: with the TICKETED forms the arrays of a ccsx_drafts are read (ccsx_submit_polish) / written (ccsx_submit_draft) by
+ * asynchronous copies: they must stay valid until ccsx_wait returns for the ticket, and they should be page-locked (ccsx_alloc_pinned) — a copy from / to
+ * pageable memory blocks the submitting thread until the stage has finished, so "three in flight" degenerates to one at a time (correct, but serial).
+ * As INPUT (ccsx_polish_batch / ccsx_submit_polish) only seq_off, len, seq and backbone are read; status, n_windows, win_bounds and win_off may be NULL.   */
 typedef struct ccsx_drafts {
     int32_t  n_zmw;
     int64_t  seq_capacity;       /* elements in seq, from ccsx_draft_layout (= the capacity layout of ccsx_result_layout)               */

@@ -386,7 +386,7 @@ def test_predicted_accuracy_is_calibrated_on_and_off_model(built):
     m, o = api.default_model(), api.default_opts()
     o.min_rq = 0.0
     bounds = {"on-model": (0.55, 1.35), "channel x1.5": (0.8, 1.6), "hp_boost 2.5": (1.0, 2.2), "lowcx": (0.6, 2.0)}
-    for name, kw in QC.DATASETS:
+    for name, kw in [(d[0], d[1]) for d in QC.DATASETS if d[0] in bounds]:      # (the four 10 x 5 kb sets; the tool's further sets run on the GPU: test_gpu_parity)
         b = lowcx.make(40, 10, 4000, 160, **kw)
         r = api.Results.allocate(b)
         O.consensus_batch(m, o, b, r, nthreads=8)

@@ -28,18 +28,17 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / SQ
                "tools/calib; MI355X_MICROARCH.md HBM section)",
        "zmws": n, "workload": workload, "kernels": {},
        "valu_note": "valu_issue_frac_if_{2,4}cyc = SQ_INSTS_VALU x {2,4} SIMD cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the bounds of the "
-                    "VALU pipe occupancy (profiles/r02_valu_peak.txt: v_add/mul_f32 and v_add_u32 issue in 2 cycles per wave64, v_fma_f32, "
-                    "v_max_i32, DPP ops in 4); lanes_active_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)"}
-# SIMD cycles one wave64 VALU instruction of each kernel's dominant mix occupies (profiles/r02_valu_peak.txt): float add / mul 2.5, fma 3.7,
-# integer max / cmp / cndmask / DPP 4.2 — k_polish mixes float multiply-adds with selects and DPP shifts, the DP kernels are DPP / max heavy
-# round 5: k_align16 came out at 1.13 "of the peak" with 4.2 cycles per instruction, also in a serial-stages pass, so its mix is cheaper than that:
-# the ISA of its column loop is ~ 45 % v_add / v_mov / shifts / logic (2.5 cycles), ~ 45 % compares and selects (4.2), ~ 10 % DPP (4.3) = 3.5 on average.  A fraction
-# above 1 is flagged in the file (calibration_inconsistent) instead of being printed as if it were a measurement.
-# second session of round 5: k_align16 no longer carries (origin, dirty bits) — its column is ~ 47 % adds / shifts / logic / v_addc (2.5), ~ 33 % compares, selects, min / max (4.2),
-# ~ 20 % DPP (4.3) = 3.45 by the single-opcode calibration, and the serial-stage counters then say 1.09 of the peak: the calibration over-estimates a MIXED stream (a 2.5-cycle
-# opcode issued between two 4-cycle ones does not wait for a whole slot).  The counters themselves bound the average from above — SQ_INSTS_VALU x c <= the kernel's SIMD cycles gives
-# c <= 3.22 — and that bound is what the table now holds: the kernel fills the VALU (waves wait 20 % of their cycles), 0.99 is "saturated", not a measurement of 1 % slack.
-CYC = {"k_polish": 3.2, "k_poa_dp": 4.2, "k_align16": 3.2, "k_align16_tb": 4.2, "k_align": 4.2, "k_rescue": 4.2, "k_kinetics": 4.2}
+                    "VALU pipe occupancy (profiles/r06_valu_peak.txt: VOP2 float / add ops issue in ~ 2.5 cycles per wave64, integer max, compares, selects "
+                    "and DPP ops in ~ 4.3); lanes_active_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)"}
+# Round 6: no per-kernel "calibrated cycles per instruction" fitted to the counters it is then compared with.  The two bounds
+# (every VALU instruction 2 cycles / 4 cycles) are what the counters say; beside them the kernel's OWN opcode histogram (tools/isa_histogram.py over hipcc -S, inner
+# loops weighted) priced with the single-opcode table gives one estimate — static, a mixed stream overlaps more than the sum of its parts, so a result above 1
+# is FLAGGED (isa_histogram_over_1), never clipped.
+try:
+    ISA = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.environ.get("ISA_HISTOGRAM", "r06_isa_histogram.json"))))
+except Exception:
+    ISA = {}
+ISA_NAME = {"k_polish": "k_polish_t"}
 tot_busy = tot_cycles = 0.0
 for k, d in sorted(val.items()):
     runs = max(1, cnt.get("k_stitch", cnt.get("k_polish", {})).get(next(iter(d)), 1))   # k_stitch: exactly one dispatch per pass (k_polish: one per piece of the slot grid)
@@ -54,17 +53,19 @@ for k, d in sorted(val.items()):
             simd_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 1024
             e["valu_issue_frac_if_2cyc"] = round(d["SQ_INSTS_VALU"] * 2 / simd_cycles, 3)
             e["valu_issue_frac_if_4cyc"] = round(d["SQ_INSTS_VALU"] * 4 / simd_cycles, 3)
-            e["valu_cycles_per_instr_calibrated"] = CYC.get(k, 4.0)
-            e["valu_frac_of_calibrated_peak"] = round(d["SQ_INSTS_VALU"] * CYC.get(k, 4.0) / simd_cycles, 3)
-            if e["valu_frac_of_calibrated_peak"] > 1.0: e["calibration_inconsistent"] = True
-            if k.startswith("k_"): tot_busy += d["SQ_INSTS_VALU"] * CYC.get(k, 4.0); tot_cycles += simd_cycles
+            c_isa = ISA.get(ISA_NAME.get(k, k), {}).get("cycles_per_valu")
+            if c_isa:
+                e["valu_cycles_from_isa_histogram"] = c_isa
+                e["valu_issue_frac_from_isa_histogram"] = round(d["SQ_INSTS_VALU"] * c_isa / simd_cycles, 3)
+                if e["valu_issue_frac_from_isa_histogram"] > 1.0: e["isa_histogram_over_1"] = True
+                if k.startswith("k_"): tot_busy += d["SQ_INSTS_VALU"] * c_isa; tot_cycles += simd_cycles
         if d.get("SQ_THREAD_CYCLES_VALU"):
             e["lanes_active_frac"] = round(d["SQ_THREAD_CYCLES_VALU"] / (64 * d["SQ_INSTS_VALU"]), 3)
     if d.get("GRBM_GUI_ACTIVE"): e["gpu_active_ms_per_pass"] = round(d["GRBM_GUI_ACTIVE"] / 8 / 2.4e6 / runs, 3)
     if "SQ_WAIT_ANY" in d and d.get("SQ_WAVE_CYCLES"): e["wave_wait_frac"] = round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 3)
     if "SQ_LDS_BANK_CONFLICT" in d and d.get("SQ_LDS_IDX_ACTIVE"): e["lds_bank_conflict_frac"] = round(d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"], 3)
     out["kernels"][k] = e
-out["valu_frac_of_calibrated_peak_whole_step"] = round(tot_busy / tot_cycles, 3) if tot_cycles else None
-out["valu_frac_note"] = ("valu_frac_of_calibrated_peak = SQ_INSTS_VALU x (calibrated SIMD cycles per instruction of the kernel's dominant opcode mix) / "
-                         "(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of the VALU issue slots the kernel fills; whole_step = the same over every k_* kernel")
+out["valu_issue_frac_from_isa_histogram_whole_step"] = round(tot_busy / tot_cycles, 3) if tot_cycles else None
+out["valu_frac_note"] = ("valu_issue_frac_from_isa_histogram = SQ_INSTS_VALU x (cycles per VALU instruction of the kernel's own opcode histogram, tools/isa_histogram.py: "
+                         + str(ISA.get("_method")) + ") / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); an estimate beside the two bounds valu_issue_frac_if_{2,4}cyc, flagged when above 1")
 print(json.dumps(out, indent=1))

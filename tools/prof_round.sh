@@ -32,5 +32,15 @@ if [ "${C4:-1}" != 0 ]; then
   python $R/tools/mk_traffic.py $D $Z4 $H "30 passes x 20 kb" > $D/traffic_c4.json
   rm -rf $D/pmc_*
 fi
+# round 6: the same counters for configs[4] (3-50 passes x 1-25 kb): its stage balance attributed, not guessed
+if [ "${C5:-1}" != 0 ]; then
+  Z5=${Z5:-8192}
+  for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM"; do
+    tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+    timeout 900 rocprofv3 --kernel-trace --pmc $set -d $D/pmc_$tag -o pmc -- python $R/bench.py --pmc --serial-stages --workload c5 --zmws $Z5 --steps 1 --warmup 1 --distinct 1 > $D/bench_c5_$tag.json 2> $D/bench_c5_$tag.err < /dev/null
+  done
+  python $R/tools/mk_traffic.py $D $Z5 $H "3-50 passes x 1-25 kb" > $D/traffic_c5.json
+  rm -rf $D/pmc_*
+fi
 rm -rf $D/trace
 ls -la $D; cat $D/traffic.json

@@ -41,12 +41,19 @@ def error_positions(cons, truth):
 
 
 def main():
+    import torch                                               # (BEFORE the first call into libccsx.so: torch brings its own HIP runtime, and whichever runtime opens the
+    gpu = torch.cuda.is_available()                            # device second finds none — bench.py and the tests import torch first as well)
     m, o = api.default_model(), api.default_opts()
     o.min_rq = 0.0                                             # every consensus is kept: calibration needs the low-rq reads too
     o.max_qv = MAX_QV
-    import torch
-    gpu = torch.cuda.is_available()
-    h = api.Handle(0, opts=o) if gpu else None
+    h = None
+    for attempt in range(4):                                   # (a device can be transiently unavailable right after another process released it)
+        if not gpu: break
+        try:
+            h = api.Handle(0, opts=o); break
+        except RuntimeError as e:
+            print(f"# Handle: {e}; retrying", file=sys.stderr); import time; time.sleep(3)
+    if gpu and h is None: raise SystemExit("no device")
     out = {"spec_version": O.spec_version(), "zmws_per_dataset": N, "max_qv": MAX_QV or 50, "engine": "HIP library" if gpu else "CPU restatement", "headline": {}, "datasets": {}}
     print(f"# predicted vs empirical accuracy, SPEC v{O.spec_version()}, max_qv {MAX_QV or 50}, {N} ZMWs per data set (half for the 10 kb / 30-pass sets), {'HIP library on one MI355X' if gpu else 'CPU restatement'} (tools/qv_calibration.py)")
     print("# a read's predicted error count = (1 - rq) x length; a base's = 10^(-QV/10); empirical = errors of the consensus against the true template")
