@@ -415,6 +415,17 @@ static void start_column(int I, int32_t *M)
     for (int l = 0; l < BAND; ++l) M[l] = (l <= I && l < g_bw) ? l * SC_INS : NEG;
 }
 
+/* STUDY HOOK (never the product's path): take the step-3 alignment of the passes that were threaded into the POA from their PATH through the
+ * graph (restricted to the consensus vertices) instead of a second DP against the draft.  orc_set_path_align(1) records every threaded pass's vertex per base and
+ * the consensus position of every vertex; the whole-ZMW driver then derives entry rows and dirty bits from them (path_align below).  Default 0 = SPEC. */
+static int g_path_align = 0;
+void orc_set_path_align(int on) { g_path_align = on; }
+#define PA_MAXREADS 64
+static __thread int32_t *pa_path[PA_MAXREADS]; static __thread int pa_len[PA_MAXREADS], pa_read[PA_MAXREADS], pa_n = 0;
+static __thread int32_t *pa_posv = NULL; static __thread int pa_nv = 0;
+static void pa_reset(void) { for (int k = 0; k < pa_n; ++k) free(pa_path[k]); pa_n = 0; free(pa_posv); pa_posv = NULL; pa_nv = 0; }
+static __thread int pa_cur_read = -1;
+
 /* Thread one read (draft orientation) into the graph.  Returns 1 if added, 0 if skipped, -1 on capacity overflow. */
 static int poa_add_read(poa_t *g, const uint8_t *r, int I, int32_t *pathv /* scratch [I] */, int first)
 {
@@ -429,8 +440,10 @@ static int poa_add_read(poa_t *g, const uint8_t *r, int I, int32_t *pathv /* scr
             if (v < 0) return -1;
             if (prev >= 0) poa_add_edge(g, prev, v);
             prev = v;
+            pathv[i] = v;
         }
         g->nadded = 1; poa_renumber(g);
+        if (g_path_align && pa_n < PA_MAXREADS) { pa_path[pa_n] = (int32_t *)malloc(sizeof(int32_t) * (I + 1)); memcpy(pa_path[pa_n], pathv, sizeof(int32_t) * I); pa_len[pa_n] = I; pa_read[pa_n] = pa_cur_read; ++pa_n; }
         return 1;
     }
     int32_t S[BAND]; start_column(I, S);
@@ -482,8 +495,10 @@ static int poa_add_read(poa_t *g, const uint8_t *r, int I, int32_t *pathv /* scr
         else { w = poa_new_vertex(g, r[i], prevp); if (w < 0) return -1; }
         if (prevp >= 0) poa_add_edge(g, prevp, w);
         prevp = w;
+        pathv[i] = w;
     }
     g->nadded += 1; poa_renumber(g);
+    if (g_path_align && pa_n < PA_MAXREADS) { pa_path[pa_n] = (int32_t *)malloc(sizeof(int32_t) * (I + 1)); memcpy(pa_path[pa_n], pathv, sizeof(int32_t) * I); pa_len[pa_n] = I; pa_read[pa_n] = pa_cur_read; ++pa_n; }
     return 1;
 }
 
@@ -504,7 +519,8 @@ static int poa_consensus(poa_t *g, uint8_t *draft, int cap)
     for (int v = vbest; v >= 0; v = bp[v]) ++len;
     if (len > cap) { free(best); free(bp); return -1; }
     int k = len;
-    for (int v = vbest; v >= 0; v = bp[v]) draft[--k] = g->base[v];
+    if (g_path_align) { free(pa_posv); pa_posv = (int32_t *)malloc(sizeof(int32_t) * n); pa_nv = n; for (int v = 0; v < n; ++v) pa_posv[v] = -1; }
+    for (int v = vbest; v >= 0; v = bp[v]) { draft[--k] = g->base[v]; if (g_path_align) pa_posv[v] = k; }
     free(best); free(bp);
     return len;
 }
@@ -530,8 +546,10 @@ int orc_poa_draft_bb(int nreads, const int64_t *base_off, const uint8_t *bases, 
     int32_t *pathv = (int32_t *)malloc(sizeof(int32_t) * (maxL + 1));
     int rev0 = flags[bb] & 1, ok = 1;
     g_poa_nscores = 0;
+    if (g_path_align) pa_reset();
     for (int rr = 0; rr < npoa && ok; ++rr) {
         int r = bb + rr < nreads ? bb + rr : bb + rr - nreads;
+        pa_cur_read = r;
         int L = (int)(base_off[r + 1] - base_off[r]);
         orient(bases + base_off[r], NULL, L, (flags[r] & 1) != rev0, ob, NULL);
         g_bw = g_poa_band; g_cells_kind = CNT_CELLS_POA;            /* SPEC: the POA runs in a POA_BAND-row band */
@@ -1391,6 +1409,37 @@ static float tract_floor(const uint8_t *v, int n, int x, int np)
     return fl;
 }
 
+/* STUDY HOOK: the step-3 alignment of a threaded pass from its path through the POA graph.  vp[i] = the vertex of read base i, posv[v] = the vertex's position in the
+ * draft or -1.  A base on a consensus vertex is a match at that position (vertices carry one base); every other base is an insertion waiting at the column after the
+ * last match; consensus positions the pass skips are deletions.  Entry rows and dirty bits as the aligner defines them (DESIGN.md §2 "Alignment"); valid iff the
+ * alignment score (+3 / -4 / -4) reaches the draft's length, the aligner's gate. */
+static int path_align(const int32_t *vp, int L, const int32_t *posv, int Ld, int32_t *rstart, uint8_t *dirty, int32_t *score_out)
+{
+    memset(dirty, 1, Ld + 1);
+    int lastp = -1, ins = 0, nm = 0, nins = 0;
+    rstart[0] = 0;
+    for (int i = 0; i < L; ++i) {
+        int p = vp[i] >= 0 ? posv[vp[i]] : -1;
+        if (p < 0) { ++ins; ++nins; continue; }
+        if (p <= lastp) return 0;                            /* (cannot happen: both are paths of one DAG) */
+        for (int q = lastp + 2; q <= p; ++q) rstart[q] = i;  /* the skipped columns and column p are entered with base i next; column lastp + 1 was entered right after its match */
+        if (lastp < 0 && p >= 1) rstart[1 <= p ? 1 : 0] = rstart[1];   /* (no-op: kept for symmetry) */
+        if (lastp < 0) for (int q = 1; q <= p; ++q) rstart[q] = i;
+        dirty[p] = 0;
+        if (ins) { if (lastp >= 0) dirty[lastp] = 1; if (lastp + 1 <= Ld) dirty[lastp + 1 < Ld ? lastp + 1 : Ld - 1] = 1; if (lastp < 0) dirty[0] = 1; }
+        if (p + 1 <= Ld) rstart[p + 1] = i + 1;
+        lastp = p; ins = 0; ++nm;
+    }
+    for (int q = lastp + 2; q <= Ld; ++q) rstart[q] = L;
+    if (lastp < 0) for (int q = 1; q <= Ld; ++q) rstart[q] = L;
+    if (ins && lastp >= 0) { dirty[lastp] = 1; if (lastp + 1 < Ld) dirty[lastp + 1] = 1; }
+    rstart[Ld] = L;
+    int ndel = Ld - nm;
+    int32_t sc = 3 * nm - 4 * nins - 4 * ndel;
+    if (score_out) *score_out = sc;
+    return sc >= Ld;
+}
+
 /* ---------------- whole-ZMW driver (steps 2,3,4,8,9,10) --------------------------------------------------- */
 typedef struct {
     int32_t status, seq_len, np, iters, n_windows;
@@ -1477,6 +1526,11 @@ int orc_consensus_zmw_kin(const orc_model *model, const orc_opts *opts, const fl
                     avalid[r] = (uint8_t)(nneed >= 2 ? orc_align_partial(ob, L, draft, Ld, need, nneed, from_end, rstart[r], &sc, dirty[r]) : 0);
                     continue;                               /* not a pass: np / fn / rn count full-length passes */
                 }
+                int from_path = 0;
+                if (g_path_align && attempt < 2 && pa_posv) {    /* STUDY HOOK: a pass that was threaded takes its alignment from its graph path */
+                    for (int k = 0; k < pa_n; ++k) if (pa_read[k] == r && pa_len[k] == L) { avalid[r] = (uint8_t)path_align(pa_path[k], L, pa_posv, Ld, rstart[r], dirty[r], &sc); from_path = 1; break; }
+                }
+                if (!from_path)
                 avalid[r] = (uint8_t)orc_align_ev_w(ob, L, draft, Ld, need, nneed, opts->disable_heuristics != 0, rstart[r], &sc, dirty[r]);
                 /* a pass much longer than the draft that failed: look for ONE large insertion (SPEC "split alignment") */
                 if (!avalid[r] && L - Ld > RESCUE_MIN_EXCESS && nneed >= 3)

@@ -76,6 +76,38 @@ def test_max_qv_option_bit_exact(built, max_qv):
         h.close()
 
 
+def test_qv_calibration_at_scale(built):
+    """the predicted accuracy is checked on a sample a CPU test cannot afford — 768 on-model ZMWs of 10 x 5 kb through the HIP library (bit-identical
+    to the restatement), errors against the true templates binned by phred QV.  Bounds from profiles/r06_qv_calibration.txt (1024 ZMWs: overall 0.87; bins Q0-10 0.91,
+    Q10-20 0.74, Q20-30 0.69 with 1014 / 357 / 73 errors; the bins above hold 23-63 errors each and scatter 0.5-1.7: they are bounded loosely and their counts printed)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import lowcx
+    import qv_calibration as QC
+    o = api.default_opts(); o.min_rq = 0.0
+    b = lowcx.make(768, 10, 5000, 61)
+    h = api.Handle(0, opts=o)
+    try:
+        r = h.consensus(b)
+    finally:
+        h.close()
+    q, e, pe, ee = [], [], 0.0, 0
+    for z in range(b.n_zmw):
+        if r.status[z] not in (0, 7): continue
+        d, err = QC.error_positions(r.sequence(z), b.tpl[b.tpl_off[z]:b.tpl_off[z + 1]])
+        if d < 0: continue
+        q.append(r.quals(z).astype(np.int32)); e.append(err.astype(np.int32))
+        pe += (1.0 - float(r.rq[z])) * int(r.seq_len[z]); ee += d
+    q, e = np.concatenate(q), np.concatenate(e)
+    assert 0.7 <= ee / pe <= 1.1, f"overall empirical / predicted = {ee / pe:.2f} ({ee} errors, {pe:.1f} predicted)"
+    assert q.max() <= 50
+    for lo, hi, rlo, rhi in [(0, 10, 0.7, 1.15), (10, 20, 0.55, 1.1), (20, 30, 0.4, 1.2), (30, 40, 0.5, 2.6), (40, 51, 0.4, 2.2)]:
+        sel = (q >= lo) & (q < hi)
+        pred, found = float(np.sum(10.0 ** (-q[sel] / 10.0))), int(e[sel].sum())
+        print(f"Q{lo}-{hi}: {int(sel.sum())} bases, predicted {pred:.1f} errors, found {found}")
+        assert rlo <= found / pred <= rhi, f"Q{lo}-{hi}: empirical / predicted = {found / pred:.2f} ({found} found, {pred:.1f} predicted)"
+
+
 def test_stages_match_oracle(handle):
     batch = api.synth(4, 6, 900, seed=11)
     handle.upload(batch); handle.run(); handle.sync()
