@@ -111,11 +111,15 @@ const char *ccsx_kernel_build_flags()
 #define LANES 64
 #define PW_MAXREADS_SPEC CCSX_MAX_PASSES      // passes of a ZMW the engine uses (k_polish / k_kinetics take them in groups of PW_MAXREADS)
 #ifdef CCSX_PROFILE_PHASES
-#define PHASE_T0() unsigned long long ph_t = __builtin_readcyclecounter(); (void)ph_t
-#define PHASE(idx) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd((unsigned long long *)P.phase + (idx), n_ - ph_t); ph_t = n_; } } while (0)
+// (round 6: the phase times of wave 0 are summed in LDS (thread 0) and flushed ONCE per workgroup — the first version added a barrier and a global atomic per phase
+// boundary, which made the instrumented kernel four times slower and every phase look alike)
+#define PHASE_T0() __shared__ unsigned long long sPh[8]; unsigned long long ph_t = __builtin_readcyclecounter(); if (threadIdx.x < 8) sPh[threadIdx.x] = 0ull; (void)ph_t
+#define PHASE(idx) do { unsigned long long n_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) sPh[(idx)] += n_ - ph_t; ph_t = n_; } while (0)
+#define PHASE_FLUSH() do { if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) for (int q_ = 0; q_ < 8; ++q_) atomicAdd((unsigned long long *)P.phase + q_, sPh[q_]); } while (0)   /* one workgroup in 64: millions of atomics on eight addresses are a workload of their own */
 #else
 #define PHASE_T0() do { } while (0)
 #define PHASE(idx) do { } while (0)
+#define PHASE_FLUSH() do { } while (0)
 #endif
 #ifdef CCSX_PROFILE_PHASES                  // one-wave kernels: lane 0's cycle counter between phases, summed over the graphs
 #define TPH_T0() unsigned long long tph_t = __builtin_readcyclecounter(); (void)tph_t
@@ -3180,6 +3184,7 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
     }
 #endif
     PHASE(6);
+    PHASE_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
