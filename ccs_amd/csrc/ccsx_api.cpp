@@ -585,6 +585,19 @@ static int enqueue_download(Slot &S, ccsx_results *res, hipStream_t s)
     return 0;
 }
 
+// the host-side part of a finished slot's outputs: the capacity-layout offsets the caller's structs carry, and the drafts' backbone words without the cascade's marks
+static void finish_outputs(Slot &S)
+{
+    if (S.res && S.res->seq_off) std::memcpy(S.res->seq_off, S.seq_off.p, (size_t)(S.P.n_zmw + 1) * 8);
+    if (ccsx_drafts *d = S.drafts_out) {
+        const int n = S.P.n_zmw;
+        std::memcpy(d->seq_off, S.seq_off.p, (size_t)(n + 1) * 8);
+        if (d->win_off) for (int z = 0; z <= n; ++z) d->win_off[z] = S.wb_off[z];
+        for (int z = 0; z < n; ++z) d->backbone[z] &= 255;   // (the device word also carries the cascade's marks)
+    }
+    S.drafts_out = nullptr;                              // (done once)
+}
+
 // ---- asynchronous pipeline -------------------------------------------------------------------------------
 // The origin of ccsx_timings.start_ms / end_ms moves forward every 5 minutes of handle lifetime so that HIP's float milliseconds keep their resolution.
 // not inside the getter (it stalled behind every queued download and relied on negative elapsed times for slots recorded before the new origin) — only when
@@ -628,9 +641,10 @@ static int submit_impl(ccsx_handle h, const ccsx_batch *b, ccsx_results *res, cc
     HIPTRY(hipSetDevice(h->device));
     if (int rc0 = rebase_epoch(h)) return rc0;
     Slot &S = h->slot[h->next_ticket % CCSX_SLOTS];
-    if (S.inflight) {                                    // the slot's previous batch was never waited for: finish it first
-        HIPTRY(hipEventSynchronize(S.ev_done));
+    if (S.inflight) {                                    // the slot's previous batch was never waited for: finish it first — INCLUDING the host-side part of its
+        HIPTRY(hipEventSynchronize(S.ev_done));          // outputs (offsets, the drafts' backbone words): the caller's buffers are complete whether or not it ever waits
         S.inflight = false;
+        finish_outputs(S);
     }
     // A failure after the first enqueue must not leave copies or kernels running on a slot the next submit would rewrite
     // (ADVICE r02): drain every stream, mark the slot unusable and refuse further batches on this handle.
@@ -727,13 +741,7 @@ int ccsx_wait(ccsx_handle h, ccsx_ticket ticket)
         // (the ticket's timings are taken NOW, as doubles against the current origin — a later move of the origin (rebase_epoch) cannot invalidate them,
         // and a caller may read them any time before the slot is reused)
         S->tm_ok = S->ran && slot_timings(h, *S, &S->tm) == 0;
-        if (S->res && S->res->seq_off) std::memcpy(S->res->seq_off, S->seq_off.p, (size_t)(S->P.n_zmw + 1) * 8);
-        if (ccsx_drafts *d = S->drafts_out) {
-            const int n = S->P.n_zmw;
-            std::memcpy(d->seq_off, S->seq_off.p, (size_t)(n + 1) * 8);
-            if (d->win_off) for (int z = 0; z <= n; ++z) d->win_off[z] = S->wb_off[z];
-            for (int z = 0; z < n; ++z) d->backbone[z] &= 255;   // (the device word also carries the cascade's marks)
-        }
+        finish_outputs(*S);
     }
     return 0;
 }
