@@ -108,6 +108,43 @@ def test_qv_calibration_at_scale(built):
         assert rlo <= found / pred <= rhi, f"Q{lo}-{hi}: empirical / predicted = {found / pred:.2f} ({found} found, {pred:.1f} predicted)"
 
 
+def test_poa_vertices_with_many_in_edges(built):
+    """Round 6: the POA graph lives by topological position — column records (in-edges 0..2) + overflow records (in-edges 3..6), ping-pong, both remapped when a pass
+    is threaded.  Passes that all differ from each other at the same few columns (every base, inserted bases, a deletion) give the vertices behind those columns four to
+    seven in-edges, the cap included: draft and consensus must equal the restatement's, at a draft coverage high enough to thread all of them."""
+    rng = np.random.default_rng(5)
+    L, P = 600, 14
+    tpl = rng.integers(0, 4, L, dtype=np.uint8)
+    hot = list(range(40, L - 40, 37))
+    reads = []
+    for k in range(P):
+        out = []
+        for j in range(L):
+            if j in hot:
+                v = (k + hot.index(j)) % 9
+                if v < 4: out.append(v)                                  # one of the four bases
+                elif v < 8: out.extend([v - 4, int(tpl[j])])            # an inserted base in front
+                # v == 8: deleted
+            else:
+                out.append(int(tpl[j]))
+        reads.append(np.array(out, np.uint8))
+    n = 3
+    bases = np.concatenate(reads * n)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in reads] * n)]).astype(np.int64)
+    batch = api.Batch(np.arange(n, dtype=np.int32), np.tile(np.array([9.0, 16.0, 8.0, 13.0], np.float32), (n, 1)), (np.arange(n + 1) * P).astype(np.int32), off, bases,
+                      np.full(len(bases), 2, np.uint8), np.full(len(bases), 5, np.uint8), np.zeros(n * P, np.uint8))
+    o = api.default_opts(); o.max_poa_cov = P; o.min_rq = 0.0
+    h = api.Handle(0, opts=o)
+    try:
+        h.upload(batch); h.run(); h.sync()
+        for z in range(n):
+            assert np.array_equal(h.stage_draft(z), O.poa_draft(batch, z, P)), f"zmw {z}: draft differs"
+        res = h.consensus(batch)
+        _compare(res, _oracle(h, batch), batch)
+    finally:
+        h.close()
+
+
 def test_stages_match_oracle(handle):
     batch = api.synth(4, 6, 900, seed=11)
     handle.upload(batch); handle.run(); handle.sync()
