@@ -355,6 +355,11 @@ def main():
         graft.build()
     from ccs_amd import api
 
+    rank_numa = None
+    if launched and world > 1:
+        # one rank per GPU under a launcher: the rank's process (its generator threads, page-locked batches, handle) lives on its device's NUMA node
+        rank_numa = {"numa_node": int(api.lib().ccsx_device_numa_node(local_rank)), "thread_bound_to_node": int(api.lib().ccsx_bind_thread_to_device(local_rank))}
+
     def make_opts():
         o = api.default_opts()
         o.hifi_kinetics = 1 if args.hifi_kinetics else 0
@@ -485,6 +490,7 @@ def main():
             "value": round(value, 2), "unit": "ZMWs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             **({"per_gpu": per_gpu, "multi_gpu": "one process, one worker thread and one engine handle per device, no collective (value = all workers' ZMWs / the slowest worker's time)"} if nloc > 1 else {}),
+            **({"rank0_numa": rank_numa, "multi_gpu": "one rank per GPU (torch.distributed.run), every rank bound to its device's NUMA node, no collective on the data path (barrier + max over ranks for the timing only)"} if rank_numa else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.passes} passes x {args.length} bp synthetic subreads (BASELINE configs[{int(args.workload[1]) - 1}] shape), "
                                    f"{args.zmws} ZMWs per GPU per step, {job.nb} distinct batches, host-pinned -> H2D -> kernels -> D2H, {args.depth} batches in flight",

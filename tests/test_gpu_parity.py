@@ -582,6 +582,9 @@ def test_bench_two_ranks_on_one_device(built, tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
     assert out["value"] > 0 and out["success_frac"] > 0.9
     assert abs(out["value"] - 2 * 48 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3      # whole-job aggregate over both ranks
+    # round 6: under a launcher every rank binds itself to its device's NUMA node before it allocates anything (rank 0's placement is in the line)
+    node = api.lib().ccsx_device_numa_node(0)
+    assert out["rank0_numa"]["numa_node"] == node and out["rank0_numa"]["thread_bound_to_node"] in (node, -1)
 
 
 def test_bench_gpus_n_runs_n_workers_in_one_process(built):
