@@ -2668,9 +2668,9 @@ __global__ __launch_bounds__(PWT, PWMIN) void k_polish_t(KParams P, int slot0)
                 // steps t = i + j in [2 i + dlo, 2 i + dhi], row i + 16 exactly 32 steps later, so with a band of at most FILL16_MAXBW = 24 diagonals the lane is
                 // idle for at least 8 steps in between and changes rows there.  The neighbour row's cell comes by a ROTATION inside the DPP row (row_ror: lane 0
                 // takes lane 15, whose row 15 precedes lane 0's row 16; while lane 0 is on row 0, lane 15 has not started and holds a zero).  A lane that is not on
-                // the band holds a zero running cell, which is what its neighbours must read past the band's edge.  Look-ups are software-pipelined as before: slot k
-                // holds DL and the (ME, INS) pair of the step's column and the context offset of the column four steps on, refilled right after use.  The row
-                // change therefore happens in two parts: the look-up side (observation row, column-entry pointer) at the first iteration whose look-ups no longer
+                // the band holds a zero running cell, which is what its neighbours must read past the band's edge.  Look-ups run four steps ahead: slot k holds DL and the
+                // (ME, INS) pair of the step's column — read from the per-column tables sDLC / sTC at a running pointer + immediate — and is refilled right after use.  The row
+                // change therefore happens in two parts: the look-up side (observation row of sTC, 16 columns back) at the first iteration whose look-ups no longer
                 // serve the old row, the compute side (activity window, store pointer) one iteration later.
                 const int quad = fu >> 1, isb = fu & 1;
                 const int g4 = lane >> 4, l16 = lane & 15;
